@@ -1,0 +1,160 @@
+/* sg_hip.h -- C ABI of libsg_hip.so, the MI355X (gfx950) core for string_grouper's hot path.
+ *
+ * Boundary.  Every entry point replaces a call the reference makes
+ * into a third-party native dependency from string_grouper/string_grouper.py (paths relative
+ * to the reference tree):
+ *
+ *   seam b1  TfidfVectorizer(min_df=1, analyzer=n_grams, dtype).fit / .transform
+ *            string_grouper.py:306 (construct), :699-707 (fit), :689-692 (transform)
+ *            -> sg_strings_*, sg_vec_fit, sg_vocab_*, sg_vec_transform
+ *   seam b2  sparse_dot_topn.sp_matmul_topn     string_grouper.py:725-732, :737-743
+ *            -> sg_postings_build (the B.transpose() + CSC->CSR step) + sg_spgemm_topn,
+ *               or the one-shot host mirror sg_sp_matmul_topn_host
+ *            sparse_dot_topn.zip_sp_matmul_topn string_grouper.py:746
+ *            -> sg_topn_zip
+ *
+ * Conventions
+ *   - plain C, no torch / scipy types.  Pointers named d_* are DEVICE pointers (HBM), all other
+ *     pointers are host pointers.  A caller that already owns device memory (e.g. a torch tensor's
+ *     data_ptr()) uses the *_from_device constructors; nothing is copied and nothing is freed.
+ *   - every function returns an sg_status; sg_last_error() gives a thread-local message.
+ *     SG_ERR_OVERFLOW is what the Python layer turns into OverflowError, the one exception the
+ *     reference handles around _build_matches (string_grouper.py:397-413).
+ *   - calls are asynchronous on the context's HIP stream unless they return data to the host.
+ *   - value type: SG_F32 or SG_F64 (the only two sparse_dot_topn accepts, string_grouper.py:18).
+ *   - column/row indices are int32, row pointers int64.
+ *   - result order ("sort" != 0): per row by (score descending, column ascending); ties at the
+ *     top-n cut are resolved by that same order; values must be STRICTLY greater than threshold.
+ */
+#ifndef SG_HIP_H
+#define SG_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+    SG_OK = 0,
+    SG_ERR_BADARG = 1,
+    SG_ERR_OOM = 2,       /* hipMalloc failed            -> MemoryError   */
+    SG_ERR_OVERFLOW = 3,  /* index space exhausted       -> OverflowError */
+    SG_ERR_HIP = 4,       /* any other HIP runtime error -> RuntimeError  */
+    SG_ERR_NODEVICE = 5,  /* no gfx950 device visible    -> RuntimeError  */
+    SG_ERR_UNSUPPORTED = 6
+} sg_status;
+
+enum { SG_F32 = 0, SG_F64 = 1 };
+
+typedef struct sg_ctx sg_ctx;           /* one per (process, GPU): device, stream, scratch pool  */
+typedef struct sg_strings sg_strings;   /* device-resident string column: bytes + int64 offsets  */
+typedef struct sg_vocab sg_vocab;       /* fitted vocabulary: n-gram key -> column, df, idf       */
+typedef struct sg_csr sg_csr;           /* device-resident CSR matrix                             */
+typedef struct sg_postings sg_postings; /* device-resident inverted index of B (= B^T), bucketed
+                                           by column tile for the LDS accumulator of the multiply */
+typedef struct sg_topn sg_topn;         /* device-resident fixed-stride top-n result             */
+
+/* ------------------------------------------------------------------ library / context */
+const char *sg_last_error(void);
+int sg_abi_version(void);
+int sg_device_count(int *count);
+/* hip_stream: a hipStream_t to launch on (e.g. torch.cuda.current_stream().cuda_stream), or NULL
+ * to let the library create its own non-blocking stream. */
+int sg_ctx_create(int device, void *hip_stream, sg_ctx **out);
+int sg_ctx_destroy(sg_ctx *ctx);
+int sg_ctx_sync(sg_ctx *ctx);
+/* Release cached scratch back to the driver. */
+int sg_ctx_trim(sg_ctx *ctx);
+
+/* ------------------------------------------------------------------ strings (input of seam b1) */
+/* Arrow large_string layout: string i = bytes[offsets[i] .. offsets[i+1]). */
+int sg_strings_from_host(sg_ctx *ctx, const uint8_t *bytes, const int64_t *offsets, int64_t n,
+                         sg_strings **out);
+int sg_strings_from_device(sg_ctx *ctx, const uint8_t *d_bytes, const int64_t *d_offsets, int64_t n,
+                           int64_t total_bytes, sg_strings **out);
+int sg_strings_free(sg_strings *s);
+
+/* ------------------------------------------------------------------ seam b1: vectoriser */
+typedef struct {
+    int32_t ngram_size;         /* StringGrouperConfig.ngram_size (string_grouper.py:189)         */
+    int32_t ascii_lower;        /* != 0: map 'A'-'Z' to 'a'-'z' on the device (ignore_case)       */
+    int32_t dtype;              /* SG_F32 / SG_F64  (tfidf_matrix_dtype)                          */
+    int32_t reserved;
+    uint8_t delete_table[128];  /* != 0: ASCII byte removed before n-gramming (the regex, :376)   */
+} sg_vec_params;
+
+/* TfidfVectorizer.fit(concat(sets)): learns the vocabulary (column = rank of the n-gram in
+ * code-point order, exactly sklearn's sorted vocabulary) and the document frequencies.
+ * Bytes >= 0x80 are dropped (== .encode('ascii','ignore') after the host's NFKD).
+ * Returns SG_ERR_BADARG with "empty vocabulary" if no n-gram exists at all. */
+int sg_vec_fit(sg_ctx *ctx, const sg_strings *const *sets, int32_t n_sets, const sg_vec_params *params,
+               sg_vocab **out);
+int sg_vocab_size(const sg_vocab *v, int64_t *n_terms, int64_t *n_docs);
+/* keys[i]: the n-gram of column i, bytes packed big-endian 7 bits each; df[i]: its document count. */
+int sg_vocab_to_host(sg_ctx *ctx, const sg_vocab *v, uint64_t *keys, int64_t *df);
+/* idf is computed by the caller from df (numpy, sklearn's exact op sequence text.py:1664-1679,
+ * so that log() is bit-identical) and installed here; dtype must match params.dtype. */
+int sg_vocab_set_idf(sg_ctx *ctx, sg_vocab *v, const void *idf, int32_t dtype);
+int sg_vocab_free(sg_vocab *v);
+/* TfidfVectorizer.transform(strings): counts -> *idf -> row L2 normalise, CSR with sorted indices. */
+int sg_vec_transform(sg_ctx *ctx, const sg_vocab *v, const sg_strings *strings, sg_csr **out);
+
+/* ------------------------------------------------------------------ CSR objects */
+int sg_csr_from_host(sg_ctx *ctx, int64_t n_rows, int64_t n_cols, const int64_t *indptr,
+                     const int32_t *indices, const void *data, int32_t dtype, sg_csr **out);
+int sg_csr_from_device(sg_ctx *ctx, int64_t n_rows, int64_t n_cols, int64_t nnz, const int64_t *d_indptr,
+                       const int32_t *d_indices, const void *d_data, int32_t dtype, sg_csr **out);
+int sg_csr_dims(const sg_csr *m, int64_t *n_rows, int64_t *n_cols, int64_t *nnz, int32_t *dtype);
+int sg_csr_device_ptrs(const sg_csr *m, const int64_t **d_indptr, const int32_t **d_indices,
+                       const void **d_data);
+int sg_csr_to_host(sg_ctx *ctx, const sg_csr *m, int64_t *indptr, int32_t *indices, void *data);
+/* Rows [r0, r1) as a view (no copy); the parent must outlive the view. */
+int sg_csr_row_block(sg_ctx *ctx, const sg_csr *m, int64_t r0, int64_t r1, sg_csr **out);
+int sg_csr_free(sg_csr *m);
+
+/* ------------------------------------------------------------------ seam b2: sparse top-n multiply */
+/* Inverted index of B (n_right x V): for every term k the (row j, value) pairs, grouped by column
+ * tile j / tile_cols.  tile_cols must be a power of two supported by the multiply (0 = default). */
+int sg_postings_build(sg_ctx *ctx, const sg_csr *B, int32_t tile_cols, sg_postings **out);
+int sg_postings_free(sg_postings *p);
+
+/* C = topn_rowwise(A . B^T restricted to > threshold).  A: n_left x V, postings of B: n_right x V.
+ * Row i of the result holds counts[i] <= top_n entries at [i*top_n, i*top_n + counts[i]). */
+int sg_spgemm_topn(sg_ctx *ctx, const sg_csr *A, const sg_postings *Bt, int32_t top_n, double threshold,
+                   int32_t sort, sg_topn **out);
+int sg_topn_dims(const sg_topn *r, int64_t *n_rows, int32_t *stride, int32_t *dtype, int64_t *n_cols);
+int sg_topn_device_ptrs(const sg_topn *r, const int32_t **d_cols, const void **d_vals, const int32_t **d_counts);
+int sg_topn_to_host(sg_ctx *ctx, const sg_topn *r, int32_t *cols, void *vals, int32_t *counts);
+/* Upload a fixed-stride result held on the host (used to feed host CSR blocks to sg_topn_zip). */
+int sg_topn_from_host(sg_ctx *ctx, int64_t n_rows, int64_t n_cols, int32_t stride, int32_t dtype,
+                      const int32_t *cols, const void *vals, const int32_t *counts, sg_topn **out);
+/* zip_sp_matmul_topn: parts[b] = A . B_b^T; columns of part b are offset by col_offsets[b]. */
+int sg_topn_zip(sg_ctx *ctx, const sg_topn *const *parts, const int64_t *col_offsets, int32_t n_parts,
+                int32_t top_n, sg_topn **out);
+int sg_topn_free(sg_topn *r);
+
+/* One-shot host mirror of sparse_dot_topn.sp_matmul_topn(A, B.T, top_n, threshold, sort):
+ * uploads A and B (both CSR over the same V columns), multiplies, downloads.  out_* hold
+ * n_left * top_n (cols, vals) and n_left counts. */
+int sg_sp_matmul_topn_host(sg_ctx *ctx, int64_t n_left, int64_t n_right, int64_t n_cols,
+                           const int64_t *a_indptr, const int32_t *a_indices, const void *a_data,
+                           const int64_t *b_indptr, const int32_t *b_indices, const void *b_data,
+                           int32_t dtype, int32_t top_n, double threshold, int32_t sort,
+                           int32_t *out_cols, void *out_vals, int32_t *out_counts);
+
+/* ------------------------------------------------------------------ measurement */
+enum { SG_K_TOKENIZE = 0, SG_K_WEIGHT = 1, SG_K_POSTINGS = 2, SG_K_SPGEMM = 3, SG_K_ZIP = 4, SG_K_COUNT = 5 };
+typedef struct {
+    float ms[SG_K_COUNT];     /* HIP-event time of the most recent launch group of each kernel      */
+    int64_t macs;             /* intermediate products of the most recent sg_spgemm_topn            */
+    int64_t spgemm_bytes;     /* its algorithmic bytes (stream model)                    */
+    int64_t out_nnz;          /* entries kept by the most recent sg_spgemm_topn                     */
+} sg_stats;
+/* Waits for the recorded events, so it is a synchronisation point. */
+int sg_ctx_stats(sg_ctx *ctx, sg_stats *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SG_HIP_H */

@@ -1,0 +1,368 @@
+"""ctypes binding of libsg_hip.so (C ABI declared in include/sg_hip.h).
+
+There is no CPU fallback: importing this module without the built library, or creating a
+context without an MI355X, raises.  The binding passes plain pointers and sizes only."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import threading
+from typing import Optional
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsg_hip.so")
+
+SG_OK, SG_ERR_BADARG, SG_ERR_OOM, SG_ERR_OVERFLOW, SG_ERR_HIP, SG_ERR_NODEVICE, SG_ERR_UNSUPPORTED = range(7)
+SG_F32, SG_F64 = 0, 1
+SG_K_TOKENIZE, SG_K_WEIGHT, SG_K_POSTINGS, SG_K_SPGEMM, SG_K_ZIP, SG_K_COUNT = range(6)
+KERNEL_NAMES = ("tokenize", "weight", "postings", "spgemm_topn", "zip")
+
+
+class SgVecParams(C.Structure):
+    _fields_ = [("ngram_size", C.c_int32), ("ascii_lower", C.c_int32), ("dtype", C.c_int32),
+                ("reserved", C.c_int32), ("delete_table", C.c_uint8 * 128)]
+
+
+class SgStats(C.Structure):
+    _fields_ = [("ms", C.c_float * SG_K_COUNT), ("macs", C.c_int64), ("spgemm_bytes", C.c_int64),
+                ("out_nnz", C.c_int64)]
+
+
+# every symbol include/sg_hip.h declares: name -> (restype, argtypes)
+_P = C.c_void_p
+_PP = C.POINTER(C.c_void_p)
+ABI = {
+    "sg_last_error": (C.c_char_p, []),
+    "sg_abi_version": (C.c_int, []),
+    "sg_device_count": (C.c_int, [C.POINTER(C.c_int)]),
+    "sg_ctx_create": (C.c_int, [C.c_int, _P, _PP]),
+    "sg_ctx_destroy": (C.c_int, [_P]),
+    "sg_ctx_sync": (C.c_int, [_P]),
+    "sg_ctx_trim": (C.c_int, [_P]),
+    "sg_strings_from_host": (C.c_int, [_P, _P, _P, C.c_int64, _PP]),
+    "sg_strings_from_device": (C.c_int, [_P, _P, _P, C.c_int64, C.c_int64, _PP]),
+    "sg_strings_free": (C.c_int, [_P]),
+    "sg_vec_fit": (C.c_int, [_P, _PP, C.c_int32, C.POINTER(SgVecParams), _PP]),
+    "sg_vocab_size": (C.c_int, [_P, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "sg_vocab_to_host": (C.c_int, [_P, _P, _P, _P]),
+    "sg_vocab_set_idf": (C.c_int, [_P, _P, _P, C.c_int32]),
+    "sg_vocab_free": (C.c_int, [_P]),
+    "sg_vec_transform": (C.c_int, [_P, _P, _P, _PP]),
+    "sg_csr_from_host": (C.c_int, [_P, C.c_int64, C.c_int64, _P, _P, _P, C.c_int32, _PP]),
+    "sg_csr_from_device": (C.c_int, [_P, C.c_int64, C.c_int64, C.c_int64, _P, _P, _P, C.c_int32, _PP]),
+    "sg_csr_dims": (C.c_int, [_P, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64),
+                              C.POINTER(C.c_int32)]),
+    "sg_csr_device_ptrs": (C.c_int, [_P, _PP, _PP, _PP]),
+    "sg_csr_to_host": (C.c_int, [_P, _P, _P, _P, _P]),
+    "sg_csr_row_block": (C.c_int, [_P, _P, C.c_int64, C.c_int64, _PP]),
+    "sg_csr_free": (C.c_int, [_P]),
+    "sg_postings_build": (C.c_int, [_P, _P, C.c_int32, _PP]),
+    "sg_postings_free": (C.c_int, [_P]),
+    "sg_spgemm_topn": (C.c_int, [_P, _P, _P, C.c_int32, C.c_double, C.c_int32, _PP]),
+    "sg_topn_dims": (C.c_int, [_P, C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.POINTER(C.c_int32),
+                               C.POINTER(C.c_int64)]),
+    "sg_topn_device_ptrs": (C.c_int, [_P, _PP, _PP, _PP]),
+    "sg_topn_to_host": (C.c_int, [_P, _P, _P, _P, _P]),
+    "sg_topn_from_host": (C.c_int, [_P, C.c_int64, C.c_int64, C.c_int32, C.c_int32, _P, _P, _P, _PP]),
+    "sg_topn_zip": (C.c_int, [_P, _PP, _P, C.c_int32, C.c_int32, _PP]),
+    "sg_topn_free": (C.c_int, [_P]),
+    "sg_sp_matmul_topn_host": (C.c_int, [_P, C.c_int64, C.c_int64, C.c_int64, _P, _P, _P, _P, _P, _P, C.c_int32,
+                                         C.c_int32, C.c_double, C.c_int32, _P, _P, _P]),
+    "sg_ctx_stats": (C.c_int, [_P, C.POINTER(SgStats)]),
+}
+
+_lib = None
+_lock = threading.Lock()
+
+
+class SgHipError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load libsg_hip.so; raise (never fall back) if it has not been built."""
+    global _lib
+    with _lock:
+        if _lib is None:
+            if not os.path.exists(LIB_PATH):
+                raise ImportError(
+                    f"{LIB_PATH} is missing: build the HIP extension first "
+                    f"(python -c 'import __graft_entry__ as g; g.build()' or make -C string_grouper_amd/csrc). "
+                    f"string_grouper_amd has no CPU fallback.")
+            handle = C.CDLL(LIB_PATH)
+            for name, (res, args) in ABI.items():
+                fn = getattr(handle, name)       # AttributeError if a declared symbol is not exported
+                fn.restype = res
+                fn.argtypes = args
+            _lib = handle
+    return _lib
+
+
+def check(status: int):
+    if status == SG_OK:
+        return
+    msg = lib().sg_last_error().decode("utf-8", "replace")
+    if status == SG_ERR_OVERFLOW:
+        raise OverflowError(msg)       # the one exception the reference's fit() handles (string_grouper.py:400)
+    if status == SG_ERR_OOM:
+        raise MemoryError(msg)
+    if status == SG_ERR_BADARG:
+        raise ValueError(msg)
+    if status == SG_ERR_UNSUPPORTED:
+        raise NotImplementedError(msg)
+    raise SgHipError(f"libsg_hip status {status}: {msg}")
+
+
+def device_count() -> int:
+    n = C.c_int(0)
+    check(lib().sg_device_count(C.byref(n)))
+    return n.value
+
+
+def np_dtype_code(dtype) -> int:
+    dt = np.dtype(dtype)
+    if dt == np.float32:
+        return SG_F32
+    if dt == np.float64:
+        return SG_F64
+    raise ValueError(f"unsupported value dtype {dt}; only float32 and float64")
+
+
+def code_np_dtype(code: int):
+    return np.float64 if code == SG_F64 else np.float32
+
+
+def _ptr(a: Optional[np.ndarray]):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class _Handle:
+    _free = None
+
+    def __init__(self, ctx: "Context", handle):
+        self.ctx = ctx
+        self.h = handle
+
+    def free(self):
+        if self.h is not None and self._free is not None:
+            getattr(lib(), self._free)(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class Strings(_Handle):
+    _free = "sg_strings_free"
+    n = 0
+
+
+class Vocab(_Handle):
+    _free = "sg_vocab_free"
+
+
+class Postings(_Handle):
+    _free = "sg_postings_free"
+
+
+class Csr(_Handle):
+    _free = "sg_csr_free"
+    parent = None  # keeps the parent of a row-block view alive
+
+    def dims(self):
+        r, c, z, d = C.c_int64(), C.c_int64(), C.c_int64(), C.c_int32()
+        check(lib().sg_csr_dims(self.h, C.byref(r), C.byref(c), C.byref(z), C.byref(d)))
+        return r.value, c.value, z.value, d.value
+
+    def to_scipy(self):
+        import scipy.sparse as sp
+        r, c, nnz, d = self.dims()
+        indptr = np.empty(r + 1, np.int64)
+        indices = np.empty(max(nnz, 1), np.int32)
+        data = np.empty(max(nnz, 1), code_np_dtype(d))
+        check(lib().sg_csr_to_host(self.ctx.h, self.h, _ptr(indptr), _ptr(indices), _ptr(data)))
+        idx_dtype = np.int32 if nnz < 2 ** 31 else np.int64
+        m = sp.csr_matrix((data[:nnz], indices[:nnz], indptr.astype(idx_dtype)), shape=(r, c))
+        m.has_sorted_indices = True
+        return m
+
+    def row_block(self, r0: int, r1: int) -> "Csr":
+        out = C.c_void_p()
+        check(lib().sg_csr_row_block(self.ctx.h, self.h, r0, r1, C.byref(out)))
+        v = Csr(self.ctx, out)
+        v.parent = self
+        return v
+
+
+class TopN(_Handle):
+    _free = "sg_topn_free"
+
+    def dims(self):
+        r, s, d, c = C.c_int64(), C.c_int32(), C.c_int32(), C.c_int64()
+        check(lib().sg_topn_dims(self.h, C.byref(r), C.byref(s), C.byref(d), C.byref(c)))
+        return r.value, s.value, d.value, c.value
+
+    def to_host(self):
+        r, s, d, c = self.dims()
+        cols = np.empty(max(r * s, 1), np.int32)
+        vals = np.empty(max(r * s, 1), code_np_dtype(d))
+        cnt = np.zeros(max(r, 1), np.int32)
+        check(lib().sg_topn_to_host(self.ctx.h, self.h, _ptr(cols), _ptr(vals), _ptr(cnt)))
+        return cols[:r * s].reshape(r, s), vals[:r * s].reshape(r, s), cnt[:r]
+
+    def to_scipy(self):
+        """CSR with the within-row order of the device result (score desc / col asc when sort=True)."""
+        import scipy.sparse as sp
+        r, s, d, c = self.dims()
+        cols, vals, cnt = self.to_host()
+        indptr = np.zeros(r + 1, np.int64)
+        np.cumsum(cnt, out=indptr[1:])
+        mask = np.arange(s, dtype=np.int32)[None, :] < cnt[:, None]
+        idx_dtype = np.int32 if indptr[-1] < 2 ** 31 else np.int64
+        return sp.csr_matrix((vals[mask], cols[mask], indptr.astype(idx_dtype)), shape=(r, c))
+
+
+class Context:
+    """One per (process, GPU).  ``stream``: an integer hipStream_t (e.g. torch's current stream)."""
+
+    def __init__(self, device: int = 0, stream: Optional[int] = None):
+        out = C.c_void_p()
+        check(lib().sg_ctx_create(int(device), C.c_void_p(stream) if stream else None, C.byref(out)))
+        self.h = out
+        self.device = device
+
+    def close(self):
+        if self.h is not None:
+            lib().sg_ctx_destroy(self.h)
+            self.h = None
+
+    def sync(self):
+        check(lib().sg_ctx_sync(self.h))
+
+    def trim(self):
+        check(lib().sg_ctx_trim(self.h))
+
+    def stats(self) -> dict:
+        st = SgStats()
+        check(lib().sg_ctx_stats(self.h, C.byref(st)))
+        d = {f"ms_{KERNEL_NAMES[i]}": float(st.ms[i]) for i in range(SG_K_COUNT)}
+        d.update(macs=int(st.macs), spgemm_bytes=int(st.spgemm_bytes), out_nnz=int(st.out_nnz))
+        return d
+
+    # ---- strings
+    def strings_from_host(self, data: np.ndarray, offsets: np.ndarray) -> Strings:
+        data = np.ascontiguousarray(data, dtype=np.uint8)
+        offsets = np.ascontiguousarray(offsets, dtype=np.int64)
+        out = C.c_void_p()
+        n = len(offsets) - 1
+        check(lib().sg_strings_from_host(self.h, _ptr(data), _ptr(offsets), n, C.byref(out)))
+        s = Strings(self, out)
+        s.n = n
+        return s
+
+    def strings_from_device(self, d_bytes: int, d_offsets: int, n: int, total_bytes: int, keepalive=None) -> Strings:
+        out = C.c_void_p()
+        check(lib().sg_strings_from_device(self.h, C.c_void_p(d_bytes), C.c_void_p(d_offsets), n, total_bytes,
+                                           C.byref(out)))
+        s = Strings(self, out)
+        s.n = n
+        s.keepalive = keepalive
+        return s
+
+    # ---- vectoriser
+    def vec_fit(self, sets, params: SgVecParams) -> Vocab:
+        arr = (C.c_void_p * len(sets))(*[s.h for s in sets])
+        out = C.c_void_p()
+        check(lib().sg_vec_fit(self.h, arr, len(sets), C.byref(params), C.byref(out)))
+        return Vocab(self, out)
+
+    def vocab_size(self, v: Vocab):
+        a, b = C.c_int64(), C.c_int64()
+        check(lib().sg_vocab_size(v.h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def vocab_to_host(self, v: Vocab):
+        n_terms, _ = self.vocab_size(v)
+        keys = np.empty(max(n_terms, 1), np.uint64)
+        df = np.empty(max(n_terms, 1), np.int64)
+        check(lib().sg_vocab_to_host(self.h, v.h, _ptr(keys), _ptr(df)))
+        return keys[:n_terms], df[:n_terms]
+
+    def vocab_set_idf(self, v: Vocab, idf: np.ndarray):
+        idf = np.ascontiguousarray(idf)
+        check(lib().sg_vocab_set_idf(self.h, v.h, _ptr(idf), np_dtype_code(idf.dtype)))
+
+    def vec_transform(self, v: Vocab, s: Strings) -> Csr:
+        out = C.c_void_p()
+        check(lib().sg_vec_transform(self.h, v.h, s.h, C.byref(out)))
+        return Csr(self, out)
+
+    # ---- CSR
+    def csr_from_scipy(self, m) -> Csr:
+        import scipy.sparse as sp
+        m = sp.csr_matrix(m)
+        if not m.has_sorted_indices:
+            m = m.sorted_indices()
+        indptr = np.ascontiguousarray(m.indptr, dtype=np.int64)
+        indices = np.ascontiguousarray(m.indices, dtype=np.int32)
+        data = np.ascontiguousarray(m.data)
+        out = C.c_void_p()
+        check(lib().sg_csr_from_host(self.h, m.shape[0], m.shape[1], _ptr(indptr), _ptr(indices), _ptr(data),
+                                     np_dtype_code(data.dtype), C.byref(out)))
+        return Csr(self, out)
+
+    def csr_from_device(self, n_rows, n_cols, nnz, d_indptr: int, d_indices: int, d_data: int, dtype,
+                        keepalive=None) -> Csr:
+        out = C.c_void_p()
+        check(lib().sg_csr_from_device(self.h, n_rows, n_cols, nnz, C.c_void_p(d_indptr), C.c_void_p(d_indices),
+                                       C.c_void_p(d_data), np_dtype_code(dtype), C.byref(out)))
+        m = Csr(self, out)
+        m.keepalive = keepalive
+        return m
+
+    # ---- multiply
+    def postings_build(self, B: Csr, tile_cols: int = 0) -> Postings:
+        out = C.c_void_p()
+        check(lib().sg_postings_build(self.h, B.h, int(tile_cols), C.byref(out)))
+        return Postings(self, out)
+
+    def spgemm_topn(self, A: Csr, Bt: Postings, top_n: int, threshold: float, sort: bool = True) -> TopN:
+        out = C.c_void_p()
+        check(lib().sg_spgemm_topn(self.h, A.h, Bt.h, int(top_n), float(threshold), 1 if sort else 0, C.byref(out)))
+        return TopN(self, out)
+
+    def topn_from_host(self, cols: np.ndarray, vals: np.ndarray, counts: np.ndarray, n_cols: int) -> TopN:
+        n_rows, stride = cols.shape
+        cols = np.ascontiguousarray(cols, dtype=np.int32)
+        vals = np.ascontiguousarray(vals)
+        counts = np.ascontiguousarray(counts, dtype=np.int32)
+        out = C.c_void_p()
+        check(lib().sg_topn_from_host(self.h, n_rows, n_cols, stride, np_dtype_code(vals.dtype), _ptr(cols),
+                                      _ptr(vals), _ptr(counts), C.byref(out)))
+        return TopN(self, out)
+
+    def topn_zip(self, parts, col_offsets, top_n: int) -> TopN:
+        arr = (C.c_void_p * len(parts))(*[p.h for p in parts])
+        offs = np.ascontiguousarray(col_offsets, dtype=np.int64)
+        out = C.c_void_p()
+        check(lib().sg_topn_zip(self.h, arr, _ptr(offs), len(parts), int(top_n), C.byref(out)))
+        return TopN(self, out)
+
+
+_default_ctx = {}
+
+
+def default_context(device: Optional[int] = None) -> Context:
+    """Process-wide context per device (device defaults to LOCAL_RANK, else 0)."""
+    if device is None:
+        device = int(os.environ.get("LOCAL_RANK", "0"))
+    ctx = _default_ctx.get(device)
+    if ctx is None or ctx.h is None:
+        ctx = Context(device)
+        _default_ctx[device] = ctx
+    return ctx

@@ -1,0 +1,469 @@
+// Context, scratch pool, object plumbing and the prefix-sum utility of libsg_hip.so.
+// gfx950 (MI355X) only; no CPU fallback lives in this library.
+#include <stdarg.h>
+
+#include "sg_internal.h"
+
+// ------------------------------------------------------------------------------------ errors
+static thread_local char g_err[512] = "";
+
+void sg_set_error(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" const char *sg_last_error(void) { return g_err; }
+extern "C" int sg_abi_version(void) { return 1; }
+
+extern "C" int sg_device_count(int *count) {
+    SG_REQUIRE(count != nullptr, "count is null");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        n = 0;
+    }
+    *count = n;
+    return SG_OK;
+}
+
+// ------------------------------------------------------------------------------------ pool
+int sg_ctx::alloc(size_t bytes, void **out) {
+    if (bytes == 0) bytes = 256;
+    bytes = (bytes + 255) & ~(size_t)255;
+    {
+        std::lock_guard<std::mutex> g(mu);
+        auto it = free_blocks.lower_bound(bytes);
+        if (it != free_blocks.end() && it->first <= bytes + bytes / 2 + 4096) {
+            *out = it->second;
+            live_blocks[it->second] = it->first;
+            free_blocks.erase(it);
+            return SG_OK;
+        }
+    }
+    void *p = nullptr;
+    hipError_t e = hipMalloc(&p, bytes);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        trim();   // give cached blocks back and retry once
+        e = hipMalloc(&p, bytes);
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            sg_set_error("hipMalloc(%zu bytes) failed: %s", bytes, hipGetErrorString(e));
+            return SG_ERR_OOM;
+        }
+    }
+    std::lock_guard<std::mutex> g(mu);
+    live_blocks[p] = bytes;
+    *out = p;
+    return SG_OK;
+}
+
+void sg_ctx::release(void *p) {
+    if (!p) return;
+    std::lock_guard<std::mutex> g(mu);
+    auto it = live_blocks.find(p);
+    if (it == live_blocks.end()) return;
+    free_blocks.emplace(it->second, p);
+    live_blocks.erase(it);
+}
+
+void sg_ctx::trim() {
+    std::vector<void *> to_free;
+    {
+        std::lock_guard<std::mutex> g(mu);
+        for (auto &kv : free_blocks) to_free.push_back(kv.second);
+        free_blocks.clear();
+    }
+    if (!to_free.empty()) (void)hipStreamSynchronize(stream);
+    for (void *p : to_free) (void)hipFree(p);
+}
+
+// ------------------------------------------------------------------------------------ context
+extern "C" int sg_ctx_create(int device, void *hip_stream, sg_ctx **out) {
+    SG_REQUIRE(out != nullptr, "out is null");
+    int n = 0;
+    sg_device_count(&n);
+    if (n <= 0) {
+        sg_set_error("no HIP device visible: libsg_hip.so needs an MI355X (gfx950) GPU and has no CPU fallback");
+        return SG_ERR_NODEVICE;
+    }
+    SG_REQUIRE(device >= 0 && device < n, "device index out of range");
+    SG_HIP_TRY(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    SG_HIP_TRY(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        sg_set_error("device %d is %s; this library is built for gfx950 only", device, prop.gcnArchName);
+        return SG_ERR_NODEVICE;
+    }
+    sg_ctx *ctx = new (std::nothrow) sg_ctx();
+    if (!ctx) return SG_ERR_OOM;
+    ctx->device = device;
+    ctx->num_cu = prop.multiProcessorCount;
+    if (hip_stream) {
+        ctx->stream = (hipStream_t)hip_stream;
+    } else {
+        SG_HIP_TRY(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+        ctx->own_stream = true;
+    }
+    for (int i = 0; i < SG_K_COUNT; ++i) {
+        SG_HIP_TRY(hipEventCreate(&ctx->ev_start[i]));
+        SG_HIP_TRY(hipEventCreate(&ctx->ev_stop[i]));
+        ctx->ev_valid[i] = false;
+    }
+    SG_HIP_TRY(hipMalloc((void **)&ctx->d_stat_words, 8 * sizeof(int64_t)));
+    SG_HIP_TRY(hipHostMalloc((void **)&ctx->h_stat_words, 8 * sizeof(int64_t), hipHostMallocDefault));
+    SG_HIP_TRY(hipMemsetAsync(ctx->d_stat_words, 0, 8 * sizeof(int64_t), ctx->stream));
+    *out = ctx;
+    return SG_OK;
+}
+
+extern "C" int sg_ctx_destroy(sg_ctx *ctx) {
+    if (!ctx) return SG_OK;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    ctx->trim();
+    for (auto &kv : ctx->live_blocks) (void)hipFree(kv.first);
+    ctx->live_blocks.clear();
+    for (int i = 0; i < SG_K_COUNT; ++i) {
+        (void)hipEventDestroy(ctx->ev_start[i]);
+        (void)hipEventDestroy(ctx->ev_stop[i]);
+    }
+    (void)hipFree(ctx->d_stat_words);
+    (void)hipHostFree(ctx->h_stat_words);
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return SG_OK;
+}
+
+extern "C" int sg_ctx_sync(sg_ctx *ctx) {
+    SG_REQUIRE(ctx != nullptr, "ctx is null");
+    SG_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return SG_OK;
+}
+
+extern "C" int sg_ctx_trim(sg_ctx *ctx) {
+    SG_REQUIRE(ctx != nullptr, "ctx is null");
+    ctx->trim();
+    return SG_OK;
+}
+
+extern "C" int sg_ctx_stats(sg_ctx *ctx, sg_stats *out) {
+    SG_REQUIRE(ctx != nullptr && out != nullptr, "null argument");
+    SG_HIP_TRY(hipMemcpyAsync(ctx->h_stat_words, ctx->d_stat_words, 8 * sizeof(int64_t), hipMemcpyDeviceToHost,
+                              ctx->stream));
+    SG_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    for (int i = 0; i < SG_K_COUNT; ++i) {
+        out->ms[i] = 0.f;
+        if (ctx->ev_valid[i]) {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, ctx->ev_start[i], ctx->ev_stop[i]) == hipSuccess) out->ms[i] = ms;
+            else (void)hipGetLastError();
+        }
+    }
+    out->macs = ctx->h_stat_words[0];
+    out->out_nnz = ctx->h_stat_words[1];
+    out->spgemm_bytes = ctx->spgemm_fixed_bytes + (out->macs + out->out_nnz) * ctx->spgemm_entry_bytes;
+    return SG_OK;
+}
+
+// ------------------------------------------------------------------------------------ strings
+extern "C" int sg_strings_from_host(sg_ctx *ctx, const uint8_t *bytes, const int64_t *offsets, int64_t n,
+                                    sg_strings **out) {
+    SG_REQUIRE(ctx && offsets && out && n >= 0, "null argument");
+    const int64_t total = offsets[n] - offsets[0];
+    SG_REQUIRE(total >= 0 && (total == 0 || bytes != nullptr), "bad offsets");
+    SG_REQUIRE(offsets[0] == 0, "offsets must start at 0");
+    sg_strings *s = new (std::nothrow) sg_strings();
+    if (!s) return SG_ERR_OOM;
+    s->ctx = ctx;
+    s->n = n;
+    s->total_bytes = total;
+    s->owned = true;
+    uint8_t *db = nullptr;
+    int64_t *doff = nullptr;
+    int st = sg_alloc(ctx, (size_t)total + 16, &db);
+    if (st == SG_OK) st = sg_alloc(ctx, (size_t)n + 1, &doff);
+    if (st != SG_OK) {
+        ctx->release(db);
+        delete s;
+        return st;
+    }
+    s->d_bytes = db;
+    s->d_offsets = doff;
+    if (total > 0) SG_HIP_TRY(hipMemcpyAsync(db, bytes, (size_t)total, hipMemcpyHostToDevice, ctx->stream));
+    SG_HIP_TRY(hipMemcpyAsync(doff, offsets, sizeof(int64_t) * (size_t)(n + 1), hipMemcpyHostToDevice, ctx->stream));
+    SG_HIP_TRY(hipStreamSynchronize(ctx->stream));   // host buffers may be pageable / reused
+    *out = s;
+    return SG_OK;
+}
+
+extern "C" int sg_strings_from_device(sg_ctx *ctx, const uint8_t *d_bytes, const int64_t *d_offsets, int64_t n,
+                                      int64_t total_bytes, sg_strings **out) {
+    SG_REQUIRE(ctx && d_offsets && out && n >= 0 && total_bytes >= 0, "null argument");
+    sg_strings *s = new (std::nothrow) sg_strings();
+    if (!s) return SG_ERR_OOM;
+    s->ctx = ctx;
+    s->d_bytes = d_bytes;
+    s->d_offsets = d_offsets;
+    s->n = n;
+    s->total_bytes = total_bytes;
+    s->owned = false;
+    *out = s;
+    return SG_OK;
+}
+
+extern "C" int sg_strings_free(sg_strings *s) {
+    if (!s) return SG_OK;
+    if (s->owned) {
+        s->ctx->release((void *)s->d_bytes);
+        s->ctx->release((void *)s->d_offsets);
+    }
+    delete s;
+    return SG_OK;
+}
+
+// ------------------------------------------------------------------------------------ CSR
+static size_t dtype_size(int32_t dtype) { return dtype == SG_F64 ? 8 : 4; }
+
+extern "C" int sg_csr_from_host(sg_ctx *ctx, int64_t n_rows, int64_t n_cols, const int64_t *indptr,
+                                const int32_t *indices, const void *data, int32_t dtype, sg_csr **out) {
+    SG_REQUIRE(ctx && indptr && out, "null argument");
+    SG_REQUIRE(n_rows >= 0 && n_cols >= 0, "negative shape");
+    SG_REQUIRE(dtype == SG_F32 || dtype == SG_F64, "dtype must be SG_F32 or SG_F64");
+    SG_REQUIRE(indptr[0] == 0, "indptr must start at 0");
+    const int64_t nnz = indptr[n_rows];
+    SG_REQUIRE(nnz >= 0 && (nnz == 0 || (indices && data)), "bad nnz");
+    if (n_cols > INT32_MAX || n_rows > INT32_MAX) {
+        sg_set_error("matrix shape (%lld x %lld) exceeds int32 indices", (long long)n_rows, (long long)n_cols);
+        return SG_ERR_OVERFLOW;
+    }
+    sg_csr *m = new (std::nothrow) sg_csr();
+    if (!m) return SG_ERR_OOM;
+    m->ctx = ctx;
+    m->n_rows = n_rows;
+    m->n_cols = n_cols;
+    m->nnz = nnz;
+    m->dtype = dtype;
+    m->owned = true;
+    int64_t *dp = nullptr;
+    int32_t *di = nullptr;
+    void *dd = nullptr;
+    int st = sg_alloc(ctx, (size_t)n_rows + 1, &dp);
+    if (st == SG_OK) st = sg_alloc(ctx, (size_t)nnz + 4, &di);
+    if (st == SG_OK) st = ctx->alloc(((size_t)nnz + 4) * dtype_size(dtype), &dd);
+    if (st != SG_OK) {
+        ctx->release(dp);
+        ctx->release(di);
+        delete m;
+        return st;
+    }
+    m->d_indptr = dp;
+    m->d_indices = di;
+    m->d_data = dd;
+    SG_HIP_TRY(hipMemcpyAsync(dp, indptr, sizeof(int64_t) * (size_t)(n_rows + 1), hipMemcpyHostToDevice, ctx->stream));
+    if (nnz > 0) {
+        SG_HIP_TRY(hipMemcpyAsync(di, indices, sizeof(int32_t) * (size_t)nnz, hipMemcpyHostToDevice, ctx->stream));
+        SG_HIP_TRY(hipMemcpyAsync(dd, data, dtype_size(dtype) * (size_t)nnz, hipMemcpyHostToDevice, ctx->stream));
+    }
+    SG_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    *out = m;
+    return SG_OK;
+}
+
+extern "C" int sg_csr_from_device(sg_ctx *ctx, int64_t n_rows, int64_t n_cols, int64_t nnz, const int64_t *d_indptr,
+                                  const int32_t *d_indices, const void *d_data, int32_t dtype, sg_csr **out) {
+    SG_REQUIRE(ctx && d_indptr && out, "null argument");
+    SG_REQUIRE(n_rows >= 0 && n_cols >= 0 && nnz >= 0, "negative shape");
+    SG_REQUIRE(dtype == SG_F32 || dtype == SG_F64, "dtype must be SG_F32 or SG_F64");
+    if (n_cols > INT32_MAX || n_rows > INT32_MAX) {
+        sg_set_error("matrix shape exceeds int32 indices");
+        return SG_ERR_OVERFLOW;
+    }
+    sg_csr *m = new (std::nothrow) sg_csr();
+    if (!m) return SG_ERR_OOM;
+    m->ctx = ctx;
+    m->n_rows = n_rows;
+    m->n_cols = n_cols;
+    m->nnz = nnz;
+    m->dtype = dtype;
+    m->d_indptr = d_indptr;
+    m->d_indices = d_indices;
+    m->d_data = d_data;
+    m->owned = false;
+    *out = m;
+    return SG_OK;
+}
+
+extern "C" int sg_csr_dims(const sg_csr *m, int64_t *n_rows, int64_t *n_cols, int64_t *nnz, int32_t *dtype) {
+    SG_REQUIRE(m != nullptr, "matrix is null");
+    if (n_rows) *n_rows = m->n_rows;
+    if (n_cols) *n_cols = m->n_cols;
+    if (nnz) *nnz = m->nnz;
+    if (dtype) *dtype = m->dtype;
+    return SG_OK;
+}
+
+extern "C" int sg_csr_device_ptrs(const sg_csr *m, const int64_t **d_indptr, const int32_t **d_indices,
+                                  const void **d_data) {
+    SG_REQUIRE(m != nullptr, "matrix is null");
+    if (d_indptr) *d_indptr = m->d_indptr;
+    if (d_indices) *d_indices = m->d_indices;
+    if (d_data) *d_data = m->d_data;
+    return SG_OK;
+}
+
+extern "C" int sg_csr_to_host(sg_ctx *ctx, const sg_csr *m, int64_t *indptr, int32_t *indices, void *data) {
+    SG_REQUIRE(ctx && m && indptr, "null argument");
+    SG_HIP_TRY(hipMemcpyAsync(indptr, m->d_indptr, sizeof(int64_t) * (size_t)(m->n_rows + 1), hipMemcpyDeviceToHost,
+                              ctx->stream));
+    SG_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    // a row-block view has absolute offsets: copy [indptr[0], indptr[n]) and rebase
+    const int64_t base = indptr[0];
+    const int64_t nnz = indptr[m->n_rows] - base;
+    if (nnz > 0) {
+        SG_REQUIRE(indices && data, "null output");
+        SG_HIP_TRY(hipMemcpyAsync(indices, m->d_indices + base, sizeof(int32_t) * (size_t)nnz, hipMemcpyDeviceToHost,
+                                  ctx->stream));
+        SG_HIP_TRY(hipMemcpyAsync(data, (const char *)m->d_data + dtype_size(m->dtype) * (size_t)base,
+                                  dtype_size(m->dtype) * (size_t)nnz, hipMemcpyDeviceToHost, ctx->stream));
+        SG_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    }
+    if (base != 0)
+        for (int64_t i = 0; i <= m->n_rows; ++i) indptr[i] -= base;
+    return SG_OK;
+}
+
+extern "C" int sg_csr_row_block(sg_ctx *ctx, const sg_csr *m, int64_t r0, int64_t r1, sg_csr **out) {
+    SG_REQUIRE(ctx && m && out, "null argument");
+    SG_REQUIRE(0 <= r0 && r0 <= r1 && r1 <= m->n_rows, "row range out of bounds");
+    sg_csr *v = new (std::nothrow) sg_csr();
+    if (!v) return SG_ERR_OOM;
+    *v = *m;
+    v->owned = false;
+    v->n_rows = r1 - r0;
+    v->d_indptr = m->d_indptr + r0;
+    int64_t ends[2] = {0, 0};
+    SG_HIP_TRY(hipMemcpyAsync(&ends[0], m->d_indptr + r0, sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
+    SG_HIP_TRY(hipMemcpyAsync(&ends[1], m->d_indptr + r1, sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
+    SG_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    v->nnz = ends[1] - ends[0];
+    *out = v;
+    return SG_OK;
+}
+
+extern "C" int sg_csr_free(sg_csr *m) {
+    if (!m) return SG_OK;
+    if (m->owned) {
+        m->ctx->release((void *)m->d_indptr);
+        m->ctx->release((void *)m->d_indices);
+        m->ctx->release((void *)m->d_data);
+    }
+    delete m;
+    return SG_OK;
+}
+
+// ------------------------------------------------------------------------------------ prefix sums
+// Three-phase scan: per-block totals -> scan of the totals (recursive) -> per-block scan + offset.
+// 256 threads x 8 items per block; HBM-bound, two reads and one write per element.
+#define SCAN_THREADS 256
+#define SCAN_ITEMS 8
+#define SCAN_BLOCK (SCAN_THREADS * SCAN_ITEMS)
+
+template <typename TO>
+__device__ __forceinline__ TO block_exclusive_scan(TO v, TO *lds_wave_tot, TO *block_total) {
+    // inclusive scan inside the 64-wide wave by shuffles, then across the 4 waves through LDS
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    TO incl = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        TO up = __shfl_up(incl, d, 64);
+        if (lane >= d) incl += up;
+    }
+    if (lane == 63) lds_wave_tot[wave] = incl;
+    __syncthreads();
+    TO wave_off = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < SCAN_THREADS / 64; ++w) {
+        TO t = lds_wave_tot[w];
+        if (w < wave) wave_off += t;
+        tot += t;
+    }
+    *block_total = tot;
+    __syncthreads();
+    return wave_off + incl - v;
+}
+
+template <typename TI, typename TO>
+__global__ void __launch_bounds__(SCAN_THREADS) scan_block_totals(const TI *in, TO *totals, int64_t n) {
+    __shared__ TO wt[SCAN_THREADS / 64];
+    const int64_t base = (int64_t)blockIdx.x * SCAN_BLOCK + (int64_t)threadIdx.x * SCAN_ITEMS;
+    TO s = 0;
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; ++i)
+        if (base + i < n) s += (TO)in[base + i];
+    TO tot;
+    (void)block_exclusive_scan<TO>(s, wt, &tot);
+    if (threadIdx.x == 0) totals[blockIdx.x] = tot;
+}
+
+template <typename TI, typename TO>
+__global__ void __launch_bounds__(SCAN_THREADS) scan_block_apply(const TI *in, TO *out, const TO *block_offsets,
+                                                                 int64_t n, TO *d_total) {
+    __shared__ TO wt[SCAN_THREADS / 64];
+    const int64_t base = (int64_t)blockIdx.x * SCAN_BLOCK + (int64_t)threadIdx.x * SCAN_ITEMS;
+    TO v[SCAN_ITEMS];
+    TO s = 0;
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; ++i) {
+        v[i] = (base + i < n) ? (TO)in[base + i] : (TO)0;
+        s += v[i];
+    }
+    TO tot;
+    TO run = block_exclusive_scan<TO>(s, wt, &tot) + (block_offsets ? block_offsets[blockIdx.x] : (TO)0);
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; ++i) {
+        if (base + i < n) out[base + i] = run;
+        run += v[i];
+    }
+    // the element one past the end receives the grand total (row-pointer convention)
+    if (d_total && blockIdx.x == gridDim.x - 1 && threadIdx.x == SCAN_THREADS - 1) *d_total = run;
+}
+
+template <typename TI, typename TO>
+static int scan_impl(sg_ctx *ctx, const TI *d_in, TO *d_out, int64_t n, TO *d_total) {
+    if (n <= 0) {
+        if (d_total) SG_HIP_TRY(hipMemsetAsync(d_total, 0, sizeof(TO), ctx->stream));
+        return SG_OK;
+    }
+    const int64_t nblocks = (n + SCAN_BLOCK - 1) / SCAN_BLOCK;
+    if (nblocks == 1) {
+        hipLaunchKernelGGL((scan_block_apply<TI, TO>), dim3(1), dim3(SCAN_THREADS), 0, ctx->stream, d_in, d_out,
+                           (const TO *)nullptr, n, d_total);
+        SG_HIP_TRY(hipGetLastError());
+        return SG_OK;
+    }
+    TO *d_tot = nullptr;
+    SG_TRY(sg_alloc(ctx, (size_t)nblocks, &d_tot));
+    hipLaunchKernelGGL((scan_block_totals<TI, TO>), dim3((unsigned)nblocks), dim3(SCAN_THREADS), 0, ctx->stream, d_in,
+                       d_tot, n);
+    int st = scan_impl<TO, TO>(ctx, d_tot, d_tot, nblocks, (TO *)nullptr);
+    if (st == SG_OK) {
+        hipLaunchKernelGGL((scan_block_apply<TI, TO>), dim3((unsigned)nblocks), dim3(SCAN_THREADS), 0, ctx->stream,
+                           d_in, d_out, (const TO *)d_tot, n, d_total);
+        if (hipGetLastError() != hipSuccess) st = SG_ERR_HIP;
+    }
+    ctx->release(d_tot);   // stream-ordered reuse: later users launch on the same stream
+    return st;
+}
+
+int sg_exclusive_scan_u32(sg_ctx *ctx, const uint32_t *d_in, uint32_t *d_out, int64_t n, uint32_t *d_total) {
+    return scan_impl<uint32_t, uint32_t>(ctx, d_in, d_out, n, d_total);
+}
+
+int sg_exclusive_scan_i32_to_i64(sg_ctx *ctx, const int32_t *d_in, int64_t *d_out, int64_t n) {
+    // d_out has n + 1 entries; d_out[n] = total
+    return scan_impl<int32_t, int64_t>(ctx, d_in, d_out, n, d_out + n);
+}

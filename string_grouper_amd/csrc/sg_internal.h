@@ -1,0 +1,147 @@
+// Internal declarations shared by the translation units of libsg_hip.so (gfx950 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <map>
+#include <mutex>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/sg_hip.h"
+
+#define SG_WAVE 64
+#define SG_NUM_XCD 8
+
+void sg_set_error(const char *fmt, ...);
+
+#define SG_HIP_TRY(expr)                                                                        \
+    do {                                                                                        \
+        hipError_t _e = (expr);                                                                 \
+        if (_e != hipSuccess) {                                                                 \
+            sg_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+            return _e == hipErrorOutOfMemory ? SG_ERR_OOM : SG_ERR_HIP;                         \
+        }                                                                                       \
+    } while (0)
+
+#define SG_TRY(expr)                  \
+    do {                              \
+        int _s = (expr);              \
+        if (_s != SG_OK) return _s;   \
+    } while (0)
+
+#define SG_REQUIRE(cond, msg)                   \
+    do {                                        \
+        if (!(cond)) {                          \
+            sg_set_error("bad argument: %s", msg); \
+            return SG_ERR_BADARG;               \
+        }                                       \
+    } while (0)
+
+// ---------------------------------------------------------------------------------------------
+// Context: device, stream, a caching scratch pool (so that a repeated "step" allocates nothing),
+// per-kernel HIP events.
+struct sg_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    int num_cu = 256;
+    size_t lds_per_cu = 160 * 1024;
+
+    std::mutex mu;
+    std::multimap<size_t, void *> free_blocks;   // size -> ptr
+    std::map<void *, size_t> live_blocks;        // ptr -> size
+
+    hipEvent_t ev_start[SG_K_COUNT];
+    hipEvent_t ev_stop[SG_K_COUNT];
+    bool ev_valid[SG_K_COUNT];
+    int64_t spgemm_entry_bytes = 0;              // 4 + s of the most recent multiply
+    int64_t spgemm_fixed_bytes = 0;              // its algorithmic bytes that do not scale with MACs
+    int64_t *d_stat_words = nullptr;             // [0]=macs [1]=out_nnz (device, zeroed per multiply)
+    int64_t *h_stat_words = nullptr;             // pinned mirror
+
+    int alloc(size_t bytes, void **out);         // pooled hipMalloc
+    void release(void *p);                       // back to the pool
+    void trim();
+};
+
+template <typename T>
+static inline int sg_alloc(sg_ctx *ctx, size_t count, T **out) {
+    void *p = nullptr;
+    int s = ctx->alloc(count * sizeof(T), &p);
+    *out = (T *)p;
+    return s;
+}
+
+struct SgTimer {   // records start/stop events of one kernel group on the context stream
+    sg_ctx *ctx;
+    int which;
+    SgTimer(sg_ctx *c, int w) : ctx(c), which(w) { (void)hipEventRecord(ctx->ev_start[w], ctx->stream); }
+    ~SgTimer() {
+        (void)hipEventRecord(ctx->ev_stop[which], ctx->stream);
+        ctx->ev_valid[which] = true;
+    }
+};
+
+// ---------------------------------------------------------------------------------------------
+struct sg_strings {
+    sg_ctx *ctx = nullptr;
+    const uint8_t *d_bytes = nullptr;
+    const int64_t *d_offsets = nullptr;
+    int64_t n = 0;
+    int64_t total_bytes = 0;
+    bool owned = false;
+};
+
+struct sg_csr {
+    sg_ctx *ctx = nullptr;
+    int64_t n_rows = 0, n_cols = 0, nnz = 0;
+    int32_t dtype = SG_F32;
+    const int64_t *d_indptr = nullptr;   // absolute offsets into d_indices / d_data (a row-block view
+    const int32_t *d_indices = nullptr;  // keeps the parent's arrays and a shifted d_indptr pointer)
+    const void *d_data = nullptr;
+    bool owned = false;
+};
+
+struct sg_postings {
+    sg_ctx *ctx = nullptr;
+    int64_t n_right = 0, n_terms = 0, nnz = 0;
+    int32_t dtype = SG_F32;
+    int32_t tile_log2 = 12;
+    int32_t n_tiles = 0;
+    // seg[k * n_tiles + t] .. seg[k * n_tiles + t + 1] = postings of term k whose row lies in tile t
+    uint32_t *d_seg = nullptr;           // n_terms * n_tiles + 1
+    int32_t *d_rows = nullptr;           // nnz   (row j of B)
+    void *d_vals = nullptr;              // nnz   (value B[j, k])
+};
+
+struct sg_topn {
+    sg_ctx *ctx = nullptr;
+    int64_t n_rows = 0, n_cols = 0;
+    int32_t stride = 0;
+    int32_t dtype = SG_F32;
+    int32_t *d_cols = nullptr;
+    void *d_vals = nullptr;
+    int32_t *d_counts = nullptr;
+};
+
+struct sg_vocab {
+    sg_ctx *ctx = nullptr;
+    sg_vec_params params;
+    int32_t bits_per_char = 7;
+    int64_t n_terms = 0, n_docs = 0;
+    int64_t key_space = 0;               // 2^(bits_per_char * ngram_size)
+    int32_t *d_key_to_col = nullptr;     // key_space entries, -1 = not in vocabulary
+    uint64_t *d_keys = nullptr;          // n_terms: key of column i (ascending)
+    int32_t *d_df = nullptr;             // n_terms
+    void *d_idf = nullptr;               // n_terms, params.dtype; null until sg_vocab_set_idf
+};
+
+// exclusive prefix sum of n uint32 values (in place allowed); total written to *d_total if non-null
+int sg_exclusive_scan_u32(sg_ctx *ctx, const uint32_t *d_in, uint32_t *d_out, int64_t n, uint32_t *d_total);
+// same for int64 outputs from int32 inputs (row pointers)
+int sg_exclusive_scan_i32_to_i64(sg_ctx *ctx, const int32_t *d_in, int64_t *d_out, int64_t n);

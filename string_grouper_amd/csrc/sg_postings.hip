@@ -1,0 +1,134 @@
+// K3 -- inverted index of the right-hand matrix, bucketed by column tile.
+//
+// Replaces what the reference does at string_grouper/string_grouper.py:727 / :738
+// (duplicate_matrix.transpose(), then sparse_dot_topn's internal CSC->CSR conversion of B^T).
+//
+// Layout in HBM.  For every term k (a column of the TF-IDF matrices) and every tile t of
+// tile_cols = 2^tile_log2 consecutive right-hand rows, the postings
+//     { (j, B[j,k]) : j in tile t }
+// are stored contiguously; segment (k, t) is [seg[k*n_tiles+t], seg[k*n_tiles+t+1]).  The multiply
+// (K4) walks the tiles of one left row with a private LDS accumulator of tile_cols values, so a tile
+// only ever streams its own slice of each posting list.  Inside a segment the order of the j is
+// irrelevant to the result (each (i,j) accumulator receives exactly one product per k), so the
+// scatter below uses atomic cursors and needs no sort: a two-pass counting sort keyed by (k, tile).
+//
+// Bound: HBM.  Algorithmic bytes = 2 * nnz * (4 + s) + 4 * (V * n_tiles + n) (read B twice,
+// write postings once, histogram + scan of the segment table).
+#include "sg_internal.h"
+
+template <typename T>
+__global__ void __launch_bounds__(256) postings_count(const int64_t *__restrict__ indptr,
+                                                      const int32_t *__restrict__ indices, int64_t n_rows,
+                                                      int32_t tile_log2, int32_t n_tiles, uint32_t *seg_counts) {
+    // one wave per 64 rows would leave lanes idle on short rows; nnz is only ~19/row, so a thread per
+    // row with a short serial loop keeps the code simple; adjacent threads touch adjacent rows.
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n_rows) return;
+    const int64_t lo = indptr[j], hi = indptr[j + 1];
+    const uint32_t t = (uint32_t)(j >> tile_log2);
+    for (int64_t p = lo; p < hi; ++p) {
+        const int64_t bin = (int64_t)indices[p] * n_tiles + t;
+        atomicAdd(&seg_counts[bin], 1u);
+    }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) postings_fill(const int64_t *__restrict__ indptr,
+                                                     const int32_t *__restrict__ indices,
+                                                     const T *__restrict__ data, int64_t n_rows, int32_t tile_log2,
+                                                     int32_t n_tiles, const uint32_t *__restrict__ seg,
+                                                     uint32_t *cursor, int32_t *out_rows, T *out_vals) {
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n_rows) return;
+    const int64_t lo = indptr[j], hi = indptr[j + 1];
+    const uint32_t t = (uint32_t)(j >> tile_log2);
+    for (int64_t p = lo; p < hi; ++p) {
+        const int64_t bin = (int64_t)indices[p] * n_tiles + t;
+        const uint32_t pos = seg[bin] + atomicAdd(&cursor[bin], 1u);
+        out_rows[pos] = (int32_t)j;
+        out_vals[pos] = data[p];
+    }
+}
+
+extern "C" int sg_postings_build(sg_ctx *ctx, const sg_csr *B, int32_t tile_cols, sg_postings **out) {
+    SG_REQUIRE(ctx && B && out, "null argument");
+    if (tile_cols == 0) tile_cols = 4096;
+    SG_REQUIRE(tile_cols >= 256 && tile_cols <= 32768 && (tile_cols & (tile_cols - 1)) == 0,
+               "tile_cols must be a power of two in [256, 32768]");
+    if (B->nnz >= (int64_t)UINT32_MAX) {
+        sg_set_error("right-hand matrix has %lld non-zeros; postings are indexed with 32 bits", (long long)B->nnz);
+        return SG_ERR_OVERFLOW;
+    }
+    int32_t tile_log2 = 0;
+    while ((1 << tile_log2) < tile_cols) ++tile_log2;
+    const int64_t n_tiles64 = B->n_rows == 0 ? 1 : ((B->n_rows + tile_cols - 1) >> tile_log2);
+    const int64_t n_bins = B->n_cols * n_tiles64;
+    if (n_bins + 1 >= (int64_t)1 << 31) {
+        sg_set_error("segment table of %lld x %lld entries is too large; use more right-hand blocks",
+                     (long long)B->n_cols, (long long)n_tiles64);
+        return SG_ERR_OVERFLOW;
+    }
+    sg_postings *p = new (std::nothrow) sg_postings();
+    if (!p) return SG_ERR_OOM;
+    p->ctx = ctx;
+    p->n_right = B->n_rows;
+    p->n_terms = B->n_cols;
+    p->nnz = B->nnz;
+    p->dtype = B->dtype;
+    p->tile_log2 = tile_log2;
+    p->n_tiles = (int32_t)n_tiles64;
+    const size_t vs = B->dtype == SG_F64 ? 8 : 4;
+    uint32_t *cursor = nullptr;
+    int st = sg_alloc(ctx, (size_t)n_bins + 1, &p->d_seg);
+    if (st == SG_OK) st = sg_alloc(ctx, (size_t)B->nnz + 64, &p->d_rows);
+    if (st == SG_OK) st = ctx->alloc(((size_t)B->nnz + 64) * vs, &p->d_vals);
+    if (st == SG_OK) st = sg_alloc(ctx, (size_t)n_bins + 1, &cursor);
+    if (st != SG_OK) {
+        sg_postings_free(p);
+        return st;
+    }
+    {
+        SgTimer timer(ctx, SG_K_POSTINGS);
+        SG_HIP_TRY(hipMemsetAsync(p->d_seg, 0, sizeof(uint32_t) * (size_t)(n_bins + 1), ctx->stream));
+        SG_HIP_TRY(hipMemsetAsync(cursor, 0, sizeof(uint32_t) * (size_t)(n_bins + 1), ctx->stream));
+        const unsigned grid = (unsigned)((B->n_rows + 255) / 256);
+        if (grid > 0) {
+            if (B->dtype == SG_F64)
+                hipLaunchKernelGGL(postings_count<double>, dim3(grid), dim3(256), 0, ctx->stream, B->d_indptr,
+                                   B->d_indices, B->n_rows, tile_log2, p->n_tiles, p->d_seg);
+            else
+                hipLaunchKernelGGL(postings_count<float>, dim3(grid), dim3(256), 0, ctx->stream, B->d_indptr,
+                                   B->d_indices, B->n_rows, tile_log2, p->n_tiles, p->d_seg);
+            SG_HIP_TRY(hipGetLastError());
+        }
+        // counts -> offsets, in place; seg[n_bins] receives the total (= nnz)
+        st = sg_exclusive_scan_u32(ctx, p->d_seg, p->d_seg, n_bins, p->d_seg + n_bins);
+        if (st == SG_OK && grid > 0) {
+            if (B->dtype == SG_F64)
+                hipLaunchKernelGGL(postings_fill<double>, dim3(grid), dim3(256), 0, ctx->stream, B->d_indptr,
+                                   B->d_indices, (const double *)B->d_data, B->n_rows, tile_log2, p->n_tiles,
+                                   p->d_seg, cursor, p->d_rows, (double *)p->d_vals);
+            else
+                hipLaunchKernelGGL(postings_fill<float>, dim3(grid), dim3(256), 0, ctx->stream, B->d_indptr,
+                                   B->d_indices, (const float *)B->d_data, B->n_rows, tile_log2, p->n_tiles,
+                                   p->d_seg, cursor, p->d_rows, (float *)p->d_vals);
+            if (hipGetLastError() != hipSuccess) st = SG_ERR_HIP;
+        }
+    }
+    ctx->release(cursor);
+    if (st != SG_OK) {
+        sg_postings_free(p);
+        return st;
+    }
+    *out = p;
+    return SG_OK;
+}
+
+extern "C" int sg_postings_free(sg_postings *p) {
+    if (!p) return SG_OK;
+    p->ctx->release(p->d_seg);
+    p->ctx->release(p->d_rows);
+    p->ctx->release(p->d_vals);
+    delete p;
+    return SG_OK;
+}

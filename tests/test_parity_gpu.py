@@ -1,0 +1,188 @@
+"""GPU parity tests proper: the HIP path (through the C ABI) against the oracle on the same
+seeded inputs.  Integer / index results must be bit-exact; scores are compared bit-exact too
+(the kernels reproduce the oracle's operation order), which implies the 1e-6 fp32 tolerance
+BASELINE.json states."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+from oracle import oracle as O
+from oracle import port as P
+
+pytestmark = pytest.mark.gpu
+
+
+def _names(n, seed=1234):
+    from string_grouper_amd.synth import synth_names
+    return synth_names(n, seed)
+
+
+def _tfidf(names, dtype):
+    (m,), vocab, idf = O.tfidf_sklearn(names, [names], dtype=dtype)
+    return m
+
+
+def assert_csr_identical(C_dev, C_ref, what=""):
+    assert C_dev.shape == C_ref.shape, what
+    np.testing.assert_array_equal(np.asarray(C_dev.indptr, np.int64), np.asarray(C_ref.indptr, np.int64), err_msg=what)
+    np.testing.assert_array_equal(C_dev.indices, C_ref.indices, err_msg=what)
+    assert C_dev.data.dtype == C_ref.data.dtype, what
+    np.testing.assert_array_equal(C_dev.data, C_ref.data, err_msg=what)      # bit-exact scores
+
+
+@pytest.fixture(scope="module")
+def mats():
+    names = _names(20000)
+    return {np.float32: _tfidf(names, np.float32), np.float64: _tfidf(names, np.float64)}
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("top_n,thr,sort", [(10, 0.8, True), (1, 0.8, True), (3, 0.5, True), (5, 0.3, False),
+                                            (40, 0.0, True), (64, 0.1, True), (65, 0.1, True), (130, 0.05, True)])
+def test_spgemm_topn_selfjoin_matches_oracle(ctx, mats, dtype, top_n, thr, sort):
+    from string_grouper_amd.sparse_dot_topn import sp_matmul_topn
+    A = mats[dtype]
+    C_dev = sp_matmul_topn(A, A.T, top_n, thr, sort=sort, ctx=ctx)
+    C_ref = P.sp_matmul_topn_port(A, A.T, top_n, thr, sort, 8)
+    assert_csr_identical(C_dev, C_ref, f"{dtype.__name__} top_n={top_n} thr={thr} sort={sort}")
+
+
+@pytest.mark.parametrize("tile_cols", [1024, 2048, 4096, 8192])
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_spgemm_tile_sizes_and_groups(ctx, mats, dtype, tile_cols, monkeypatch):
+    A = mats[dtype][:5000]
+    B = mats[dtype][3000:20000]
+    C_ref = P.sp_matmul_topn_port(A, B.T, 10, 0.6, True, 8)
+    dA, dB = ctx.csr_from_scipy(A), ctx.csr_from_scipy(B)
+    post = ctx.postings_build(dB, tile_cols)
+    for group in ("1", "3", "0"):
+        monkeypatch.setenv("SG_TILE_GROUP", group)
+        res = ctx.spgemm_topn(dA, post, 10, 0.6, True)
+        assert_csr_identical(res.to_scipy(), C_ref, f"tile={tile_cols} group={group}")
+
+
+def test_spgemm_against_scipy_oracle_small(ctx, mats):
+    """The scipy-product oracle itself (not only the C port) at a size it finishes in seconds."""
+    from string_grouper_amd.sparse_dot_topn import sp_matmul_topn
+    A = mats[np.float32][:3000]
+    B = mats[np.float32][:6000]
+    C_dev = sp_matmul_topn(A, B.T, 7, 0.4, sort=True, ctx=ctx)
+    C_ref = O.sp_matmul_topn(A, B.T, 7, 0.4, True)
+    assert_csr_identical(C_dev, C_ref)
+
+
+def test_spgemm_edge_cases(ctx):
+    from string_grouper_amd.sparse_dot_topn import sp_matmul_topn
+    rng = np.random.default_rng(7)
+    # empty rows, rows longer than 64 non-zeros, more top_n than right rows, single right row
+    A = sp.random(300, 500, density=0.05, random_state=3, dtype=np.float64, format="csr")
+    A.data = np.abs(A.data) + 0.01
+    dense_row = sp.csr_matrix(np.abs(rng.standard_normal((1, 500))) + 0.01)
+    A = sp.vstack([A[:100], sp.csr_matrix((5, 500)), dense_row, A[100:]]).tocsr()
+    B = sp.random(37, 500, density=0.3, random_state=5, dtype=np.float64, format="csr")
+    B.data = np.abs(B.data) + 0.01
+    for dtype in (np.float32, np.float64):
+        Ad, Bd = A.astype(dtype), B.astype(dtype)
+        for top_n, thr in ((5, 0.0), (100, 0.5), (37, 0.0), (1, 2.0)):
+            C_dev = sp_matmul_topn(Ad, Bd.T, top_n, thr, sort=True, ctx=ctx)
+            C_ref = P.sp_matmul_topn_port(Ad, Bd.T, top_n, thr, True, 2)
+            assert_csr_identical(C_dev, C_ref, f"{dtype.__name__} top_n={top_n} thr={thr}")
+        C_dev = sp_matmul_topn(Ad, Bd[:1].T, 3, 0.0, sort=True, ctx=ctx)
+        assert_csr_identical(C_dev, P.sp_matmul_topn_port(Ad, Bd[:1].T, 3, 0.0, True, 1), "one right row")
+    # all-empty left matrix
+    Z = sp.csr_matrix((10, 500), dtype=np.float32)
+    C_dev = sp_matmul_topn(Z, B.astype(np.float32).T, 3, 0.0, sort=True, ctx=ctx)
+    assert C_dev.nnz == 0 and C_dev.shape == (10, 37)
+
+
+def test_ties_at_the_cut_are_canonical(ctx):
+    """Exact duplicates all score 1.0: the cut must keep the lowest columns (score desc, col asc)."""
+    from string_grouper_amd.sparse_dot_topn import sp_matmul_topn
+    names = ["ACME HOLDINGS INC"] * 40 + ["OTHER THING LLC"] * 3
+    for dtype in (np.float32, np.float64):
+        A = _tfidf(names, dtype)
+        C_dev = sp_matmul_topn(A, A.T, 5, 0.8, sort=True, ctx=ctx)
+        C_ref = P.sp_matmul_topn_port(A, A.T, 5, 0.8, True, 1)
+        assert_csr_identical(C_dev, C_ref)
+        assert list(C_dev[7].indices) == [0, 1, 2, 3, 4]
+
+
+def test_zip_matches_oracle(ctx, mats):
+    from string_grouper_amd.sparse_dot_topn import sp_matmul_topn, zip_sp_matmul_topn
+    A = mats[np.float32][:4000]
+    B = mats[np.float32][:9000]
+    blocks = [B[0:2500], B[2500:2600], B[2600:9000]]
+    Cs = [sp_matmul_topn(A, Bi.T, 6, 0.5, sort=True, ctx=ctx) for Bi in blocks]
+    C_zip = zip_sp_matmul_topn(6, Cs, ctx=ctx)
+    C_ref = O.zip_sp_matmul_topn(6, [P.sp_matmul_topn_port(A, Bi.T, 6, 0.5, True, 4) for Bi in blocks])
+    assert_csr_identical(C_zip, C_ref)
+    # and the zipped result equals the unblocked multiply (the reference's own invariant, test:191-336)
+    C_one = sp_matmul_topn(A, B.T, 6, 0.5, sort=True, ctx=ctx)
+    assert_csr_identical(C_zip, C_one)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_vectoriser_matches_sklearn_bitexact(ctx, dtype):
+    from string_grouper_amd.vectorizer import HipTfidfVectorizer
+    names = _names(30000, seed=99)
+    names[17] = "ab"                 # shorter than an n-gram: empty row
+    names[18] = ""                   # empty string
+    names[19] = "A. B. C. Enterprises, Inc./-"  # punctuation removed by the regex
+    names[20] = "x" * 300            # long row (> 64 n-grams, single distinct n-gram)
+    names[21] = "".join(chr(97 + (i * 7) % 26) for i in range(500))
+    (m_ref,), vocab, idf = O.tfidf_sklearn(names, [names], dtype=dtype)
+    vec = HipTfidfVectorizer(dtype=dtype, ctx=ctx)
+    m_dev = vec.fit(names).transform(names)
+    assert vec.vocabulary_ == vocab
+    np.testing.assert_array_equal(vec.idf_, idf)
+    assert_csr_identical(m_dev, sp.csr_matrix(m_ref))
+
+
+def test_vectoriser_master_and_duplicates(ctx):
+    """fit on master + duplicates, transform each (string_grouper.py:689-706); out-of-vocabulary
+    n-grams of a third series are dropped like sklearn does."""
+    from string_grouper_amd.vectorizer import HipTfidfVectorizer
+    master = _names(5000, seed=1)
+    dupes = _names(3000, seed=2)
+    other = _names(1000, seed=3)
+    (a_ref, b_ref, c_ref), vocab, idf = O.tfidf_sklearn(master + dupes, [master, dupes, other], dtype=np.float32)
+    vec = HipTfidfVectorizer(dtype=np.float32, ctx=ctx)
+    pm, pd_, po = vec.prepare(master), vec.prepare(dupes), vec.prepare(other)
+    vec.fit_prepared([pm, pd_])
+    assert vec.vocabulary_ == vocab
+    assert_csr_identical(vec.transform_prepared(pm).to_scipy(), sp.csr_matrix(a_ref))
+    assert_csr_identical(vec.transform_prepared(pd_).to_scipy(), sp.csr_matrix(b_ref))
+    assert_csr_identical(vec.transform_prepared(po).to_scipy(), sp.csr_matrix(c_ref))
+
+
+def test_vectoriser_unicode_case_and_ngram_sizes(ctx):
+    from string_grouper_amd.vectorizer import HipTfidfVectorizer
+    names = ["ÀbracâDABRÀ Straße GmbH", "McDonalds", "mcdonald's İstanbul", "Hyper-Startup Inc.", "ﬁne ﬂour Ⅻ", "naïve café"] * 3
+    for kw in (dict(), dict(ignore_case=False), dict(ngram_size=2), dict(ngram_size=4), dict(ngram_size=5),
+               dict(regex=r"[aeiou]"), dict(regex=r"inc\.?|\s")):
+        (m_ref,), vocab, idf = O.tfidf_sklearn(names, [names], dtype=np.float64, **kw)
+        vec = HipTfidfVectorizer(dtype=np.float64, ctx=ctx, **kw)
+        m_dev = vec.fit(names).transform(names)
+        assert vec.vocabulary_ == vocab, kw
+        assert_csr_identical(m_dev, sp.csr_matrix(m_ref), str(kw))
+
+
+def test_run_twice_is_bitwise_identical(ctx, mats):
+    """Determinism: per-row independence + fixed summation order (no race shows up as a diff)."""
+    from string_grouper_amd.sparse_dot_topn import sp_matmul_topn
+    A = mats[np.float32]
+    C1 = sp_matmul_topn(A, A.T, 10, 0.7, sort=True, ctx=ctx)
+    C2 = sp_matmul_topn(A, A.T, 10, 0.7, sort=True, ctx=ctx)
+    assert_csr_identical(C1, C2)
+
+
+def test_100k_selfjoin_matches_port(ctx):
+    """BASELINE.json configs[1]: 100k synthetic names, 3-gram TF-IDF, ntop=10, min_sim=0.8, fp32."""
+    from string_grouper_amd.sparse_dot_topn import sp_matmul_topn
+    A = _tfidf(_names(100000), np.float32)
+    C_dev = sp_matmul_topn(A, A.T, 10, 0.8, sort=True, ctx=ctx)
+    C_ref = P.sp_matmul_topn_port(A, A.T, 10, 0.8, True, 16)
+    assert_csr_identical(C_dev, C_ref)
+    # size-independent properties: diagonal present with score ~1
+    d = C_dev.diagonal()
+    assert (np.abs(d[d > 0] - 1) < 1e-5).all()
