@@ -1,0 +1,140 @@
+"""Compute engine behind the StringGrouper front end: the MI355X library, nothing else.
+
+The front end (string_grouper_amd/string_grouper.py) talks to an engine object with four
+operations -- vectorise, wrap a host matrix, top-n multiply, blocked top-n multiply -- so that the
+host logic can be unit-tested on a machine without a GPU by injecting a test double
+(tests/_oracle_engine.py).  The product ships exactly one engine, ``HipEngine``; there is no CPU
+engine in this package and ``get_engine()`` raises if the HIP library cannot be used.
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+import scipy.sparse as sp
+
+from . import _native as N
+from .vectorizer import HipTfidfVectorizer
+
+
+class DeviceMatrix:
+    """A CSR matrix resident in HBM (rows = strings, columns = n-grams)."""
+
+    def __init__(self, csr: "N.Csr"):
+        self.csr = csr
+        r, c, nnz, d = csr.dims()
+        self.shape = (r, c)
+        self.nnz = nnz
+        self.dtype = N.code_np_dtype(d)
+        self._host: Optional[sp.csr_matrix] = None
+
+    def to_scipy(self) -> sp.csr_matrix:
+        if self._host is None:
+            self._host = self.csr.to_scipy()
+        return self._host
+
+
+def chunk_ranges(length: int, n_chunks: int) -> List[Tuple[int, int]]:
+    """Contiguous ranges of ceil(length / n_chunks) rows (the reference's define_chunks,
+    string_grouper.py:714-722)."""
+    size = int(np.ceil(length / n_chunks))
+    return [(lo, min(lo + size, length)) for lo in range(0, length, size)] if length > 0 else []
+
+
+class HipEngine:
+    name = "hip"
+
+    def __init__(self, ctx: Optional[N.Context] = None):
+        self._ctx = ctx
+
+    @property
+    def ctx(self) -> N.Context:
+        if self._ctx is None:
+            self._ctx = N.default_context()
+        return self._ctx
+
+    # ------------------------------------------------------------------ seam b1
+    def tfidf(self, master, duplicates, ngram_size, regex, ignore_case, normalize_to_ascii, dtype):
+        """fit on master (+ duplicates), transform both (string_grouper.py:685-707).  One
+        tokenisation pass per series: transform reuses the tokens of fit."""
+        vec = HipTfidfVectorizer(ngram_size=ngram_size, regex=regex, ignore_case=ignore_case,
+                                 normalize_to_ascii=normalize_to_ascii, dtype=dtype, ctx=self.ctx)
+        pm = vec.prepare(master)
+        sets = [pm]
+        if duplicates is not None:
+            pd_ = vec.prepare(duplicates)
+            sets.append(pd_)
+        vec.fit_prepared(sets)
+        A = DeviceMatrix(vec.transform_prepared(pm))
+        B = A if duplicates is None else DeviceMatrix(vec.transform_prepared(sets[1]))
+        return A, B, vec
+
+    def wrap(self, m) -> DeviceMatrix:
+        if isinstance(m, DeviceMatrix):
+            return m
+        m = sp.csr_matrix(m)
+        if m.dtype not in (np.float32, np.float64):
+            m = m.astype(np.float64)
+        d = DeviceMatrix(self.ctx.csr_from_scipy(m))
+        return d
+
+    # ------------------------------------------------------------------ seam b2
+    def topn_multiply(self, A: DeviceMatrix, B: DeviceMatrix, top_n: int, threshold: float) -> sp.csr_matrix:
+        """sp_matmul_topn(A, B.T, top_n, threshold, sort=True) (string_grouper.py:725-732)."""
+        post = self.ctx.postings_build(B.csr)
+        res = self.ctx.spgemm_topn(A.csr, post, top_n, threshold, True)
+        C = res.to_scipy()
+        res.free()
+        post.free()
+        return C
+
+    def topn_multiply_blocked(self, A: DeviceMatrix, B: DeviceMatrix, n_blocks: Tuple[int, int], top_n: int,
+                              threshold: float) -> sp.csr_matrix:
+        """Block-pair products, zipped over right blocks, stacked over left blocks
+        (string_grouper.py:733-752)."""
+        ctx = self.ctx
+        a_ranges = chunk_ranges(A.shape[0], n_blocks[0])
+        b_ranges = chunk_ranges(B.shape[0], n_blocks[1])
+        b_views = [B.csr.row_block(lo, hi) for lo, hi in b_ranges]
+        b_posts = [ctx.postings_build(v) for v in b_views]
+        offsets = np.array([lo for lo, _ in b_ranges], dtype=np.int64)
+        stacked = []
+        for lo, hi in a_ranges:
+            a_view = A.csr.row_block(lo, hi)
+            parts = [ctx.spgemm_topn(a_view, p, top_n, threshold, True) for p in b_posts]
+            if len(parts) == 1:
+                stacked.append(parts[0].to_scipy())
+            else:
+                z = ctx.topn_zip(parts, offsets, top_n)
+                C = z.to_scipy()
+                stacked.append(sp.csr_matrix((C.data, C.indices, C.indptr), shape=(hi - lo, B.shape[0])))
+                z.free()
+            for p in parts:
+                p.free()
+            a_view.free()
+        for p in b_posts:
+            p.free()
+        for v in b_views:
+            v.free()
+        if not stacked:
+            return sp.csr_matrix((A.shape[0], B.shape[0]), dtype=np.float64)
+        return sp.vstack(stacked, dtype=np.float64).tocsr()
+
+
+_engine = None
+
+
+def get_engine():
+    """The process-wide engine.  Raises (ImportError / RuntimeError) when libsg_hip.so is missing or
+    no MI355X is visible -- the package never substitutes a CPU implementation."""
+    global _engine
+    if _engine is None:
+        N.lib()
+        _engine = HipEngine()
+    return _engine
+
+
+def set_engine(engine) -> None:
+    """Test hook: inject an engine double (tests/_oracle_engine.py).  Not used by the product."""
+    global _engine
+    _engine = engine
