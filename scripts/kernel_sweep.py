@@ -40,14 +40,15 @@ def main():
                 from oracle import oracle as O
                 (m,), _, _ = O.tfidf_sklearn(names, [names], dtype=dtype)
                 A = ctx.csr_from_scipy(m)
-            for tile in (2048, 4096, 8192):
+            for tile in (1024, 2048, 4096, 8192):
                 t0 = time.perf_counter()
                 post = ctx.postings_build(A, tile)
                 ctx.sync()
                 t_post = time.perf_counter() - t0
-                for group in (0, 1, 4, 16, 100000):
+                for group, depth in [(0, 4), (0, 8), (0, 16), (100000, 16), (8, 16)]:
                     for wpc in (0,):
                         os.environ["SG_TILE_GROUP"] = str(group)
+                        os.environ["SG_DEPTH"] = str(depth)
                         if wpc:
                             os.environ["SG_WAVES_PER_CU"] = str(wpc)
                         else:
@@ -62,7 +63,7 @@ def main():
                             res.free()
                             best = dt if best is None else min(best, dt)
                         print(json.dumps({"what": "spgemm", "n": n, "dtype": np.dtype(dtype).name, "tile": tile,
-                                          "group": group, "wall_s": best, "ms_event": st["ms_spgemm_topn"],
+                                          "group": group, "depth": depth, "wall_s": best, "ms_event": st["ms_spgemm_topn"],
                                           "ms_postings": st["ms_postings"], "post_wall_s": t_post,
                                           "macs": st["macs"], "bytes": st["spgemm_bytes"], "out_nnz": st["out_nnz"],
                                           "alg_TBps": st["spgemm_bytes"] / (st["ms_spgemm_topn"] * 1e-3) / 1e12,

@@ -32,6 +32,21 @@ __global__ void __launch_bounds__(256) postings_count(const int64_t *__restrict_
     }
 }
 
+// posting entry layout (read by Post<T>::load in sg_spgemm_topn.hip):
+//   f32: packed {int32 row, float value}, 8 bytes, in the vals array (rows array unused)
+//   f64: rows[] (int32) + vals[] (double)
+template <typename T>
+__device__ __forceinline__ void store_posting(int32_t *rows, T *vals, uint32_t pos, int32_t j, T v);
+template <>
+__device__ __forceinline__ void store_posting<float>(int32_t *, float *vals, uint32_t pos, int32_t j, float v) {
+    reinterpret_cast<uint2 *>(vals)[pos] = make_uint2((uint32_t)j, __float_as_uint(v));
+}
+template <>
+__device__ __forceinline__ void store_posting<double>(int32_t *rows, double *vals, uint32_t pos, int32_t j, double v) {
+    rows[pos] = j;
+    vals[pos] = v;
+}
+
 template <typename T>
 __global__ void __launch_bounds__(256) postings_fill(const int64_t *__restrict__ indptr,
                                                      const int32_t *__restrict__ indices,
@@ -45,8 +60,7 @@ __global__ void __launch_bounds__(256) postings_fill(const int64_t *__restrict__
     for (int64_t p = lo; p < hi; ++p) {
         const int64_t bin = (int64_t)indices[p] * n_tiles + t;
         const uint32_t pos = seg[bin] + atomicAdd(&cursor[bin], 1u);
-        out_rows[pos] = (int32_t)j;
-        out_vals[pos] = data[p];
+        store_posting<T>(out_rows, out_vals, pos, (int32_t)j, data[p]);
     }
 }
 
@@ -77,10 +91,10 @@ extern "C" int sg_postings_build(sg_ctx *ctx, const sg_csr *B, int32_t tile_cols
     p->dtype = B->dtype;
     p->tile_log2 = tile_log2;
     p->n_tiles = (int32_t)n_tiles64;
-    const size_t vs = B->dtype == SG_F64 ? 8 : 4;
+    const size_t vs = 8;   // f64 value, or packed {row, f32 value}
     uint32_t *cursor = nullptr;
     int st = sg_alloc(ctx, (size_t)n_bins + 1, &p->d_seg);
-    if (st == SG_OK) st = sg_alloc(ctx, (size_t)B->nnz + 64, &p->d_rows);
+    if (st == SG_OK && B->dtype == SG_F64) st = sg_alloc(ctx, (size_t)B->nnz + 64, &p->d_rows);
     if (st == SG_OK) st = ctx->alloc(((size_t)B->nnz + 64) * vs, &p->d_vals);
     if (st == SG_OK) st = sg_alloc(ctx, (size_t)n_bins + 1, &cursor);
     if (st != SG_OK) {

@@ -96,7 +96,152 @@ struct TopList {   // lane r holds the r-th best (score, col); empty slots are (
     }
 };
 
-template <typename T, int TILE_LOG2>
+// posting entry: f32 -> packed {int32 row, float value} (one 8-byte load per lane);
+//                f64 -> rows[] + vals[] (4 + 8 bytes)
+template <typename T>
+struct Post;
+template <>
+struct Post<float> {
+    typedef uint2 reg_t;
+    static __device__ __forceinline__ reg_t load(const int32_t *, const float *vals, uint32_t idx) {
+        return reinterpret_cast<const uint2 *>(vals)[idx];
+    }
+    static __device__ __forceinline__ int row(const reg_t &r) { return (int)r.x; }
+    static __device__ __forceinline__ float val(const reg_t &r) { return __uint_as_float(r.y); }
+};
+template <>
+struct Post<double> {
+    struct reg_t {
+        int j;
+        double v;
+    };
+    static __device__ __forceinline__ reg_t load(const int32_t *rows, const double *vals, uint32_t idx) {
+        reg_t r;
+        r.j = rows[idx];
+        r.v = vals[idx];
+        return r;
+    }
+    static __device__ __forceinline__ int row(const reg_t &r) { return r.j; }
+    static __device__ __forceinline__ double val(const reg_t &r) { return r.v; }
+};
+
+// The postings a row needs from one column tile -- up to 64 segments (one per non-zero of the row,
+// lane l owns segment l: [lo_l, lo_l + len_l)) -- are walked as ONE flat list of S = sum(len) entries
+// in ascending segment (= ascending k) order, 64 entries ("a window") per step, every lane busy.
+// Windows are processed in batches: the loads of a whole batch (DEPTH windows = DEPTH x 512 B per
+// wave) are issued back to back in straight-line code and only then consumed, so DEPTH loads are in
+// flight per wave and the compiler emits counted vmcnt waits (15, 14, ...) while consuming.  This is
+// what hides the ~1-2 us L2/MALL latency: the first version of this kernel waited for every posting
+// segment separately and ran at 1.5 TB/s algorithmic.
+// Consuming a window keeps the bit-exact order: lanes of one segment carry distinct columns, so each
+// segment present in the window gets its own exec-masked ds_add, issued in ascending k.
+template <typename T, int TILE>
+struct FlatWalk {
+    T *acc;
+    const int32_t *__restrict__ post_rows;
+    const T *__restrict__ post_vals;
+    uint32_t end;    // inclusive prefix sum of the segment lengths (lane l: end of segment l)
+    uint32_t base;   // lo_l - start_l: posting index of flat position p in segment l is base_l + p
+    T a;             // lane l: value of the row's non-zero l
+    uint32_t S;      // total entries
+    uint32_t sb;     // first segment whose end lies beyond the next window (uniform)
+    int nseg;
+    int lane;
+
+    __device__ __forceinline__ void locate(uint32_t w, uint32_t &s, uint32_t &idx) {
+        const uint32_t p0 = w << 6;
+        const uint32_t p = p0 + lane;
+        const uint32_t last = p0 + 63;
+        s = sb;
+        uint32_t q = sb;
+        while (q < (uint32_t)nseg) {   // segment ends that fall inside this window
+            const uint32_t e = wave_read<uint32_t>(end, (int)q);
+            if (e > last) break;
+            s += (p >= e) ? 1u : 0u;
+            ++q;
+        }
+        sb = q;
+        const bool valid = p < S;
+        if (!valid) s = 0;
+        const uint32_t bs = __shfl(base, (int)s, 64);
+        idx = bs + p;
+        if (!valid) {          // idle lanes of the last window: read entry lo_0 (in bounds: the arrays are
+            idx = bs;          // padded by 64 entries) and stay masked out of the adds
+            s |= 0x80000000u;
+        }
+    }
+
+    __device__ __forceinline__ void consume(const typename Post<T>::reg_t &r, uint32_t s) {
+        const bool valid = (s & 0x80000000u) == 0;
+        const uint32_t sl = s & 63u;
+        const T as = __shfl(a, (int)sl, 64);
+        const T prod = mul_rn<T>(as, Post<T>::val(r));
+        const int j = Post<T>::row(r);
+        uint64_t pend = __ballot(valid);
+        while (pend) {   // one masked DS instruction per segment present, ascending k
+            const int f = __builtin_ctzll(pend);
+            const uint32_t sc = wave_read<uint32_t>(sl, f);
+            const bool mine = valid && sl == sc;
+            if (mine) lds_add<T>(&acc[j & (TILE - 1)], prod);
+            pend &= ~__ballot(mine);
+        }
+    }
+
+    template <int B>
+    __device__ __forceinline__ void batch(uint32_t w) {
+        uint32_t s[B], idx[B];
+        typename Post<T>::reg_t r[B];
+#pragma unroll
+        for (int b = 0; b < B; ++b) locate(w + b, s[b], idx[b]);
+#pragma unroll
+        for (int b = 0; b < B; ++b) r[b] = Post<T>::load(post_rows, post_vals, idx[b]);
+#pragma unroll
+        for (int b = 0; b < B; ++b) consume(r[b], s[b]);
+    }
+};
+
+template <typename T, int TILE, int DEPTH>
+__device__ __forceinline__ void accumulate_flat(T *acc, const int32_t *__restrict__ post_rows,
+                                                const T *__restrict__ post_vals, uint32_t lo, uint32_t len,
+                                                T a, int nseg, int lane) {
+    // inclusive scan of the segment lengths over the lanes
+    uint32_t end = len;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t up = __shfl_up(end, d, 64);
+        if (lane >= d) end += up;
+    }
+    const uint32_t S = wave_read<uint32_t>(end, 63);
+    if (S == 0) return;
+    FlatWalk<T, TILE> fw;
+    fw.acc = acc;
+    fw.post_rows = post_rows;
+    fw.post_vals = post_vals;
+    fw.end = end;
+    fw.base = lo - (end - len);
+    fw.a = a;
+    fw.S = S;
+    fw.sb = 0;
+    fw.nseg = nseg;
+    fw.lane = lane;
+    const uint32_t W = (S + 63) >> 6;   // windows of this (row, tile)
+    uint32_t w = 0;
+    while (W - w >= (uint32_t)DEPTH) {
+        fw.template batch<DEPTH>(w);
+        w += DEPTH;
+    }
+    if (DEPTH > 4)
+        while (W - w >= 4u) {
+            fw.template batch<4>(w);
+            w += 4;
+        }
+    while (w < W) {
+        fw.template batch<1>(w);
+        w += 1;
+    }
+}
+
+template <typename T, int TILE_LOG2, int DEPTH>
 __global__ void __launch_bounds__(64)
 spgemm_topn_kernel(const int64_t *__restrict__ a_indptr, const int32_t *__restrict__ a_indices,
                    const T *__restrict__ a_data, uint32_t n_left, const uint32_t *__restrict__ seg,
@@ -152,60 +297,41 @@ spgemm_topn_kernel(const int64_t *__restrict__ a_indptr, const int32_t *__restri
                 k0 = a_indices[rlo + lane];
                 a0 = a_data[rlo + lane];
             }
-            uint32_t hi0 = 0;   // = seg[bin(k0, t)] for the current t, carried as next tile's lo
-            if (k0 >= 0) hi0 = seg[(int64_t)k0 * n_tiles + tile_begin];
+            // segment bounds of (k0, t): lo is the previous tile's hi; the next tile's hi is fetched
+            // one tile ahead so that its latency hides behind this tile's work
+            uint32_t lo0 = 0, hi0 = 0, hi_next = 0;
+            if (k0 >= 0) {
+                const uint32_t *sp = seg + (int64_t)k0 * n_tiles + tile_begin;
+                lo0 = sp[0];
+                hi0 = sp[1];
+            }
 
             for (int t = tile_begin; t < tile_end; ++t) {
+                if (k0 >= 0 && t + 1 < tile_end) hi_next = seg[(int64_t)k0 * n_tiles + t + 2];
                 bool touched = false;
                 for (int c0 = 0; c0 < nnz; c0 += 64) {
-                    int k;
                     T a;
                     uint32_t lo = 0, hi = 0;
                     if (c0 == 0) {
-                        k = k0;
                         a = a0;
-                        if (k >= 0) {
-                            lo = hi0;
-                            hi = seg[(int64_t)k * n_tiles + t + 1];
-                            hi0 = hi;
-                        }
+                        lo = lo0;
+                        hi = hi0;
                     } else {
-                        k = -1;
                         a = (T)0;
                         if (c0 + lane < nnz) {
-                            k = a_indices[rlo + c0 + lane];
+                            const int k = a_indices[rlo + c0 + lane];
                             a = a_data[rlo + c0 + lane];
                             lo = seg[(int64_t)k * n_tiles + t];
                             hi = seg[(int64_t)k * n_tiles + t + 1];
                         }
                     }
-                    uint64_t m = __ballot(hi > lo);
-                    touched |= (m != 0);
-                    while (m) {   // ascending lane == ascending k (CSR rows have sorted indices)
-                        const int src = __builtin_ctzll(m);
-                        m &= m - 1;
-                        const uint32_t slo = wave_read<uint32_t>(lo, src);
-                        const uint32_t shi = wave_read<uint32_t>(hi, src);
-                        const T sa = wave_read<T>(a, src);
-                        for (uint32_t base = slo; base < shi; base += 256) {
-                            int j[4];
-                            T b[4];
-#pragma unroll
-                            for (int u = 0; u < 4; ++u) {
-                                const uint32_t p = base + u * 64 + lane;
-                                j[u] = -1;
-                                b[u] = (T)0;
-                                if (p < shi) {
-                                    j[u] = post_rows[p];
-                                    b[u] = post_vals[p];
-                                }
-                            }
-#pragma unroll
-                            for (int u = 0; u < 4; ++u)
-                                if (j[u] >= 0) lds_add<T>(&acc[j[u] & (TILE - 1)], mul_rn<T>(sa, b[u]));
-                        }
-                    }
+                    if (__ballot(hi > lo) == 0) continue;
+                    touched = true;
+                    const int nseg = nnz - c0 < 64 ? nnz - c0 : 64;
+                    accumulate_flat<T, TILE, DEPTH>(acc, post_rows, post_vals, lo, hi - lo, a, nseg, lane);
                 }
+                lo0 = hi0;
+                hi0 = hi_next;
                 if (!touched) continue;   // accumulators are still all zero
 
                 // ---- sweep the tile: find values > thr, re-zero
@@ -361,11 +487,11 @@ static int env_int(const char *name, int dflt) {
     return atoi(v);
 }
 
-template <typename T, int TILE_LOG2>
+template <typename T, int TILE_LOG2, int DEPTH>
 static int launch_spgemm(sg_ctx *ctx, const sg_csr *A, const sg_postings *Bt, int32_t tile_begin, int32_t tile_end,
                          int32_t keep, int32_t pass_off, sg_topn *r, T thr, uint32_t *counter, unsigned grid) {
     const size_t lds = sizeof(T) << TILE_LOG2;
-    auto kern = spgemm_topn_kernel<T, TILE_LOG2>;
+    auto kern = spgemm_topn_kernel<T, TILE_LOG2, DEPTH>;
     if (lds > 48 * 1024) {
         static bool done = false;   // per instantiation
         if (!done) {
@@ -381,14 +507,26 @@ static int launch_spgemm(sg_ctx *ctx, const sg_csr *A, const sg_postings *Bt, in
     return SG_OK;
 }
 
+template <typename T, int TILE_LOG2>
+static int dispatch_depth(sg_ctx *ctx, const sg_csr *A, const sg_postings *Bt, int32_t tile_begin, int32_t tile_end,
+                          int32_t keep, int32_t pass_off, sg_topn *r, T thr, uint32_t *counter, unsigned grid,
+                          int depth) {
+    switch (depth) {
+        case 4: return launch_spgemm<T, TILE_LOG2, 4>(ctx, A, Bt, tile_begin, tile_end, keep, pass_off, r, thr, counter, grid);
+        case 16: return launch_spgemm<T, TILE_LOG2, 16>(ctx, A, Bt, tile_begin, tile_end, keep, pass_off, r, thr, counter, grid);
+        default: return launch_spgemm<T, TILE_LOG2, 8>(ctx, A, Bt, tile_begin, tile_end, keep, pass_off, r, thr, counter, grid);
+    }
+}
+
 template <typename T>
 static int dispatch_spgemm(sg_ctx *ctx, const sg_csr *A, const sg_postings *Bt, int32_t tile_begin, int32_t tile_end,
                            int32_t keep, int32_t pass_off, sg_topn *r, T thr, uint32_t *counter, unsigned grid) {
+    const int depth = env_int("SG_DEPTH", 8);
     switch (Bt->tile_log2) {
-        case 10: return launch_spgemm<T, 10>(ctx, A, Bt, tile_begin, tile_end, keep, pass_off, r, thr, counter, grid);
-        case 11: return launch_spgemm<T, 11>(ctx, A, Bt, tile_begin, tile_end, keep, pass_off, r, thr, counter, grid);
-        case 12: return launch_spgemm<T, 12>(ctx, A, Bt, tile_begin, tile_end, keep, pass_off, r, thr, counter, grid);
-        case 13: return launch_spgemm<T, 13>(ctx, A, Bt, tile_begin, tile_end, keep, pass_off, r, thr, counter, grid);
+        case 10: return dispatch_depth<T, 10>(ctx, A, Bt, tile_begin, tile_end, keep, pass_off, r, thr, counter, grid, depth);
+        case 11: return dispatch_depth<T, 11>(ctx, A, Bt, tile_begin, tile_end, keep, pass_off, r, thr, counter, grid, depth);
+        case 12: return dispatch_depth<T, 12>(ctx, A, Bt, tile_begin, tile_end, keep, pass_off, r, thr, counter, grid, depth);
+        case 13: return dispatch_depth<T, 13>(ctx, A, Bt, tile_begin, tile_end, keep, pass_off, r, thr, counter, grid, depth);
         default:
             sg_set_error("postings tile of 2^%d columns is not supported by the multiply (2^10..2^13)", Bt->tile_log2);
             return SG_ERR_UNSUPPORTED;

@@ -1,0 +1,151 @@
+"""CPU tests of the host-side mirror (string_grouper_amd/string_grouper.py) with an engine double:
+the reference's public behaviour, its golden vectors, and -- when the reference tree is mounted --
+the reference's own unit tests executed against the mirror."""
+import os
+import shutil
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+import pandas as pd
+import pytest
+
+from tests import _golden as G
+from tests._oracle_engine import OracleEngine
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture()
+def api():
+    import string_grouper_amd
+    import string_grouper_amd.engine as E
+    old = E._engine
+    eng = OracleEngine()
+    E.set_engine(eng)
+    string_grouper_amd._test_engine = eng
+    yield string_grouper_amd
+    E.set_engine(old)
+
+
+def test_golden_cases_through_public_api(api):
+    G.run_api_checks(api)
+
+
+def test_product_engine_refuses_to_run_without_gpu():
+    """No CPU fallback: with no engine injected the package needs the HIP library AND a GPU."""
+    import string_grouper_amd.engine as E
+    from string_grouper_amd import _native as N
+    old = E._engine
+    E.set_engine(None)
+    try:
+        if N.device_count() == 0:
+            with pytest.raises(Exception) as ei:
+                E.get_engine().ctx
+            assert "no HIP device" in str(ei.value) or "gfx950" in str(ei.value)
+    finally:
+        E.set_engine(old)
+
+
+def test_config_and_validation(api):
+    cfg = api.StringGrouperConfig()
+    assert (cfg.ngram_size, cfg.max_n_matches, cfg.min_similarity, cfg.regex) == (3, 20, 0.8, r'[,-./]|\s')
+    assert cfg.tfidf_matrix_dtype is np.float64 and cfg.n_blocks is None and cfg.normalize_to_ascii
+    with pytest.raises(Exception):
+        cfg.min_similarity = 0.1
+    with pytest.raises(TypeError):
+        api.StringGrouper(pd.Series(["a"]), not_an_option=1)
+    s = pd.Series(["foo", "bar"])
+    for bad in (2, (0, 2), (1, 2.5), (1, 2, 3), (1,)):
+        with pytest.raises(Exception):
+            api.match_strings(s, n_blocks=bad)
+    for bad in (None, 0, "whatever"):
+        with pytest.raises(Exception):
+            api.match_strings(s, tfidf_matrix_dtype=bad)
+    with pytest.raises(TypeError):
+        api.StringGrouper("foo", "bar")
+    with pytest.raises(TypeError):
+        api.StringGrouper(pd.Series(["foo", "bar"]), pd.Series(["foo", 1]))
+    with pytest.raises(TypeError):
+        api.StringGrouper(pd.Series(["foo", np.nan]))
+    with pytest.raises(api.StringGrouperNotFitException):
+        api.StringGrouper(s).get_matches()
+    with pytest.raises(Exception):
+        api.StringGrouper(s, duplicates_id=pd.Series([1, 2]))
+    with pytest.raises(Exception):
+        api.group_similar_strings(s, group_rep="nonsense")
+
+
+def test_guessed_blocks_use_one_device_multiply_and_explicit_blocks_are_honoured(api):
+    eng = api._test_engine
+    names = pd.Series(G.INPUTS["accounts_names"])
+    ref = api.match_strings(names, min_similarity=0.5)
+    assert [c[0] for c in eng.calls] == ["single"]
+    eng.calls.clear()
+    got = api.match_strings(names, min_similarity=0.5, n_blocks=(2, 3))
+    assert eng.calls == [("blocked", (14, 74), (14, 74), (2, 3))]
+    key = ["left_index", "right_index"]
+    pd.testing.assert_frame_equal(ref.sort_values(key).reset_index(drop=True), got.sort_values(key).reset_index(drop=True))
+    assert got.similarity.dtype == np.float64
+
+
+def test_overflow_error_triggers_the_reference_fallback(api):
+    """fit() retries block-wise when the single multiply reports OverflowError
+    (string_grouper.py:397-413); SG_ERR_OVERFLOW of the C ABI maps to that exception."""
+    names = pd.Series(G.INPUTS["customers2"])
+    sg = api.StringGrouper(names, min_similarity=0.1)
+    real = sg._build_matches
+    seen = []
+
+    def flaky(a, b, n_blocks):
+        seen.append(n_blocks)
+        if len(seen) == 1:
+            raise OverflowError
+        return real(a, b, n_blocks)
+    sg._build_matches = flaky
+    ref = api.match_strings(names, min_similarity=0.1)
+    got = sg.match_strings(names, n_blocks=(1, 1))
+    assert len(seen) == 2 and seen[0] == (1, 1)
+    pd.testing.assert_frame_equal(ref, got)
+
+
+def test_add_and_remove_match(api):
+    s = pd.Series(['foooo', 'no match', 'baz', 'foooo'])
+    sg = api.StringGrouper(s).fit()
+    sg.add_match('no match', 'baz')
+    m = sg.get_matches()
+    assert len(m[(m.left_side == 'no match') & (m.right_side == 'baz')]) == 1
+    assert len(m[(m.left_side == 'baz') & (m.right_side == 'no match')]) == 1
+    with pytest.raises(ValueError):
+        sg.add_match('doesnt exist', 'baz')
+    sg2 = api.StringGrouper(pd.Series(['foooo', 'no match', 'baz', 'foooob'])).fit()
+    sg2.remove_match('foooo', 'foooob')
+    m = sg2.get_matches()
+    assert len(m[(m.left_side == 'foooo') & (m.right_side == 'foooob')]) == 0
+    assert len(m[(m.left_side == 'foooob') & (m.right_side == 'foooo')]) == 0
+
+
+def test_drop_in_alias_is_the_same_module(api):
+    import string_grouper
+    import string_grouper.string_grouper as inner
+    import string_grouper_amd.string_grouper as impl
+    assert inner is impl and string_grouper.match_strings is impl.match_strings
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/string_grouper"), reason="reference tree not mounted")
+def test_reference_unit_tests_pass_against_the_mirror():
+    """The reference's 53 unit tests, unmodified (copied to a temp dir only for collection), run
+    against this package through the drop-in alias with the oracle engine injected."""
+    d = tempfile.mkdtemp()
+    try:
+        shutil.copy("/root/reference/string_grouper/test/test_string_grouper.py", os.path.join(d, "test_ref_copy.py"))
+        with open(os.path.join(d, "conftest.py"), "w") as f:
+            f.write("import sys\nsys.path.insert(0, %r)\nsys.path.insert(0, %r)\n"
+                    "from _oracle_engine import OracleEngine\nimport string_grouper_amd.engine as E\n"
+                    "E.set_engine(OracleEngine())\nimport string_grouper\n" % (ROOT, os.path.join(ROOT, "tests")))
+        r = subprocess.run([sys.executable, "-m", "pytest", d, "-q", "-p", "no:cacheprovider", "--rootdir=" + d],
+                           cwd=d, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0 and "53 passed" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
