@@ -33,8 +33,9 @@ __global__ void __launch_bounds__(256) postings_count(const int64_t *__restrict_
 }
 
 // posting entry layout (read by Post<T>::load in sg_spgemm_topn.hip):
-//   f32: packed {int32 row, float value}, 8 bytes, in the vals array (rows array unused)
-//   f64: rows[] (int32) + vals[] (double)
+//   f32: packed {uint32 slot, float value}, 8 bytes, in the vals array (rows array unused)
+//   f64: slots[] (uint32, in the rows array) + vals[] (double)
+// slot = (j mod tile_cols) * sizeof(T), the byte offset of column j's accumulator in the LDS tile
 template <typename T>
 __device__ __forceinline__ void store_posting(int32_t *rows, T *vals, uint32_t pos, int32_t j, T v);
 template <>
@@ -60,13 +61,15 @@ __global__ void __launch_bounds__(256) postings_fill(const int64_t *__restrict__
     for (int64_t p = lo; p < hi; ++p) {
         const int64_t bin = (int64_t)indices[p] * n_tiles + t;
         const uint32_t pos = seg[bin] + atomicAdd(&cursor[bin], 1u);
-        store_posting<T>(out_rows, out_vals, pos, (int32_t)j, data[p]);
+        // the multiply wants the byte offset of the accumulator inside its LDS tile, not j itself
+        const int32_t slot = (int32_t)((j & (((int64_t)1 << tile_log2) - 1)) * (int64_t)sizeof(T));
+        store_posting<T>(out_rows, out_vals, pos, slot, data[p]);
     }
 }
 
 extern "C" int sg_postings_build(sg_ctx *ctx, const sg_csr *B, int32_t tile_cols, sg_postings **out) {
     SG_REQUIRE(ctx && B && out, "null argument");
-    if (tile_cols == 0) tile_cols = 4096;
+    if (tile_cols == 0) tile_cols = B->dtype == SG_F64 ? 1024 : 2048;   // 8 KiB of LDS per wave: 20 waves per CU
     SG_REQUIRE(tile_cols >= 256 && tile_cols <= 32768 && (tile_cols & (tile_cols - 1)) == 0,
                "tile_cols must be a power of two in [256, 32768]");
     if (B->nnz >= (int64_t)UINT32_MAX) {

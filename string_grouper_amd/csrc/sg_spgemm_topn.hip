@@ -32,7 +32,28 @@
 
 #include "sg_internal.h"
 
-#define SG_TOPN_LANES 64   // entries of the register-resident list = lanes of a wave
+#define SG_TOPN_LANES 64
+
+// Debug aid (-DSG_WATCHDOG): every data-dependent loop counts its iterations; an overrun records which
+// loop it was in g_sg_watch and makes all loops wind down instead of hanging the GPU.
+#ifdef SG_WATCHDOG
+__device__ int g_sg_watch[4];
+#define SG_WD_DECL(c) int c = 0
+#define SG_WD(c, limit, code)                                   \
+    if (++(c) > (int)(limit) || ((volatile int *)g_sg_watch)[0]) { \
+        if (((volatile int *)g_sg_watch)[0] == 0) {             \
+            g_sg_watch[0] = (code);                             \
+            g_sg_watch[1] = (int)(c);                           \
+        }                                                       \
+        break;                                                  \
+    }
+extern "C" int sg_debug_watch(int32_t *out4) {
+    return hipMemcpyFromSymbol(out4, HIP_SYMBOL(g_sg_watch), 16) == hipSuccess ? 0 : 4;
+}
+#else
+#define SG_WD_DECL(c)
+#define SG_WD(c, limit, code)
+#endif   // entries of the register-resident list = lanes of a wave
 
 template <typename T>
 __device__ __forceinline__ T wave_read(T v, int src_lane);   // value of v in lane src_lane (uniform src)
@@ -65,10 +86,11 @@ template <>
 __device__ __forceinline__ double mul_rn<double>(double a, double b) { return __dmul_rn(a, b); }
 
 template <typename T>
-__device__ __forceinline__ void lds_add(T *p, T v) {
-    // LDS float atomic add without return (ds_add_f32 / ds_add_f64): one DS instruction per 64 MACs
-    (void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-}
+__device__ __forceinline__ T add_rn(T a, T b);
+template <>
+__device__ __forceinline__ float add_rn<float>(float a, float b) { return __fadd_rn(a, b); }
+template <>
+__device__ __forceinline__ double add_rn<double>(double a, double b) { return __dadd_rn(a, b); }
 
 template <typename T>
 struct TopList {   // lane r holds the r-th best (score, col); empty slots are (-inf, INT_MAX)
@@ -96,152 +118,275 @@ struct TopList {   // lane r holds the r-th best (score, col); empty slots are (
     }
 };
 
-// posting entry: f32 -> packed {int32 row, float value} (one 8-byte load per lane);
-//                f64 -> rows[] + vals[] (4 + 8 bytes)
+// Posting entry (written by K3): f32 -> packed {uint32 slot, float value}, one 8-byte load per lane;
+// f64 -> slots[] (uint32) + vals[] (double).  "slot" is the BYTE offset of the entry's accumulator
+// inside its column tile, (j mod TILE) * sizeof(T): the multiply never needs j itself -- the tile
+// sweep recovers columns from positions -- so the address arithmetic is done once, in K3.
 template <typename T>
 struct Post;
 template <>
 struct Post<float> {
     typedef uint2 reg_t;
-    static __device__ __forceinline__ reg_t load(const int32_t *, const float *vals, uint32_t idx) {
-        return reinterpret_cast<const uint2 *>(vals)[idx];
+    static constexpr int STRIDE = 8;
+    static __device__ __forceinline__ reg_t load(const char *seg_base, const char *, uint32_t entry) {
+        return *reinterpret_cast<const uint2 *>(seg_base + (size_t)entry * 8);
     }
-    static __device__ __forceinline__ int row(const reg_t &r) { return (int)r.x; }
+    static __device__ __forceinline__ uint32_t slot(const reg_t &r) { return r.x; }
     static __device__ __forceinline__ float val(const reg_t &r) { return __uint_as_float(r.y); }
 };
 template <>
 struct Post<double> {
     struct reg_t {
-        int j;
+        uint32_t j;
         double v;
     };
-    static __device__ __forceinline__ reg_t load(const int32_t *rows, const double *vals, uint32_t idx) {
+    static constexpr int STRIDE = 8;
+    static __device__ __forceinline__ reg_t load(const char *val_base, const char *slot_base, uint32_t entry) {
         reg_t r;
-        r.j = rows[idx];
-        r.v = vals[idx];
+        r.j = *reinterpret_cast<const uint32_t *>(slot_base + (size_t)entry * 4);
+        r.v = *reinterpret_cast<const double *>(val_base + (size_t)entry * 8);
         return r;
     }
-    static __device__ __forceinline__ int row(const reg_t &r) { return r.j; }
+    static __device__ __forceinline__ uint32_t slot(const reg_t &r) { return r.j; }
     static __device__ __forceinline__ double val(const reg_t &r) { return r.v; }
 };
 
-// The postings a row needs from one column tile -- up to 64 segments (one per non-zero of the row,
-// lane l owns segment l: [lo_l, lo_l + len_l)) -- are walked as ONE flat list of S = sum(len) entries
-// in ascending segment (= ascending k) order, 64 entries ("a window") per step, every lane busy.
-// Windows are processed in batches: the loads of a whole batch (DEPTH windows = DEPTH x 512 B per
-// wave) are issued back to back in straight-line code and only then consumed, so DEPTH loads are in
-// flight per wave and the compiler emits counted vmcnt waits (15, 14, ...) while consuming.  This is
-// what hides the ~1-2 us L2/MALL latency: the first version of this kernel waited for every posting
-// segment separately and ran at 1.5 TB/s algorithmic.
-// Consuming a window keeps the bit-exact order: lanes of one segment carry distinct columns, so each
-// segment present in the window gets its own exec-masked ds_add, issued in ascending k.
-template <typename T, int TILE>
-struct FlatWalk {
-    T *acc;
-    const int32_t *__restrict__ post_rows;
-    const T *__restrict__ post_vals;
-    uint32_t end;    // inclusive prefix sum of the segment lengths (lane l: end of segment l)
-    uint32_t base;   // lo_l - start_l: posting index of flat position p in segment l is base_l + p
-    T a;             // lane l: value of the row's non-zero l
-    uint32_t S;      // total entries
-    uint32_t sb;     // first segment whose end lies beyond the next window (uniform)
-    int nseg;
-    int lane;
+// "does any of the 16 bytes' worth of accumulators exceed thr": accumulators and thr are >= +0, so
+// IEEE order equals unsigned integer order and one v_max3_u32 + v_max_u32 + compare covers 4 floats
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef double f64x2 __attribute__((ext_vector_type(2)));
+template <typename T, typename V>
+__device__ __forceinline__ bool any_above(const V &v, T thr);
+template <>
+__device__ __forceinline__ bool any_above<float, f32x4>(const f32x4 &v, float thr) {
+    const uint32_t a = __float_as_uint(v[0]), b = __float_as_uint(v[1]), c = __float_as_uint(v[2]),
+                   d = __float_as_uint(v[3]);
+    const uint32_t ab = a > b ? a : b, cd = c > d ? c : d;
+    return (ab > cd ? ab : cd) > __float_as_uint(thr);
+}
+template <>
+__device__ __forceinline__ bool any_above<double, f64x2>(const f64x2 &v, double thr) {
+    return __builtin_fmax(v[0], v[1]) > thr;
+}
 
-    __device__ __forceinline__ void locate(uint32_t w, uint32_t &s, uint32_t &idx) {
-        const uint32_t p0 = w << 6;
-        const uint32_t p = p0 + lane;
-        const uint32_t last = p0 + 63;
-        s = sb;
-        uint32_t q = sb;
-        while (q < (uint32_t)nseg) {   // segment ends that fall inside this window
-            const uint32_t e = wave_read<uint32_t>(end, (int)q);
-            if (e > last) break;
-            s += (p >= e) ? 1u : 0u;
-            ++q;
-        }
-        sb = q;
-        const bool valid = p < S;
-        if (!valid) s = 0;
-        const uint32_t bs = __shfl(base, (int)s, 64);
-        idx = bs + p;
-        if (!valid) {          // idle lanes of the last window: read entry lo_0 (in bounds: the arrays are
-            idx = bs;          // padded by 64 entries) and stay masked out of the adds
-            s |= 0x80000000u;
+template <typename T>
+__device__ __forceinline__ T *acc_at(T *acc, uint32_t byte_off) {
+    return reinterpret_cast<T *>(reinterpret_cast<char *>(acc) + byte_off);
+}
+
+// One posting segment (term k, column tile t) = entries [lo, lo + n).  All its columns are distinct,
+// so a plain LDS read-add-write per lane is race-free, and because the segments of a row are visited
+// in ascending k and DS instructions of a wave execute in order, every accumulator receives its
+// products in ascending k -- the reference's summation order, hence bit-equal scores.
+// (LDS float atomics were measured at ~190 cycles per wave instruction and are not used.)
+template <typename T>
+struct StreamStep {   // 4 windows (256 entries) of one long posting list
+    typename Post<T>::reg_t r[4];
+    __device__ __forceinline__ void load(const char *vals, const char *slots, uint32_t lo, uint32_t n, uint32_t off,
+                                         int lane) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            uint32_t p = off + u * 64 + lane;
+            p = p < n ? p : n - 1;   // clamp instead of masking: idle lanes re-read the last entry
+            r[u] = Post<T>::load(vals, slots, lo + p);
         }
     }
-
-    __device__ __forceinline__ void consume(const typename Post<T>::reg_t &r, uint32_t s) {
-        const bool valid = (s & 0x80000000u) == 0;
-        const uint32_t sl = s & 63u;
-        const T as = __shfl(a, (int)sl, 64);
-        const T prod = mul_rn<T>(as, Post<T>::val(r));
-        const int j = Post<T>::row(r);
-        uint64_t pend = __ballot(valid);
-        while (pend) {   // one masked DS instruction per segment present, ascending k
-            const int f = __builtin_ctzll(pend);
-            const uint32_t sc = wave_read<uint32_t>(sl, f);
-            const bool mine = valid && sl == sc;
-            if (mine) lds_add<T>(&acc[j & (TILE - 1)], prod);
-            pend &= ~__ballot(mine);
+    __device__ __forceinline__ void apply(T *acc, uint32_t n, uint32_t off, T a, int lane) const {
+        T cur[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) cur[u] = *acc_at(acc, Post<T>::slot(r[u]));
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const T sum = add_rn<T>(cur[u], mul_rn<T>(a, Post<T>::val(r[u])));
+            if (off + u * 64 + lane < n) *acc_at(acc, Post<T>::slot(r[u])) = sum;
         }
-    }
-
-    template <int B>
-    __device__ __forceinline__ void batch(uint32_t w) {
-        uint32_t s[B], idx[B];
-        typename Post<T>::reg_t r[B];
-#pragma unroll
-        for (int b = 0; b < B; ++b) locate(w + b, s[b], idx[b]);
-#pragma unroll
-        for (int b = 0; b < B; ++b) r[b] = Post<T>::load(post_rows, post_vals, idx[b]);
-#pragma unroll
-        for (int b = 0; b < B; ++b) consume(r[b], s[b]);
     }
 };
 
-template <typename T, int TILE, int DEPTH>
-__device__ __forceinline__ void accumulate_flat(T *acc, const int32_t *__restrict__ post_rows,
-                                                const T *__restrict__ post_vals, uint32_t lo, uint32_t len,
-                                                T a, int nseg, int lane) {
-    // inclusive scan of the segment lengths over the lanes
-    uint32_t end = len;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const uint32_t up = __shfl_up(end, d, 64);
-        if (lane >= d) end += up;
-    }
-    const uint32_t S = wave_read<uint32_t>(end, 63);
-    if (S == 0) return;
-    FlatWalk<T, TILE> fw;
-    fw.acc = acc;
-    fw.post_rows = post_rows;
-    fw.post_vals = post_vals;
-    fw.end = end;
-    fw.base = lo - (end - len);
-    fw.a = a;
-    fw.S = S;
-    fw.sb = 0;
-    fw.nseg = nseg;
-    fw.lane = lane;
-    const uint32_t W = (S + 63) >> 6;   // windows of this (row, tile)
-    uint32_t w = 0;
-    while (W - w >= (uint32_t)DEPTH) {
-        fw.template batch<DEPTH>(w);
-        w += DEPTH;
-    }
-    if (DEPTH > 4)
-        while (W - w >= 4u) {
-            fw.template batch<4>(w);
-            w += 4;
-        }
-    while (w < W) {
-        fw.template batch<1>(w);
-        w += 1;
+// Entries beyond the first window of a long posting list ('inc', 'llc', ...).  Software-pipelined:
+// the loads of step i+1 are in flight while step i is applied (two register sets, ping-pong), because
+// at ~1 us per L2/MALL round trip a load-wait-apply loop left the waves waiting 2/3 of the time.
+template <typename T>
+__device__ __forceinline__ void stream_rest(T *acc, const char *vals, const char *slots, uint32_t lo, uint32_t n, T a,
+                                            int lane) {
+    StreamStep<T> s0, s1;
+    uint32_t off = 64;
+    s0.load(vals, slots, lo, n, off, lane);
+    for (;;) {   // loads are unconditional (clamped indices) so that the compiler can count them: vmcnt(4)
+        s1.load(vals, slots, lo, n, off + 256, lane);
+        s0.apply(acc, n, off, a, lane);
+        if (off + 256 >= n) break;
+        s0.load(vals, slots, lo, n, off + 512, lane);
+        s1.apply(acc, n, off + 256, a, lane);
+        if (off + 512 >= n) break;
+        off += 512;
     }
 }
 
-template <typename T, int TILE_LOG2, int DEPTH>
+// Next left row for this wave: one global atomic by lane 0, broadcast.  The result is made
+// explicitly wave-uniform so that everything derived from it stays in SGPRs / uniform branches.
+__device__ __forceinline__ uint32_t next_row(uint32_t *row_counter, int lane) {
+    uint32_t r = 0;
+    if (lane == 0) r = __hip_atomic_fetch_add(row_counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return (uint32_t)__builtin_amdgcn_readfirstlane((int)r);
+}
+
+template <typename T, int TILE_LOG2, int NB>
+__device__ __forceinline__ void process_row(T *acc, uint32_t row, const int64_t *__restrict__ a_indptr,
+                                            const int32_t *__restrict__ a_indices, const T *__restrict__ a_data,
+                                            const uint32_t *__restrict__ seg, const int32_t *__restrict__ post_rows,
+                                            const T *__restrict__ post_vals, int32_t n_tiles, int32_t tile_begin,
+                                            int32_t tile_end, int32_t keep, int32_t pass_off, int32_t out_stride, T thr,
+                                            int32_t *__restrict__ out_cols, T *__restrict__ out_vals,
+                                            int32_t *__restrict__ out_cnt, int lane) {
+    constexpr int TILE = 1 << TILE_LOG2;
+    constexpr int VEC = 16 / sizeof(T);   // values per 16-byte LDS access
+    typedef T vec_t __attribute__((ext_vector_type(VEC)));
+    vec_t *acc_v = reinterpret_cast<vec_t *>(acc);
+    const char *vals = reinterpret_cast<const char *>(post_vals);
+    const char *slots = reinterpret_cast<const char *>(post_rows);
+
+    const int64_t rlo = a_indptr[row];
+    const int nnz = (int)(a_indptr[row + 1] - rlo);
+    const size_t obase = (size_t)row * (size_t)out_stride + (size_t)pass_off;
+
+    // ---- restore the row's running state (written by the previous tile group / pass)
+    TopList<T> top;
+    top.clear();
+    T floor_s = INFINITY;
+    int floor_c = -1;
+    int prev_cnt = 0;
+    if (tile_begin > 0 || pass_off > 0) prev_cnt = __builtin_amdgcn_readfirstlane(out_cnt[row]);
+    if (pass_off > 0) {
+        if (prev_cnt < pass_off) return;                // earlier passes did not fill up: row is complete
+        floor_s = out_vals[obase - 1];
+        floor_c = out_cols[obase - 1];
+    }
+    if (tile_begin > 0) {
+        const int have = prev_cnt - pass_off;           // entries collected so far in this pass
+        if (lane < have) {
+            top.s = out_vals[obase + lane];
+            top.c = out_cols[obase + lane];
+        }
+    }
+
+    if (nnz > 0) {
+        // first 64 non-zeros of the row stay in registers for all tiles (lane l holds non-zero l)
+        int k0 = -1;
+        T a0 = (T)0;
+        if (lane < nnz) {
+            k0 = a_indices[rlo + lane];
+            a0 = a_data[rlo + lane];
+        }
+        // segment bounds of (k0, t): lo is the previous tile's hi; the next tile's hi is fetched
+        // one tile ahead so that its latency hides behind this tile's work
+        uint32_t lo0 = 0, hi0 = 0, hi_next = 0;
+        if (k0 >= 0) {
+            const uint32_t *sp = seg + (int64_t)k0 * n_tiles + tile_begin;
+            lo0 = sp[0];
+            hi0 = sp[1];
+        }
+
+        SG_WD_DECL(wd_t);
+        for (int t = tile_begin; t < tile_end; ++t) {
+            SG_WD(wd_t, n_tiles + 2, 2)
+            if (k0 >= 0 && t + 1 < tile_end) hi_next = seg[(int64_t)k0 * n_tiles + t + 2];
+            bool touched = false;
+            SG_WD_DECL(wd_c);
+            for (int c0 = 0; c0 < nnz; c0 += 64) {
+                SG_WD(wd_c, 100000, 3)
+                T a;
+                uint32_t lo = 0, hi = 0;
+                if (c0 == 0) {
+                    a = a0;
+                    lo = lo0;
+                    hi = hi0;
+                } else {
+                    a = (T)0;
+                    if (c0 + lane < nnz) {
+                        const int k = a_indices[rlo + c0 + lane];
+                        a = a_data[rlo + c0 + lane];
+                        lo = seg[(int64_t)k * n_tiles + t];
+                        hi = seg[(int64_t)k * n_tiles + t + 1];
+                    }
+                }
+                uint64_t m = __ballot(hi > lo);   // non-empty segments, ascending lane == ascending k
+                touched |= (m != 0);
+                SG_WD_DECL(wd_m);
+                while (m) {
+                    SG_WD(wd_m, 70, 4)
+                    // ---- issue: first window of the next NB segments, loads back to back.  Lanes beyond
+                    // a short segment re-read its last entry (no exec masking on the load / LDS read);
+                    // only the final LDS write is masked.
+                    uint32_t slo[NB], sn[NB];
+                    T sa[NB];
+                    bool has[NB];
+                    typename Post<T>::reg_t r[NB];
+#pragma unroll
+                    for (int b = 0; b < NB; ++b) {
+                        has[b] = m != 0;
+                        if (has[b]) {
+                            const int f = __builtin_ctzll(m);
+                            m &= m - 1;
+                            slo[b] = wave_read<uint32_t>(lo, f);
+                            sn[b] = wave_read<uint32_t>(hi, f) - slo[b];
+                            sa[b] = wave_read<T>(a, f);
+                            const uint32_t e = (uint32_t)lane < sn[b] ? (uint32_t)lane : sn[b] - 1;
+                            r[b] = Post<T>::load(vals, slots, slo[b] + e);
+                        }
+                    }
+                    // ---- consume in ascending k: read-add-write, then the rest of a long list
+#pragma unroll
+                    for (int b = 0; b < NB; ++b) {
+                        if (has[b]) {
+                            T *slot = acc_at(acc, Post<T>::slot(r[b]));
+                            const T sum = add_rn<T>(*slot, mul_rn<T>(sa[b], Post<T>::val(r[b])));
+                            if ((uint32_t)lane < sn[b]) *slot = sum;   // idle lanes computed a duplicate: drop it
+                            if (sn[b] > 64) stream_rest<T>(acc, vals, slots, slo[b], sn[b], sa[b], lane);
+                        }
+                    }
+                }
+            }
+            lo0 = hi0;
+            hi0 = hi_next;
+            if (touched) {   // otherwise the accumulators are still all zero
+                // ---- sweep the tile: find values > thr, re-zero
+                const int col_base = t << TILE_LOG2;
+#pragma unroll 4
+                for (int x0 = 0; x0 < TILE / VEC; x0 += 64) {
+                    const vec_t v = acc_v[x0 + lane];
+                    acc_v[x0 + lane] = (vec_t)(T)0;
+                    if (__ballot(any_above<T>(v, thr)) != 0) {   // rare: an accumulator of this stripe passes
+#pragma unroll
+                        for (int e = 0; e < VEC; ++e) {
+                            uint64_t hm = __ballot(v[e] > thr);
+                            SG_WD_DECL(wd_h);
+                            while (hm) {
+                                SG_WD(wd_h, 70, 9)
+                                const int src = __builtin_ctzll(hm);
+                                hm &= hm - 1;
+                                const T ns = wave_read<T>(v[e], src);
+                                const int nc = col_base + (x0 + src) * VEC + e;
+                                if (ns < floor_s || (ns == floor_s && nc > floor_c)) top.insert(ns, nc, lane);
+                            }
+                        }
+                    }
+                }
+            }
+        }
+    }
+
+    // ---- store the row's state (final when tile_end == n_tiles)
+    int cnt = __popcll(__ballot(top.c != INT32_MAX));
+    if (cnt > keep) cnt = keep;
+    if (lane < cnt) {
+        out_vals[obase + lane] = top.s;
+        out_cols[obase + lane] = top.c;
+    }
+    if (lane == 0) out_cnt[row] = pass_off + cnt;
+}
+
+template <typename T, int TILE_LOG2, int NB>
 __global__ void __launch_bounds__(64)
 spgemm_topn_kernel(const int64_t *__restrict__ a_indptr, const int32_t *__restrict__ a_indices,
                    const T *__restrict__ a_data, uint32_t n_left, const uint32_t *__restrict__ seg,
@@ -250,118 +395,20 @@ spgemm_topn_kernel(const int64_t *__restrict__ a_indptr, const int32_t *__restri
                    int32_t pass_off /* 64 * pass */, int32_t out_stride, T thr, int32_t *__restrict__ out_cols,
                    T *__restrict__ out_vals, int32_t *__restrict__ out_cnt, uint32_t *row_counter) {
     constexpr int TILE = 1 << TILE_LOG2;
-    constexpr int VEC = 16 / sizeof(T);   // values per 16-byte LDS access
+    constexpr int VEC = 16 / sizeof(T);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     T *acc = reinterpret_cast<T *>(smem);
     const int lane = threadIdx.x;
-
     typedef T vec_t __attribute__((ext_vector_type(VEC)));
     vec_t *acc_v = reinterpret_cast<vec_t *>(acc);
     for (int x = lane; x < TILE / VEC; x += 64) acc_v[x] = (vec_t)(T)0;
 
-    for (;;) {
-        uint32_t row = 0;
-        if (lane == 0) row = atomicAdd(row_counter, 1u);
-        row = (uint32_t)__builtin_amdgcn_readfirstlane((int)row);
-        if (row >= n_left) break;
-
-        const int64_t rlo = a_indptr[row];
-        const int nnz = (int)(a_indptr[row + 1] - rlo);
-        const size_t obase = (size_t)row * (size_t)out_stride + (size_t)pass_off;
-
-        // ---- restore the row's running state (written by the previous tile group / pass)
-        TopList<T> top;
-        top.clear();
-        T floor_s = INFINITY;
-        int floor_c = -1;
-        int prev_cnt = 0;
-        if (tile_begin > 0 || pass_off > 0) prev_cnt = out_cnt[row];
-        if (pass_off > 0) {
-            if (prev_cnt < pass_off) continue;              // earlier passes did not fill up: row is complete
-            floor_s = out_vals[obase - 1];
-            floor_c = out_cols[obase - 1];
-        }
-        if (tile_begin > 0) {
-            const int have = prev_cnt - pass_off;           // entries collected so far in this pass
-            if (lane < have) {
-                top.s = out_vals[obase + lane];
-                top.c = out_cols[obase + lane];
-            }
-        }
-
-        if (nnz > 0) {
-            // first 64 non-zeros of the row stay in registers for all tiles (lane l holds non-zero l)
-            int k0 = -1;
-            T a0 = (T)0;
-            if (lane < nnz) {
-                k0 = a_indices[rlo + lane];
-                a0 = a_data[rlo + lane];
-            }
-            // segment bounds of (k0, t): lo is the previous tile's hi; the next tile's hi is fetched
-            // one tile ahead so that its latency hides behind this tile's work
-            uint32_t lo0 = 0, hi0 = 0, hi_next = 0;
-            if (k0 >= 0) {
-                const uint32_t *sp = seg + (int64_t)k0 * n_tiles + tile_begin;
-                lo0 = sp[0];
-                hi0 = sp[1];
-            }
-
-            for (int t = tile_begin; t < tile_end; ++t) {
-                if (k0 >= 0 && t + 1 < tile_end) hi_next = seg[(int64_t)k0 * n_tiles + t + 2];
-                bool touched = false;
-                for (int c0 = 0; c0 < nnz; c0 += 64) {
-                    T a;
-                    uint32_t lo = 0, hi = 0;
-                    if (c0 == 0) {
-                        a = a0;
-                        lo = lo0;
-                        hi = hi0;
-                    } else {
-                        a = (T)0;
-                        if (c0 + lane < nnz) {
-                            const int k = a_indices[rlo + c0 + lane];
-                            a = a_data[rlo + c0 + lane];
-                            lo = seg[(int64_t)k * n_tiles + t];
-                            hi = seg[(int64_t)k * n_tiles + t + 1];
-                        }
-                    }
-                    if (__ballot(hi > lo) == 0) continue;
-                    touched = true;
-                    const int nseg = nnz - c0 < 64 ? nnz - c0 : 64;
-                    accumulate_flat<T, TILE, DEPTH>(acc, post_rows, post_vals, lo, hi - lo, a, nseg, lane);
-                }
-                lo0 = hi0;
-                hi0 = hi_next;
-                if (!touched) continue;   // accumulators are still all zero
-
-                // ---- sweep the tile: find values > thr, re-zero
-                const int col_base = t << TILE_LOG2;
-                for (int x0 = 0; x0 < TILE / VEC; x0 += 64) {
-                    const vec_t v = acc_v[x0 + lane];
-                    acc_v[x0 + lane] = (vec_t)(T)0;
-#pragma unroll
-                    for (int e = 0; e < VEC; ++e) {
-                        uint64_t hm = __ballot(v[e] > thr);
-                        while (hm) {
-                            const int src = __builtin_ctzll(hm);
-                            hm &= hm - 1;
-                            const T ns = wave_read<T>(v[e], src);
-                            const int nc = col_base + (x0 + src) * VEC + e;
-                            if (ns < floor_s || (ns == floor_s && nc > floor_c)) top.insert(ns, nc, lane);
-                        }
-                    }
-                }
-            }
-        }
-
-        // ---- store the row's state (final when tile_end == n_tiles)
-        int cnt = __popcll(__ballot(top.c != INT32_MAX));
-        if (cnt > keep) cnt = keep;
-        if (lane < cnt) {
-            out_vals[obase + lane] = top.s;
-            out_cols[obase + lane] = top.c;
-        }
-        if (lane == 0) out_cnt[row] = pass_off + cnt;
+    SG_WD_DECL(wd_rows);
+    for (uint32_t row = next_row(row_counter, lane); row < n_left; row = next_row(row_counter, lane)) {
+        SG_WD(wd_rows, n_left + 2, 1)
+        process_row<T, TILE_LOG2, NB>(acc, row, a_indptr, a_indices, a_data, seg, post_rows, post_vals, n_tiles,
+                                      tile_begin, tile_end, keep, pass_off, out_stride, thr, out_cols, out_vals,
+                                      out_cnt, lane);
     }
 }
 
@@ -576,10 +623,14 @@ extern "C" int sg_spgemm_topn(sg_ctx *ctx, const sg_csr *A, const sg_postings *B
 
     // tiles per launch: keep one launch's postings (~ nnz*(4+s)/n_tiles per tile) near 2 MiB so that
     // they stay in every XCD's 4 MiB L2 while all rows stream over them
+    // Tile groups (separate launches over a few tiles each, running state kept in the output arrays)
+    // exist for right-hand sides whose postings exceed the 256 MiB Infinity Cache; below that one launch
+    // is faster (measured: 280 ms vs 415 ms at 663 k -- every launch has a tail and a state round trip).
     int group = env_int("SG_TILE_GROUP", 0);
     if (group <= 0) {
-        const double per_tile = (double)Bt->nnz * (double)(4 + s) / (double)(Bt->n_tiles > 0 ? Bt->n_tiles : 1);
-        group = (int)(2.0 * 1024 * 1024 / (per_tile > 1.0 ? per_tile : 1.0));
+        const double bytes = (double)Bt->nnz * (double)(4 + s);
+        const double budget = 192.0 * 1024 * 1024;
+        group = bytes <= budget ? Bt->n_tiles : (int)((double)Bt->n_tiles * budget / bytes);
         if (group < 1) group = 1;
     }
     if (group > Bt->n_tiles) group = Bt->n_tiles;
