@@ -52,7 +52,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    distributed = world > 1
+    distributed = world > 1 or os.environ.get("SG_BENCH_FORCE_DIST") == "1"   # (the latter: 1-rank RCCL self-test)
     dtype = np.float32 if args.dtype == "f32" else np.float64
 
     import torch
@@ -60,7 +60,8 @@ def main():
     if distributed:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     from string_grouper_amd import _native as N
     from string_grouper_amd.synth import synth_names
     from string_grouper_amd.vectorizer import HipTfidfVectorizer

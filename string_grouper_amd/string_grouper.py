@@ -296,27 +296,34 @@ class StringGrouper(object):
     # ------------------------------------------------------------------ post-processing
     @staticmethod
     def _fix_diagonal(m):
-        """Every string matches itself with similarity exactly 1 (string_grouper.py:954-958)."""
-        m = sp.csr_matrix(m).tolil() if not sp.isspmatrix_lil(m) else m
-        r = np.arange(m.shape[0])
-        m[r, r] = 1
-        return m
+        """Every string matches itself with similarity exactly 1 (string_grouper.py:954-958): every
+        diagonal entry is set to 1, also for rows that had none."""
+        coo = sp.coo_matrix(m)
+        n = coo.shape[0]
+        off = coo.row != coo.col
+        diag = np.arange(n, dtype=coo.row.dtype)
+        rows = np.concatenate([coo.row[off], diag])
+        cols = np.concatenate([coo.col[off], diag])
+        vals = np.concatenate([coo.data[off], np.ones(n, dtype=coo.data.dtype)])
+        return sp.coo_matrix((vals, (rows, cols)), shape=coo.shape)
 
     @staticmethod
     def _symmetrize_matrix(m):
-        """If (r, c) is stored so is (c, r) with the same value (string_grouper.py:960-964)."""
+        """If (r, c) is stored so is (c, r) with the same value (string_grouper.py:960-964); rows come
+        back sorted by column, as the reference's lil round trip leaves them."""
         coo = sp.coo_matrix(m)
-        r, c, v = coo.row, coo.col, coo.data
-        rows = np.concatenate([r, c])
-        cols = np.concatenate([c, r])
-        vals = np.concatenate([v, v])
-        # first occurrence wins == the stored (r, c) value; mirrored copies only fill holes
-        order = np.lexsort((np.arange(len(rows)), cols, rows))
-        rows, cols, vals = rows[order], cols[order], vals[order]
-        keep = np.ones(len(rows), dtype=bool)
-        keep[1:] = (rows[1:] != rows[:-1]) | (cols[1:] != cols[:-1])
-        out = sp.csr_matrix((vals[keep], (rows[keep], cols[keep])), shape=coo.shape)
-        out.sort_indices()
+        n_cols = np.int64(coo.shape[1])
+        r = coo.row.astype(np.int64)
+        c = coo.col.astype(np.int64)
+        keys = np.concatenate([r * n_cols + c, c * n_cols + r])       # stored entries first: they win
+        vals = np.concatenate([coo.data, coo.data])
+        uniq, first = np.unique(keys, return_index=True)
+        rows = uniq // n_cols
+        indptr = np.zeros(coo.shape[0] + 1, dtype=np.int64)
+        np.cumsum(np.bincount(rows, minlength=coo.shape[0]), out=indptr[1:])
+        idx_dtype = np.int32 if max(coo.shape[1], len(uniq)) < 2 ** 31 else np.int64
+        out = sp.csr_matrix((vals[first], (uniq % n_cols).astype(idx_dtype), indptr.astype(idx_dtype)), shape=coo.shape)
+        out.has_sorted_indices = True
         return out
 
     def _get_matches_list(self, matches) -> pd.DataFrame:
@@ -366,8 +373,8 @@ class StringGrouper(object):
 
         def prefixed(obj, prefix):
             if isinstance(obj, pd.DataFrame):
-                return obj.rename(columns={c: f"{prefix}{c}" for c in obj.columns})
-            return obj.rename(f"{prefix}{obj.name}")
+                return obj.rename(columns={c: f"{prefix}{c}" for c in obj.columns}, copy=False)
+            return obj.rename(f"{prefix}{obj.name}", copy=False)
 
         left = side(self._master, pairs.master_side, DEFAULT_COLUMN_NAME, ignore_index, False)
         right = side(right_source, pairs.dupe_side, DEFAULT_COLUMN_NAME, ignore_index, True)
@@ -380,7 +387,7 @@ class StringGrouper(object):
             right_id = side(right_ids, pairs.dupe_side, DEFAULT_ID_NAME, True, True)
             parts = [prefixed(left, LEFT_PREFIX), prefixed(left_id, LEFT_PREFIX), similarity,
                      prefixed(right_id, RIGHT_PREFIX), prefixed(right, RIGHT_PREFIX)]
-        return pd.concat(parts, axis=1)
+        return pd.concat(parts, axis=1, copy=False)
 
     @validate_is_fit
     def get_groups(self, ignore_index: Optional[bool] = None,

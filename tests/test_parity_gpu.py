@@ -186,3 +186,73 @@ def test_100k_selfjoin_matches_port(ctx):
     # size-independent properties: diagonal present with score ~1
     d = C_dev.diagonal()
     assert (np.abs(d[d > 0] - 1) < 1e-5).all()
+
+
+def test_public_api_golden_cases_on_gpu(ctx):
+    """The reference's golden vectors (tests/golden, made by the unmodified reference) through the
+    drop-in API with the HIP engine: match frames, groups, most-similar, known answers."""
+    import string_grouper_amd as sga
+    import string_grouper_amd.engine as E
+    from tests import _golden as G
+    old = E._engine
+    E.set_engine(E.HipEngine(ctx))
+    try:
+        G.run_api_checks(sga)
+    finally:
+        E.set_engine(old)
+
+
+def test_blocked_equals_unblocked_on_gpu(ctx, mats):
+    """n_blocks only cuts the work differently (reference invariant, test_string_grouper.py:191-336)."""
+    import string_grouper_amd.engine as E
+    eng = E.HipEngine(ctx)
+    A = eng.wrap(mats[np.float64][:3000])
+    B = eng.wrap(mats[np.float64][:5000])
+    ref = eng.topn_multiply(A, B, 8, 0.4).astype(np.float64)
+    for nb in ((1, 3), (2, 1), (3, 4)):
+        got = eng.topn_multiply_blocked(A, B, nb, 8, 0.4)
+        assert_csr_identical(got, ref, str(nb))
+
+
+def test_device_resident_inputs_and_rccl_plumbing(ctx):
+    """sg_strings_from_device / sg_csr_from_device / zero-copy torch views, and the single-rank form
+    of the multi-GPU path (RCCL process group of size 1 on this GPU)."""
+    import os
+    import torch
+    import torch.distributed as dist
+    from string_grouper_amd import distributed as D
+    from string_grouper_amd.vectorizer import HipTfidfVectorizer
+    names = _names(6000, seed=11)
+    vec = HipTfidfVectorizer(dtype=np.float32, ctx=ctx)
+    p = vec.prepare(names)
+    # strings handed over as device pointers (torch tensors own the memory)
+    t_bytes = torch.from_numpy(p.data.copy()).cuda()
+    t_offs = torch.from_numpy(p.offsets.copy()).cuda()
+    torch.cuda.synchronize()
+    p2 = type(p)(p.data, p.offsets)
+    p2.dev = ctx.strings_from_device(t_bytes.data_ptr(), t_offs.data_ptr(), p.n, int(p.offsets[-1]), keepalive=(t_bytes, t_offs))
+    vec.fit_prepared([p2])
+    A = vec.transform_prepared(p2)
+    ctx.sync()
+    (A_ref,), _, _ = O.tfidf_sklearn(names, [names], dtype=np.float32)
+    assert_csr_identical(A.to_scipy(), sp.csr_matrix(A_ref))
+    # zero-copy torch view of the library's CSR and back
+    ip, ix, d = D.csr_as_torch(A)
+    assert ip.shape[0] == len(names) + 1 and int(ip[-1]) == A_ref.nnz
+    A2 = D.csr_from_torch(ctx, ip.clone(), ix.clone(), d.clone(), A.dims()[:2])
+    torch.cuda.synchronize()
+    assert_csr_identical(A2.to_scipy(), sp.csr_matrix(A_ref))
+    # the sharded driver with a one-rank RCCL group
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29577")
+    if not dist.is_initialized():
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        res, (lo, hi), n_total = D.sharded_self_join(ctx, p, lambda: HipTfidfVectorizer(dtype=np.float32, ctx=ctx), 10, 0.8)
+        assert (lo, hi, n_total) == (0, len(names), len(names))
+        C_ref = P.sp_matmul_topn_port(A_ref, A_ref.T, 10, 0.8, True, 4)
+        assert_csr_identical(res.to_scipy(), C_ref)
+        counts = D.gather_counts(torch.from_numpy(np.diff(C_ref.indptr).astype(np.int32)).cuda(), n_total)
+        assert counts.cpu().numpy().tolist() == np.diff(C_ref.indptr).tolist()
+    finally:
+        dist.destroy_process_group()
