@@ -91,6 +91,13 @@ def lib():
                     f"{LIB_PATH} is missing: build the HIP extension first "
                     f"(python -c 'import __graft_entry__ as g; g.build()' or make -C string_grouper_amd/csrc). "
                     f"string_grouper_amd has no CPU fallback.")
+            # When PyTorch is present it must load ITS bundled HIP runtime first: both runtimes carry the
+            # SONAME libamdhip64.so.7, the first one loaded serves the whole process, and PyTorch initialised
+            # on top of a different runtime than it was built for intermittently reports "No HIP GPUs".
+            try:
+                import torch  # noqa: F401
+            except Exception:
+                pass
             handle = C.CDLL(LIB_PATH)
             for name, (res, args) in ABI.items():
                 fn = getattr(handle, name)       # AttributeError if a declared symbol is not exported

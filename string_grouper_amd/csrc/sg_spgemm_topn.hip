@@ -128,8 +128,11 @@ template <>
 struct Post<float> {
     typedef uint2 reg_t;
     static constexpr int STRIDE = 8;
-    static __device__ __forceinline__ reg_t load(const char *seg_base, const char *, uint32_t entry) {
-        return *reinterpret_cast<const uint2 *>(seg_base + (size_t)entry * 8);
+    // seg_lo is wave-uniform (SGPR), entry is the lane's 32-bit index inside the segment: the address is
+    // "scalar base + 32-bit vector offset", which costs no 64-bit vector arithmetic
+    static __device__ __forceinline__ reg_t load(const char *vals, const char *, uint32_t seg_lo, uint32_t entry) {
+        const char *base = vals + (size_t)seg_lo * 8;
+        return *reinterpret_cast<const uint2 *>(base + entry * 8u);
     }
     static __device__ __forceinline__ uint32_t slot(const reg_t &r) { return r.x; }
     static __device__ __forceinline__ float val(const reg_t &r) { return __uint_as_float(r.y); }
@@ -141,10 +144,10 @@ struct Post<double> {
         double v;
     };
     static constexpr int STRIDE = 8;
-    static __device__ __forceinline__ reg_t load(const char *val_base, const char *slot_base, uint32_t entry) {
+    static __device__ __forceinline__ reg_t load(const char *vals, const char *slots, uint32_t seg_lo, uint32_t entry) {
         reg_t r;
-        r.j = *reinterpret_cast<const uint32_t *>(slot_base + (size_t)entry * 4);
-        r.v = *reinterpret_cast<const double *>(val_base + (size_t)entry * 8);
+        r.j = *reinterpret_cast<const uint32_t *>(slots + (size_t)seg_lo * 4 + entry * 4u);
+        r.v = *reinterpret_cast<const double *>(vals + (size_t)seg_lo * 8 + entry * 8u);
         return r;
     }
     static __device__ __forceinline__ uint32_t slot(const reg_t &r) { return r.j; }
@@ -169,9 +172,12 @@ __device__ __forceinline__ bool any_above<double, f64x2>(const f64x2 &v, double 
     return __builtin_fmax(v[0], v[1]) > thr;
 }
 
+// The accumulator tile is the kernel's only LDS object, so it starts at LDS address 0 and a posting's
+// "slot" IS the LDS address: form the pointer from the integer instead of adding a base per access.
 template <typename T>
-__device__ __forceinline__ T *acc_at(T *acc, uint32_t byte_off) {
-    return reinterpret_cast<T *>(reinterpret_cast<char *>(acc) + byte_off);
+__device__ __forceinline__ T *acc_at(T *, uint32_t byte_off) {
+    typedef __attribute__((address_space(3))) T lds_t;
+    return (T *)(lds_t *)(uintptr_t)byte_off;
 }
 
 // One posting segment (term k, column tile t) = entries [lo, lo + n).  All its columns are distinct,
@@ -186,9 +192,8 @@ struct StreamStep {   // 4 windows (256 entries) of one long posting list
                                          int lane) {
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            uint32_t p = off + u * 64 + lane;
-            p = p < n ? p : n - 1;   // clamp instead of masking: idle lanes re-read the last entry
-            r[u] = Post<T>::load(vals, slots, lo + p);
+            const uint32_t p = min(off + u * 64 + lane, n - 1u);   // clamp, not mask: idle lanes re-read the last entry
+            r[u] = Post<T>::load(vals, slots, lo, p);
         }
     }
     __device__ __forceinline__ void apply(T *acc, uint32_t n, uint32_t off, T a, int lane) const {
@@ -331,8 +336,8 @@ __device__ __forceinline__ void process_row(T *acc, uint32_t row, const int64_t 
                             slo[b] = wave_read<uint32_t>(lo, f);
                             sn[b] = wave_read<uint32_t>(hi, f) - slo[b];
                             sa[b] = wave_read<T>(a, f);
-                            const uint32_t e = (uint32_t)lane < sn[b] ? (uint32_t)lane : sn[b] - 1;
-                            r[b] = Post<T>::load(vals, slots, slo[b] + e);
+                            const uint32_t e = min((uint32_t)lane, sn[b] - 1u);   // one v_min_u32
+                            r[b] = Post<T>::load(vals, slots, slo[b], e);
                         }
                     }
                     // ---- consume in ascending k: read-add-write, then the rest of a long list

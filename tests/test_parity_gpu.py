@@ -256,3 +256,95 @@ def test_device_resident_inputs_and_rccl_plumbing(ctx):
         assert counts.cpu().numpy().tolist() == np.diff(C_ref.indptr).tolist()
     finally:
         dist.destroy_process_group()
+
+
+def _check_slice_properties(res, lo, n_left_block, n_right, top_n, thr, self_join, A_host, B_host, sample, what):
+    """Size-independent properties of one row block of C plus an exact comparison of ``sample`` rows
+    against the CPU port."""
+    cols, vals, cnt = res.to_host()
+    assert cols.shape == (n_left_block, top_n)
+    assert cnt.min() >= 0 and cnt.max() <= top_n, what
+    mask = np.arange(top_n)[None, :] < cnt[:, None]
+    assert (vals[mask] > np.float32(thr)).all(), what                      # strictly above the threshold
+    assert ((cols[mask] >= 0) & (cols[mask] < n_right)).all(), what
+    v = np.where(mask, vals, -np.inf)
+    assert (v[:, :-1] >= v[:, 1:]).all(), what                             # score descending within a row
+    ties = mask[:, 1:] & (v[:, :-1] == v[:, 1:])
+    assert (cols[:, :-1][ties] < cols[:, 1:][ties]).all(), what            # ties: column ascending
+    if self_join:                                                          # every non-empty row matches itself ~1
+        rows_with_grams = np.diff(A_host.indptr)[lo:lo + n_left_block] > 0
+        own = (cols == (np.arange(n_left_block) + lo)[:, None]) & mask
+        full = cnt == top_n
+        assert (own.any(axis=1) | full | ~rows_with_grams).all(), what
+        assert np.abs(vals[own] - 1.0).max() < 1e-5, what
+    rng = np.random.default_rng(5)
+    pick = np.sort(rng.choice(n_left_block, size=min(sample, n_left_block), replace=False))
+    C_ref = P.sp_matmul_topn_port(A_host[lo + pick], B_host.T, top_n, thr, True, 32)
+    for r, i in enumerate(pick):
+        ref_c = C_ref.indices[C_ref.indptr[r]:C_ref.indptr[r + 1]]
+        ref_v = C_ref.data[C_ref.indptr[r]:C_ref.indptr[r + 1]]
+        assert cnt[i] == len(ref_c), f"{what}: row {lo + i} count"
+        assert np.array_equal(cols[i, :cnt[i]], ref_c) and np.array_equal(vals[i, :cnt[i]], ref_v), f"{what}: row {lo + i}"
+
+
+@pytest.mark.timeout(900)
+def test_config4_5M_selfjoin_one_of_eight_row_blocks(ctx):
+    """BASELINE.json configs[3]: 5M synthetic names self-join, left CSR row-blocked over 8 GPUs -- here
+    the block rank 3 would own, against the full right-hand side (postings exceed the Infinity Cache,
+    so the tile-group path runs).  Properties at full size + sampled rows against the CPU port."""
+    from string_grouper_amd import distributed as D
+    from string_grouper_amd.vectorizer import HipTfidfVectorizer
+    n = 5_000_000
+    names = _names(n, seed=1234)
+    vec = HipTfidfVectorizer(dtype=np.float32, ctx=ctx)
+    p = vec.prepare(names)
+    vec.fit_prepared([p])
+    A = vec.transform_prepared(p)
+    A_host = A.to_scipy()
+    post = ctx.postings_build(A)
+    lo, hi = D.row_block(3, 8, n)
+    blk = A.row_block(lo, hi)
+    res = ctx.spgemm_topn(blk, post, 10, 0.8, True)
+    st = ctx.stats()
+    print(f"config4 block: rows {hi - lo}, K4 {st['ms_spgemm_topn']:.1f} ms, macs {st['macs']:.3e}, "
+          f"{st['spgemm_bytes'] / st['ms_spgemm_topn'] / 1e9:.2f} TB/s algorithmic")
+    _check_slice_properties(res, lo, hi - lo, n, 10, 0.8, True, A_host, A_host, 300, "config4")
+    for h in (res, blk, post, A):
+        h.free()
+    ctx.trim()
+
+
+@pytest.mark.timeout(900)
+def test_config5_asymmetric_10M_x_1M_one_of_eight_row_blocks(ctx):
+    """BASELINE.json configs[4]: master 10M x duplicates 1M, ntop=20, min_sim=0.7 (match_most_similar
+    path: top-n per MASTER row, string_grouper.py:728-729) -- one of the eight master row blocks."""
+    from string_grouper_amd import distributed as D
+    from string_grouper_amd.synth import synth_names
+    from string_grouper_amd.vectorizer import HipTfidfVectorizer
+    n_m, n_d = 10_000_000, 1_000_000
+    master = _names(n_m, seed=1234)
+    dupes = synth_names(n_d, seed=4321, perturb_of=master, perturb_frac=0.5)
+    vec = HipTfidfVectorizer(dtype=np.float32, ctx=ctx)
+    pm, pd_ = vec.prepare(master), vec.prepare(dupes)
+    del master
+    vec.fit_prepared([pm, pd_])
+    A = vec.transform_prepared(pm)
+    B = vec.transform_prepared(pd_)
+    B_host = B.to_scipy()
+    post = ctx.postings_build(B)
+    lo, hi = D.row_block(5, 8, n_m)
+    blk = A.row_block(lo, hi)
+    res = ctx.spgemm_topn(blk, post, 20, 0.7, True)
+    st = ctx.stats()
+    print(f"config5 block: rows {hi - lo}, K4 {st['ms_spgemm_topn']:.1f} ms, macs {st['macs']:.3e}")
+    A_blk_host = blk.to_scipy()
+    # _check_slice_properties indexes the left matrix with lo + pick: hand it a matrix whose row 0 is row lo
+    class _Shift:
+        def __init__(self, m, lo):
+            self.m, self.lo, self.indptr = m, lo, None
+        def __getitem__(self, idx):
+            return self.m[np.asarray(idx) - self.lo]
+    _check_slice_properties(res, lo, hi - lo, n_d, 20, 0.7, False, _Shift(A_blk_host, lo), B_host, 300, "config5")
+    for h in (res, blk, post, A, B):
+        h.free()
+    ctx.trim()
