@@ -45,7 +45,7 @@ def main():
                 post = ctx.postings_build(A, tile)
                 ctx.sync()
                 t_post = time.perf_counter() - t0
-                for group, depth in [(0, 8)]:
+                for group, depth in [(0, 4), (0, 8), (0, 16)]:
                     for wpc in (0,):
                         os.environ["SG_TILE_GROUP"] = str(group)
                         os.environ["SG_DEPTH"] = str(depth)

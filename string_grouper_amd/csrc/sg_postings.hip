@@ -72,8 +72,9 @@ extern "C" int sg_postings_build(sg_ctx *ctx, const sg_csr *B, int32_t tile_cols
     if (tile_cols == 0) tile_cols = B->dtype == SG_F64 ? 1024 : 2048;   // 8 KiB of LDS per wave: 20 waves per CU
     SG_REQUIRE(tile_cols >= 256 && tile_cols <= 32768 && (tile_cols & (tile_cols - 1)) == 0,
                "tile_cols must be a power of two in [256, 32768]");
-    if (B->nnz >= (int64_t)UINT32_MAX) {
-        sg_set_error("right-hand matrix has %lld non-zeros; postings are indexed with 32 bits", (long long)B->nnz);
+    if (B->nnz + 64 >= ((int64_t)1 << 29)) {   // the multiply addresses postings with 32-bit BYTE offsets (8 B entries)
+        sg_set_error("right-hand matrix has %lld non-zeros; one postings block holds < 2^29 (use more right-hand blocks)",
+                     (long long)B->nnz);
         return SG_ERR_OVERFLOW;
     }
     int32_t tile_log2 = 0;

@@ -128,11 +128,9 @@ template <>
 struct Post<float> {
     typedef uint2 reg_t;
     static constexpr int STRIDE = 8;
-    // seg_lo is wave-uniform (SGPR), entry is the lane's 32-bit index inside the segment: the address is
-    // "scalar base + 32-bit vector offset", which costs no 64-bit vector arithmetic
+    // address = kernel-constant base (SGPR pair) + 32-bit byte offset per lane: no 64-bit arithmetic at all
     static __device__ __forceinline__ reg_t load(const char *vals, const char *, uint32_t seg_lo, uint32_t entry) {
-        const char *base = vals + (size_t)seg_lo * 8;
-        return *reinterpret_cast<const uint2 *>(base + entry * 8u);
+        return *reinterpret_cast<const uint2 *>(vals + ((seg_lo + entry) << 3));   // 32-bit offset: < 2^29 entries
     }
     static __device__ __forceinline__ uint32_t slot(const reg_t &r) { return r.x; }
     static __device__ __forceinline__ float val(const reg_t &r) { return __uint_as_float(r.y); }
@@ -146,8 +144,8 @@ struct Post<double> {
     static constexpr int STRIDE = 8;
     static __device__ __forceinline__ reg_t load(const char *vals, const char *slots, uint32_t seg_lo, uint32_t entry) {
         reg_t r;
-        r.j = *reinterpret_cast<const uint32_t *>(slots + (size_t)seg_lo * 4 + entry * 4u);
-        r.v = *reinterpret_cast<const double *>(vals + (size_t)seg_lo * 8 + entry * 8u);
+        r.j = *reinterpret_cast<const uint32_t *>(slots + ((seg_lo + entry) << 2));
+        r.v = *reinterpret_cast<const double *>(vals + ((seg_lo + entry) << 3));
         return r;
     }
     static __device__ __forceinline__ uint32_t slot(const reg_t &r) { return r.j; }
@@ -225,6 +223,44 @@ __device__ __forceinline__ void stream_rest(T *acc, const char *vals, const char
         s1.apply(acc, n, off + 256, a, lane);
         if (off + 512 >= n) break;
         off += 512;
+    }
+}
+
+// wave-uniform "clear bit f of m" in one scalar instruction (the compiler expands m &= m - 1 to three)
+__device__ __forceinline__ void clear_bit(uint64_t &m, int f) {
+    asm("s_bitset0_b64 %0, %1" : "+s"(m) : "s"(f));
+}
+
+// One batch of up to NB posting segments of the current (row, tile): issue the first window of each,
+// then read-add-write them in ascending k.  Lanes beyond a short segment re-read its last entry (no
+// exec masking on the load or the LDS read); only the LDS write is masked.
+template <typename T, int NB, bool PARTIAL>
+__device__ __forceinline__ void segment_batch(T *acc, const char *vals, const char *slots, uint64_t &m, uint32_t lo,
+                                              uint32_t hi, T a, int lane) {
+    uint32_t slo[NB], sn[NB];
+    T sa[NB];
+    bool has[NB];
+    typename Post<T>::reg_t r[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        has[b] = PARTIAL ? (m != 0) : true;
+        if (has[b]) {
+            const int f = __builtin_ctzll(m);
+            clear_bit(m, f);
+            slo[b] = wave_read<uint32_t>(lo, f);
+            sn[b] = wave_read<uint32_t>(hi, f) - slo[b];
+            sa[b] = wave_read<T>(a, f);
+            r[b] = Post<T>::load(vals, slots, slo[b], min((uint32_t)lane, sn[b] - 1u));
+        }
+    }
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        if (has[b]) {
+            T *slot = acc_at(acc, Post<T>::slot(r[b]));
+            const T sum = add_rn<T>(*slot, mul_rn<T>(sa[b], Post<T>::val(r[b])));
+            if ((uint32_t)lane < sn[b]) *slot = sum;   // idle lanes computed a duplicate: drop it
+            if (sn[b] > 64) stream_rest<T>(acc, vals, slots, slo[b], sn[b], sa[b], lane);
+        }
     }
 }
 
@@ -317,62 +353,43 @@ __device__ __forceinline__ void process_row(T *acc, uint32_t row, const int64_t 
                 }
                 uint64_t m = __ballot(hi > lo);   // non-empty segments, ascending lane == ascending k
                 touched |= (m != 0);
+                // batches of NB segments: the first-window loads of a batch are issued back to back, then
+                // consumed in ascending k.  Full batches carry no per-segment "is there one" test.
                 SG_WD_DECL(wd_m);
-                while (m) {
+                while (__popcll(m) >= NB) {
                     SG_WD(wd_m, 70, 4)
-                    // ---- issue: first window of the next NB segments, loads back to back.  Lanes beyond
-                    // a short segment re-read its last entry (no exec masking on the load / LDS read);
-                    // only the final LDS write is masked.
-                    uint32_t slo[NB], sn[NB];
-                    T sa[NB];
-                    bool has[NB];
-                    typename Post<T>::reg_t r[NB];
-#pragma unroll
-                    for (int b = 0; b < NB; ++b) {
-                        has[b] = m != 0;
-                        if (has[b]) {
-                            const int f = __builtin_ctzll(m);
-                            m &= m - 1;
-                            slo[b] = wave_read<uint32_t>(lo, f);
-                            sn[b] = wave_read<uint32_t>(hi, f) - slo[b];
-                            sa[b] = wave_read<T>(a, f);
-                            const uint32_t e = min((uint32_t)lane, sn[b] - 1u);   // one v_min_u32
-                            r[b] = Post<T>::load(vals, slots, slo[b], e);
-                        }
-                    }
-                    // ---- consume in ascending k: read-add-write, then the rest of a long list
-#pragma unroll
-                    for (int b = 0; b < NB; ++b) {
-                        if (has[b]) {
-                            T *slot = acc_at(acc, Post<T>::slot(r[b]));
-                            const T sum = add_rn<T>(*slot, mul_rn<T>(sa[b], Post<T>::val(r[b])));
-                            if ((uint32_t)lane < sn[b]) *slot = sum;   // idle lanes computed a duplicate: drop it
-                            if (sn[b] > 64) stream_rest<T>(acc, vals, slots, slo[b], sn[b], sa[b], lane);
-                        }
-                    }
+                    segment_batch<T, NB, false>(acc, vals, slots, m, lo, hi, a, lane);
                 }
+                if (m) segment_batch<T, NB, true>(acc, vals, slots, m, lo, hi, a, lane);
             }
             lo0 = hi0;
             hi0 = hi_next;
             if (touched) {   // otherwise the accumulators are still all zero
                 // ---- sweep the tile: find values > thr, re-zero
                 const int col_base = t << TILE_LOG2;
-#pragma unroll 4
-                for (int x0 = 0; x0 < TILE / VEC; x0 += 64) {
-                    const vec_t v = acc_v[x0 + lane];
-                    acc_v[x0 + lane] = (vec_t)(T)0;
-                    if (__ballot(any_above<T>(v, thr)) != 0) {   // rare: an accumulator of this stripe passes
+                for (int x1 = 0; x1 < TILE / VEC; x1 += 256) {   // 4 stripes per step: reads first, then zero + test
+                    vec_t vv[4];
 #pragma unroll
-                        for (int e = 0; e < VEC; ++e) {
-                            uint64_t hm = __ballot(v[e] > thr);
-                            SG_WD_DECL(wd_h);
-                            while (hm) {
-                                SG_WD(wd_h, 70, 9)
-                                const int src = __builtin_ctzll(hm);
-                                hm &= hm - 1;
-                                const T ns = wave_read<T>(v[e], src);
-                                const int nc = col_base + (x0 + src) * VEC + e;
-                                if (ns < floor_s || (ns == floor_s && nc > floor_c)) top.insert(ns, nc, lane);
+                    for (int u = 0; u < 4; ++u) vv[u] = acc_v[x1 + u * 64 + lane];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) acc_v[x1 + u * 64 + lane] = (vec_t)(T)0;
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const vec_t v = vv[u];
+                        const int x0 = x1 + u * 64;
+                        if (__ballot(any_above<T>(v, thr)) != 0) {   // rare: an accumulator of this stripe passes
+#pragma unroll
+                            for (int e = 0; e < VEC; ++e) {
+                                uint64_t hm = __ballot(v[e] > thr);
+                                SG_WD_DECL(wd_h);
+                                while (hm) {
+                                    SG_WD(wd_h, 70, 9)
+                                    const int src = __builtin_ctzll(hm);
+                                    hm &= hm - 1;
+                                    const T ns = wave_read<T>(v[e], src);
+                                    const int nc = col_base + (x0 + src) * VEC + e;
+                                    if (ns < floor_s || (ns == floor_s && nc > floor_c)) top.insert(ns, nc, lane);
+                                }
                             }
                         }
                     }
