@@ -10,8 +10,9 @@ is quoted on -- 663k-name self-join, 3-grams, ntop=10, min_sim=0.8, fp32 -- on S
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-N > 1 is strong scaling of the same workload: rank 0 vectorises, its CSR is broadcast once over
-RCCL, every rank multiplies its row block (string_grouper_amd/distributed.py).
+N > 1 is strong scaling of the same workload: rank 0's string column is broadcast once over RCCL,
+every rank vectorises and multiplies its contiguous block of left rows
+(string_grouper_amd/distributed.py).
 
 Prints ONE JSON line (rank 0) with ``roofline`` (K4, live HIP-event time on the library's stream)
 and ``cpu_baseline`` (the C/OpenMP port of sparse_dot_topn on a bounded row sample, rank 0, N=1).
@@ -49,6 +50,11 @@ def parse_args():
 
 def main():
     args = parse_args()
+    # RCCL prints a version banner to stdout when the first communicator is created; the contract is ONE
+    # JSON line on stdout, so everything else this process (and its libraries) writes goes to stderr
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -73,10 +79,23 @@ def main():
     make_vec = lambda: HipTfidfVectorizer(dtype=dtype, ctx=ctx)  # noqa: E731
     prepared = make_vec().prepare(names) if (rank == 0 or not distributed) else None   # strings -> HBM (untimed)
 
+    dev_strings = (None, None)
+    if distributed and rank == 0:
+        from string_grouper_amd.distributed import strings_to_device_tensors
+        dev_strings = strings_to_device_tensors(prepared, torch.device("cuda", local_rank))   # HBM-resident input
+
     def step():
         if distributed:
-            from string_grouper_amd.distributed import sharded_self_join
-            res, _, _ = sharded_self_join(ctx, prepared, make_vec, args.top_n, args.min_similarity)
+            # the one exchange: rank 0's string column (bytes + offsets, resident in HBM) goes to every rank
+            # over RCCL; then each rank vectorises and multiplies its block of left rows, no further collective
+            from string_grouper_amd.distributed import broadcast_strings, sharded_self_join_replicated
+            mode = os.environ.get("SG_BENCH_DIST_MODE", "strings")
+            if mode == "csr":
+                from string_grouper_amd.distributed import sharded_self_join
+                res, _, _ = sharded_self_join(ctx, prepared, make_vec, args.top_n, args.min_similarity)
+                return res
+            local = broadcast_strings(ctx, *dev_strings)
+            res, _, _ = sharded_self_join_replicated(ctx, local, make_vec, args.top_n, args.min_similarity)
             return res
         vec = make_vec()
         vec.fit_prepared([prepared])
@@ -142,7 +161,7 @@ def main():
         "data": "synthetic (SynthNames-v1 seed 1234; sec__edgar names are not distributable)",
         "config": {"workload": f"{args.rows}-name self-join (BASELINE.json configs[2] on the synthetic stand-in)",
                    "ngram_size": 3, "max_n_matches": args.top_n, "min_similarity": args.min_similarity,
-                   "parallelism": "single GPU" if world == 1 else f"left rows in {world} blocks, B broadcast over RCCL"},
+                   "parallelism": "single GPU" if world == 1 else f"left rows in {world} contiguous blocks, one per GPU; string column broadcast once over RCCL, each rank vectorises"},
         "kernels_ms": {k[3:]: round(v, 4) for k, v in stats.items() if k.startswith("ms_")},
         "matches": int(job_nnz),
         "macs": int(job_macs),
@@ -209,7 +228,8 @@ def main():
         result["end_to_end_match_strings_s"] = time.perf_counter() - t0
         result["end_to_end_rows"] = len(df)
 
-    print(json.dumps(result), flush=True)
+    sys.stdout.flush()
+    os.write(json_fd, (json.dumps(result) + "\n").encode())
     if distributed:
         dist.destroy_process_group()
 

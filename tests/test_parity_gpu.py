@@ -254,6 +254,12 @@ def test_device_resident_inputs_and_rccl_plumbing(ctx):
         assert_csr_identical(res.to_scipy(), C_ref)
         counts = D.gather_counts(torch.from_numpy(np.diff(C_ref.indptr).astype(np.int32)).cuda(), n_total)
         assert counts.cpu().numpy().tolist() == np.diff(C_ref.indptr).tolist()
+        # string-broadcast form (what bench.py uses for N > 1)
+        tb, to = D.strings_to_device_tensors(p, torch.device("cuda", 0))
+        local = D.broadcast_strings(ctx, tb, to)
+        res2, blk, n2 = D.sharded_self_join_replicated(ctx, local, lambda: HipTfidfVectorizer(dtype=np.float32, ctx=ctx), 10, 0.8)
+        assert blk == (0, len(names)) and n2 == len(names)
+        assert_csr_identical(res2.to_scipy(), C_ref)
     finally:
         dist.destroy_process_group()
 
