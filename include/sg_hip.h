@@ -143,6 +143,11 @@ int sg_sp_matmul_topn_host(sg_ctx *ctx, int64_t n_left, int64_t n_right, int64_t
                            int32_t dtype, int32_t top_n, double threshold, int32_t sort,
                            int32_t *out_cols, void *out_vals, int32_t *out_counts);
 
+/* Cost estimate of every left row for load balancing across GPUs: out_cost[i] = number of
+ * intermediate products row i generates = sum over its non-zeros of the posting-list length.
+ * (The reference has no analogue: its n_blocks[0] split is by row count, string_grouper.py:714-722.) */
+int sg_row_costs(sg_ctx *ctx, const sg_csr *A, const sg_postings *Bt, int64_t *out_cost);
+
 /* ------------------------------------------------------------------ measurement */
 enum { SG_K_TOKENIZE = 0, SG_K_WEIGHT = 1, SG_K_POSTINGS = 2, SG_K_SPGEMM = 3, SG_K_ZIP = 4, SG_K_COUNT = 5 };
 typedef struct {

@@ -70,6 +70,7 @@ ABI = {
     "sg_topn_free": (C.c_int, [_P]),
     "sg_sp_matmul_topn_host": (C.c_int, [_P, C.c_int64, C.c_int64, C.c_int64, _P, _P, _P, _P, _P, _P, C.c_int32,
                                          C.c_int32, C.c_double, C.c_int32, _P, _P, _P]),
+    "sg_row_costs": (C.c_int, [_P, _P, _P, _P]),
     "sg_ctx_stats": (C.c_int, [_P, C.POINTER(SgStats)]),
 }
 
@@ -342,6 +343,11 @@ class Context:
         out = C.c_void_p()
         check(lib().sg_spgemm_topn(self.h, A.h, Bt.h, int(top_n), float(threshold), 1 if sort else 0, C.byref(out)))
         return TopN(self, out)
+
+    def row_costs(self, A: Csr, Bt: Postings) -> np.ndarray:
+        out = np.zeros(max(A.dims()[0], 1), np.int64)
+        check(lib().sg_row_costs(self.h, A.h, Bt.h, _ptr(out)))
+        return out[:A.dims()[0]]
 
     def topn_from_host(self, cols: np.ndarray, vals: np.ndarray, counts: np.ndarray, n_cols: int) -> TopN:
         n_rows, stride = cols.shape

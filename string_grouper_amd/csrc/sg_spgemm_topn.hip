@@ -450,6 +450,20 @@ __global__ void __launch_bounds__(256) count_macs_kernel(const int64_t *__restri
     if ((threadIdx.x & 63) == 0 && local) atomicAdd(out_macs, local);
 }
 
+__global__ void __launch_bounds__(256) row_cost_kernel(const int64_t *__restrict__ a_indptr,
+                                                       const int32_t *__restrict__ a_indices, int64_t n_left,
+                                                       const uint32_t *__restrict__ seg, int32_t n_tiles,
+                                                       int64_t *__restrict__ out_cost) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_left) return;
+    int64_t c = 0;
+    for (int64_t p = a_indptr[i]; p < a_indptr[i + 1]; ++p) {
+        const int64_t k = a_indices[p];
+        c += seg[(k + 1) * n_tiles] - seg[k * n_tiles];
+    }
+    out_cost[i] = c;
+}
+
 __global__ void __launch_bounds__(256) sum_counts_kernel(const int32_t *__restrict__ cnt, int64_t n,
                                                          unsigned long long *out) {
     unsigned long long local = 0;
@@ -731,6 +745,24 @@ extern "C" int sg_spgemm_topn(sg_ctx *ctx, const sg_csr *A, const sg_postings *B
         return st;
     }
     *out = r;
+    return SG_OK;
+}
+
+extern "C" int sg_row_costs(sg_ctx *ctx, const sg_csr *A, const sg_postings *Bt, int64_t *out_cost) {
+    SG_REQUIRE(ctx && A && Bt && out_cost, "null argument");
+    SG_REQUIRE(A->n_cols == Bt->n_terms, "A and B have different numbers of columns");
+    if (A->n_rows == 0) return SG_OK;
+    int64_t *d = nullptr;
+    SG_TRY(sg_alloc(ctx, (size_t)A->n_rows, &d));
+    hipLaunchKernelGGL(row_cost_kernel, dim3((unsigned)((A->n_rows + 255) / 256)), dim3(256), 0, ctx->stream,
+                       A->d_indptr, A->d_indices, A->n_rows, (const uint32_t *)Bt->d_seg, Bt->n_tiles, d);
+    hipError_t e = hipMemcpyAsync(out_cost, d, sizeof(int64_t) * (size_t)A->n_rows, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    ctx->release(d);
+    if (e != hipSuccess) {
+        sg_set_error("sg_row_costs: %s", hipGetErrorString(e));
+        return SG_ERR_HIP;
+    }
     return SG_OK;
 }
 

@@ -146,18 +146,24 @@ def broadcast_strings(ctx, t_bytes, t_offs, src: int = 0, group=None):
 
 
 def sharded_self_join_replicated(ctx, prepared_dev, vectorizer_factory, top_n: int, threshold: float,
-                                 group=None, tile_cols: int = 0):
+                                 group=None, tile_cols: int = 0, balance: bool = True):
     """Strong-scaled self-join when every rank holds the string column in HBM (after
     ``broadcast_strings``): each rank vectorises (K1 + K2, ~4 ms at 663 k -- cheaper than receiving the
     CSR), builds the postings (K3) and multiplies ITS contiguous block of left rows (K4).  No collective
-    inside.  Returns (TopN of the local block, (row_lo, row_hi), n_rows_total)."""
+    inside.  ``balance``: cut the rows so that every rank gets the same number of intermediate products
+    (sg_row_costs) instead of the same number of rows -- matters when the input is sorted.  Returns (TopN of the local block, (row_lo, row_hi), n_rows_total)."""
     rank, world = dist.get_rank(group), dist.get_world_size(group)
     vec = vectorizer_factory()
     vec.fit_prepared([prepared_dev])
     A = vec.transform_prepared(prepared_dev)
     post = ctx.postings_build(A, tile_cols)
     n = A.dims()[0]
-    lo, hi = row_block(rank, world, n)
+    if balance and world > 1:
+        # every rank computes the same cuts from the same costs: no exchange needed
+        cuts = weighted_row_blocks(ctx.row_costs(A, post), world)
+        lo, hi = int(cuts[rank]), int(cuts[rank + 1])
+    else:
+        lo, hi = row_block(rank, world, n)
     block = A.row_block(lo, hi)
     res = ctx.spgemm_topn(block, post, top_n, threshold, True)
     ctx.sync()

@@ -354,3 +354,38 @@ def test_config5_asymmetric_10M_x_1M_one_of_eight_row_blocks(ctx):
     for h in (res, blk, post, A, B):
         h.free()
     ctx.trim()
+
+
+def test_vectoriser_fuzz_against_python_semantics(ctx):
+    """Seeded fuzz of K1/K2 against the reference's analyzer + sklearn: every ASCII byte (controls,
+    punctuation, the \\x1c-\\x1f separators \\s matches), case, non-ASCII that NFKD folds to ASCII,
+    folds to several characters, or drops entirely; empty strings and strings shorter than an n-gram."""
+    from string_grouper_amd.vectorizer import HipTfidfVectorizer
+    rng = np.random.default_rng(2024)
+    ascii_pool = [chr(c) for c in range(1, 128)]
+    uni_pool = list("ÀâÉèïÖüßÑçŁøÆœ") + ["ﬁ", "ﬂ", "Ⅻ", "½", "İ", "ı", "ǅ", "ẞ", "K", "Å", "中", "文", "😀", " ", " ", "́"]
+    words = ["inc", "LLC", "Corp.", "holdings", "a.b.c", "X-Ray", "O'Neil", "  ", "\t", "GmbH & Co. KG"]
+    strings = []
+    for _ in range(4000):
+        kind = rng.integers(0, 4)
+        if kind == 0:
+            n = int(rng.integers(0, 40))
+            s = "".join(ascii_pool[int(x)] for x in rng.integers(0, len(ascii_pool), n))
+        elif kind == 1:
+            n = int(rng.integers(0, 30))
+            s = "".join(uni_pool[int(rng.integers(0, len(uni_pool)))] if rng.random() < 0.3
+                        else ascii_pool[int(rng.integers(31, 127))] for _ in range(n))
+        elif kind == 2:
+            s = " ".join(words[int(x)] for x in rng.integers(0, len(words), int(rng.integers(1, 6))))
+        else:
+            s = "".join(chr(int(x)) for x in rng.integers(97, 123, int(rng.integers(0, 130))))
+        strings.append(s)
+    strings += ["", "a", "ab", "abc", "ABC", "a b c", "...", "\x1c\x1d\x1e\x1f", "ǅ", "İi"]
+    for kw in (dict(), dict(ignore_case=False), dict(ngram_size=2), dict(ngram_size=4)):
+        for dtype in (np.float32, np.float64):
+            (m_ref,), vocab, idf = O.tfidf_sklearn(strings, [strings], dtype=dtype, **kw)
+            vec = HipTfidfVectorizer(dtype=dtype, ctx=ctx, **kw)
+            m_dev = vec.fit(strings).transform(strings)
+            assert vec.vocabulary_ == vocab, kw
+            np.testing.assert_array_equal(vec.idf_, idf)
+            assert_csr_identical(m_dev, sp.csr_matrix(m_ref), f"{kw} {dtype.__name__}")
