@@ -173,6 +173,16 @@ def main():
                              "profiles/ (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE passes)"},
     }
 
+    # measured HBM-side traffic of the same kernel on the same workload, from the committed PMC passes
+    try:
+        with open(os.path.join(ROOT, "profiles", "k4_traffic.json")) as f:
+            tr = json.load(f)
+        if tr.get("workload_rows") == args.rows and tr.get("dtype") == args.dtype and world == 1:
+            result["roofline"]["traffic"] = tr["traffic_bytes_per_launch_raw"]
+            result["roofline"]["traffic_note"] = tr["source"] + "; " + tr["note"]
+    except Exception:
+        pass
+
     if world == 1 and not args.no_cpu_baseline:
         from oracle import oracle as O
         from oracle import port as P

@@ -126,6 +126,7 @@ int sg_spgemm_topn(sg_ctx *ctx, const sg_csr *A, const sg_postings *Bt, int32_t 
 int sg_topn_dims(const sg_topn *r, int64_t *n_rows, int32_t *stride, int32_t *dtype, int64_t *n_cols);
 int sg_topn_device_ptrs(const sg_topn *r, const int32_t **d_cols, const void **d_vals, const int32_t **d_counts);
 int sg_topn_to_host(sg_ctx *ctx, const sg_topn *r, int32_t *cols, void *vals, int32_t *counts);
+int sg_topn_counts_to_host(sg_ctx *ctx, const sg_topn *r, int32_t *counts);   /* the per-row counts only */
 /* Upload a fixed-stride result held on the host (used to feed host CSR blocks to sg_topn_zip). */
 int sg_topn_from_host(sg_ctx *ctx, int64_t n_rows, int64_t n_cols, int32_t stride, int32_t dtype,
                       const int32_t *cols, const void *vals, const int32_t *counts, sg_topn **out);
@@ -142,6 +143,21 @@ int sg_sp_matmul_topn_host(sg_ctx *ctx, int64_t n_left, int64_t n_right, int64_t
                            const int64_t *b_indptr, const int32_t *b_indices, const void *b_data,
                            int32_t dtype, int32_t top_n, double threshold, int32_t sort,
                            int32_t *out_cols, void *out_vals, int32_t *out_counts);
+
+/* ------------------------------------------------------------------ match list (fit() tail) */
+/* Device version of what fit() does with the multiply's result (string_grouper.py:417-431, :755-763):
+ * fix_diagonal: every (r, r) := 1 (added when absent, :954-958); symmetrize: every stored (r, c) also
+ * stored as (c, r) (:960-964); rows come back sorted by column.  With both flags 0 it is a plain
+ * fixed-stride -> CSR compaction that keeps the within-row order unless sort_by_column is set (the
+ * reference's vstack(..., dtype=np.float64) at :750 re-sorts the rows of a float32 result by column as a
+ * side effect of scipy's up-cast; a float64 result keeps the multiply's order).  Entry i of row r is
+ * (r, cols[row_ptr[r] + i], vals[...]). */
+typedef struct sg_matchlist sg_matchlist;
+int sg_matchlist_build(sg_ctx *ctx, const sg_topn *r, int32_t fix_diagonal, int32_t symmetrize,
+                       int32_t sort_by_column, sg_matchlist **out);
+int sg_matchlist_dims(const sg_matchlist *ml, int64_t *n_rows, int64_t *n_entries, int32_t *dtype);
+int sg_matchlist_to_host(sg_ctx *ctx, const sg_matchlist *ml, int64_t *row_ptr, int32_t *cols, void *vals);
+int sg_matchlist_free(sg_matchlist *ml);
 
 /* Cost estimate of every left row for load balancing across GPUs: out_cost[i] = number of
  * intermediate products row i generates = sum over its non-zeros of the posting-list length.

@@ -65,11 +65,16 @@ ABI = {
                                C.POINTER(C.c_int64)]),
     "sg_topn_device_ptrs": (C.c_int, [_P, _PP, _PP, _PP]),
     "sg_topn_to_host": (C.c_int, [_P, _P, _P, _P, _P]),
+    "sg_topn_counts_to_host": (C.c_int, [_P, _P, _P]),
     "sg_topn_from_host": (C.c_int, [_P, C.c_int64, C.c_int64, C.c_int32, C.c_int32, _P, _P, _P, _PP]),
     "sg_topn_zip": (C.c_int, [_P, _PP, _P, C.c_int32, C.c_int32, _PP]),
     "sg_topn_free": (C.c_int, [_P]),
     "sg_sp_matmul_topn_host": (C.c_int, [_P, C.c_int64, C.c_int64, C.c_int64, _P, _P, _P, _P, _P, _P, C.c_int32,
                                          C.c_int32, C.c_double, C.c_int32, _P, _P, _P]),
+    "sg_matchlist_build": (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, _PP]),
+    "sg_matchlist_dims": (C.c_int, [_P, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int32)]),
+    "sg_matchlist_to_host": (C.c_int, [_P, _P, _P, _P, _P]),
+    "sg_matchlist_free": (C.c_int, [_P]),
     "sg_row_costs": (C.c_int, [_P, _P, _P, _P]),
     "sg_ctx_stats": (C.c_int, [_P, C.POINTER(SgStats)]),
 }
@@ -223,6 +228,12 @@ class TopN(_Handle):
         check(lib().sg_topn_to_host(self.ctx.h, self.h, _ptr(cols), _ptr(vals), _ptr(cnt)))
         return cols[:r * s].reshape(r, s), vals[:r * s].reshape(r, s), cnt[:r]
 
+    def counts(self) -> np.ndarray:
+        r = self.dims()[0]
+        cnt = np.zeros(max(r, 1), np.int32)
+        check(lib().sg_topn_counts_to_host(self.ctx.h, self.h, _ptr(cnt)))
+        return cnt[:r]
+
     def to_scipy(self):
         """CSR with the within-row order of the device result (score desc / col asc when sort=True)."""
         import scipy.sparse as sp
@@ -233,6 +244,20 @@ class TopN(_Handle):
         mask = np.arange(s, dtype=np.int32)[None, :] < cnt[:, None]
         idx_dtype = np.int32 if indptr[-1] < 2 ** 31 else np.int64
         return sp.csr_matrix((vals[mask], cols[mask], indptr.astype(idx_dtype)), shape=(r, c))
+
+
+class MatchList(_Handle):
+    _free = "sg_matchlist_free"
+
+    def to_host(self):
+        """(row_ptr int64[n+1], cols int32[m], vals[m])"""
+        r, m, d = C.c_int64(), C.c_int64(), C.c_int32()
+        check(lib().sg_matchlist_dims(self.h, C.byref(r), C.byref(m), C.byref(d)))
+        row_ptr = np.empty(r.value + 1, np.int64)
+        cols = np.empty(max(m.value, 1), np.int32)
+        vals = np.empty(max(m.value, 1), code_np_dtype(d.value))
+        check(lib().sg_matchlist_to_host(self.ctx.h, self.h, _ptr(row_ptr), _ptr(cols), _ptr(vals)))
+        return row_ptr, cols[:m.value], vals[:m.value]
 
 
 class Context:
@@ -343,6 +368,12 @@ class Context:
         out = C.c_void_p()
         check(lib().sg_spgemm_topn(self.h, A.h, Bt.h, int(top_n), float(threshold), 1 if sort else 0, C.byref(out)))
         return TopN(self, out)
+
+    def matchlist_build(self, res: TopN, fix_diagonal: bool, symmetrize: bool, sort_by_column: bool = False) -> MatchList:
+        out = C.c_void_p()
+        check(lib().sg_matchlist_build(self.h, res.h, 1 if fix_diagonal else 0, 1 if symmetrize else 0,
+                                       1 if sort_by_column else 0, C.byref(out)))
+        return MatchList(self, out)
 
     def row_costs(self, A: Csr, Bt: Postings) -> np.ndarray:
         out = np.zeros(max(A.dims()[0], 1), np.int64)

@@ -799,6 +799,14 @@ extern "C" int sg_topn_to_host(sg_ctx *ctx, const sg_topn *r, int32_t *cols, voi
     return SG_OK;
 }
 
+extern "C" int sg_topn_counts_to_host(sg_ctx *ctx, const sg_topn *r, int32_t *counts) {
+    SG_REQUIRE(ctx && r && counts, "null argument");
+    if (r->n_rows > 0)
+        SG_HIP_TRY(hipMemcpyAsync(counts, r->d_counts, (size_t)r->n_rows * 4, hipMemcpyDeviceToHost, ctx->stream));
+    SG_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return SG_OK;
+}
+
 extern "C" int sg_topn_from_host(sg_ctx *ctx, int64_t n_rows, int64_t n_cols, int32_t stride, int32_t dtype,
                                  const int32_t *cols, const void *vals, const int32_t *counts, sg_topn **out) {
     SG_REQUIRE(ctx && counts && out && n_rows >= 0 && stride >= 1, "bad argument");

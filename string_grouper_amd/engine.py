@@ -88,6 +88,25 @@ class HipEngine:
         post.free()
         return C
 
+    # ------------------------------------------------------------------ fused tail of fit() (K6)
+    def match_list(self, A: DeviceMatrix, B: DeviceMatrix, top_n: int, threshold: float, self_join_fix: bool):
+        """Multiply and build the match list without leaving the device: (master_side, dupe_side,
+        similarity, true_max_n_matches).  ``self_join_fix``: set the diagonal to 1 and symmetrise
+        (string_grouper.py:419-427); the rows then come back sorted by column."""
+        post = self.ctx.postings_build(B.csr)
+        res = self.ctx.spgemm_topn(A.csr, post, top_n, threshold, True)
+        cnt = res.counts()
+        true_max = int(cnt.max()) if len(cnt) else 0
+        # the reference up-casts a float32 result to float64 through scipy (vstack(dtype=float64), :750),
+        # which re-sorts every row by column; a float64 result keeps the multiply's score-descending order
+        ml = self.ctx.matchlist_build(res, self_join_fix, self_join_fix,
+                                      sort_by_column=(not self_join_fix) and A.dtype == np.float32)
+        row_ptr, cols, vals = ml.to_host()
+        for h in (ml, res, post):
+            h.free()
+        rows = np.repeat(np.arange(len(row_ptr) - 1, dtype=np.int64), np.diff(row_ptr))
+        return rows, cols.astype(np.int64), vals, true_max
+
     def topn_multiply_blocked(self, A: DeviceMatrix, B: DeviceMatrix, n_blocks: Tuple[int, int], top_n: int,
                               threshold: float) -> sp.csr_matrix:
         """Block-pair products, zipped over right blocks, stacked over left blocks

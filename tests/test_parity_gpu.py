@@ -389,3 +389,40 @@ def test_vectoriser_fuzz_against_python_semantics(ctx):
             assert vec.vocabulary_ == vocab, kw
             np.testing.assert_array_equal(vec.idf_, idf)
             assert_csr_identical(m_dev, sp.csr_matrix(m_ref), f"{kw} {dtype.__name__}")
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_fused_device_tail_equals_host_tail(ctx, dtype):
+    """K6 (diagonal := 1, symmetrise, match list on the device) against the host implementation of the
+    same reference semantics (string_grouper.py:417-431, :954-964, :755-763), self-join with hub rows
+    (many exact duplicates, max_n_matches small so that mirrors overflow the per-row cap) and two-series."""
+    import pandas as pd
+    import string_grouper_amd as sga
+    import string_grouper_amd.engine as E
+    old = E._engine
+    E.set_engine(E.HipEngine(ctx))
+    try:
+        names = _names(20000, seed=3) + ["ACME HOLDINGS INC"] * 300 + ["ACME HOLDING INC"] * 5 + ["", "ab"]
+        s = pd.Series(names)
+        for kw in (dict(max_n_matches=3, min_similarity=0.6), dict(max_n_matches=20, min_similarity=0.8)):
+            sg_dev = sga.StringGrouper(s, tfidf_matrix_dtype=dtype, **kw)
+            sg_dev.fit()
+            sg_host = sga.StringGrouper(s, tfidf_matrix_dtype=dtype, **kw)
+            sg_host._can_fuse_on_device = lambda: False
+            sg_host.fit()
+            pd.testing.assert_frame_equal(sg_dev._matches_list, sg_host._matches_list)
+            assert sg_dev._true_max_n_matches == sg_host._true_max_n_matches
+            # reference invariants: every string matches itself with similarity exactly 1, list is symmetric
+            ml = sg_dev._matches_list
+            diag = ml[ml.master_side == ml.dupe_side]
+            assert len(diag) == len(s) and (diag.similarity == 1.0).all()
+            fwd = set(zip(ml.master_side.tolist(), ml.dupe_side.tolist()))
+            assert all((c, r) in fwd for r, c in fwd)
+        d = pd.Series(_names(3000, seed=4))
+        sg_dev = sga.StringGrouper(s, d, tfidf_matrix_dtype=dtype, max_n_matches=5, min_similarity=0.5).fit()
+        sg_host = sga.StringGrouper(s, d, tfidf_matrix_dtype=dtype, max_n_matches=5, min_similarity=0.5)
+        sg_host._can_fuse_on_device = lambda: False
+        sg_host.fit()
+        pd.testing.assert_frame_equal(sg_dev._matches_list, sg_host._matches_list)
+    finally:
+        E.set_engine(old)
