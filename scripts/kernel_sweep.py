@@ -28,7 +28,7 @@ def tfidf_device(ctx, names, dtype):
 
 
 def main():
-    sizes = [int(x) for x in (sys.argv[1] if len(sys.argv) > 1 else "100000,663000").split(",")]
+    sizes = [int(x) for x in (sys.argv[1] if len(sys.argv) > 1 else "663000").split(",")]
     ctx = N.default_context(0)
     for n in sizes:
         names = synth_names(n, 1234)
@@ -40,12 +40,12 @@ def main():
                 from oracle import oracle as O
                 (m,), _, _ = O.tfidf_sklearn(names, [names], dtype=dtype)
                 A = ctx.csr_from_scipy(m)
-            for tile in (2048, 4096):
+            for tile in (1024, 2048):
                 t0 = time.perf_counter()
                 post = ctx.postings_build(A, tile)
                 ctx.sync()
                 t_post = time.perf_counter() - t0
-                for group, depth in [(0, 4), (0, 8), (0, 16)]:
+                for group, depth in [(0, 8), (0, 16)]:
                     for wpc in (0,):
                         os.environ["SG_TILE_GROUP"] = str(group)
                         os.environ["SG_DEPTH"] = str(depth)
