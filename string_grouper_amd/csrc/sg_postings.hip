@@ -14,6 +14,8 @@
 //
 // Bound: HBM.  Algorithmic bytes = 2 * nnz * (4 + s) + 4 * (V * n_tiles + n) (read B twice,
 // write postings once, histogram + scan of the segment table).
+#include <stdlib.h>
+
 #include "sg_internal.h"
 
 template <typename T>
@@ -72,7 +74,12 @@ extern "C" int sg_postings_build(sg_ctx *ctx, const sg_csr *B, int32_t tile_cols
     if (tile_cols == 0) tile_cols = B->dtype == SG_F64 ? 1024 : 2048;   // 8 KiB of LDS per wave: 20 waves per CU
     SG_REQUIRE(tile_cols >= 256 && tile_cols <= 32768 && (tile_cols & (tile_cols - 1)) == 0,
                "tile_cols must be a power of two in [256, 32768]");
-    if (B->nnz + 64 >= ((int64_t)1 << 29)) {   // the multiply addresses postings with 32-bit BYTE offsets (8 B entries)
+    int64_t max_entries = (int64_t)1 << 29;   // the multiply addresses postings with 32-bit BYTE offsets (8 B entries)
+    if (const char *v = getenv("SG_MAX_POSTINGS")) {   // test hook: force the right-hand split at small sizes
+        const long long o = atoll(v);
+        if (o > 0 && o < max_entries) max_entries = o;
+    }
+    if (B->nnz + 64 >= max_entries) {
         sg_set_error("right-hand matrix has %lld non-zeros; one postings block holds < 2^29 (use more right-hand blocks)",
                      (long long)B->nnz);
         return SG_ERR_OVERFLOW;

@@ -79,13 +79,48 @@ class HipEngine:
         return d
 
     # ------------------------------------------------------------------ seam b2
+    def _topn_device(self, A: DeviceMatrix, B: DeviceMatrix, top_n: int, threshold: float) -> "N.TopN":
+        """Top-n multiply with the result left on the device.  One inverted index normally; when the
+        right-hand side is too large for one (SG_ERR_OVERFLOW -> OverflowError, what the reference's
+        fit() reacts to by splitting, string_grouper.py:397-413) it is cut into the fewest row blocks that
+        fit and the partial results are merged on the device (K5 = zip_sp_matmul_topn)."""
+        ctx = self.ctx
+        try:
+            post = ctx.postings_build(B.csr)
+        except OverflowError:
+            post = None
+        if post is not None:
+            res = ctx.spgemm_topn(A.csr, post, top_n, threshold, True)
+            post.free()
+            return res
+        n_blocks = 2
+        while True:
+            ranges = chunk_ranges(B.shape[0], n_blocks)
+            views, posts = [], []
+            try:
+                for lo, hi in ranges:
+                    v = B.csr.row_block(lo, hi)
+                    views.append(v)
+                    posts.append(ctx.postings_build(v))
+                break
+            except OverflowError:
+                for h in posts + views:
+                    h.free()
+                n_blocks *= 2
+                if n_blocks > max(B.shape[0], 2):
+                    raise
+        parts = [ctx.spgemm_topn(A.csr, p, top_n, threshold, True) for p in posts]
+        res = ctx.topn_zip(parts, np.array([lo for lo, _ in ranges], dtype=np.int64), top_n)
+        for h in parts + posts + views:
+            h.free()
+        return res
+
     def topn_multiply(self, A: DeviceMatrix, B: DeviceMatrix, top_n: int, threshold: float) -> sp.csr_matrix:
         """sp_matmul_topn(A, B.T, top_n, threshold, sort=True) (string_grouper.py:725-732)."""
-        post = self.ctx.postings_build(B.csr)
-        res = self.ctx.spgemm_topn(A.csr, post, top_n, threshold, True)
+        res = self._topn_device(A, B, top_n, threshold)
         C = res.to_scipy()
+        C = sp.csr_matrix((C.data, C.indices, C.indptr), shape=(A.shape[0], B.shape[0]))
         res.free()
-        post.free()
         return C
 
     # ------------------------------------------------------------------ fused tail of fit() (K6)
@@ -93,8 +128,7 @@ class HipEngine:
         """Multiply and build the match list without leaving the device: (master_side, dupe_side,
         similarity, true_max_n_matches).  ``self_join_fix``: set the diagonal to 1 and symmetrise
         (string_grouper.py:419-427); the rows then come back sorted by column."""
-        post = self.ctx.postings_build(B.csr)
-        res = self.ctx.spgemm_topn(A.csr, post, top_n, threshold, True)
+        res = self._topn_device(A, B, top_n, threshold)
         cnt = res.counts()
         true_max = int(cnt.max()) if len(cnt) else 0
         # the reference up-casts a float32 result to float64 through scipy (vstack(dtype=float64), :750),
@@ -102,7 +136,7 @@ class HipEngine:
         ml = self.ctx.matchlist_build(res, self_join_fix, self_join_fix,
                                       sort_by_column=(not self_join_fix) and A.dtype == np.float32)
         row_ptr, cols, vals = ml.to_host()
-        for h in (ml, res, post):
+        for h in (ml, res):
             h.free()
         rows = np.repeat(np.arange(len(row_ptr) - 1, dtype=np.int64), np.diff(row_ptr))
         return rows, cols.astype(np.int64), vals, true_max

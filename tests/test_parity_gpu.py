@@ -426,3 +426,20 @@ def test_fused_device_tail_equals_host_tail(ctx, dtype):
         pd.testing.assert_frame_equal(sg_dev._matches_list, sg_host._matches_list)
     finally:
         E.set_engine(old)
+
+
+def test_oversized_right_hand_side_is_split_and_zipped(ctx, mats, monkeypatch):
+    """When one inverted index cannot hold the right-hand side the engine cuts it into blocks and merges
+    on the device -- same result (forced here at a small size through the SG_MAX_POSTINGS test hook)."""
+    import string_grouper_amd.engine as E
+    eng = E.HipEngine(ctx)
+    A = eng.wrap(mats[np.float32][:6000])
+    B = eng.wrap(mats[np.float32])
+    ref = eng.topn_multiply(A, B, 10, 0.6)
+    monkeypatch.setenv("SG_MAX_POSTINGS", "120000")          # 20 k rows x 19 nnz = 380 k entries -> 4 blocks
+    got = eng.topn_multiply(A, B, 10, 0.6)
+    assert_csr_identical(got, ref)
+    rows, cols, sims, tmax = eng.match_list(B, B, 10, 0.8, True)
+    monkeypatch.delenv("SG_MAX_POSTINGS")
+    rows2, cols2, sims2, tmax2 = eng.match_list(B, B, 10, 0.8, True)
+    assert np.array_equal(rows, rows2) and np.array_equal(cols, cols2) and np.array_equal(sims, sims2) and tmax == tmax2
