@@ -115,7 +115,9 @@ int sg_csr_free(sg_csr *m);
 
 /* ------------------------------------------------------------------ seam b2: sparse top-n multiply */
 /* Inverted index of B (n_right x V): for every term k the (row j, value) pairs, grouped by column
- * tile j / tile_cols.  tile_cols must be a power of two supported by the multiply (0 = default). */
+ * tile j / tile_cols.  tile_cols must be a power of two supported by the multiply (0 = default).
+ * The postings keep a reference to B's arrays (the multiply re-scores candidates against B's rows):
+ * B must stay alive until the postings are freed. */
 int sg_postings_build(sg_ctx *ctx, const sg_csr *B, int32_t tile_cols, sg_postings **out);
 int sg_postings_free(sg_postings *p);
 

@@ -114,6 +114,11 @@ struct sg_postings {
     int32_t tile_log2 = 12;
     int32_t n_tiles = 0;
     // seg[k * n_tiles + t] .. seg[k * n_tiles + t + 1] = postings of term k whose row lies in tile t
+    // the CSR the postings were built from (borrowed: it must outlive the postings); the fast path of the
+    // multiply re-scores its candidates by merging row i of A with row j of this matrix
+    const int64_t *b_indptr = nullptr;
+    const int32_t *b_indices = nullptr;
+    const void *b_data = nullptr;
     uint32_t *d_seg = nullptr;           // n_terms * n_tiles + 1
     int32_t *d_rows = nullptr;           // nnz   (row j of B)
     void *d_vals = nullptr;              // nnz   (value B[j, k])

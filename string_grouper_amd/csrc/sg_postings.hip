@@ -102,6 +102,9 @@ extern "C" int sg_postings_build(sg_ctx *ctx, const sg_csr *B, int32_t tile_cols
     p->dtype = B->dtype;
     p->tile_log2 = tile_log2;
     p->n_tiles = (int32_t)n_tiles64;
+    p->b_indptr = B->d_indptr;
+    p->b_indices = B->d_indices;
+    p->b_data = B->d_data;
     const size_t vs = 8;   // f64 value, or packed {row, f32 value}
     uint32_t *cursor = nullptr;
     int st = sg_alloc(ctx, (size_t)n_bins + 1, &p->d_seg);
