@@ -415,9 +415,7 @@ spgemm_topn_kernel(const int64_t *__restrict__ a_indptr, const int32_t *__restri
                    const int32_t *__restrict__ post_rows, const T *__restrict__ post_vals, int32_t n_tiles,
                    int32_t tile_begin, int32_t tile_end, int32_t keep /* <= 64 entries this pass */,
                    int32_t pass_off /* 64 * pass */, int32_t out_stride, T thr, int32_t *__restrict__ out_cols,
-                   T *__restrict__ out_vals, int32_t *__restrict__ out_cnt, uint32_t *row_counter,
-                   const uint32_t *__restrict__ row_list /* null: all rows */,
-                   const uint32_t *__restrict__ row_list_len) {
+                   T *__restrict__ out_vals, int32_t *__restrict__ out_cnt, uint32_t *row_counter) {
     constexpr int TILE = 1 << TILE_LOG2;
     constexpr int VEC = 16 / sizeof(T);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -426,224 +424,13 @@ spgemm_topn_kernel(const int64_t *__restrict__ a_indptr, const int32_t *__restri
     typedef T vec_t __attribute__((ext_vector_type(VEC)));
     vec_t *acc_v = reinterpret_cast<vec_t *>(acc);
     for (int x = lane; x < TILE / VEC; x += 64) acc_v[x] = (vec_t)(T)0;
-    if (row_list) n_left = row_list_len[0];   // the rows the fast path handed over (often none)
 
     SG_WD_DECL(wd_rows);
-    for (uint32_t idx = next_row(row_counter, lane); idx < n_left; idx = next_row(row_counter, lane)) {
+    for (uint32_t row = next_row(row_counter, lane); row < n_left; row = next_row(row_counter, lane)) {
         SG_WD(wd_rows, n_left + 2, 1)
-        const uint32_t row = row_list ? row_list[idx] : idx;
         process_row<T, TILE_LOG2, NB>(acc, row, a_indptr, a_indices, a_data, seg, post_rows, post_vals, n_tiles,
                                       tile_begin, tile_end, keep, pass_off, out_stride, thr, out_cols, out_vals,
                                       out_cnt, lane);
-    }
-}
-
-// =================================================================================================
-// Fast path (top_n <= 64, threshold well above 0, one launch): order-free accumulation + exact re-scoring.
-//
-// The exact kernel above spends most of its instructions on posting segments that hold 1-4 entries
-// (62 % of all segment visits, 20 % of the products): each costs a full visit (descriptor through
-// v_readlane, load, read-add-write) for a handful of useful lanes, and they cannot share an instruction
-// because two segments may hit the same column and the summation order must stay ascending in k.
-// Here that constraint is lifted where it is cheap to restore exactness afterwards:
-//   1. tiny segments (<= TINY entries) are processed lane-per-segment: lane l walks ITS segment, all
-//      lanes at once, with LDS float atomics (collision safe, order free); longer segments keep the
-//      batched read-add-write.  The accumulated scores are therefore correct up to rounding order:
-//      |approx - exact| <= 128 u (u = unit round-off), far below eps = SG_EPS.
-//   2. the tile sweep collects every column with approx > thr - eps (a superset of the true matches)
-//      into the register list and counts them; a row with more than 64 candidates (a "hub" with dozens
-//      of duplicates) is handed to the exact kernel through a row list.
-//   3. at the end of the row each lane re-scores one candidate EXACTLY: sorted merge of CSR row i of A
-//      and row j of B in ascending k, product and sum rounded separately -- the reference's arithmetic
-//      -- then the strict threshold, the canonical order (score desc, column asc) and the top-n cut are
-//      applied to exact scores.  Output is bit-identical to the exact kernel (tests compare the two).
-template <typename T>
-struct Eps;
-template <>
-struct Eps<float> {
-    static constexpr float value = 1e-5f;
-};
-template <>
-struct Eps<double> {
-    static constexpr double value = 1e-13;
-};
-
-template <typename T>
-__device__ __forceinline__ void lds_atomic_add(T *p, T v) {
-    (void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-}
-
-// sort the 64 (score, col) pairs of a wave by (score desc, col asc): bitonic network over lanes
-template <typename T>
-__device__ __forceinline__ void wave_sort_desc(T &s, int &c, int lane) {
-#pragma unroll
-    for (int k = 2; k <= 64; k <<= 1) {
-#pragma unroll
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            const T os = __shfl_xor(s, j, 64);
-            const int oc = __shfl_xor(c, j, 64);
-            const bool mine_first = (s > os) || (s == os && c < oc);   // "I rank before the partner"
-            const bool lower = (lane & j) == 0;                         // I am the lower lane of the pair
-            const bool asc_block = (lane & k) == 0;                     // this block sorts best-first
-            const bool keep_mine = (lower == asc_block) ? mine_first : !mine_first;
-            if (!keep_mine) {
-                s = os;
-                c = oc;
-            }
-        }
-    }
-}
-
-template <typename T, int TILE_LOG2, int NB, int TINY>
-__global__ void __launch_bounds__(64)
-spgemm_topn_fast_kernel(const int64_t *__restrict__ a_indptr, const int32_t *__restrict__ a_indices,
-                        const T *__restrict__ a_data, uint32_t n_left, const uint32_t *__restrict__ seg,
-                        const int32_t *__restrict__ post_rows, const T *__restrict__ post_vals, int32_t n_tiles,
-                        const int64_t *__restrict__ b_indptr, const int32_t *__restrict__ b_indices,
-                        const T *__restrict__ b_data, int32_t keep, int32_t out_stride, T thr,
-                        int32_t *__restrict__ out_cols, T *__restrict__ out_vals, int32_t *__restrict__ out_cnt,
-                        uint32_t *row_counter, uint32_t *flagged_count, uint32_t *flagged_rows) {
-    constexpr int TILE = 1 << TILE_LOG2;
-    constexpr int VEC = 16 / sizeof(T);
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    T *acc = reinterpret_cast<T *>(smem);
-    const int lane = threadIdx.x;
-    typedef T vec_t __attribute__((ext_vector_type(VEC)));
-    vec_t *acc_v = reinterpret_cast<vec_t *>(acc);
-    for (int x = lane; x < TILE / VEC; x += 64) acc_v[x] = (vec_t)(T)0;
-    const char *vals = reinterpret_cast<const char *>(post_vals);
-    const char *slots = reinterpret_cast<const char *>(post_rows);
-    const T thr_c = thr - Eps<T>::value;   // candidate threshold (caller guarantees thr_c > 0)
-
-    for (uint32_t row = next_row(row_counter, lane); row < n_left; row = next_row(row_counter, lane)) {
-        const int64_t rlo = a_indptr[row];
-        const int nnz = (int)(a_indptr[row + 1] - rlo);
-        const size_t obase = (size_t)row * (size_t)out_stride;
-        if (nnz > 64) {   // rows with more non-zeros than lanes: exact kernel
-            if (lane == 0) flagged_rows[atomicAdd(flagged_count, 1u)] = row;
-            continue;
-        }
-        TopList<T> top;
-        top.clear();
-        uint32_t n_cand = 0;
-        if (nnz > 0) {
-            int k0 = -1;
-            T a0 = (T)0;
-            if (lane < nnz) {
-                k0 = a_indices[rlo + lane];
-                a0 = a_data[rlo + lane];
-            }
-            uint32_t lo0 = 0, hi0 = 0, hi_next = 0;
-            if (k0 >= 0) {
-                const uint32_t *sp = seg + (int64_t)k0 * n_tiles;
-                lo0 = sp[0];
-                hi0 = sp[1];
-            }
-            for (int t = 0; t < n_tiles; ++t) {
-                if (k0 >= 0 && t + 1 < n_tiles) hi_next = seg[(int64_t)k0 * n_tiles + t + 2];
-                const uint32_t len = hi0 - lo0;
-                const uint64_t any = __ballot(len > 0);
-                if (any) {
-                    // ---- tiny segments: lane-per-segment, loads first, then LDS atomics
-                    const bool tiny = len > 0 && len <= (uint32_t)TINY;
-                    if (__ballot(tiny) != 0) {
-                        typename Post<T>::reg_t r[TINY];
-#pragma unroll
-                        for (int e = 0; e < TINY; ++e)
-                            if (tiny && (uint32_t)e < len) r[e] = Post<T>::load(vals, slots, lo0, (uint32_t)e);
-#pragma unroll
-                        for (int e = 0; e < TINY; ++e)
-                            if (tiny && (uint32_t)e < len)
-                                lds_atomic_add<T>(acc_at(acc, Post<T>::slot(r[e])), mul_rn<T>(a0, Post<T>::val(r[e])));
-                    }
-                    // ---- longer segments: batched read-add-write as in the exact kernel
-                    uint64_t m = __ballot(len > (uint32_t)TINY);
-                    while (__popcll(m) >= NB) segment_batch<T, NB, false>(acc, vals, slots, m, lo0, hi0, a0, lane);
-                    if (m) segment_batch<T, NB, true>(acc, vals, slots, m, lo0, hi0, a0, lane);
-                    // ---- sweep: candidates are accumulators above thr - eps
-                    const int col_base = t << TILE_LOG2;
-                    for (int x1 = 0; x1 < TILE / VEC; x1 += 256) {
-                        vec_t vv[4];
-#pragma unroll
-                        for (int u = 0; u < 4; ++u) vv[u] = acc_v[x1 + u * 64 + lane];
-#pragma unroll
-                        for (int u = 0; u < 4; ++u) acc_v[x1 + u * 64 + lane] = (vec_t)(T)0;
-#pragma unroll
-                        for (int u = 0; u < 4; ++u) {
-                            const vec_t v = vv[u];
-                            const int x0 = x1 + u * 64;
-                            if (__ballot(any_above<T>(v, thr_c)) != 0) {
-#pragma unroll
-                                for (int e = 0; e < VEC; ++e) {
-                                    uint64_t hm = __ballot(v[e] > thr_c);
-                                    n_cand += __popcll(hm);
-                                    while (hm) {
-                                        const int src = __builtin_ctzll(hm);
-                                        hm &= hm - 1;
-                                        top.insert(wave_read<T>(v[e], src), col_base + (x0 + src) * VEC + e, lane);
-                                    }
-                                }
-                            }
-                        }
-                    }
-                }
-                lo0 = hi0;
-                hi0 = hi_next;
-            }
-        }
-        if (n_cand > 64) {   // more candidates than the list holds: exact kernel for this row
-            if (lane == 0) flagged_rows[atomicAdd(flagged_count, 1u)] = row;
-            continue;
-        }
-        // ---- exact re-scoring: lane q takes candidate q; row i of A is staged in the (all-zero) tile
-        if (n_cand > 0) {
-            int *lk = reinterpret_cast<int *>(acc);
-            T *la = reinterpret_cast<T *>(reinterpret_cast<char *>(acc) + 64 * sizeof(int));
-            if (lane < nnz) {
-                lk[lane] = a_indices[rlo + lane];
-                la[lane] = a_data[rlo + lane];
-            }
-            __syncthreads();
-            T exact = -INFINITY;
-            int col = INT32_MAX;
-            if ((uint32_t)lane < n_cand) {
-                col = top.c;
-                int64_t pb = b_indptr[col];
-                const int64_t pb_end = b_indptr[col + 1];
-                int pa = 0;
-                T sum = (T)0;
-                while (pa < nnz && pb < pb_end) {
-                    const int ka = lk[pa];
-                    const int kb = b_indices[pb];
-                    if (ka == kb) {
-                        sum = add_rn<T>(sum, mul_rn<T>(la[pa], b_data[pb]));
-                        ++pa;
-                        ++pb;
-                    } else if (ka < kb) {
-                        ++pa;
-                    } else {
-                        ++pb;
-                    }
-                }
-                if (sum > thr) exact = sum;
-                else col = INT32_MAX;
-            }
-            __syncthreads();
-            if (lane < nnz) {   // give the tile back all-zero
-                lk[lane] = 0;
-                la[lane] = (T)0;
-            }
-            wave_sort_desc<T>(exact, col, lane);
-            int cnt = __popcll(__ballot(col != INT32_MAX));
-            if (cnt > keep) cnt = keep;
-            if (lane < cnt) {
-                out_vals[obase + lane] = exact;
-                out_cols[obase + lane] = col;
-            }
-            if (lane == 0) out_cnt[row] = cnt;
-        } else if (lane == 0) {
-            out_cnt[row] = 0;
-        }
     }
 }
 
@@ -785,8 +572,7 @@ static int env_int(const char *name, int dflt) {
 
 template <typename T, int TILE_LOG2, int DEPTH>
 static int launch_spgemm(sg_ctx *ctx, const sg_csr *A, const sg_postings *Bt, int32_t tile_begin, int32_t tile_end,
-                         int32_t keep, int32_t pass_off, sg_topn *r, T thr, uint32_t *counter, unsigned grid,
-                         const uint32_t *row_list = nullptr, const uint32_t *row_list_len = nullptr) {
+                         int32_t keep, int32_t pass_off, sg_topn *r, T thr, uint32_t *counter, unsigned grid) {
     const size_t lds = sizeof(T) << TILE_LOG2;
     auto kern = spgemm_topn_kernel<T, TILE_LOG2, DEPTH>;
     if (lds > 48 * 1024) {
@@ -799,37 +585,9 @@ static int launch_spgemm(sg_ctx *ctx, const sg_csr *A, const sg_postings *Bt, in
     hipLaunchKernelGGL(kern, dim3(grid), dim3(64), lds, ctx->stream, A->d_indptr, A->d_indices, (const T *)A->d_data,
                        (uint32_t)A->n_rows, (const uint32_t *)Bt->d_seg, (const int32_t *)Bt->d_rows,
                        (const T *)Bt->d_vals, Bt->n_tiles, tile_begin, tile_end, keep, pass_off, r->stride, thr,
-                       r->d_cols, (T *)r->d_vals, r->d_counts, counter, row_list, row_list_len);
+                       r->d_cols, (T *)r->d_vals, r->d_counts, counter);
     SG_HIP_TRY(hipGetLastError());
     return SG_OK;
-}
-
-// fast path: order-free accumulation + exact re-scoring, then the exact kernel on the rows it handed over
-template <typename T, int TILE_LOG2>
-static int launch_fast(sg_ctx *ctx, const sg_csr *A, const sg_postings *Bt, int32_t keep, sg_topn *r, T thr,
-                       uint32_t *counters /* [0] fast rows, [1] exact rows, [2] flagged count */,
-                       uint32_t *flagged_rows, unsigned grid) {
-    const size_t lds = sizeof(T) << TILE_LOG2;
-    hipLaunchKernelGGL((spgemm_topn_fast_kernel<T, TILE_LOG2, 8, 4>), dim3(grid), dim3(64), lds, ctx->stream,
-                       A->d_indptr, A->d_indices, (const T *)A->d_data, (uint32_t)A->n_rows,
-                       (const uint32_t *)Bt->d_seg, (const int32_t *)Bt->d_rows, (const T *)Bt->d_vals, Bt->n_tiles,
-                       Bt->b_indptr, Bt->b_indices, (const T *)Bt->b_data, keep, r->stride, thr, r->d_cols,
-                       (T *)r->d_vals, r->d_counts, counters + 0, counters + 2, flagged_rows);
-    SG_HIP_TRY(hipGetLastError());
-    // rows with > 64 candidates or > 64 non-zeros: exact kernel over the row list (reads its length on the device)
-    return launch_spgemm<T, TILE_LOG2, 8>(ctx, A, Bt, 0, Bt->n_tiles, keep, 0, r, thr, counters + 1, grid, flagged_rows,
-                                          counters + 2);
-}
-
-template <typename T>
-static int dispatch_fast(sg_ctx *ctx, const sg_csr *A, const sg_postings *Bt, int32_t keep, sg_topn *r, T thr,
-                         uint32_t *counters, uint32_t *flagged_rows, unsigned grid) {
-    switch (Bt->tile_log2) {
-        case 10: return launch_fast<T, 10>(ctx, A, Bt, keep, r, thr, counters, flagged_rows, grid);
-        case 11: return launch_fast<T, 11>(ctx, A, Bt, keep, r, thr, counters, flagged_rows, grid);
-        case 12: return launch_fast<T, 12>(ctx, A, Bt, keep, r, thr, counters, flagged_rows, grid);
-        default: return SG_ERR_UNSUPPORTED;
-    }
 }
 
 template <typename T, int TILE_LOG2>
@@ -924,33 +682,20 @@ extern "C" int sg_spgemm_topn(sg_ctx *ctx, const sg_csr *A, const sg_postings *B
     unsigned grid = (unsigned)ctx->num_cu * (unsigned)waves_per_cu;
     if ((int64_t)grid > A->n_rows) grid = (unsigned)(A->n_rows > 0 ? A->n_rows : 1);
 
-    // fast path (see spgemm_topn_fast_kernel): needs the whole result in one register list (top_n <= 64),
-    // a candidate threshold thr - eps that is still > 0, one launch, and the source CSR of the postings
-    const bool fast = stride <= SG_TOPN_LANES && threshold >= 0.25 && n_groups == 1 && Bt->b_indptr != nullptr &&
-                      Bt->tile_log2 >= 10 && Bt->tile_log2 <= 12 && A->n_rows > 0 && env_int("SG_EXACT_ONLY", 0) == 0;
     uint32_t *counters = nullptr;
-    uint32_t *flagged_rows = nullptr;
-    int st = sg_alloc(ctx, (size_t)n_launch + 4, &counters);
-    if (st == SG_OK && fast) st = sg_alloc(ctx, (size_t)A->n_rows + 1, &flagged_rows);
+    int st = sg_alloc(ctx, (size_t)n_launch + 1, &counters);
     if (st != SG_OK) {
-        ctx->release(counters);
         sg_topn_free(r);
         return st;
     }
     {
         SgTimer timer(ctx, SG_K_SPGEMM);
         st = SG_OK;
-        if (hipMemsetAsync(counters, 0, sizeof(uint32_t) * (size_t)(n_launch + 4), ctx->stream) != hipSuccess ||
+        if (hipMemsetAsync(counters, 0, sizeof(uint32_t) * (size_t)(n_launch + 1), ctx->stream) != hipSuccess ||
             hipMemsetAsync(r->d_counts, 0, sizeof(int32_t) * (size_t)A->n_rows, ctx->stream) != hipSuccess)
             st = SG_ERR_HIP;
         int li = 0;
-        if (fast && st == SG_OK) {
-            if (A->dtype == SG_F64)
-                st = dispatch_fast<double>(ctx, A, Bt, stride, r, (double)threshold, counters, flagged_rows, grid);
-            else
-                st = dispatch_fast<float>(ctx, A, Bt, stride, r, (float)threshold, counters, flagged_rows, grid);
-        }
-        for (int pass = 0; pass < n_pass && st == SG_OK && A->n_rows > 0 && !fast; ++pass) {
+        for (int pass = 0; pass < n_pass && st == SG_OK && A->n_rows > 0; ++pass) {
             const int pass_off = pass * SG_TOPN_LANES;
             const int keep = stride - pass_off < SG_TOPN_LANES ? stride - pass_off : SG_TOPN_LANES;
             for (int g = 0; g < n_groups && st == SG_OK; ++g, ++li) {
@@ -995,7 +740,6 @@ extern "C" int sg_spgemm_topn(sg_ctx *ctx, const sg_csr *A, const sg_postings *B
         if (hipGetLastError() != hipSuccess) st = SG_ERR_HIP;
     }
     ctx->release(counters);
-    ctx->release(flagged_rows);
     if (st != SG_OK) {
         sg_topn_free(r);
         return st;
