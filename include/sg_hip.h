@@ -173,6 +173,11 @@ typedef struct {
     int64_t macs;             /* intermediate products of the most recent sg_spgemm_topn            */
     int64_t spgemm_bytes;     /* its algorithmic bytes (stream model)                    */
     int64_t out_nnz;          /* entries kept by the most recent sg_spgemm_topn                     */
+    /* the most recent multiply, when it took the pruned kernel (all zero otherwise):                */
+    int64_t prune_rows;       /* left rows it processed                                             */
+    int64_t prune_postings;   /* postings it streamed (of `macs` the exact kernel would)            */
+    int64_t prune_survivors;  /* candidate pairs it scored exactly                                  */
+    int64_t exact_rows;       /* left rows it handed to the exact kernel                            */
 } sg_stats;
 /* Waits for the recorded events, so it is a synchronisation point. */
 int sg_ctx_stats(sg_ctx *ctx, sg_stats *out);

@@ -165,6 +165,10 @@ extern "C" int sg_ctx_stats(sg_ctx *ctx, sg_stats *out) {
     }
     out->macs = ctx->h_stat_words[0];
     out->out_nnz = ctx->h_stat_words[1];
+    out->prune_rows = ctx->h_stat_words[2];
+    out->prune_postings = ctx->h_stat_words[3];
+    out->prune_survivors = ctx->h_stat_words[4];
+    out->exact_rows = ctx->h_stat_words[5];
     out->spgemm_bytes = ctx->spgemm_fixed_bytes + (out->macs + out->out_nnz) * ctx->spgemm_entry_bytes;
     return SG_OK;
 }

@@ -61,7 +61,7 @@ struct sg_ctx {
     bool ev_valid[SG_K_COUNT];
     int64_t spgemm_entry_bytes = 0;              // 4 + s of the most recent multiply
     int64_t spgemm_fixed_bytes = 0;              // its algorithmic bytes that do not scale with MACs
-    int64_t *d_stat_words = nullptr;             // [0]=macs [1]=out_nnz (device, zeroed per multiply)
+    int64_t *d_stat_words = nullptr;             // [0]=macs [1]=out_nnz [2..4]=pruned rows/postings/survivors [5]=rows handed to K4
     int64_t *h_stat_words = nullptr;             // pinned mirror
 
     int alloc(size_t bytes, void **out);         // pooled hipMalloc
@@ -105,6 +105,9 @@ struct sg_csr {
     const int32_t *d_indices = nullptr;  // keeps the parent's arrays and a shifted d_indptr pointer)
     const void *d_data = nullptr;
     bool owned = false;
+    // lazily computed by sg_csr_props (sg_spgemm_pruned.hip): 0 unknown, 1 cosine-like, 2 not
+    mutable int props_state = 0;
+    mutable float props_max_norm2 = 0.f;
 };
 
 struct sg_postings {
@@ -114,14 +117,21 @@ struct sg_postings {
     int32_t tile_log2 = 12;
     int32_t n_tiles = 0;
     // seg[k * n_tiles + t] .. seg[k * n_tiles + t + 1] = postings of term k whose row lies in tile t
-    // the CSR the postings were built from (borrowed: it must outlive the postings); the fast path of the
-    // multiply re-scores its candidates by merging row i of A with row j of this matrix
+    // the CSR the postings were built from (borrowed: it must outlive the postings); the pruned multiply
+    // scores its surviving candidates by merging row i of A with row j of this matrix
     const int64_t *b_indptr = nullptr;
     const int32_t *b_indices = nullptr;
     const void *b_data = nullptr;
     uint32_t *d_seg = nullptr;           // n_terms * n_tiles + 1
     int32_t *d_rows = nullptr;           // nnz   (row j of B)
     void *d_vals = nullptr;              // nnz   (value B[j, k])
+    // rows of B packed for the pruned multiply's exact scoring (built only for cosine-like B):
+    // f32: {int32 term, float value} (8 B), f64: {int32 term, pad, double value} (16 B); row j = entries
+    // [d_fwd_ptr[j], d_fwd_ptr[j+1])
+    void *d_fwd = nullptr;
+    uint32_t *d_fwd_ptr = nullptr;       // n_right + 1
+    bool cosine_like = false;            // B: values >= 0, sorted rows, row norms <= 1 (sg_csr_props)
+    float max_norm2 = 0.f;               // max ||row of B||^2, rounded up
 };
 
 struct sg_topn {
@@ -145,6 +155,13 @@ struct sg_vocab {
     int32_t *d_df = nullptr;             // n_terms
     void *d_idf = nullptr;               // n_terms, params.dtype; null until sg_vocab_set_idf
 };
+
+// sg_spgemm_pruned.hip
+int sg_csr_props(sg_ctx *ctx, const sg_csr *m, bool *cosine_like, float *max_norm2);
+bool sg_pruned_supports_tile(int32_t tile_log2);
+int sg_spgemm_pruned_launch(sg_ctx *ctx, const sg_csr *A, const sg_postings *Bt, int32_t keep, sg_topn *r,
+                            double threshold, double delta, float max_norm2_b, uint32_t *row_counter,
+                            uint32_t *flagged_count, uint32_t *flagged_rows, unsigned long long *stats);
 
 // exclusive prefix sum of n uint32 values (in place allowed); total written to *d_total if non-null
 int sg_exclusive_scan_u32(sg_ctx *ctx, const uint32_t *d_in, uint32_t *d_out, int64_t n, uint32_t *d_total);

@@ -69,9 +69,37 @@ __global__ void __launch_bounds__(256) postings_fill(const int64_t *__restrict__
     }
 }
 
+// Packed copy of B's rows for the pruned multiply (one 16-byte load = two f32 entries or one f64 entry).
+template <typename T>
+__global__ void __launch_bounds__(256) fwd_pack(const int64_t *__restrict__ indptr, const int32_t *__restrict__ indices,
+                                                const T *__restrict__ data, int64_t n_rows, uint32_t *__restrict__ fwd_ptr,
+                                                void *__restrict__ fwd) {
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j > n_rows) return;
+    const int64_t base = indptr[0];
+    fwd_ptr[j] = (uint32_t)(indptr[j] - base);
+    if (j == n_rows) return;
+    for (int64_t p = indptr[j]; p < indptr[j + 1]; ++p) {
+        if (sizeof(T) == 4) {
+            reinterpret_cast<int2 *>(fwd)[p - base] = make_int2(indices[p], __float_as_int((float)data[p]));
+        } else {
+            const long long bits = __double_as_longlong((double)data[p]);
+            reinterpret_cast<int4 *>(fwd)[p - base] = make_int4(indices[p], 0, (int)(bits & 0xffffffffll), (int)(bits >> 32));
+        }
+    }
+}
+
 extern "C" int sg_postings_build(sg_ctx *ctx, const sg_csr *B, int32_t tile_cols, sg_postings **out) {
     SG_REQUIRE(ctx && B && out, "null argument");
-    if (tile_cols == 0) tile_cols = B->dtype == SG_F64 ? 1024 : 2048;   // 8 KiB of LDS per wave: 20 waves per CU
+    // cosine-like right-hand sides (non-negative, sorted rows, norms <= 1: TF-IDF) take the pruned multiply,
+    // whose 16-bit accumulators make a 4096-column tile 8 KiB; everything else the exact kernel with 8 KiB
+    // of float / double accumulators per wave
+    bool cosine_like = false;
+    float max_norm2 = 0.f;
+    SG_TRY(sg_csr_props(ctx, B, &cosine_like, &max_norm2));
+    const char *pr = getenv("SG_PRUNE");
+    const bool want_pruned = cosine_like && !(pr && pr[0] == '0');
+    if (tile_cols == 0) tile_cols = want_pruned ? 4096 : (B->dtype == SG_F64 ? 1024 : 2048);
     SG_REQUIRE(tile_cols >= 256 && tile_cols <= 32768 && (tile_cols & (tile_cols - 1)) == 0,
                "tile_cols must be a power of two in [256, 32768]");
     int64_t max_entries = (int64_t)1 << 29;   // the multiply addresses postings with 32-bit BYTE offsets (8 B entries)
@@ -105,12 +133,18 @@ extern "C" int sg_postings_build(sg_ctx *ctx, const sg_csr *B, int32_t tile_cols
     p->b_indptr = B->d_indptr;
     p->b_indices = B->d_indices;
     p->b_data = B->d_data;
+    p->cosine_like = cosine_like;
+    p->max_norm2 = max_norm2;
     const size_t vs = 8;   // f64 value, or packed {row, f32 value}
     uint32_t *cursor = nullptr;
     int st = sg_alloc(ctx, (size_t)n_bins + 1, &p->d_seg);
     if (st == SG_OK && B->dtype == SG_F64) st = sg_alloc(ctx, (size_t)B->nnz + 64, &p->d_rows);
     if (st == SG_OK) st = ctx->alloc(((size_t)B->nnz + 64) * vs, &p->d_vals);
     if (st == SG_OK) st = sg_alloc(ctx, (size_t)n_bins + 1, &cursor);
+    if (st == SG_OK && want_pruned) {
+        st = ctx->alloc(((size_t)B->nnz + 8) * (B->dtype == SG_F64 ? 16 : 8), &p->d_fwd);
+        if (st == SG_OK) st = sg_alloc(ctx, (size_t)B->n_rows + 2, &p->d_fwd_ptr);
+    }
     if (st != SG_OK) {
         sg_postings_free(p);
         return st;
@@ -142,6 +176,16 @@ extern "C" int sg_postings_build(sg_ctx *ctx, const sg_csr *B, int32_t tile_cols
                                    p->d_seg, cursor, p->d_rows, (float *)p->d_vals);
             if (hipGetLastError() != hipSuccess) st = SG_ERR_HIP;
         }
+        if (st == SG_OK && p->d_fwd) {
+            const unsigned g2 = (unsigned)((B->n_rows + 1 + 255) / 256);
+            if (B->dtype == SG_F64)
+                hipLaunchKernelGGL(fwd_pack<double>, dim3(g2), dim3(256), 0, ctx->stream, B->d_indptr, B->d_indices,
+                                   (const double *)B->d_data, B->n_rows, p->d_fwd_ptr, p->d_fwd);
+            else
+                hipLaunchKernelGGL(fwd_pack<float>, dim3(g2), dim3(256), 0, ctx->stream, B->d_indptr, B->d_indices,
+                                   (const float *)B->d_data, B->n_rows, p->d_fwd_ptr, p->d_fwd);
+            if (hipGetLastError() != hipSuccess) st = SG_ERR_HIP;
+        }
     }
     ctx->release(cursor);
     if (st != SG_OK) {
@@ -157,6 +201,8 @@ extern "C" int sg_postings_free(sg_postings *p) {
     p->ctx->release(p->d_seg);
     p->ctx->release(p->d_rows);
     p->ctx->release(p->d_vals);
+    p->ctx->release(p->d_fwd);
+    p->ctx->release(p->d_fwd_ptr);
     delete p;
     return SG_OK;
 }

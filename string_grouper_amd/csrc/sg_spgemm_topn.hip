@@ -32,125 +32,7 @@
 
 #include "sg_internal.h"
 
-#define SG_TOPN_LANES 64
-
-// Debug aid (-DSG_WATCHDOG): every data-dependent loop counts its iterations; an overrun records which
-// loop it was in g_sg_watch and makes all loops wind down instead of hanging the GPU.
-#ifdef SG_WATCHDOG
-__device__ int g_sg_watch[4];
-#define SG_WD_DECL(c) int c = 0
-#define SG_WD(c, limit, code)                                   \
-    if (++(c) > (int)(limit) || ((volatile int *)g_sg_watch)[0]) { \
-        if (((volatile int *)g_sg_watch)[0] == 0) {             \
-            g_sg_watch[0] = (code);                             \
-            g_sg_watch[1] = (int)(c);                           \
-        }                                                       \
-        break;                                                  \
-    }
-extern "C" int sg_debug_watch(int32_t *out4) {
-    return hipMemcpyFromSymbol(out4, HIP_SYMBOL(g_sg_watch), 16) == hipSuccess ? 0 : 4;
-}
-#else
-#define SG_WD_DECL(c)
-#define SG_WD(c, limit, code)
-#endif   // entries of the register-resident list = lanes of a wave
-
-template <typename T>
-__device__ __forceinline__ T wave_read(T v, int src_lane);   // value of v in lane src_lane (uniform src)
-
-template <>
-__device__ __forceinline__ float wave_read<float>(float v, int src_lane) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), src_lane));
-}
-template <>
-__device__ __forceinline__ int wave_read<int>(int v, int src_lane) {
-    return __builtin_amdgcn_readlane(v, src_lane);
-}
-template <>
-__device__ __forceinline__ uint32_t wave_read<uint32_t>(uint32_t v, int src_lane) {
-    return (uint32_t)__builtin_amdgcn_readlane((int)v, src_lane);
-}
-template <>
-__device__ __forceinline__ double wave_read<double>(double v, int src_lane) {
-    const uint64_t u = __builtin_bit_cast(uint64_t, v);
-    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)u, src_lane);
-    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(u >> 32), src_lane);
-    return __builtin_bit_cast(double, ((uint64_t)hi << 32) | lo);
-}
-
-template <typename T>
-__device__ __forceinline__ T mul_rn(T a, T b);
-template <>
-__device__ __forceinline__ float mul_rn<float>(float a, float b) { return __fmul_rn(a, b); }
-template <>
-__device__ __forceinline__ double mul_rn<double>(double a, double b) { return __dmul_rn(a, b); }
-
-template <typename T>
-__device__ __forceinline__ T add_rn(T a, T b);
-template <>
-__device__ __forceinline__ float add_rn<float>(float a, float b) { return __fadd_rn(a, b); }
-template <>
-__device__ __forceinline__ double add_rn<double>(double a, double b) { return __dadd_rn(a, b); }
-
-template <typename T>
-struct TopList {   // lane r holds the r-th best (score, col); empty slots are (-inf, INT_MAX)
-    T s;
-    int c;
-    __device__ __forceinline__ void clear() {
-        s = -INFINITY;
-        c = INT32_MAX;
-    }
-    // (ns, nc) are wave-uniform.  floor_*: only entries strictly after the floor key are eligible
-    // (used by the passes that collect ranks 64.. of a row; floor_s = +inf disables it).
-    __device__ __forceinline__ void insert(T ns, int nc, int lane) {
-        const bool mine_first = (s > ns) || (s == ns && c < nc);
-        const int pos = __popcll(__ballot(mine_first));
-        if (pos >= SG_TOPN_LANES) return;
-        const T us = __shfl_up(s, 1, 64);
-        const int uc = __shfl_up(c, 1, 64);
-        if (lane > pos) {
-            s = us;
-            c = uc;
-        } else if (lane == pos) {
-            s = ns;
-            c = nc;
-        }
-    }
-};
-
-// Posting entry (written by K3): f32 -> packed {uint32 slot, float value}, one 8-byte load per lane;
-// f64 -> slots[] (uint32) + vals[] (double).  "slot" is the BYTE offset of the entry's accumulator
-// inside its column tile, (j mod TILE) * sizeof(T): the multiply never needs j itself -- the tile
-// sweep recovers columns from positions -- so the address arithmetic is done once, in K3.
-template <typename T>
-struct Post;
-template <>
-struct Post<float> {
-    typedef uint2 reg_t;
-    static constexpr int STRIDE = 8;
-    // address = kernel-constant base (SGPR pair) + 32-bit byte offset per lane: no 64-bit arithmetic at all
-    static __device__ __forceinline__ reg_t load(const char *vals, const char *, uint32_t seg_lo, uint32_t entry) {
-        return *reinterpret_cast<const uint2 *>(vals + ((seg_lo + entry) << 3));   // 32-bit offset: < 2^29 entries
-    }
-    static __device__ __forceinline__ uint32_t slot(const reg_t &r) { return r.x; }
-    static __device__ __forceinline__ float val(const reg_t &r) { return __uint_as_float(r.y); }
-};
-template <>
-struct Post<double> {
-    struct reg_t {
-        uint32_t j;
-        double v;
-    };
-    static constexpr int STRIDE = 8;
-    static __device__ __forceinline__ reg_t load(const char *vals, const char *slots, uint32_t seg_lo, uint32_t entry) {
-        reg_t r;
-        r.j = *reinterpret_cast<const uint32_t *>(slots + ((seg_lo + entry) << 2));
-        r.v = *reinterpret_cast<const double *>(vals + ((seg_lo + entry) << 3));
-        return r;
-    }
-    static __device__ __forceinline__ uint32_t slot(const reg_t &r) { return r.j; }
-    static __device__ __forceinline__ double val(const reg_t &r) { return r.v; }
-};
+#include "sg_k4_device.h"
 
 // "does any of the 16 bytes' worth of accumulators exceed thr": accumulators and thr are >= +0, so
 // IEEE order equals unsigned integer order and one v_max3_u32 + v_max_u32 + compare covers 4 floats
@@ -228,7 +110,11 @@ __device__ __forceinline__ void stream_rest(T *acc, const char *vals, const char
 
 // wave-uniform "clear bit f of m" in one scalar instruction (the compiler expands m &= m - 1 to three)
 __device__ __forceinline__ void clear_bit(uint64_t &m, int f) {
+#ifdef SG_WATCHDOG   // the watchdog's breaks make m look divergent to the compiler: no scalar asm then
+    m &= ~(1ull << f);
+#else
     asm("s_bitset0_b64 %0, %1" : "+s"(m) : "s"(f));
+#endif
 }
 
 // One batch of up to NB posting segments of the current (row, tile): issue the first window of each,
@@ -262,14 +148,6 @@ __device__ __forceinline__ void segment_batch(T *acc, const char *vals, const ch
             if (sn[b] > 64) stream_rest<T>(acc, vals, slots, slo[b], sn[b], sa[b], lane);
         }
     }
-}
-
-// Next left row for this wave: one global atomic by lane 0, broadcast.  The result is made
-// explicitly wave-uniform so that everything derived from it stays in SGPRs / uniform branches.
-__device__ __forceinline__ uint32_t next_row(uint32_t *row_counter, int lane) {
-    uint32_t r = 0;
-    if (lane == 0) r = __hip_atomic_fetch_add(row_counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    return (uint32_t)__builtin_amdgcn_readfirstlane((int)r);
 }
 
 template <typename T, int TILE_LOG2, int NB>
@@ -415,7 +293,9 @@ spgemm_topn_kernel(const int64_t *__restrict__ a_indptr, const int32_t *__restri
                    const int32_t *__restrict__ post_rows, const T *__restrict__ post_vals, int32_t n_tiles,
                    int32_t tile_begin, int32_t tile_end, int32_t keep /* <= 64 entries this pass */,
                    int32_t pass_off /* 64 * pass */, int32_t out_stride, T thr, int32_t *__restrict__ out_cols,
-                   T *__restrict__ out_vals, int32_t *__restrict__ out_cnt, uint32_t *row_counter) {
+                   T *__restrict__ out_vals, int32_t *__restrict__ out_cnt, uint32_t *row_counter,
+                   const uint32_t *__restrict__ row_list /* null: all rows */,
+                   const uint32_t *__restrict__ row_list_len) {
     constexpr int TILE = 1 << TILE_LOG2;
     constexpr int VEC = 16 / sizeof(T);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -424,10 +304,12 @@ spgemm_topn_kernel(const int64_t *__restrict__ a_indptr, const int32_t *__restri
     typedef T vec_t __attribute__((ext_vector_type(VEC)));
     vec_t *acc_v = reinterpret_cast<vec_t *>(acc);
     for (int x = lane; x < TILE / VEC; x += 64) acc_v[x] = (vec_t)(T)0;
+    if (row_list) n_left = row_list_len[0];   // only the rows the pruned kernel handed over (often none)
 
     SG_WD_DECL(wd_rows);
-    for (uint32_t row = next_row(row_counter, lane); row < n_left; row = next_row(row_counter, lane)) {
+    for (uint32_t idx = next_row(row_counter, lane); idx < n_left; idx = next_row(row_counter, lane)) {
         SG_WD(wd_rows, n_left + 2, 1)
+        const uint32_t row = row_list ? row_list[idx] : idx;
         process_row<T, TILE_LOG2, NB>(acc, row, a_indptr, a_indices, a_data, seg, post_rows, post_vals, n_tiles,
                                       tile_begin, tile_end, keep, pass_off, out_stride, thr, out_cols, out_vals,
                                       out_cnt, lane);
@@ -564,6 +446,12 @@ __global__ void __launch_bounds__(64) topn_zip_kernel(const ZipPart<T> *__restri
 // ================================================================================================
 // host side
 // ================================================================================================
+static double env_double(const char *name, double dflt) {
+    const char *v = getenv(name);
+    if (!v || !*v) return dflt;
+    return atof(v);
+}
+
 static int env_int(const char *name, int dflt) {
     const char *v = getenv(name);
     if (!v || !*v) return dflt;
@@ -572,7 +460,8 @@ static int env_int(const char *name, int dflt) {
 
 template <typename T, int TILE_LOG2, int DEPTH>
 static int launch_spgemm(sg_ctx *ctx, const sg_csr *A, const sg_postings *Bt, int32_t tile_begin, int32_t tile_end,
-                         int32_t keep, int32_t pass_off, sg_topn *r, T thr, uint32_t *counter, unsigned grid) {
+                         int32_t keep, int32_t pass_off, sg_topn *r, T thr, uint32_t *counter, unsigned grid,
+                         const uint32_t *row_list, const uint32_t *row_list_len) {
     const size_t lds = sizeof(T) << TILE_LOG2;
     auto kern = spgemm_topn_kernel<T, TILE_LOG2, DEPTH>;
     if (lds > 48 * 1024) {
@@ -585,7 +474,7 @@ static int launch_spgemm(sg_ctx *ctx, const sg_csr *A, const sg_postings *Bt, in
     hipLaunchKernelGGL(kern, dim3(grid), dim3(64), lds, ctx->stream, A->d_indptr, A->d_indices, (const T *)A->d_data,
                        (uint32_t)A->n_rows, (const uint32_t *)Bt->d_seg, (const int32_t *)Bt->d_rows,
                        (const T *)Bt->d_vals, Bt->n_tiles, tile_begin, tile_end, keep, pass_off, r->stride, thr,
-                       r->d_cols, (T *)r->d_vals, r->d_counts, counter);
+                       r->d_cols, (T *)r->d_vals, r->d_counts, counter, row_list, row_list_len);
     SG_HIP_TRY(hipGetLastError());
     return SG_OK;
 }
@@ -593,23 +482,24 @@ static int launch_spgemm(sg_ctx *ctx, const sg_csr *A, const sg_postings *Bt, in
 template <typename T, int TILE_LOG2>
 static int dispatch_depth(sg_ctx *ctx, const sg_csr *A, const sg_postings *Bt, int32_t tile_begin, int32_t tile_end,
                           int32_t keep, int32_t pass_off, sg_topn *r, T thr, uint32_t *counter, unsigned grid,
-                          int depth) {
+                          int depth, const uint32_t *row_list, const uint32_t *row_list_len) {
     switch (depth) {
-        case 4: return launch_spgemm<T, TILE_LOG2, 4>(ctx, A, Bt, tile_begin, tile_end, keep, pass_off, r, thr, counter, grid);
-        case 16: return launch_spgemm<T, TILE_LOG2, 16>(ctx, A, Bt, tile_begin, tile_end, keep, pass_off, r, thr, counter, grid);
-        default: return launch_spgemm<T, TILE_LOG2, 8>(ctx, A, Bt, tile_begin, tile_end, keep, pass_off, r, thr, counter, grid);
+        case 4: return launch_spgemm<T, TILE_LOG2, 4>(ctx, A, Bt, tile_begin, tile_end, keep, pass_off, r, thr, counter, grid, row_list, row_list_len);
+        case 16: return launch_spgemm<T, TILE_LOG2, 16>(ctx, A, Bt, tile_begin, tile_end, keep, pass_off, r, thr, counter, grid, row_list, row_list_len);
+        default: return launch_spgemm<T, TILE_LOG2, 8>(ctx, A, Bt, tile_begin, tile_end, keep, pass_off, r, thr, counter, grid, row_list, row_list_len);
     }
 }
 
 template <typename T>
 static int dispatch_spgemm(sg_ctx *ctx, const sg_csr *A, const sg_postings *Bt, int32_t tile_begin, int32_t tile_end,
-                           int32_t keep, int32_t pass_off, sg_topn *r, T thr, uint32_t *counter, unsigned grid) {
+                           int32_t keep, int32_t pass_off, sg_topn *r, T thr, uint32_t *counter, unsigned grid,
+                           const uint32_t *row_list = nullptr, const uint32_t *row_list_len = nullptr) {
     const int depth = env_int("SG_DEPTH", 8);
     switch (Bt->tile_log2) {
-        case 10: return dispatch_depth<T, 10>(ctx, A, Bt, tile_begin, tile_end, keep, pass_off, r, thr, counter, grid, depth);
-        case 11: return dispatch_depth<T, 11>(ctx, A, Bt, tile_begin, tile_end, keep, pass_off, r, thr, counter, grid, depth);
-        case 12: return dispatch_depth<T, 12>(ctx, A, Bt, tile_begin, tile_end, keep, pass_off, r, thr, counter, grid, depth);
-        case 13: return dispatch_depth<T, 13>(ctx, A, Bt, tile_begin, tile_end, keep, pass_off, r, thr, counter, grid, depth);
+        case 10: return dispatch_depth<T, 10>(ctx, A, Bt, tile_begin, tile_end, keep, pass_off, r, thr, counter, grid, depth, row_list, row_list_len);
+        case 11: return dispatch_depth<T, 11>(ctx, A, Bt, tile_begin, tile_end, keep, pass_off, r, thr, counter, grid, depth, row_list, row_list_len);
+        case 12: return dispatch_depth<T, 12>(ctx, A, Bt, tile_begin, tile_end, keep, pass_off, r, thr, counter, grid, depth, row_list, row_list_len);
+        case 13: return dispatch_depth<T, 13>(ctx, A, Bt, tile_begin, tile_end, keep, pass_off, r, thr, counter, grid, depth, row_list, row_list_len);
         default:
             sg_set_error("postings tile of 2^%d columns is not supported by the multiply (2^10..2^13)", Bt->tile_log2);
             return SG_ERR_UNSUPPORTED;
@@ -682,18 +572,49 @@ extern "C" int sg_spgemm_topn(sg_ctx *ctx, const sg_csr *A, const sg_postings *B
     unsigned grid = (unsigned)ctx->num_cu * (unsigned)waves_per_cu;
     if ((int64_t)grid > A->n_rows) grid = (unsigned)(A->n_rows > 0 ? A->n_rows : 1);
 
+    // ---- pruned multiply (sg_spgemm_pruned.hip) when both sides are cosine-like and one register list
+    //      holds the row's result; its survivor threshold needs some room below the threshold
+    bool prune = false;
+    double delta = 0.0;
+    {
+        const char *pr = getenv("SG_PRUNE");
+        if (!(pr && pr[0] == '0') && Bt->cosine_like && Bt->d_fwd && stride <= SG_TOPN_LANES && A->n_rows > 0 && Bt->nnz > 0 &&
+            sg_pruned_supports_tile(Bt->tile_log2) && threshold >= 0.1) {
+            delta = env_double("SG_PRUNE_DELTA", 0.2);
+            if (delta > 0.5 * threshold) delta = 0.5 * threshold;
+            if (delta < 0.02) delta = 0.02;
+            bool a_ok = false;
+            float a_n2 = 0.f;
+            const int pst = sg_csr_props(ctx, A, &a_ok, &a_n2);
+            if (pst != SG_OK) {
+                sg_topn_free(r);
+                return pst;
+            }
+            prune = a_ok;
+        }
+    }
+
+    // counters: [0, n_launch] row counters of the exact launches; then the pruned kernel's row counter, the
+    // number of rows it handed over, and their list
+    const size_t n_words = (size_t)n_launch + 4;
     uint32_t *counters = nullptr;
-    int st = sg_alloc(ctx, (size_t)n_launch + 1, &counters);
+    int st = sg_alloc(ctx, n_words + (prune ? (size_t)A->n_rows : 0), &counters);
     if (st != SG_OK) {
         sg_topn_free(r);
         return st;
     }
+    uint32_t *handed_count = counters + n_launch + 2;
+    uint32_t *handed_rows = counters + n_words;
     {
         SgTimer timer(ctx, SG_K_SPGEMM);
         st = SG_OK;
-        if (hipMemsetAsync(counters, 0, sizeof(uint32_t) * (size_t)(n_launch + 1), ctx->stream) != hipSuccess ||
-            hipMemsetAsync(r->d_counts, 0, sizeof(int32_t) * (size_t)A->n_rows, ctx->stream) != hipSuccess)
+        if (hipMemsetAsync(counters, 0, sizeof(uint32_t) * n_words, ctx->stream) != hipSuccess ||
+            hipMemsetAsync(r->d_counts, 0, sizeof(int32_t) * (size_t)A->n_rows, ctx->stream) != hipSuccess ||
+            hipMemsetAsync(ctx->d_stat_words + 2, 0, 4 * sizeof(int64_t), ctx->stream) != hipSuccess)
             st = SG_ERR_HIP;
+        if (prune && st == SG_OK)
+            st = sg_spgemm_pruned_launch(ctx, A, Bt, stride, r, threshold, delta, Bt->max_norm2, counters + n_launch + 1,
+                                         handed_count, handed_rows, (unsigned long long *)(ctx->d_stat_words + 2));
         int li = 0;
         for (int pass = 0; pass < n_pass && st == SG_OK && A->n_rows > 0; ++pass) {
             const int pass_off = pass * SG_TOPN_LANES;
@@ -703,12 +624,15 @@ extern "C" int sg_spgemm_topn(sg_ctx *ctx, const sg_csr *A, const sg_postings *B
                 const int te = tb + group < Bt->n_tiles ? tb + group : Bt->n_tiles;
                 if (A->dtype == SG_F64)
                     st = dispatch_spgemm<double>(ctx, A, Bt, tb, te, keep, pass_off, r, (double)threshold,
-                                                 counters + li, grid);
+                                                 counters + li, grid, prune ? handed_rows : nullptr, handed_count);
                 else
                     st = dispatch_spgemm<float>(ctx, A, Bt, tb, te, keep, pass_off, r, (float)threshold,
-                                                counters + li, grid);
+                                                counters + li, grid, prune ? handed_rows : nullptr, handed_count);
             }
         }
+        if (prune && st == SG_OK &&
+            hipMemcpyAsync(ctx->d_stat_words + 5, handed_count, 4, hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess)
+            st = SG_ERR_HIP;
     }
     if (st == SG_OK && !sort && A->n_rows > 0) {
         unsigned g2 = (unsigned)(A->n_rows < 65535 * 16 ? A->n_rows : 65535 * 16);

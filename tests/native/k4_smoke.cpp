@@ -39,13 +39,16 @@ int main(int argc, char **argv) {
     int rc = sg_sp_matmul_topn_host(ctx, nL, nR, V, aip.data(), aix.data(), ad.data(), bip.data(), bix.data(), bd.data(),
                                     SG_F32, top_n, thr, 1, oc.data(), ov.data(), cnt.data());
     printf("rc=%d %s\n", rc, rc ? sg_last_error() : "");
-    if (auto fn = (int (*)(int32_t *))dlsym(RTLD_DEFAULT, "sg_debug_watch")) {   // only in -DSG_WATCHDOG builds
-        int32_t w[4] = {0, 0, 0, 0};
-        fn(w);
-        printf("watchdog: code %d count %d\n", w[0], w[1]);
-    }
+    for (const char *sym : {"sg_debug_watch", "sg_debug_watch_pruned"})   // only in -DSG_WATCHDOG builds
+        if (auto fn = (int (*)(int32_t *))dlsym(RTLD_DEFAULT, sym)) {
+            int32_t w[4] = {0, 0, 0, 0};
+            fn(w);
+            printf("%s: code %d count %d\n", sym, w[0], w[1]);
+        }
     sg_stats st; sg_ctx_stats(ctx, &st);
-    printf("K4 %.3f ms, macs %lld, out %lld\n", st.ms[SG_K_SPGEMM], (long long)st.macs, (long long)st.out_nnz);
+    printf("K4 %.3f ms, macs %lld, out %lld; pruned rows %lld postings %lld survivors %lld, exact rows %lld\n",
+           st.ms[SG_K_SPGEMM], (long long)st.macs, (long long)st.out_nnz, (long long)st.prune_rows,
+           (long long)st.prune_postings, (long long)st.prune_survivors, (long long)st.exact_rows);
     // CPU check
     long bad = 0;
     std::vector<float> acc(nR);

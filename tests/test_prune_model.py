@@ -1,0 +1,71 @@
+"""The pruning rule of the pruned multiply (string_grouper_amd/csrc/sg_spgemm_pruned.hip), restated in
+numpy with the kernel's arithmetic (float32 bound, truncated 2^15 fixed point, the same slack terms)
+and checked against the oracle: every pair the oracle keeps must be among the kernel's survivors.
+This pins the MATH of the filter on the CPU; the kernel itself is compared bit for bit with the
+oracle by the GPU parity tests."""
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from string_grouper_amd.synth import synth_names
+
+f32 = np.float32
+
+
+def survivors_of_row(a_idx, a_val, Bt_indptr, Bt_rows, Bt_vals, thr, delta, norm_b):
+    """Columns the kernel would score exactly for one left row (model of the kernel, float32 data)."""
+    nnz = len(a_idx)
+    df = (Bt_indptr[a_idx + 1] - Bt_indptr[a_idx]).astype(np.int64)
+    beta = thr - delta
+    budget = np.nextafter(f32((beta / norm_b) ** 2 * (1.0 - 1e-6)), f32(0))
+    w = (a_val.astype(f32) * a_val.astype(f32) * f32(1.00001)).astype(f32)
+    cum = np.zeros(nnz, f32)
+    for lane in range(nnz):
+        c = f32(0)
+        for q in range(nnz):
+            if df[q] > df[lane] or (df[q] == df[lane] and q <= lane):
+                c = f32(c + w[q])
+        cum[lane] = c
+    in_s = cum <= budget
+    in_p = ~in_s
+    if not in_p.any():
+        return np.zeros(0, np.int64), 0
+    bs2 = cum[in_s].max() if in_s.any() else f32(0)
+    b_s = f32(f32(np.sqrt(bs2)) * f32(norm_b) * f32(1.000002))
+    n_p = int(in_p.sum())
+    tqf = np.floor(f32(f32(f32(thr) - b_s - f32(1e-5)) * f32(32768.0))) - n_p - 3.0
+    assert tqf >= 1.0
+    q = {}
+    streamed = 0
+    for t in np.nonzero(in_p)[0]:
+        lo, hi = Bt_indptr[a_idx[t]], Bt_indptr[a_idx[t] + 1]
+        x = (f32(a_val[t]) * Bt_vals[lo:hi].astype(f32)).astype(f32) * f32(32768.0)
+        x = x.astype(np.uint32)   # truncation
+        streamed += hi - lo
+        for j, xv in zip(Bt_rows[lo:hi], x):
+            q[j] = q.get(j, 0) + int(xv)
+    surv = np.array(sorted(j for j, v in q.items() if v >= tqf), dtype=np.int64)
+    return surv, streamed
+
+
+@pytest.mark.parametrize("thr,delta", [(0.8, 0.2), (0.8, 0.05), (0.5, 0.2), (0.95, 0.3)])
+def test_survivors_cover_every_oracle_match(thr, delta):
+    names = synth_names(3000, 77)
+    (m,), _, _ = O.tfidf_sklearn(names, [names], dtype=np.float32)
+    m = m.tocsr()
+    m.sort_indices()
+    mt = m.T.tocsr()
+    mt.sort_indices()
+    C = O.sp_matmul_topn(m, m.T.tocsr(), 10_000, thr, sort=True)   # uncapped: every pair above thr
+    norm_b = float(np.sqrt(np.asarray(m.multiply(m).sum(axis=1)).max())) * (1 + 1e-6)
+    total_streamed = total_full = total_surv = 0
+    for i in range(0, m.shape[0], 7):
+        lo, hi = m.indptr[i], m.indptr[i + 1]
+        surv, streamed = survivors_of_row(m.indices[lo:hi], m.data[lo:hi], mt.indptr, mt.indices, mt.data, thr, delta,
+                                          norm_b)
+        want = C.indices[C.indptr[i]:C.indptr[i + 1]]
+        assert set(want) <= set(surv), (i, sorted(set(want) - set(surv)))
+        total_streamed += streamed
+        total_surv += len(surv)
+        total_full += int((mt.indptr[m.indices[lo:hi] + 1] - mt.indptr[m.indices[lo:hi]]).sum())
+    assert total_streamed < total_full   # the filter does prune
