@@ -12,10 +12,14 @@ from string_grouper_amd.synth import synth_names  # noqa: E402
 from string_grouper_amd.vectorizer import HipTfidfVectorizer  # noqa: E402
 
 
-def run(ctx, A, top_n, thr, prune, delta=None, reps=2):
+def run(ctx, A, top_n, thr, prune, delta=None, reps=2, freq=None, tile=None):
+    if tile is not None:
+        os.environ["SG_PRUNE_TILE"] = str(tile)
     os.environ["SG_PRUNE"] = "1" if prune else "0"
     if delta is not None:
         os.environ["SG_PRUNE_DELTA"] = str(delta)
+    if freq is not None:
+        os.environ["SG_PRUNE_FREQ"] = str(freq)
     post = ctx.postings_build(A, 0)
     best, out, st = None, None, None
     for _ in range(reps):
@@ -37,6 +41,8 @@ def main():
     sizes = [int(x) for x in (sys.argv[1] if len(sys.argv) > 1 else "20000,200000,663000").split(",")]
     deltas = [float(x) for x in (sys.argv[2] if len(sys.argv) > 2 else "0.2").split(",")]
     dtypes = [np.float32, np.float64] if (len(sys.argv) > 3 and sys.argv[3] == "both") else [np.float32]
+    freqs = [float(x) for x in (sys.argv[4] if len(sys.argv) > 4 else "0.003").split(",")]
+    tiles = [int(x) for x in (sys.argv[5] if len(sys.argv) > 5 else "12").split(",")]
     ctx = N.default_context(0)
     for n in sizes:
         names = synth_names(n, 1234)
@@ -49,8 +55,8 @@ def main():
                 t_ex, o_ex, st_ex = run(ctx, A, top_n, thr, False)
                 print(json.dumps({"n": n, "dtype": np.dtype(dtype).name, "mode": "exact", "ms": st_ex["ms_spgemm_topn"],
                                   "wall_ms": t_ex * 1e3, "macs": st_ex["macs"], "out": st_ex["out_nnz"]}), flush=True)
-                for delta in deltas:
-                    t_pr, o_pr, st_pr = run(ctx, A, top_n, thr, True, delta)
+                for tile, delta, freq in [(t, d, f) for t in tiles for f in freqs for d in deltas]:
+                    t_pr, o_pr, st_pr = run(ctx, A, top_n, thr, True, delta, freq=freq, tile=tile)
                     mask = np.arange(o_ex[0].shape[1])[None, :] < o_ex[2][:, None]
                     same = (np.array_equal(o_ex[2], o_pr[2]) and np.array_equal(o_ex[0][mask], o_pr[0][mask])
                             and np.array_equal(o_ex[1][mask], o_pr[1][mask]))
@@ -59,7 +65,7 @@ def main():
                         bad = np.nonzero(cnt_e != cnt_p)[0]
                         print(json.dumps({"count_mismatch_rows": int(len(bad)), "first": bad[:5].tolist(),
                                           "cnt_exact": cnt_e[bad[:5]].tolist(), "cnt_pruned": cnt_p[bad[:5]].tolist()}))
-                    print(json.dumps({"n": n, "dtype": np.dtype(dtype).name, "mode": "pruned", "delta": delta,
+                    print(json.dumps({"n": n, "dtype": np.dtype(dtype).name, "mode": "pruned", "tile": tile, "delta": delta, "freq": freq,
                                       "ms": st_pr["ms_spgemm_topn"], "wall_ms": t_pr * 1e3, "identical": bool(same),
                                       "rows": st_pr["prune_rows"], "postings": st_pr["prune_postings"],
                                       "survivors": st_pr["prune_survivors"], "exact_rows": st_pr["exact_rows"],

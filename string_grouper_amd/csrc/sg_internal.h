@@ -130,6 +130,13 @@ struct sg_postings {
     // [d_fwd_ptr[j], d_fwd_ptr[j+1])
     void *d_fwd = nullptr;
     uint32_t *d_fwd_ptr = nullptr;       // n_right + 1
+    // 4-byte "filter postings", same order as the postings proper (only for cosine-like B):
+    //   bits [0, L) column inside the tile (L = tile_log2), [L, L+8) fq, [L+8, 32) bq   with
+    //   b <= bq / bq_max * norm_up   and
+    //   || b_j restricted to the frequent terms (list length >= freq_min) || <= fq / 255 * norm_up
+    uint32_t *d_filt = nullptr;
+    float norm_up = 0.f;                 // max ||row of B||, rounded up
+    uint32_t freq_min = 0;               // list length from which a term counts as frequent
     bool cosine_like = false;            // B: values >= 0, sorted rows, row norms <= 1 (sg_csr_props)
     float max_norm2 = 0.f;               // max ||row of B||^2, rounded up
 };
@@ -160,7 +167,7 @@ struct sg_vocab {
 int sg_csr_props(sg_ctx *ctx, const sg_csr *m, bool *cosine_like, float *max_norm2);
 bool sg_pruned_supports_tile(int32_t tile_log2);
 int sg_spgemm_pruned_launch(sg_ctx *ctx, const sg_csr *A, const sg_postings *Bt, int32_t keep, sg_topn *r,
-                            double threshold, double delta, float max_norm2_b, uint32_t *row_counter,
+                            double threshold, double delta, uint32_t *row_counter,
                             uint32_t *flagged_count, uint32_t *flagged_rows, unsigned long long *stats);
 
 // exclusive prefix sum of n uint32 values (in place allowed); total written to *d_total if non-null

@@ -55,17 +55,35 @@ __global__ void __launch_bounds__(256) postings_fill(const int64_t *__restrict__
                                                      const int32_t *__restrict__ indices,
                                                      const T *__restrict__ data, int64_t n_rows, int32_t tile_log2,
                                                      int32_t n_tiles, const uint32_t *__restrict__ seg,
-                                                     uint32_t *cursor, int32_t *out_rows, T *out_vals) {
+                                                     uint32_t *cursor, int32_t *out_rows, T *out_vals,
+                                                     uint32_t *out_filt /* null: no filter postings */,
+                                                     uint32_t freq_min, float inv_norm_up) {
     const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= n_rows) return;
     const int64_t lo = indptr[j], hi = indptr[j + 1];
     const uint32_t t = (uint32_t)(j >> tile_log2);
+    const uint32_t col = (uint32_t)(j & (((int64_t)1 << tile_log2) - 1));
+    uint32_t fq = 0;
+    if (out_filt) {   // norm of the row's frequent part, quantised upwards to 8 bits (relative to norm_up)
+        double f2 = 0.0;
+        for (int64_t p = lo; p < hi; ++p) {
+            const int64_t k = indices[p];
+            if (seg[(k + 1) * n_tiles] - seg[k * n_tiles] >= freq_min) f2 += (double)data[p] * (double)data[p];
+        }
+        fq = (uint32_t)ceilf(__double2float_ru(sqrt(f2)) * inv_norm_up * 255.0f * 1.000002f);
+        if (fq > 255u) fq = 255u;
+    }
     for (int64_t p = lo; p < hi; ++p) {
         const int64_t bin = (int64_t)indices[p] * n_tiles + t;
         const uint32_t pos = seg[bin] + atomicAdd(&cursor[bin], 1u);
         // the multiply wants the byte offset of the accumulator inside its LDS tile, not j itself
-        const int32_t slot = (int32_t)((j & (((int64_t)1 << tile_log2) - 1)) * (int64_t)sizeof(T));
-        store_posting<T>(out_rows, out_vals, pos, slot, data[p]);
+        store_posting<T>(out_rows, out_vals, pos, (int32_t)(col * (uint32_t)sizeof(T)), data[p]);
+        if (out_filt) {
+            const uint32_t bq_max = (1u << (24 - tile_log2)) - 1u;   // the bits the column and fq leave
+            uint32_t bq = (uint32_t)ceilf((float)data[p] * inv_norm_up * (float)bq_max * 1.000002f);
+            if (bq > bq_max) bq = bq_max;
+            out_filt[pos] = col | (fq << tile_log2) | (bq << (tile_log2 + 8));
+        }
     }
 }
 
@@ -99,7 +117,13 @@ extern "C" int sg_postings_build(sg_ctx *ctx, const sg_csr *B, int32_t tile_cols
     SG_TRY(sg_csr_props(ctx, B, &cosine_like, &max_norm2));
     const char *pr = getenv("SG_PRUNE");
     const bool want_pruned = cosine_like && !(pr && pr[0] == '0');
-    if (tile_cols == 0) tile_cols = want_pruned ? 4096 : (B->dtype == SG_F64 ? 1024 : 2048);
+    if (tile_cols == 0) {
+        tile_cols = B->dtype == SG_F64 ? 1024 : 2048;
+        if (want_pruned) {
+            tile_cols = 4096;
+            if (const char *v = getenv("SG_PRUNE_TILE")) tile_cols = atoi(v) == 13 ? 8192 : (atoi(v) == 11 ? 2048 : 4096);
+        }
+    }
     SG_REQUIRE(tile_cols >= 256 && tile_cols <= 32768 && (tile_cols & (tile_cols - 1)) == 0,
                "tile_cols must be a power of two in [256, 32768]");
     int64_t max_entries = (int64_t)1 << 29;   // the multiply addresses postings with 32-bit BYTE offsets (8 B entries)
@@ -141,9 +165,18 @@ extern "C" int sg_postings_build(sg_ctx *ctx, const sg_csr *B, int32_t tile_cols
     if (st == SG_OK && B->dtype == SG_F64) st = sg_alloc(ctx, (size_t)B->nnz + 64, &p->d_rows);
     if (st == SG_OK) st = ctx->alloc(((size_t)B->nnz + 64) * vs, &p->d_vals);
     if (st == SG_OK) st = sg_alloc(ctx, (size_t)n_bins + 1, &cursor);
-    if (st == SG_OK && want_pruned) {
+    if (st == SG_OK && want_pruned && sg_pruned_supports_tile(tile_log2) && n_bins < ((int64_t)1 << 30)) {
         st = ctx->alloc(((size_t)B->nnz + 8) * (B->dtype == SG_F64 ? 16 : 8), &p->d_fwd);
         if (st == SG_OK) st = sg_alloc(ctx, (size_t)B->n_rows + 2, &p->d_fwd_ptr);
+        if (st == SG_OK) st = sg_alloc(ctx, (size_t)B->nnz + 64, &p->d_filt);
+        p->norm_up = __builtin_nextafterf(sqrtf(max_norm2) * 1.000001f, 2.f);
+        // a term is "frequent" when it occurs in at least this share of the right-hand rows: the suffix of a
+        // left row is drawn from frequent terms only, which lets the survivor test use each candidate's own
+        // frequent-part norm instead of 1 (profiles/r01_prune_tuning.log)
+        double frac = 0.003;
+        if (const char *v = getenv("SG_PRUNE_FREQ")) frac = atof(v);
+        const double fm = frac * (double)B->n_rows;
+        p->freq_min = fm < 1.0 ? 1u : (uint32_t)fm;
     }
     if (st != SG_OK) {
         sg_postings_free(p);
@@ -169,11 +202,13 @@ extern "C" int sg_postings_build(sg_ctx *ctx, const sg_csr *B, int32_t tile_cols
             if (B->dtype == SG_F64)
                 hipLaunchKernelGGL(postings_fill<double>, dim3(grid), dim3(256), 0, ctx->stream, B->d_indptr,
                                    B->d_indices, (const double *)B->d_data, B->n_rows, tile_log2, p->n_tiles,
-                                   p->d_seg, cursor, p->d_rows, (double *)p->d_vals);
+                                   p->d_seg, cursor, p->d_rows, (double *)p->d_vals, p->d_filt, p->freq_min,
+                                   p->d_filt ? 1.0f / p->norm_up : 0.f);
             else
                 hipLaunchKernelGGL(postings_fill<float>, dim3(grid), dim3(256), 0, ctx->stream, B->d_indptr,
                                    B->d_indices, (const float *)B->d_data, B->n_rows, tile_log2, p->n_tiles,
-                                   p->d_seg, cursor, p->d_rows, (float *)p->d_vals);
+                                   p->d_seg, cursor, p->d_rows, (float *)p->d_vals, p->d_filt, p->freq_min,
+                                   p->d_filt ? 1.0f / p->norm_up : 0.f);
             if (hipGetLastError() != hipSuccess) st = SG_ERR_HIP;
         }
         if (st == SG_OK && p->d_fwd) {
@@ -203,6 +238,7 @@ extern "C" int sg_postings_free(sg_postings *p) {
     p->ctx->release(p->d_vals);
     p->ctx->release(p->d_fwd);
     p->ctx->release(p->d_fwd_ptr);
+    p->ctx->release(p->d_filt);
     delete p;
     return SG_OK;
 }

@@ -7,48 +7,39 @@
 // (hard part 3): a handful of n-grams ('inc', 'llc', ' co') are present in a fifth
 // of all rows and generate most of the intermediate products, yet carry almost no weight.
 //
-// For left row i (non-zeros a_k) the terms are split into a suffix S (the most frequent terms, as
-// many as fit under  ||a_S|| * max_j ||b_j|| <= beta = threshold - delta) and a prefix P (the rest,
-// the rare terms).  By Cauchy-Schwarz
-//        score(i, j) = sum_{k in P} a_k b_jk + sum_{k in S} a_k b_jk <= p_ij + beta
+// For left row i (non-zeros a_k) the terms are split into a suffix S -- the most frequent terms, all of
+// them "frequent" (list length >= freq_min), as many as fit under ||a_S|| * max_j ||b_j|| <= beta =
+// threshold - delta -- and a prefix P (the rest: the rare terms).  With f_j = ||b_j restricted to the
+// frequent terms||, Cauchy-Schwarz gives
+//        score(i, j) = sum_{k in P} a_k b_jk + sum_{k in S} a_k b_jk <= p_ij + ||a_S|| f_j <= p_ij + beta
 // so (1) a right row j that shares no term of P with row i cannot reach the threshold -- only the
 // posting lists of P are streamed (4-25x fewer entries than all lists), and (2) of the rows that do,
-// only those with p_ij > threshold - beta need their score computed.  Those "survivors" are scored
-// EXACTLY -- sorted merge of CSR row i of A and row j of B in ascending k, product and sum rounded
-// separately: the reference's arithmetic and summation order -- then the strict threshold, the
-// canonical order (score desc, column asc) and the top-n cut are applied as in K4.
+// only those with p_ij > threshold - ||a_S|| f_j need their score computed.  Those "survivors" are
+// scored EXACTLY -- row j of B is walked in ascending k, every term looked up in row i, product and sum
+// rounded separately: the reference's arithmetic and summation order -- then the strict threshold,
+// the canonical order (score desc, column asc) and the top-n cut are applied as in K4.
 //
-// p_ij is only a filter, so it needs neither float nor a summation order: it is accumulated in
-// 16-bit fixed point (scale 2^15, products truncated; all rounding is accounted for in the survivor
-// threshold, see prune_threshold) with LDS integer atomics.  That removes K4's structural cost --
-// one wave instruction per posting segment because two segments may hit the same column -- here every
+// p_ij is only a filter: any upper bound will do, in any summation order.  K3 therefore writes, next
+// to the postings proper, 4-byte "filter postings" {column in tile: L bits, fq: 8, bq: 24 - L} with the
+// value b and the norm f_j quantised UPWARDS, and the kernel accumulates upper bounds of a * b in
+// 16-bit fixed point (scale 2^15) with LDS integer atomics.  That removes K4's structural cost -- one
+// wave instruction per posting segment because two segments may hit the same column -- here every
 // lane of the wave carries a posting of whatever term: lanes are dealt to the terms of P in
 // proportion to their list lengths, lane (term g, u of G_g) walks postings lo_g + u, lo_g + u + G_g, ...
 // of the current column tile.  ds_add_rtn_u32 returns the previous value, so the lane whose add takes
-// an accumulator across the survivor threshold knows it (values only grow) and appends the column to
-// the wave's survivor list -- no sweep of the tile, it is just cleared.  Measured on MI355X: 7.6-13
-// cycles per 64-lane ds_add(_rtn)_u32 per CU against 16.5 for a plain read-add-write and 212 for
-// ds_add_f32 (profiles/r01_lds_atomic_microbench.log).
+// an accumulator across its column's survivor threshold knows it (values only grow) and appends the
+// column to the wave's survivor list -- no sweep of the tile, it is just cleared.  Measured on MI355X:
+// 7.6-13 cycles per 64-lane ds_add(_rtn)_u32 per CU against 16.5 for a plain read-add-write and 212
+// for ds_add_f32 (profiles/r01_lds_atomic_microbench.log).
 //
 // One 64-lane wave per left row, single-wave workgroups, persistent waves fed by a global row
-// counter, as K4.  LDS per wave: the tile's 2^TILE_LOG2 u16 accumulators (two per word), row i
-// (term -> value hash, for the exact scoring) and the survivor buffer: 10.75 KiB at TILE 4096 -> 14 waves per CU.
+// counter, as K4.  LDS per wave: the tile's 4096 u16 accumulators (two per word), row i as a term ->
+// value hash (for the exact scoring) and the survivor buffer: 10.75 KiB -> 14 waves per CU.
 // Rows the kernel does not handle (more than 64 non-zeros) are appended to a list and processed by K4.
 #define SG_WATCH_NAME sg_debug_watch_pruned
 #include "sg_k4_device.h"
 
 #define SG_SURV_CAP 320   // survivors buffered per wave (verified 64 at a time as soon as 64 are there)
-
-template <typename T>
-__device__ __forceinline__ uint32_t to_fixed(T a, T b);   // floor(a * b * 2^15) up to one rounding of the product
-template <>
-__device__ __forceinline__ uint32_t to_fixed<float>(float a, float b) {
-    return (uint32_t)(__fmul_rn(__fmul_rn(a, b), 32768.0f));
-}
-template <>
-__device__ __forceinline__ uint32_t to_fixed<double>(double a, double b) {
-    return (uint32_t)__dmul_rn(__dmul_rn(a, b), 32768.0);
-}
 
 template <typename T>
 __device__ __forceinline__ T wave_shfl(T v, int src) {
@@ -140,18 +131,18 @@ __device__ __forceinline__ void verify_chunk(int j, const int *hk, const T *ha, 
     }
 }
 
-// Four postings per lane of one column tile: lane (term g, u of G) holds entries idx, idx + G, idx + 2G,
-// idx + 3G of its term's segment.  The loads are unconditional (lanes without an entry re-read posting 0)
-// so that a batch can stay in flight while the previous one is applied.
-template <typename T>
-struct PostBatch {
-    typename Post<T>::reg_t r[4];
+// Four filter postings per lane of one column tile: lane (term g, u of G) holds entries idx, idx + G,
+// idx + 2G, idx + 3G of its term's segment.  The loads are unconditional (lanes without an entry re-read
+// posting 0) so that a batch can stay in flight while the previous one is applied.
+struct FiltBatch {
+    uint32_t r[4];
     bool ok[4];
-    __device__ __forceinline__ void issue(const char *vals, const char *slots, uint32_t idx, uint32_t hi, uint32_t g) {
+    __device__ __forceinline__ void issue(const uint32_t *__restrict__ filt, uint32_t idx, uint32_t hi, uint32_t g) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             ok[e] = g != 0 && idx + e * g < hi;
-            r[e] = Post<T>::load(vals, slots, 0u, ok[e] ? idx + e * g : 0u);
+            const uint32_t off = (ok[e] ? idx + e * g : 0u) << 2;   // kernel-constant base + 32-bit byte offset
+            r[e] = *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(filt) + off);
         }
     }
 };
@@ -160,10 +151,10 @@ template <typename T, int TILE_LOG2>
 __global__ void __launch_bounds__(64)
 spgemm_topn_pruned_kernel(const int64_t *__restrict__ a_indptr, const int32_t *__restrict__ a_indices,
                           const T *__restrict__ a_data, uint32_t n_left, const uint32_t *__restrict__ seg,
-                          const int32_t *__restrict__ post_rows, const T *__restrict__ post_vals, int32_t n_tiles,
-                          const uint32_t *__restrict__ fwd_ptr, const void *__restrict__ fwd, int32_t keep,
-                          int32_t out_stride, T thr,
+                          const uint32_t *__restrict__ filt, int32_t n_tiles, const uint32_t *__restrict__ fwd_ptr,
+                          const void *__restrict__ fwd, int32_t keep, int32_t out_stride, T thr,
                           float s_budget /* (beta / max ||b_j||)^2, rounded down */, float norm_b /* max ||b_j||, rounded up */,
+                          uint32_t freq_min /* list length from which a term may join the suffix */,
                           int32_t *__restrict__ out_cols, T *__restrict__ out_vals, int32_t *__restrict__ out_cnt,
                           uint32_t *row_counter, uint32_t *flagged_count, uint32_t *flagged_rows,
                           unsigned long long *stats /* [0] rows [1] postings streamed [2] survivors */) {
@@ -176,13 +167,13 @@ spgemm_topn_pruned_kernel(const int64_t *__restrict__ a_indptr, const int32_t *_
     uint4 *tab_v = reinterpret_cast<uint4 *>(smem);
     const int lane = threadIdx.x;
     for (int x = lane; x < TILE * 2 / 16; x += 64) tab_v[x] = make_uint4(0, 0, 0, 0);
-    const char *vals = reinterpret_cast<const char *>(post_vals);
-    const char *slots = reinterpret_cast<const char *>(post_rows);
     const uint64_t lanes_below = (1ull << lane) - 1ull;
     unsigned long long st_rows = 0, st_post = 0, st_surv = 0;
 
+    // rows are handed out four at a time: one global atomic per row capped the kernel at ~88 rows/us
     SG_WD_DECL(wd_rows);
-    for (uint32_t row = next_row(row_counter, lane); row < n_left; row = next_row(row_counter, lane)) {
+    for (uint32_t row0 = next_row(row_counter, lane) * 4u; row0 < n_left; row0 = next_row(row_counter, lane) * 4u)
+    for (uint32_t row = row0; row < min(row0 + 4u, n_left); ++row) {
         SG_WD(wd_rows, n_left + 2, 11)
         const int64_t rlo = a_indptr[row];
         const int nnz = __builtin_amdgcn_readfirstlane((int)(a_indptr[row + 1] - rlo));
@@ -211,7 +202,7 @@ spgemm_topn_pruned_kernel(const int64_t *__restrict__ a_indptr, const int32_t *_
             const bool before = dq > df || (dq == df && q <= lane);
             cum += before ? wq : 0.f;
         }
-        const bool in_s = lane < nnz && cum <= s_budget;
+        const bool in_s = lane < nnz && cum <= s_budget && df >= freq_min;   // a prefix of the (df desc) order
         const bool in_p = lane < nnz && !in_s;
         const uint64_t pm = __ballot(in_p);
         if (pm == 0) continue;   // ||a|| * max ||b|| <= beta < threshold: no match possible
@@ -225,17 +216,19 @@ spgemm_topn_pruned_kernel(const int64_t *__restrict__ a_indptr, const int32_t *_
         bs2 = wave_read<float>(bs2, 0);     // explicitly wave-uniform: the branches below must not diverge
         dsum = wave_read<float>(dsum, 0);
         if (!(dsum > 0.f)) continue;   // every list of P is empty
+        st_post += (unsigned long long)dsum;   // statistic (float sum of the list lengths)
         const int np = __popcll(pm);
-        // ---- survivor threshold in fixed point (prune_threshold in DESIGN.md): a column survives when
-        //      q_ij >= tq, with q_ij = sum of truncated products.  Conservative by construction:
-        //      score~ <= p + ||a_S|| max||b|| + 1e-5   and   p * 2^15 <= q + np + 1
-        const float b_s = sqrtf(bs2) * norm_b * 1.000002f;
-        const float tqf = floorf(((float)thr - b_s - 1e-5f) * 32768.0f) - (float)np - 3.0f;
-        if (!(tqf >= 1.0f)) {   // delta too small for the fixed-point resolution: exact kernel
+        // ---- survivor test in fixed point (scale 2^15).  q_ij accumulates UPPER bounds of the products, so
+        //      p_ij * 2^15 <= q_ij; the exact kernel's float score obeys  score~ <= score + 1e-5  and
+        //      score <= p_ij + ||a_S|| f_j  with  f_j <= fq_j / 255 * norm_b.  Column j survives when
+        //      q_ij >= tq_j = (thr - 1e-5) * 2^15 - c1 * fq_j - 2   (the 2 covers the float evaluation).
+        const float b_s = sqrtf(bs2) * 1.000002f;
+        const float t0 = ((float)thr - 1e-5f) * 32768.0f - 2.0f;
+        const float c1 = b_s * norm_b * (32768.0f / 255.0f) * 1.000002f;
+        if (!(t0 - c1 * 255.0f >= 1.0f)) {   // delta too small for the fixed-point resolution: exact kernel
             if (lane == 0) flagged_rows[atomicAdd(flagged_count, 1u)] = row;
             continue;
         }
-        const uint32_t tq = (uint32_t)tqf;
 
         // ---- deal the 64 lanes to the terms of P in proportion to their list lengths
         uint32_t G = in_p ? 1u + (uint32_t)((float)(64 - np) * 0.999f * ((float)df / dsum)) : 0u;
@@ -265,8 +258,12 @@ spgemm_topn_pruned_kernel(const int64_t *__restrict__ a_indptr, const int32_t *_
             }
         }
         const int my_k = wave_shfl<int>(k, src);
-        const T my_a = wave_shfl<T>(a, src);
-        const uint32_t *msp = seg + (int64_t)my_k * n_tiles;
+        // upper bound of a * b * 2^15 from the bq of a filter posting: (uint32)(c_a * bq) + 1
+        const float c_a = (float)wave_shfl<T>(a, src) * norm_b * (32768.0f / (float)((1 << (24 - TILE_LOG2)) - 1)) * 1.000002f;
+        const uint32_t seg_off = (uint32_t)my_k * (uint32_t)n_tiles;   // < 2^30 bins (checked when the postings are built)
+        auto seg_at = [&](uint32_t i) {
+            return *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(seg) + ((seg_off + i) << 2));
+        };
 
         // ---- stage row i for the exact scoring: term -> value hash (filled by compare-and-swap, one wave)
         hk[lane] = -1;
@@ -288,21 +285,22 @@ spgemm_topn_pruned_kernel(const int64_t *__restrict__ a_indptr, const int32_t *_
         uint32_t n_surv = 0;
         // applies one batch to the tile's accumulators; a lane whose add takes an accumulator across tq
         // appends the column to the survivor buffer; full waves of survivors are scored at once
-        auto apply = [&](const PostBatch<T> &bt, int t) {
+        auto apply = [&](const FiltBatch &bt, int t) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
+                if (e > 0 && __ballot(bt.ok[e]) == 0) break;   // a lane's entries fill its slots in order
                 bool cross = false;
                 uint32_t c = 0;
                 if (bt.ok[e]) {
-                    c = Post<T>::slot(bt.r[e]) / (uint32_t)sizeof(T);
-                    const uint32_t x = to_fixed<T>(my_a, Post<T>::val(bt.r[e]));
+                    c = bt.r[e] & (uint32_t)(TILE - 1);
+                    const uint32_t x = (uint32_t)(c_a * (float)(bt.r[e] >> (TILE_LOG2 + 8))) + 1u;
+                    const uint32_t tq = (uint32_t)(t0 - c1 * (float)((bt.r[e] >> TILE_LOG2) & 0xffu));
                     const uint32_t sh = (c & 1u) << 4;
                     const uint32_t old = __hip_atomic_fetch_add(&tab[c >> 1], x << sh, __ATOMIC_RELAXED,
                                                                 __HIP_MEMORY_SCOPE_WORKGROUP);
                     const uint32_t oh = (old >> sh) & 0xffffu;
                     cross = oh < tq && oh + x >= tq;
                 }
-                st_post += __popcll(__ballot(bt.ok[e]));
                 const uint64_t cm = __ballot(cross);
                 if (cm) {
                     if (cross) surv[n_surv + __popcll(cm & lanes_below)] = (t << TILE_LOG2) + (int)c;
@@ -326,40 +324,54 @@ spgemm_topn_pruned_kernel(const int64_t *__restrict__ a_indptr, const int32_t *_
             }
         };
 
-        // segment bounds of (my term, tile t), t + 1 and t + 2: the bounds are fetched two tiles ahead and
-        // the first batch of tile t + 1 is in flight while tile t is applied
-        uint32_t lo = 0, hi = 0, hi1 = 0, hi2 = 0;
+        // Software pipeline over the column tiles: while tile t is applied, the first batches of tiles t + 1
+        // and t + 2 are in flight and the segment bound needed for tile t + 3 is being fetched (b0..b4 =
+        // seg[t .. t + 4] of my term).  The multiply is bound by load latency (~1-2 us to the Infinity
+        // Cache at 14 waves per CU), not by bandwidth or issue: every level of prefetch paid off.
+        const uint32_t last = (uint32_t)n_tiles;
+        uint32_t b0 = 0, b1 = 0, b2 = 0, b3 = 0, b4 = 0;
         if (g) {
-            lo = msp[0];
-            hi = msp[1];
-            hi1 = n_tiles > 1 ? msp[2] : hi;
+            b0 = seg_at(0);
+            b1 = seg_at(min(1u, last));
+            b2 = seg_at(min(2u, last));
+            b3 = seg_at(min(3u, last));
         }
-        PostBatch<T> cur;
-        cur.issue(vals, slots, lo + u, hi, g);
+        FiltBatch cur, nx1;
+        cur.issue(filt, b0 + u, b1, g);
+        nx1.issue(filt, b1 + u, b2, g);
         SG_WD_DECL(wd_t);
         for (int t = 0; t < n_tiles; ++t) {
             SG_WD(wd_t, n_tiles + 2, 13)
-            hi2 = hi1;
-            if (g && t + 3 <= n_tiles) hi2 = msp[t + 3];
-            PostBatch<T> nxt;
-            nxt.issue(vals, slots, hi + u, hi1, g);   // past the last tile hi1 == hi: nothing to load
+            if (g) b4 = seg_at(min((uint32_t)t + 4u, last));
+            FiltBatch nx2;
+            nx2.issue(filt, b2 + u, b3, g);   // past the last tile the bounds coincide: nothing to load
             if (__ballot(cur.ok[0]) != 0) {
                 apply(cur, t);
-                uint32_t idx = lo + u + 4 * g;
-                SG_WD_DECL(wd_b);
-                while (__ballot(g != 0 && idx < hi) != 0) {   // segments longer than the dealt lanes cover in one batch
-                    SG_WD(wd_b, 1 << 24, 14)
-                    PostBatch<T> more;
-                    more.issue(vals, slots, idx, hi, g);
-                    apply(more, t);
-                    idx += 4 * g;
+                uint32_t idx = b0 + u + 4 * g;
+                if (__ballot(g != 0 && idx < b1) == 0) {
+                    // re-zero only what was touched (a few dozen of the tile's accumulators): sweeping the
+                    // tile for every row costs rows * columns * 2 B of LDS writes, 11 ms at 663 k
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (cur.ok[e]) tab[(cur.r[e] & (uint32_t)(TILE - 1)) >> 1] = 0u;
+                } else {
+                    SG_WD_DECL(wd_b);
+                    do {   // segments longer than the dealt lanes cover in one batch
+                        SG_WD(wd_b, 1 << 24, 14)
+                        FiltBatch more;
+                        more.issue(filt, idx, b1, g);
+                        apply(more, t);
+                        idx += 4 * g;
+                    } while (__ballot(g != 0 && idx < b1) != 0);
+                    for (int x = lane; x < TILE * 2 / 16; x += 64) tab_v[x] = make_uint4(0, 0, 0, 0);
                 }
-                for (int x = lane; x < TILE * 2 / 16; x += 64) tab_v[x] = make_uint4(0, 0, 0, 0);
             }
-            lo = hi;
-            hi = hi1;
-            hi1 = hi2;
-            cur = nxt;
+            b0 = b1;
+            b1 = b2;
+            b2 = b3;
+            b3 = b4;
+            cur = nx1;
+            nx1 = nx2;
         }
         if (n_surv > 0) {   // fewer than 64 left
             verify_chunk<T>((uint32_t)lane < n_surv ? surv[lane] : -1, hk, ha, fwd_ptr, fwd, thr, top, lane);
@@ -453,8 +465,8 @@ int sg_csr_props(sg_ctx *ctx, const sg_csr *m, bool *cosine_like, float *max_nor
 // ------------------------------------------------------------------------------------------------
 template <typename T, int TILE_LOG2>
 static int launch_pruned(sg_ctx *ctx, const sg_csr *A, const sg_postings *Bt, int32_t keep, sg_topn *r, T thr,
-                         float s_budget, float norm_b, uint32_t *row_counter, uint32_t *flagged_count,
-                         uint32_t *flagged_rows, unsigned long long *stats) {
+                         float s_budget, uint32_t *row_counter, uint32_t *flagged_count, uint32_t *flagged_rows,
+                         unsigned long long *stats) {
     const size_t lds = ((size_t)2 << TILE_LOG2) + 512 + 1024 + (size_t)SG_SURV_CAP * 4;
     int waves_per_cu = (int)(ctx->lds_per_cu / lds);
     if (waves_per_cu > 32) waves_per_cu = 32;
@@ -465,8 +477,9 @@ static int launch_pruned(sg_ctx *ctx, const sg_csr *A, const sg_postings *Bt, in
     if ((int64_t)grid > A->n_rows) grid = (unsigned)(A->n_rows > 0 ? A->n_rows : 1);
     hipLaunchKernelGGL((spgemm_topn_pruned_kernel<T, TILE_LOG2>), dim3(grid), dim3(64), lds, ctx->stream, A->d_indptr,
                        A->d_indices, (const T *)A->d_data, (uint32_t)A->n_rows, (const uint32_t *)Bt->d_seg,
-                       (const int32_t *)Bt->d_rows, (const T *)Bt->d_vals, Bt->n_tiles, (const uint32_t *)Bt->d_fwd_ptr,
-                       (const void *)Bt->d_fwd, keep, r->stride, thr, s_budget, norm_b, r->d_cols, (T *)r->d_vals,
+                       (const uint32_t *)Bt->d_filt, Bt->n_tiles, (const uint32_t *)Bt->d_fwd_ptr,
+                       (const void *)Bt->d_fwd, keep, r->stride, thr, s_budget, Bt->norm_up, Bt->freq_min, r->d_cols,
+                       (T *)r->d_vals,
                        r->d_counts, row_counter, flagged_count, flagged_rows, stats);
     SG_HIP_TRY(hipGetLastError());
     return SG_OK;
@@ -474,12 +487,12 @@ static int launch_pruned(sg_ctx *ctx, const sg_csr *A, const sg_postings *Bt, in
 
 template <typename T>
 static int dispatch_pruned(sg_ctx *ctx, const sg_csr *A, const sg_postings *Bt, int32_t keep, sg_topn *r, T thr,
-                           float s_budget, float norm_b, uint32_t *row_counter, uint32_t *flagged_count,
-                           uint32_t *flagged_rows, unsigned long long *stats) {
+                           float s_budget, uint32_t *row_counter, uint32_t *flagged_count, uint32_t *flagged_rows,
+                           unsigned long long *stats) {
     switch (Bt->tile_log2) {
-        case 11: return launch_pruned<T, 11>(ctx, A, Bt, keep, r, thr, s_budget, norm_b, row_counter, flagged_count, flagged_rows, stats);
-        case 12: return launch_pruned<T, 12>(ctx, A, Bt, keep, r, thr, s_budget, norm_b, row_counter, flagged_count, flagged_rows, stats);
-        case 13: return launch_pruned<T, 13>(ctx, A, Bt, keep, r, thr, s_budget, norm_b, row_counter, flagged_count, flagged_rows, stats);
+        case 11: return launch_pruned<T, 11>(ctx, A, Bt, keep, r, thr, s_budget, row_counter, flagged_count, flagged_rows, stats);
+        case 12: return launch_pruned<T, 12>(ctx, A, Bt, keep, r, thr, s_budget, row_counter, flagged_count, flagged_rows, stats);
+        case 13: return launch_pruned<T, 13>(ctx, A, Bt, keep, r, thr, s_budget, row_counter, flagged_count, flagged_rows, stats);
         default:
             sg_set_error("postings tile of 2^%d columns is not supported by the pruned multiply (2^11..2^13)", Bt->tile_log2);
             return SG_ERR_UNSUPPORTED;
@@ -489,17 +502,16 @@ static int dispatch_pruned(sg_ctx *ctx, const sg_csr *A, const sg_postings *Bt, 
 bool sg_pruned_supports_tile(int32_t tile_log2) { return tile_log2 >= 11 && tile_log2 <= 13; }
 
 int sg_spgemm_pruned_launch(sg_ctx *ctx, const sg_csr *A, const sg_postings *Bt, int32_t keep, sg_topn *r,
-                            double threshold, double delta, float max_norm2_b, uint32_t *row_counter,
-                            uint32_t *flagged_count, uint32_t *flagged_rows, unsigned long long *stats) {
+                            double threshold, double delta, uint32_t *row_counter, uint32_t *flagged_count,
+                            uint32_t *flagged_rows, unsigned long long *stats) {
     // beta = threshold - delta bounds ||a_S|| * max ||b_j||; the kernel compares sums of squares of a
-    const double nb = sqrt((double)max_norm2_b) * (1.0 + 1e-6);
+    const double nb = (double)Bt->norm_up;
     const double beta = threshold - delta;
     const double budget = (beta / nb) * (beta / nb) * (1.0 - 1e-6);
     const float s_budget = __builtin_nextafterf((float)budget, 0.f);
-    const float norm_b = __builtin_nextafterf((float)nb, 2.f);
     if (A->dtype == SG_F64)
-        return dispatch_pruned<double>(ctx, A, Bt, keep, r, (double)threshold, s_budget, norm_b, row_counter,
-                                       flagged_count, flagged_rows, stats);
-    return dispatch_pruned<float>(ctx, A, Bt, keep, r, (float)threshold, s_budget, norm_b, row_counter, flagged_count,
+        return dispatch_pruned<double>(ctx, A, Bt, keep, r, (double)threshold, s_budget, row_counter, flagged_count,
+                                       flagged_rows, stats);
+    return dispatch_pruned<float>(ctx, A, Bt, keep, r, (float)threshold, s_budget, row_counter, flagged_count,
                                   flagged_rows, stats);
 }

@@ -578,7 +578,7 @@ extern "C" int sg_spgemm_topn(sg_ctx *ctx, const sg_csr *A, const sg_postings *B
     double delta = 0.0;
     {
         const char *pr = getenv("SG_PRUNE");
-        if (!(pr && pr[0] == '0') && Bt->cosine_like && Bt->d_fwd && stride <= SG_TOPN_LANES && A->n_rows > 0 && Bt->nnz > 0 &&
+        if (!(pr && pr[0] == '0') && Bt->cosine_like && Bt->d_filt && stride <= SG_TOPN_LANES && A->n_rows > 0 && Bt->nnz > 0 &&
             sg_pruned_supports_tile(Bt->tile_log2) && threshold >= 0.1) {
             delta = env_double("SG_PRUNE_DELTA", 0.2);
             if (delta > 0.5 * threshold) delta = 0.5 * threshold;
@@ -613,7 +613,7 @@ extern "C" int sg_spgemm_topn(sg_ctx *ctx, const sg_csr *A, const sg_postings *B
             hipMemsetAsync(ctx->d_stat_words + 2, 0, 4 * sizeof(int64_t), ctx->stream) != hipSuccess)
             st = SG_ERR_HIP;
         if (prune && st == SG_OK)
-            st = sg_spgemm_pruned_launch(ctx, A, Bt, stride, r, threshold, delta, Bt->max_norm2, counters + n_launch + 1,
+            st = sg_spgemm_pruned_launch(ctx, A, Bt, stride, r, threshold, delta, counters + n_launch + 1,
                                          handed_count, handed_rows, (unsigned long long *)(ctx->d_stat_words + 2));
         int li = 0;
         for (int pass = 0; pass < n_pass && st == SG_OK && A->n_rows > 0; ++pass) {

@@ -1,5 +1,6 @@
 """The pruning rule of the pruned multiply (string_grouper_amd/csrc/sg_spgemm_pruned.hip), restated in
-numpy with the kernel's arithmetic (float32 bound, truncated 2^15 fixed point, the same slack terms)
+numpy with the kernel's arithmetic (float32 bound, upward-quantised filter postings, 2^15 fixed point,
+the same slack terms)
 and checked against the oracle: every pair the oracle keeps must be among the kernel's survivors.
 This pins the MATH of the filter on the CPU; the kernel itself is compared bit for bit with the
 oracle by the GPU parity tests."""
@@ -12,12 +13,26 @@ from string_grouper_amd.synth import synth_names
 f32 = np.float32
 
 
-def survivors_of_row(a_idx, a_val, Bt_indptr, Bt_rows, Bt_vals, thr, delta, norm_b):
+def quantise_right(m, mt, freq_min, norm_up):
+    """K3's filter postings: per right row fq (8 bits, frequent-part norm) and per posting bq (12 bits),
+    both rounded up relative to norm_up (sg_postings.hip, postings_fill)."""
+    df = np.diff(mt.indptr)
+    inv = f32(1.0) / f32(norm_up)
+    frequent = df[m.indices] >= freq_min
+    f2 = np.zeros(m.shape[0])
+    np.add.at(f2, np.repeat(np.arange(m.shape[0]), np.diff(m.indptr))[frequent],
+              m.data[frequent].astype(np.float64) ** 2)
+    fq = np.minimum(255, np.ceil(np.nextafter(np.sqrt(f2).astype(f32), f32(2)) * inv * f32(255.0) * f32(1.000002)))
+    bq_t = np.minimum(4095, np.ceil(mt.data.astype(f32) * inv * f32(4095.0) * f32(1.000002)))
+    return fq.astype(np.int64), bq_t.astype(np.int64)
+
+
+def survivors_of_row(a_idx, a_val, Bt_indptr, Bt_rows, bq_t, fq, thr, delta, norm_up, freq_min):
     """Columns the kernel would score exactly for one left row (model of the kernel, float32 data)."""
     nnz = len(a_idx)
     df = (Bt_indptr[a_idx + 1] - Bt_indptr[a_idx]).astype(np.int64)
     beta = thr - delta
-    budget = np.nextafter(f32((beta / norm_b) ** 2 * (1.0 - 1e-6)), f32(0))
+    budget = np.nextafter(f32((beta / norm_up) ** 2 * (1.0 - 1e-6)), f32(0))
     w = (a_val.astype(f32) * a_val.astype(f32) * f32(1.00001)).astype(f32)
     cum = np.zeros(nnz, f32)
     for lane in range(nnz):
@@ -26,30 +41,32 @@ def survivors_of_row(a_idx, a_val, Bt_indptr, Bt_rows, Bt_vals, thr, delta, norm
             if df[q] > df[lane] or (df[q] == df[lane] and q <= lane):
                 c = f32(c + w[q])
         cum[lane] = c
-    in_s = cum <= budget
+    in_s = (cum <= budget) & (df >= freq_min)
     in_p = ~in_s
     if not in_p.any():
         return np.zeros(0, np.int64), 0
     bs2 = cum[in_s].max() if in_s.any() else f32(0)
-    b_s = f32(f32(np.sqrt(bs2)) * f32(norm_b) * f32(1.000002))
-    n_p = int(in_p.sum())
-    tqf = np.floor(f32(f32(f32(thr) - b_s - f32(1e-5)) * f32(32768.0))) - n_p - 3.0
-    assert tqf >= 1.0
+    b_s = f32(f32(np.sqrt(bs2)) * f32(1.000002))
+    t0 = f32(f32(f32(thr) - f32(1e-5)) * f32(32768.0)) - f32(2.0)
+    c1 = f32(f32(f32(b_s * f32(norm_up)) * f32(32768.0 / 255.0)) * f32(1.000002))
+    assert t0 - c1 * f32(255.0) >= 1.0
     q = {}
     streamed = 0
     for t in np.nonzero(in_p)[0]:
         lo, hi = Bt_indptr[a_idx[t]], Bt_indptr[a_idx[t] + 1]
-        x = (f32(a_val[t]) * Bt_vals[lo:hi].astype(f32)).astype(f32) * f32(32768.0)
-        x = x.astype(np.uint32)   # truncation
+        c_a = f32(f32(f32(f32(a_val[t]) * f32(norm_up)) * f32(32768.0 / 4095.0)) * f32(1.000002))
+        x = (c_a * bq_t[lo:hi].astype(f32)).astype(f32).astype(np.uint32) + 1   # truncation, then + 1
         streamed += hi - lo
         for j, xv in zip(Bt_rows[lo:hi], x):
             q[j] = q.get(j, 0) + int(xv)
-    surv = np.array(sorted(j for j, v in q.items() if v >= tqf), dtype=np.int64)
+    assert max(q.values()) < 65536
+    surv = np.array(sorted(j for j, v in q.items() if v >= np.uint32(t0 - c1 * f32(fq[j]))), dtype=np.int64)
     return surv, streamed
 
 
-@pytest.mark.parametrize("thr,delta", [(0.8, 0.2), (0.8, 0.05), (0.5, 0.2), (0.95, 0.3)])
-def test_survivors_cover_every_oracle_match(thr, delta):
+@pytest.mark.parametrize("thr,delta,freq", [(0.8, 0.2, 0.003), (0.8, 0.05, 0.0), (0.5, 0.2, 0.01), (0.95, 0.3, 0.05),
+                                            (0.8, 0.1, 0.003)])
+def test_survivors_cover_every_oracle_match(thr, delta, freq):
     names = synth_names(3000, 77)
     (m,), _, _ = O.tfidf_sklearn(names, [names], dtype=np.float32)
     m = m.tocsr()
@@ -57,12 +74,14 @@ def test_survivors_cover_every_oracle_match(thr, delta):
     mt = m.T.tocsr()
     mt.sort_indices()
     C = O.sp_matmul_topn(m, m.T.tocsr(), 10_000, thr, sort=True)   # uncapped: every pair above thr
-    norm_b = float(np.sqrt(np.asarray(m.multiply(m).sum(axis=1)).max())) * (1 + 1e-6)
+    norm_up = np.nextafter(f32(np.sqrt(f32(np.asarray(m.multiply(m).sum(axis=1)).max())) * f32(1.000001)), f32(2))
+    freq_min = max(1, int(freq * m.shape[0]))
+    fq, bq_t = quantise_right(m, mt, freq_min, norm_up)
     total_streamed = total_full = total_surv = 0
     for i in range(0, m.shape[0], 7):
         lo, hi = m.indptr[i], m.indptr[i + 1]
-        surv, streamed = survivors_of_row(m.indices[lo:hi], m.data[lo:hi], mt.indptr, mt.indices, mt.data, thr, delta,
-                                          norm_b)
+        surv, streamed = survivors_of_row(m.indices[lo:hi], m.data[lo:hi], mt.indptr, mt.indices, bq_t, fq, thr, delta,
+                                          norm_up, freq_min)
         want = C.indices[C.indptr[i]:C.indptr[i + 1]]
         assert set(want) <= set(surv), (i, sorted(set(want) - set(surv)))
         total_streamed += streamed
