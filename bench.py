@@ -14,8 +14,10 @@ N > 1 is strong scaling of the same workload: rank 0's string column is broadcas
 every rank vectorises and multiplies its contiguous block of left rows
 (string_grouper_amd/distributed.py).
 
-Prints ONE JSON line (rank 0) with ``roofline`` (K4, live HIP-event time on the library's stream)
-and ``cpu_baseline`` (the C/OpenMP port of sparse_dot_topn on a bounded row sample, rank 0, N=1).
+Prints ONE JSON line (rank 0) with ``roofline`` (the multiply kernel of the step -- the pruned kernel
+K4p on this workload -- live HIP-event time on the library's stream, priced on its own algorithmic
+bytes), ``exact_kernel`` (K4 timed live on the same input; results compared bit for bit) and
+``cpu_baseline`` (the C/OpenMP port of sparse_dot_topn on a bounded row sample, rank 0, N=1).
 """
 from __future__ import annotations
 
@@ -44,6 +46,7 @@ def parse_args():
     ap.add_argument("--dtype", default="f32", choices=["f32", "f64"])
     ap.add_argument("--cpu-sample-rows", type=int, default=0, help="left rows of the CPU baseline (0 = auto)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-exact-kernel", action="store_true", help="skip the live run of the exact kernel K4")
     ap.add_argument("--end-to-end", action="store_true", help="also time match_strings() incl. PCIe and pandas")
     return ap.parse_args()
 
@@ -144,7 +147,12 @@ def main():
 
     ms_per_step = elapsed / args.steps * 1e3
     k4_avg_ms = float(np.mean(k4_ms))
-    achieved = stats["spgemm_bytes"] / (k4_avg_ms * 1e-3) / 1e9        # this rank's launch group, GB/s
+    pruned = stats["prune_rows"] > 0
+    # dominant kernel of the step.  Pruned multiply: ITS OWN algorithmic bytes (4 B per filter posting it
+    # streams + one packed row of B per pair it scores exactly + A + out), not the bytes of the products it
+    # proved unnecessary.  Exact multiply: the stream model, (4+s) B per intermediate product + A + out.
+    k4_bytes = stats["prune_bytes"] if pruned else stats["spgemm_bytes"]
+    achieved = k4_bytes / (k4_avg_ms * 1e-3) / 1e9        # this rank's launch group, GB/s
     result = {
         "metric": "match_strings rows/sec (hot path: tokenise + tf-idf + postings + SpGEMM-topn), "
                   "663k-name self-join ntop=10 min_sim=0.8",
@@ -165,23 +173,63 @@ def main():
         "kernels_ms": {k[3:]: round(v, 4) for k, v in stats.items() if k.startswith("ms_")},
         "matches": int(job_nnz),
         "macs": int(job_macs),
-        "roofline": {"bound": "hbm", "kernel": "spgemm_topn_kernel (K4)", "achieved": achieved, "peak": HBM_PEAK_GBPS,
-                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
-                     "algorithmic_bytes_per_launch_group": int(stats["spgemm_bytes"]),
-                     "avg_ms": k4_avg_ms,
-                     "note": "algorithmic = stream model (4+s) B per intermediate product + A + out; traffic: see "
-                             "profiles/ (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE passes)"},
+        "roofline": {"bound": "hbm",
+                     "kernel": "spgemm_topn_pruned_kernel (K4p)" if pruned else "spgemm_topn_kernel (K4)",
+                     "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
+                     "traffic": None, "algorithmic_bytes_per_launch": int(k4_bytes), "avg_ms": k4_avg_ms,
+                     "note": ("algorithmic = 4 B per filter posting streamed + (8 + mean packed row) B per pair scored "
+                              "exactly + A + out; the kernel is latency/occupancy bound, not bandwidth bound (DESIGN.md)")
+                     if pruned else
+                     "algorithmic = stream model (4+s) B per intermediate product + A + out"},
     }
+    if pruned:
+        result["pruning"] = {"rows": stats["prune_rows"], "postings_streamed": stats["prune_postings"],
+                             "of_intermediate_products": stats["macs"], "pairs_scored_exactly": stats["prune_survivors"],
+                             "rows_handed_to_exact_kernel": stats["exact_rows"]}
 
     # measured HBM-side traffic of the same kernel on the same workload, from the committed PMC passes
     try:
         with open(os.path.join(ROOT, "profiles", "k4_traffic.json")) as f:
             tr = json.load(f)
-        if tr.get("workload_rows") == args.rows and tr.get("dtype") == args.dtype and world == 1:
+        if (tr.get("workload_rows") == args.rows and tr.get("dtype") == args.dtype and world == 1
+                and tr.get("kernel", "K4") == ("K4p" if pruned else "K4")):
             result["roofline"]["traffic"] = tr["traffic_bytes_per_launch_raw"]
             result["roofline"]["traffic_note"] = tr["source"] + "; " + tr["note"]
     except Exception:
         pass
+
+    if world == 1 and pruned and not args.no_exact_kernel:
+        # the exact kernel (K4) on the same input, timed live beside the pruned one: it is what runs when the
+        # data is not cosine-like or top_n > 64, and the pruned result must equal it bit for bit
+        os.environ["SG_PRUNE"] = "0"
+        vec = make_vec()
+        vec.fit_prepared([prepared])
+        A = vec.transform_prepared(prepared)
+        post = ctx.postings_build(A)
+        ex_ms = []
+        for _ in range(2):
+            r_ex = ctx.spgemm_topn(A, post, args.top_n, args.min_similarity, True)
+            ctx.sync()
+            st_ex = ctx.stats()
+            ex_ms.append(st_ex["ms_spgemm_topn"])
+            if len(ex_ms) < 2:
+                r_ex.free()
+        os.environ.pop("SG_PRUNE")
+        r_pr = step()
+        h_ex, h_pr = r_ex.to_host(), r_pr.to_host()
+        mask = np.arange(h_ex[0].shape[1])[None, :] < h_ex[2][:, None]
+        identical = bool(np.array_equal(h_ex[2], h_pr[2]) and np.array_equal(h_ex[0][mask], h_pr[0][mask])
+                         and np.array_equal(h_ex[1][mask], h_pr[1][mask]))
+        r_ex.free()
+        r_pr.free()
+        post.free()
+        A.free()
+        ex_gbps = st_ex["spgemm_bytes"] / (min(ex_ms) * 1e-3) / 1e9
+        result["exact_kernel"] = {"kernel": "spgemm_topn_kernel (K4)", "ms": min(ex_ms), "achieved": ex_gbps,
+                                  "unit": "GB/s", "frac": ex_gbps / HBM_PEAK_GBPS,
+                                  "algorithmic_bytes_per_launch": int(st_ex["spgemm_bytes"]),
+                                  "pruned_result_identical": identical,
+                                  "note": "stream model (4+s) B per intermediate product + A + out"}
 
     if world == 1 and not args.no_cpu_baseline:
         from oracle import oracle as O

@@ -178,6 +178,8 @@ typedef struct {
     int64_t prune_postings;   /* postings it streamed (of `macs` the exact kernel would)            */
     int64_t prune_survivors;  /* candidate pairs it scored exactly                                  */
     int64_t exact_rows;       /* left rows it handed to the exact kernel                            */
+    int64_t prune_bytes;      /* its algorithmic bytes: 4 per posting streamed + one packed row of  */
+                              /* B (and its two row pointers) per survivor + A + out    */
 } sg_stats;
 /* Waits for the recorded events, so it is a synchronisation point. */
 int sg_ctx_stats(sg_ctx *ctx, sg_stats *out);

@@ -43,6 +43,7 @@ def main():
     dtypes = [np.float32, np.float64] if (len(sys.argv) > 3 and sys.argv[3] == "both") else [np.float32]
     freqs = [float(x) for x in (sys.argv[4] if len(sys.argv) > 4 else "0.003").split(",")]
     tiles = [int(x) for x in (sys.argv[5] if len(sys.argv) > 5 else "12").split(",")]
+    thresholds = [float(x) for x in (sys.argv[6] if len(sys.argv) > 6 else "0.8").split(",")]
     ctx = N.default_context(0)
     for n in sizes:
         names = synth_names(n, 1234)
@@ -51,9 +52,9 @@ def main():
             p = vec.prepare(names)
             vec.fit_prepared([p])
             A = vec.transform_prepared(p)
-            for top_n, thr in ((10, 0.8),):
+            for top_n, thr in [(10, t) for t in thresholds]:
                 t_ex, o_ex, st_ex = run(ctx, A, top_n, thr, False)
-                print(json.dumps({"n": n, "dtype": np.dtype(dtype).name, "mode": "exact", "ms": st_ex["ms_spgemm_topn"],
+                print(json.dumps({"n": n, "dtype": np.dtype(dtype).name, "mode": "exact", "thr": thr, "ms": st_ex["ms_spgemm_topn"],
                                   "wall_ms": t_ex * 1e3, "macs": st_ex["macs"], "out": st_ex["out_nnz"]}), flush=True)
                 for tile, delta, freq in [(t, d, f) for t in tiles for f in freqs for d in deltas]:
                     t_pr, o_pr, st_pr = run(ctx, A, top_n, thr, True, delta, freq=freq, tile=tile)
@@ -65,7 +66,7 @@ def main():
                         bad = np.nonzero(cnt_e != cnt_p)[0]
                         print(json.dumps({"count_mismatch_rows": int(len(bad)), "first": bad[:5].tolist(),
                                           "cnt_exact": cnt_e[bad[:5]].tolist(), "cnt_pruned": cnt_p[bad[:5]].tolist()}))
-                    print(json.dumps({"n": n, "dtype": np.dtype(dtype).name, "mode": "pruned", "tile": tile, "delta": delta, "freq": freq,
+                    print(json.dumps({"n": n, "dtype": np.dtype(dtype).name, "mode": "pruned", "thr": thr, "tile": tile, "delta": delta, "freq": freq,
                                       "ms": st_pr["ms_spgemm_topn"], "wall_ms": t_pr * 1e3, "identical": bool(same),
                                       "rows": st_pr["prune_rows"], "postings": st_pr["prune_postings"],
                                       "survivors": st_pr["prune_survivors"], "exact_rows": st_pr["exact_rows"],

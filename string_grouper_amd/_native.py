@@ -28,7 +28,7 @@ class SgVecParams(C.Structure):
 class SgStats(C.Structure):
     _fields_ = [("ms", C.c_float * SG_K_COUNT), ("macs", C.c_int64), ("spgemm_bytes", C.c_int64),
                 ("out_nnz", C.c_int64), ("prune_rows", C.c_int64), ("prune_postings", C.c_int64),
-                ("prune_survivors", C.c_int64), ("exact_rows", C.c_int64)]
+                ("prune_survivors", C.c_int64), ("exact_rows", C.c_int64), ("prune_bytes", C.c_int64)]
 
 
 # every symbol include/sg_hip.h declares: name -> (restype, argtypes)
@@ -287,7 +287,8 @@ class Context:
         d = {f"ms_{KERNEL_NAMES[i]}": float(st.ms[i]) for i in range(SG_K_COUNT)}
         d.update(macs=int(st.macs), spgemm_bytes=int(st.spgemm_bytes), out_nnz=int(st.out_nnz),
                  prune_rows=int(st.prune_rows), prune_postings=int(st.prune_postings),
-                 prune_survivors=int(st.prune_survivors), exact_rows=int(st.exact_rows))
+                 prune_survivors=int(st.prune_survivors), exact_rows=int(st.exact_rows),
+                 prune_bytes=int(st.prune_bytes))
         return d
 
     # ---- strings

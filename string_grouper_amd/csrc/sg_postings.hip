@@ -173,7 +173,7 @@ extern "C" int sg_postings_build(sg_ctx *ctx, const sg_csr *B, int32_t tile_cols
         // a term is "frequent" when it occurs in at least this share of the right-hand rows: the suffix of a
         // left row is drawn from frequent terms only, which lets the survivor test use each candidate's own
         // frequent-part norm instead of 1 (profiles/r01_prune_tuning.log)
-        double frac = 0.003;
+        double frac = 0.0045;
         if (const char *v = getenv("SG_PRUNE_FREQ")) frac = atof(v);
         const double fm = frac * (double)B->n_rows;
         p->freq_min = fm < 1.0 ? 1u : (uint32_t)fm;

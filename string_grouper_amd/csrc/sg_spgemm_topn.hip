@@ -579,8 +579,8 @@ extern "C" int sg_spgemm_topn(sg_ctx *ctx, const sg_csr *A, const sg_postings *B
     {
         const char *pr = getenv("SG_PRUNE");
         if (!(pr && pr[0] == '0') && Bt->cosine_like && Bt->d_filt && stride <= SG_TOPN_LANES && A->n_rows > 0 && Bt->nnz > 0 &&
-            sg_pruned_supports_tile(Bt->tile_log2) && threshold >= 0.1) {
-            delta = env_double("SG_PRUNE_DELTA", 0.2);
+            sg_pruned_supports_tile(Bt->tile_log2) && threshold >= env_double("SG_PRUNE_MIN_THRESHOLD", 0.45)) {   // below ~0.4 the filter passes too much (profiles/r01_prune_tuning.log)
+            delta = env_double("SG_PRUNE_DELTA", 0.05);   // tuned at 663 k: profiles/r01_prune_tuning.log
             if (delta > 0.5 * threshold) delta = 0.5 * threshold;
             if (delta < 0.02) delta = 0.02;
             bool a_ok = false;
@@ -661,6 +661,7 @@ extern "C" int sg_spgemm_topn(sg_ctx *ctx, const sg_csr *A, const sg_postings *B
         // the MAC and output terms are added in sg_ctx_stats once the device counters are read
         ctx->spgemm_entry_bytes = (int64_t)(4 + s);
         ctx->spgemm_fixed_bytes = A->nnz * (int64_t)(4 + s) + (A->n_rows + Bt->n_terms + 2) * 4;
+        ctx->prune_row_bytes = 8.0 + (Bt->n_right > 0 ? (double)Bt->nnz / (double)Bt->n_right : 0.0) * (s == 8 ? 16.0 : 8.0);
         if (hipGetLastError() != hipSuccess) st = SG_ERR_HIP;
     }
     ctx->release(counters);

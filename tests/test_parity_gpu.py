@@ -443,3 +443,120 @@ def test_oversized_right_hand_side_is_split_and_zipped(ctx, mats, monkeypatch):
     monkeypatch.delenv("SG_MAX_POSTINGS")
     rows2, cols2, sims2, tmax2 = eng.match_list(B, B, 10, 0.8, True)
     assert np.array_equal(rows, rows2) and np.array_equal(cols, cols2) and np.array_equal(sims, sims2) and tmax == tmax2
+
+
+# ------------------------------------------------------------------------------------------------
+# The pruned multiply (K4p, sg_spgemm_pruned.hip) must be indistinguishable from the exact kernel (K4)
+# and from the oracle: same entries, same bits, same order.
+def _multiply_both_ways(ctx, dA, dB, top_n, thr, monkeypatch, **env):
+    out = {}
+    for prune in ("1", "0"):
+        monkeypatch.setenv("SG_PRUNE", prune)
+        for k, v in env.items():
+            monkeypatch.setenv(k, str(v))
+        post = ctx.postings_build(dB)
+        res = ctx.spgemm_topn(dA, post, top_n, thr, True)
+        st = ctx.stats()
+        out[prune] = (res.to_scipy(), st)
+        res.free()
+        post.free()
+    return out
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("top_n,thr", [(10, 0.8), (64, 0.3), (5, 0.95), (20, 0.7), (3, 0.1), (1, 0.5), (64, 0.6)])
+def test_pruned_multiply_equals_exact_and_oracle(ctx, mats, dtype, top_n, thr, monkeypatch):
+    A = mats[dtype]
+    dA = ctx.csr_from_scipy(A)
+    out = _multiply_both_ways(ctx, dA, dA, top_n, thr, monkeypatch)
+    st = out["1"][1]
+    if thr >= 0.45:   # it did take the pruned kernel, and pruned
+        assert st["prune_rows"] > 0 and st["prune_postings"] < st["macs"], st
+    else:             # low thresholds pass too much through the filter: the library keeps the exact kernel
+        assert st["prune_rows"] == 0, st
+    assert out["0"][1]["prune_rows"] == 0
+    what = f"{dtype.__name__} top_n={top_n} thr={thr}"
+    assert_csr_identical(out["1"][0], out["0"][0], what + " pruned vs exact")
+    assert_csr_identical(out["1"][0], P.sp_matmul_topn_port(A, A.T, top_n, thr, True, 8), what + " pruned vs oracle")
+
+
+def test_low_thresholds_can_be_forced_through_the_pruned_kernel(ctx, mats, monkeypatch):
+    A = mats[np.float32][:6000]
+    dA = ctx.csr_from_scipy(A)
+    for thr in (0.1, 0.3):
+        out = _multiply_both_ways(ctx, dA, dA, 10, thr, monkeypatch, SG_PRUNE_MIN_THRESHOLD=0.05)
+        assert out["1"][1]["prune_rows"] > 0
+        assert_csr_identical(out["1"][0], out["0"][0], f"thr {thr}")
+        assert_csr_identical(out["1"][0], P.sp_matmul_topn_port(A, A.T, 10, thr, True, 8), f"thr {thr}")
+
+
+@pytest.mark.parametrize("env", [{"SG_PRUNE_DELTA": 0.02}, {"SG_PRUNE_DELTA": 0.35}, {"SG_PRUNE_FREQ": 0.0},
+                                 {"SG_PRUNE_FREQ": 0.05}, {"SG_PRUNE_FREQ": 2.0}, {"SG_PRUNE_TILE": 11},
+                                 {"SG_PRUNE_TILE": 13}])
+def test_pruned_multiply_is_exact_for_every_tuning(ctx, mats, env, monkeypatch):
+    """delta / the frequent-term share / the tile only move work between the filter and the exact scoring."""
+    A = mats[np.float32][:8000]
+    B = mats[np.float32][2000:20000]
+    dA, dB = ctx.csr_from_scipy(A), ctx.csr_from_scipy(B)
+    out = _multiply_both_ways(ctx, dA, dB, 10, 0.8, monkeypatch, **env)
+    assert out["1"][1]["prune_rows"] > 0
+    assert_csr_identical(out["1"][0], out["0"][0], str(env))
+    assert_csr_identical(out["1"][0], P.sp_matmul_topn_port(A, B.T, 10, 0.8, True, 8), str(env))
+
+
+def test_pruned_multiply_hands_long_rows_to_the_exact_kernel(ctx, monkeypatch):
+    """Rows with more than 64 distinct n-grams do not fit the pruned kernel's lanes."""
+    rng = np.random.default_rng(5)
+    letters = np.array(list("ABCDEFGHIJKLMNOPQRSTUVWXYZ "))
+    long_names = ["".join(rng.choice(letters, 150)) for _ in range(40)]
+    names = list(_names(3000, 9)) + long_names + [s[:140] + "X" for s in long_names]
+    A = _tfidf(names, np.float32)
+    assert (np.diff(A.indptr) > 64).sum() >= 80
+    dA = ctx.csr_from_scipy(A)
+    out = _multiply_both_ways(ctx, dA, dA, 5, 0.6, monkeypatch)
+    st = out["1"][1]
+    assert st["exact_rows"] >= 80 and st["prune_rows"] > 0, st
+    assert_csr_identical(out["1"][0], out["0"][0])
+    assert_csr_identical(out["1"][0], P.sp_matmul_topn_port(A, A.T, 5, 0.6, True, 8))
+
+
+def test_pruned_multiply_with_hubs_of_duplicates(ctx, monkeypatch):
+    """Hundreds of identical / near-identical names: the survivor buffer drains many times per row and
+    the top-n cut falls inside a block of equal scores."""
+    base = list(_names(2000, 3))
+    names = base + [base[7]] * 300 + [base[11] + " INC"] * 200 + [base[11]] * 150
+    for dtype in (np.float32, np.float64):
+        A = _tfidf(names, dtype)
+        dA = ctx.csr_from_scipy(A)
+        for top_n, thr in ((64, 0.5), (10, 0.9)):
+            out = _multiply_both_ways(ctx, dA, dA, top_n, thr, monkeypatch)
+            assert out["1"][1]["prune_rows"] > 0
+            assert_csr_identical(out["1"][0], out["0"][0], f"{dtype.__name__} {top_n} {thr}")
+            assert_csr_identical(out["1"][0], P.sp_matmul_topn_port(A, A.T, top_n, thr, True, 8))
+
+
+def test_matrices_that_are_not_cosine_like_take_the_exact_kernel(ctx, mats, monkeypatch):
+    """Row norms above 1, negative values or unsorted rows: no pruning (its bounds would not hold)."""
+    monkeypatch.delenv("SG_PRUNE", raising=False)
+    A = mats[np.float32][:4000].copy()
+    scaled = A * np.float32(1.5)
+    negative = A.copy()
+    negative.data[::7] *= np.float32(-1.0)
+    for M, thr in ((scaled, 0.8), (negative, 0.5)):
+        M = sp.csr_matrix(M)
+        d = ctx.csr_from_scipy(M)
+        post = ctx.postings_build(d)
+        res = ctx.spgemm_topn(d, post, 10, thr, True)
+        st = ctx.stats()
+        assert st["prune_rows"] == 0, st
+        assert_csr_identical(res.to_scipy(), P.sp_matmul_topn_port(M, M.T, 10, thr, True, 8))
+        res.free()
+        post.free()
+    # a cosine-like right-hand side with a left-hand side that is not: exact kernel as well
+    dB, dA = ctx.csr_from_scipy(A), ctx.csr_from_scipy(sp.csr_matrix(scaled))
+    post = ctx.postings_build(dB)
+    res = ctx.spgemm_topn(dA, post, 10, 0.8, True)
+    assert ctx.stats()["prune_rows"] == 0
+    assert_csr_identical(res.to_scipy(), P.sp_matmul_topn_port(sp.csr_matrix(scaled), A.T, 10, 0.8, True, 8))
+    res.free()
+    post.free()
