@@ -10,7 +10,8 @@ echo "== bench (with cpu baseline)" >> $LOG
 timeout 900 python bench.py --steps 5 --warmup 1 --end-to-end > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err
 cat gpurun_out/${TAG}_bench.json >> $LOG
 cd /tmp && export TMPDIR=/tmp && cd $OLDPWD
-BENCH="python bench.py --steps 3 --warmup 1 --no-cpu-baseline"
+BENCH="python bench.py --steps 3 --warmup 1 --no-cpu-baseline"          # incl. one live run of the exact kernel
+BENCH_PMC="python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-exact-kernel"
 echo "== rocprofv3 --kernel-trace --stats" >> $LOG
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${TAG}_stats -o k -- $BENCH > gpurun_out/${TAG}_stats.out 2>&1
 for f in $(find gpurun_out/${TAG}_stats -name "*kernel_stats.csv" | head -1); do cat $f >> $LOG; cp $f gpurun_out/${TAG}_kernel_stats.csv; done
@@ -20,7 +21,7 @@ for ctrs in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_
             "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum"; do
   i=$((i+1))
   echo "== pmc pass $i: $ctrs" >> $LOG
-  timeout 300 rocprofv3 --pmc $ctrs --output-format csv -d gpurun_out/${TAG}_pmc$i -o k -- $BENCH > gpurun_out/${TAG}_pmc$i.out 2>&1
+  timeout 300 rocprofv3 --pmc $ctrs --output-format csv -d gpurun_out/${TAG}_pmc$i -o k -- $BENCH_PMC > gpurun_out/${TAG}_pmc$i.out 2>&1
   python scripts/pmc_summary.py gpurun_out/${TAG}_pmc$i | head -12 >> $LOG 2>&1
 done
 rm -rf gpurun_out/${TAG}_stats gpurun_out/${TAG}_pmc[0-9]

@@ -313,7 +313,8 @@ def test_config4_5M_selfjoin_one_of_eight_row_blocks(ctx):
     res = ctx.spgemm_topn(blk, post, 10, 0.8, True)
     st = ctx.stats()
     print(f"config4 block: rows {hi - lo}, K4 {st['ms_spgemm_topn']:.1f} ms, macs {st['macs']:.3e}, "
-          f"{st['spgemm_bytes'] / st['ms_spgemm_topn'] / 1e9:.2f} TB/s algorithmic")
+          f"{st['spgemm_bytes'] / st['ms_spgemm_topn'] / 1e9:.2f} TB/s (stream model of the exact kernel); pruned rows "
+          f"{st['prune_rows']}, postings streamed {st['prune_postings']:.3e}, pairs scored {st['prune_survivors']:.3e}")
     _check_slice_properties(res, lo, hi - lo, n, 10, 0.8, True, A_host, A_host, 300, "config4")
     for h in (res, blk, post, A):
         h.free()
@@ -342,7 +343,8 @@ def test_config5_asymmetric_10M_x_1M_one_of_eight_row_blocks(ctx):
     blk = A.row_block(lo, hi)
     res = ctx.spgemm_topn(blk, post, 20, 0.7, True)
     st = ctx.stats()
-    print(f"config5 block: rows {hi - lo}, K4 {st['ms_spgemm_topn']:.1f} ms, macs {st['macs']:.3e}")
+    print(f"config5 block: rows {hi - lo}, K4 {st['ms_spgemm_topn']:.1f} ms, macs {st['macs']:.3e}; pruned rows "
+          f"{st['prune_rows']}, postings streamed {st['prune_postings']:.3e}, pairs scored {st['prune_survivors']:.3e}")
     A_blk_host = blk.to_scipy()
     # _check_slice_properties indexes the left matrix with lo + pick: hand it a matrix whose row 0 is row lo
     class _Shift:
