@@ -161,6 +161,18 @@ int sg_matchlist_dims(const sg_matchlist *ml, int64_t *n_rows, int64_t *n_entrie
 int sg_matchlist_to_host(sg_ctx *ctx, const sg_matchlist *ml, int64_t *row_ptr, int32_t *cols, void *vals);
 int sg_matchlist_free(sg_matchlist *ml);
 
+/* The two reductions the reference runs over the match list, on the device: one int32 per string comes
+ * back instead of the list.
+ * sg_matchlist_best_master (match_most_similar, string_grouper.py:803-807: groupby('dupe_side') max
+ *   similarity, then min master_side): out_best[c] = the row with the largest similarity in column c, the
+ *   lowest such row among equals, -1 when the column has no entry.  out_best: n_cols of the list (host).
+ * sg_matchlist_group_reps (group_similar_strings, string_grouper.py:851-904: scipy connected_components
+ *   + group_rep): out_rep[i] = the representative of string i's group -- centroid == 0: the member with
+ *   the lowest index ('first'); centroid != 0: the member with the largest row sum of similarities, the
+ *   lowest index among equals.  Needs a square list (self-join).  out_rep: n_rows (host). */
+int sg_matchlist_best_master(sg_ctx *ctx, const sg_matchlist *ml, int32_t *out_best);
+int sg_matchlist_group_reps(sg_ctx *ctx, const sg_matchlist *ml, int32_t centroid, int32_t *out_rep);
+
 /* Cost estimate of every left row for load balancing across GPUs: out_cost[i] = number of
  * intermediate products row i generates = sum over its non-zeros of the posting-list length.
  * (The reference has no analogue: its n_blocks[0] split is by row count, string_grouper.py:714-722.) */

@@ -76,6 +76,8 @@ ABI = {
     "sg_matchlist_dims": (C.c_int, [_P, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int32)]),
     "sg_matchlist_to_host": (C.c_int, [_P, _P, _P, _P, _P]),
     "sg_matchlist_free": (C.c_int, [_P]),
+    "sg_matchlist_best_master": (C.c_int, [_P, _P, _P]),
+    "sg_matchlist_group_reps": (C.c_int, [_P, _P, C.c_int32, _P]),
     "sg_row_costs": (C.c_int, [_P, _P, _P, _P]),
     "sg_ctx_stats": (C.c_int, [_P, C.POINTER(SgStats)]),
 }
@@ -249,6 +251,27 @@ class TopN(_Handle):
 
 class MatchList(_Handle):
     _free = "sg_matchlist_free"
+
+    def dims(self):
+        """(n_rows, n_entries, dtype code)"""
+        r, m, d = C.c_int64(), C.c_int64(), C.c_int32()
+        check(lib().sg_matchlist_dims(self.h, C.byref(r), C.byref(m), C.byref(d)))
+        return r.value, m.value, d.value
+
+    def best_master(self, n_cols: int) -> np.ndarray:
+        """Per column (duplicate) the row (master) with the largest similarity, lowest row among equals;
+        -1 where the column has no entry (string_grouper.py:803-807)."""
+        out = np.full(max(n_cols, 1), -1, np.int32)
+        check(lib().sg_matchlist_best_master(self.ctx.h, self.h, _ptr(out)))
+        return out[:n_cols]
+
+    def group_reps(self, centroid: bool) -> np.ndarray:
+        """Representative of every string's group: connected components of the list + group_rep
+        'first' / 'centroid' (string_grouper.py:851-904)."""
+        n = self.dims()[0]
+        out = np.zeros(max(n, 1), np.int32)
+        check(lib().sg_matchlist_group_reps(self.ctx.h, self.h, 1 if centroid else 0, _ptr(out)))
+        return out[:n]
 
     def to_host(self):
         """(row_ptr int64[n+1], cols int32[m], vals[m])"""

@@ -164,6 +164,10 @@ struct sg_vocab {
     void *d_idf = nullptr;               // n_terms, params.dtype; null until sg_vocab_set_idf
 };
 
+// sg_matchlist.hip
+int sg_matchlist_device_view(const sg_matchlist *ml, int64_t *n_rows, int64_t *n_cols, int64_t *n_entries, int32_t *dtype,
+                             const int64_t **row_ptr, const int32_t **cols, const void **vals);
+
 // sg_spgemm_pruned.hip
 int sg_csr_props(sg_ctx *ctx, const sg_csr *m, bool *cosine_like, float *max_norm2);
 bool sg_pruned_supports_tile(int32_t tile_log2);

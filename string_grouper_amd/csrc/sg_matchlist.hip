@@ -21,6 +21,20 @@ struct sg_matchlist {
     void *d_vals = nullptr;
 };
 
+// for the reductions over the list (sg_reduce.hip)
+int sg_matchlist_device_view(const sg_matchlist *ml, int64_t *n_rows, int64_t *n_cols, int64_t *n_entries, int32_t *dtype,
+                             const int64_t **row_ptr, const int32_t **cols, const void **vals) {
+    SG_REQUIRE(ml != nullptr, "match list is null");
+    *n_rows = ml->n_rows;
+    *n_cols = ml->n_cols;
+    *n_entries = ml->n_entries;
+    *dtype = ml->dtype;
+    *row_ptr = ml->d_row_ptr;
+    *cols = ml->d_cols;
+    *vals = ml->d_vals;
+    return SG_OK;
+}
+
 __device__ __forceinline__ bool row_has(const int32_t *cols, const int32_t *cnt, int32_t stride, int64_t row, int32_t col) {
     const int32_t *rc = cols + (size_t)row * stride;
     const int n = cnt[row];

@@ -145,14 +145,29 @@ def broadcast_strings(ctx, t_bytes, t_offs, src: int = 0, group=None):
     return p
 
 
+def pruned_multiply_expected(top_n: int, threshold: float) -> bool:
+    """The library's rule for taking the pruned multiply on TF-IDF input (sg_spgemm_topn).
+    Its cost per left row is nearly uniform (the column-tile loop dominates), whereas the exact kernel's
+    follows the row's intermediate products -- which decides how left rows are best cut across ranks."""
+    import os
+    if os.environ.get("SG_PRUNE", "1").startswith("0"):
+        return False
+    return top_n <= 64 and threshold >= float(os.environ.get("SG_PRUNE_MIN_THRESHOLD", "0.45"))
+
+
 def sharded_self_join_replicated(ctx, prepared_dev, vectorizer_factory, top_n: int, threshold: float,
-                                 group=None, tile_cols: int = 0, balance: bool = True):
+                                 group=None, tile_cols: int = 0, balance: Optional[bool] = None):
     """Strong-scaled self-join when every rank holds the string column in HBM (after
     ``broadcast_strings``): each rank vectorises (K1 + K2, ~4 ms at 663 k -- cheaper than receiving the
     CSR), builds the postings (K3) and multiplies ITS contiguous block of left rows (K4).  No collective
     inside.  ``balance``: cut the rows so that every rank gets the same number of intermediate products
-    (sg_row_costs) instead of the same number of rows -- matters when the input is sorted.  Returns (TopN of the local block, (row_lo, row_hi), n_rows_total)."""
+    (sg_row_costs) instead of the same number of rows -- matters for the exact kernel when the input is
+    sorted; default: only when the exact kernel will run (the pruned kernel's cost per row is uniform and
+    the cost pass + its host round trip would cost more than they save).  Returns (TopN of the local
+    block, (row_lo, row_hi), n_rows_total)."""
     rank, world = dist.get_rank(group), dist.get_world_size(group)
+    if balance is None:
+        balance = not pruned_multiply_expected(top_n, threshold)
     vec = vectorizer_factory()
     vec.fit_prepared([prepared_dev])
     A = vec.transform_prepared(prepared_dev)

@@ -41,6 +41,26 @@ def chunk_ranges(length: int, n_chunks: int) -> List[Tuple[int, int]]:
     return [(lo, min(lo + size, length)) for lo in range(0, length, size)] if length > 0 else []
 
 
+class DeviceMatchList:
+    """The match list of one fit(), resident in HBM, for the reductions the reference runs over it:
+    best master per duplicate (K7) and group representatives (K8)."""
+
+    def __init__(self, ml: "N.MatchList", n_cols: int):
+        self.ml = ml
+        self.n_cols = n_cols
+
+    def best_master(self) -> np.ndarray:
+        return self.ml.best_master(self.n_cols)
+
+    def group_reps(self, centroid: bool) -> np.ndarray:
+        return self.ml.group_reps(centroid)
+
+    def free(self):
+        if self.ml is not None:
+            self.ml.free()
+            self.ml = None
+
+
 class HipEngine:
     name = "hip"
 
@@ -124,10 +144,12 @@ class HipEngine:
         return C
 
     # ------------------------------------------------------------------ fused tail of fit() (K6)
-    def match_list(self, A: DeviceMatrix, B: DeviceMatrix, top_n: int, threshold: float, self_join_fix: bool):
+    def match_list(self, A: DeviceMatrix, B: DeviceMatrix, top_n: int, threshold: float, self_join_fix: bool,
+                   keep_on_device: bool = False):
         """Multiply and build the match list without leaving the device: (master_side, dupe_side,
         similarity, true_max_n_matches).  ``self_join_fix``: set the diagonal to 1 and symmetrise
-        (string_grouper.py:419-427); the rows then come back sorted by column."""
+        (string_grouper.py:419-427); the rows then come back sorted by column.  ``keep_on_device``: a fifth
+        element, the device-resident list (``DeviceMatchList``), for the reductions over it (K7, K8)."""
         res = self._topn_device(A, B, top_n, threshold)
         cnt = res.counts()
         true_max = int(cnt.max()) if len(cnt) else 0
@@ -136,9 +158,11 @@ class HipEngine:
         ml = self.ctx.matchlist_build(res, self_join_fix, self_join_fix,
                                       sort_by_column=(not self_join_fix) and A.dtype == np.float32)
         row_ptr, cols, vals = ml.to_host()
-        for h in (ml, res):
-            h.free()
+        res.free()
         rows = np.repeat(np.arange(len(row_ptr) - 1, dtype=np.int64), np.diff(row_ptr))
+        if keep_on_device:
+            return rows, cols.astype(np.int64), vals, true_max, DeviceMatchList(ml, B.shape[0])
+        ml.free()
         return rows, cols.astype(np.int64), vals, true_max
 
     def topn_multiply_blocked(self, A: DeviceMatrix, B: DeviceMatrix, n_blocks: Tuple[int, int], top_n: int,

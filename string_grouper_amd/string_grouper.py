@@ -156,6 +156,23 @@ class StringGrouper(object):
         self._set_data(master, duplicates, master_id, duplicates_id)
         self._set_options(**kwargs)
 
+    # The match list is a plain attribute in the reference (tests and add_match / remove_match assign to
+    # it).  Here an assignment also drops the device-resident copy of the previous fit(): the reductions
+    # over the list (K7, K8) must never see a list the caller has edited on the host.
+    @property
+    def _matches_list(self):
+        return self.__dict__.get('_matches_list_df')
+
+    @_matches_list.setter
+    def _matches_list(self, value):
+        self.__dict__['_matches_list_df'] = value
+        self._drop_device_matches()
+
+    def _drop_device_matches(self):
+        dml = self.__dict__.pop('_device_matches', None)
+        if dml is not None:
+            dml.free()
+
     # ------------------------------------------------------------------ data / options
     def _set_data(self, master, duplicates=None, master_id=None, duplicates_id=None):
         self.master = master
@@ -272,10 +289,14 @@ class StringGrouper(object):
             # symmetrise, compaction (K3 + K4 + K6); only (master_side, dupe_side, similarity) comes back
             eng = _engine_mod.get_engine()
             fix = bool(self._config.force_symmetries and self._duplicates is None)
-            rows, cols, sims, self._true_max_n_matches = eng.match_list(
-                master_matrix, duplicate_matrix, self._max_n_matches, self._config.min_similarity, fix)
+            out = eng.match_list(master_matrix, duplicate_matrix, self._max_n_matches, self._config.min_similarity,
+                                 fix, keep_on_device=True)
+            rows, cols, sims, self._true_max_n_matches = out[:4]
             self._matches_list = pd.DataFrame({'master_side': rows, 'dupe_side': cols,
                                                'similarity': sims.astype(np.float64, copy=False)})
+            # the same list stays in HBM for get_groups(): best master per duplicate (K7) / group
+            # representatives (K8) come back as one int32 per string
+            self.__dict__['_device_matches'] = out[4]
             self.is_build = True
             return self
         if self._n_blocks == (1, 1):
@@ -503,13 +524,20 @@ class StringGrouper(object):
             dupes = pd.concat([dupes, self._duplicates_id.rename('duplicates_id').reset_index(drop=True)], axis=1)
 
         # best master per duplicate: highest similarity, ties -> lowest master position (:803-807)
-        ml = self._matches_list
-        ms, ds, sim = ml.master_side.to_numpy(), ml.dupe_side.to_numpy(), ml.similarity.to_numpy()
-        order = np.lexsort((ms, -sim, ds))
-        ds_sorted = ds[order]
-        first = np.ones(len(order), dtype=bool)
-        first[1:] = ds_sorted[1:] != ds_sorted[:-1]
-        best = pd.DataFrame({'dupe_side': ds_sorted[first], 'master_side': ms[order][first]})
+        dml = self.__dict__.get('_device_matches')
+        if dml is not None:     # reduced on the device (K7): one int32 per duplicate crosses PCIe
+            bm = dml.best_master()
+            has = bm >= 0
+            best = pd.DataFrame({'dupe_side': np.flatnonzero(has).astype(np.int64),
+                                 'master_side': bm[has].astype(np.int64)})
+        else:                   # the list was edited on the host (add_match / remove_match) or built there
+            ml = self._matches_list
+            ms, ds, sim = ml.master_side.to_numpy(), ml.dupe_side.to_numpy(), ml.similarity.to_numpy()
+            order = np.lexsort((ms, -sim, ds))
+            ds_sorted = ds[order]
+            first = np.ones(len(order), dtype=bool)
+            first[1:] = ds_sorted[1:] != ds_sorted[:-1]
+            best = pd.DataFrame({'dupe_side': ds_sorted[first], 'master_side': ms[order][first]})
 
         table = best.merge(dupes, left_on='dupe_side', right_index=True, how='outer')
         table = table.merge(master, left_on='master_side', right_index=True, how='left')
@@ -536,8 +564,29 @@ class StringGrouper(object):
 
     # ---- group_similar_strings result (string_grouper.py:851-904)
     def _deduplicate(self, ignore_index=False) -> Union[pd.DataFrame, pd.Series]:
-        pairs = self._matches_list
         n = len(self._master)
+        dml = self.__dict__.get('_device_matches')
+        if dml is not None:     # connected components + representatives on the device (K8)
+            rep = dml.group_reps(self._config.group_rep == GROUP_REP_CENTROID).astype(np.int64)
+        else:
+            rep = self._group_reps_on_host(n)
+
+        prefix = GROUP_REP_PREFIX
+        label = f'{prefix}{self._master.name}' if self._master.name else prefix[:-1]
+        output = self._master.iloc[rep].rename(label).reset_index(drop=ignore_index)
+        if isinstance(output, pd.DataFrame):
+            output.rename(columns={c: f'{prefix}{c}' for c in output.columns if str(c) != label}, inplace=True)
+        if self._master_id is not None:
+            id_label = f'{prefix}{self._master_id.name if self._master_id.name else DEFAULT_ID_NAME}'
+            output_id = self._master_id.iloc[rep].rename(id_label).reset_index(drop=True)
+            output = pd.concat([output_id, output], axis=1)
+        output.index = self._master.index
+        return output
+
+    def _group_reps_on_host(self, n: int) -> np.ndarray:
+        """Representative of every string's group from the host copy of the match list (used when the
+        list was edited on the host, or built there)."""
+        pairs = self._matches_list
         ms, ds = pairs.master_side.to_numpy(), pairs.dupe_side.to_numpy()
         graph = sp.csr_matrix((np.full(len(pairs), 1), (ms, ds)), shape=(n, n))
         _, labels = connected_components(csgraph=graph, directed=True)
@@ -553,19 +602,7 @@ class StringGrouper(object):
         head[1:] = lab_sorted[1:] != lab_sorted[:-1]
         rep_of_label = np.empty(labels.max() + 1 if n else 0, dtype=np.int64)
         rep_of_label[lab_sorted[head]] = order[head]
-        rep = rep_of_label[labels]
-
-        prefix = GROUP_REP_PREFIX
-        label = f'{prefix}{self._master.name}' if self._master.name else prefix[:-1]
-        output = self._master.iloc[rep].rename(label).reset_index(drop=ignore_index)
-        if isinstance(output, pd.DataFrame):
-            output.rename(columns={c: f'{prefix}{c}' for c in output.columns if str(c) != label}, inplace=True)
-        if self._master_id is not None:
-            id_label = f'{prefix}{self._master_id.name if self._master_id.name else DEFAULT_ID_NAME}'
-            output_id = self._master_id.iloc[rep].rename(id_label).reset_index(drop=True)
-            output = pd.concat([output_id, output], axis=1)
-        output.index = self._master.index
-        return output
+        return rep_of_label[labels]
 
     # ---- validation (string_grouper.py:916-1010)
     def _validate_group_rep_specs(self):

@@ -149,3 +149,30 @@ def test_reference_unit_tests_pass_against_the_mirror():
         assert r.returncode == 0 and "53 passed" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
     finally:
         shutil.rmtree(d, ignore_errors=True)
+
+
+def test_assigning_the_match_list_drops_a_device_copy():
+    """K7/K8 reduce the device-resident match list of the last fit(); any host-side edit of the list
+    (add_match, remove_match, a test assigning the attribute) must invalidate that copy."""
+    import pandas as pd
+    import string_grouper_amd as sga
+
+    class FakeDeviceList:
+        freed = False
+
+        def free(self):
+            self.freed = True
+
+    sg = sga.StringGrouper(pd.Series(["a b c", "a b d"]))
+    fake = FakeDeviceList()
+    sg.__dict__["_device_matches"] = fake
+    sg._matches_list = pd.DataFrame({"master_side": [0], "dupe_side": [0], "similarity": [1.0]})
+    assert fake.freed and "_device_matches" not in sg.__dict__
+    assert len(sg._matches_list) == 1
+
+
+def test_pruned_multiply_rule_used_for_the_row_split():
+    from string_grouper_amd.distributed import pruned_multiply_expected
+    assert pruned_multiply_expected(10, 0.8)
+    assert not pruned_multiply_expected(65, 0.8)
+    assert not pruned_multiply_expected(10, 0.3)

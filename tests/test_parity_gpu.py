@@ -562,3 +562,92 @@ def test_matrices_that_are_not_cosine_like_take_the_exact_kernel(ctx, mats, monk
     assert_csr_identical(res.to_scipy(), P.sp_matmul_topn_port(sp.csr_matrix(scaled), A.T, 10, 0.8, True, 8))
     res.free()
     post.free()
+
+
+# ------------------------------------------------------------------------------------------------
+# K7 / K8: the reductions over the match list on the device (best master per duplicate, group
+# representatives) against the host formulation of the same reference code on the same match list.
+def _groups_both_ways(sg):
+    assert "_device_matches" in sg.__dict__, "fit() did not keep the match list on the device"
+    on_device = sg.get_groups()
+    sg._drop_device_matches()
+    on_host = sg.get_groups()
+    return on_device, on_host
+
+
+def _assert_same_frames(a, b):
+    import pandas as pd
+    assert type(a) is type(b)
+    if isinstance(a, pd.Series):
+        pd.testing.assert_series_equal(a, b)
+    else:
+        pd.testing.assert_frame_equal(a, b)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("group_rep", ["centroid", "first"])
+def test_group_representatives_on_device_equal_host(ctx, dtype, group_rep):
+    import pandas as pd
+    import string_grouper_amd as sga
+    import string_grouper_amd.engine as E
+    E.set_engine(E.HipEngine(ctx))
+    base = list(_names(6000, 21))
+    # a long chain (every name one edit away from the next: a component with a large diameter), hubs of
+    # duplicates (equal row sums: the tie goes to the lowest index) and ordinary names
+    chain = ["ALPHABETAGAMMADELTAEPSILONZETA HOLDINGS INTERNATIONAL CORPORATION"]
+    for i in range(120):
+        s = chain[-1]
+        chain.append(s[:5 + (i % 40)] + "X" + s[6 + (i % 40):])
+    hub = [base[9] + " " + str(i % 7) for i in range(300)]        # rows with > 128 entries of unequal similarity
+    names = base + chain + [base[3]] * 40 + [base[5] + " INC"] * 25 + hub
+    s = pd.Series(names)
+    sg = sga.StringGrouper(s, min_similarity=0.8, tfidf_matrix_dtype=dtype, group_rep=group_rep,
+                           max_n_matches=400).fit()
+    dev, host = _groups_both_ways(sg)
+    _assert_same_frames(dev, host)
+    reps = dev if isinstance(dev, pd.Series) else dev.iloc[:, -1]
+    assert reps.nunique() < len(names)         # it did group something
+    # with ids
+    ids = pd.Series(np.arange(len(names)) * 7)
+    sg = sga.StringGrouper(s, master_id=ids, min_similarity=0.7, tfidf_matrix_dtype=dtype, group_rep=group_rep).fit()
+    dev, host = _groups_both_ways(sg)
+    _assert_same_frames(dev, host)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_best_master_per_duplicate_on_device_equals_host(ctx, dtype):
+    import pandas as pd
+    import string_grouper_amd as sga
+    import string_grouper_amd.engine as E
+    from string_grouper_amd.synth import synth_names
+    E.set_engine(E.HipEngine(ctx))
+    master = list(_names(8000, 31))
+    master = master + master[:500]                      # exact duplicates inside the master: ties at the maximum
+    dupes = list(synth_names(5000, seed=32, perturb_of=np.asarray(master, dtype=object), perturb_frac=0.6))
+    m, d = pd.Series(master), pd.Series(dupes)
+    for kw in (dict(min_similarity=0.8), dict(min_similarity=0.6, max_n_matches=5),
+               dict(min_similarity=0.7, ignore_index=True)):
+        sg = sga.StringGrouper(m, d, tfidf_matrix_dtype=dtype, **kw).fit()
+        dev, host = _groups_both_ways(sg)
+        _assert_same_frames(dev, host)
+    # and through the public function, with ids
+    mid, did = pd.Series(np.arange(len(master))), pd.Series(np.arange(len(dupes)) + 10 ** 6)
+    out = sga.match_most_similar(m, d, master_id=mid, duplicates_id=did, min_similarity=0.8, tfidf_matrix_dtype=dtype)
+    sg = sga.StringGrouper(m, d, mid, did, min_similarity=0.8, tfidf_matrix_dtype=dtype, max_n_matches=1).fit()
+    sg._drop_device_matches()          # (match_most_similar asks for one match per master row, string_grouper.py:120)
+    _assert_same_frames(out, sg.get_groups())
+
+
+def test_editing_the_match_list_drops_the_device_copy(ctx):
+    import pandas as pd
+    import string_grouper_amd as sga
+    import string_grouper_amd.engine as E
+    E.set_engine(E.HipEngine(ctx))
+    s = pd.Series(list(_names(500, 41)))
+    sg = sga.StringGrouper(s, min_similarity=0.8).fit()
+    assert "_device_matches" in sg.__dict__
+    sg = sg.add_match(s.iloc[1], s.iloc[2])
+    assert "_device_matches" not in sg.__dict__
+    groups = sg.get_groups()
+    reps = groups if isinstance(groups, pd.Series) else groups.iloc[:, -1]
+    assert reps.iloc[1] == reps.iloc[2]
