@@ -113,6 +113,13 @@ int sg_csr_to_host(sg_ctx *ctx, const sg_csr *m, int64_t *indptr, int32_t *indic
 int sg_csr_row_block(sg_ctx *ctx, const sg_csr *m, int64_t r0, int64_t r1, sg_csr **out);
 int sg_csr_free(sg_csr *m);
 
+/* Row-wise similarity of two matrices of the same shape (StringGrouper.dot / compute_pairwise_similarities,
+ * string_grouper.py:433-440: np.asarray(master_matrix.multiply(duplicate_matrix).sum(axis=1))):
+ * out_host[i] = sum over the common columns of A[i, k] * B[i, k], products rounded to the value type and
+ * added in the order scipy + numpy use (ascending column; first + pairwise sum of the rest), so the result
+ * is bit-identical.  out_host: n_rows values of the matrices' type.  Rows must be sorted by column. */
+int sg_csr_rowwise_dot(sg_ctx *ctx, const sg_csr *A, const sg_csr *B, void *out_host);
+
 /* ------------------------------------------------------------------ seam b2: sparse top-n multiply */
 /* Inverted index of B (n_right x V): for every term k the (row j, value) pairs, grouped by column
  * tile j / tile_cols.  tile_cols must be a power of two supported by the multiply (0 = default).

@@ -79,6 +79,7 @@ ABI = {
     "sg_matchlist_best_master": (C.c_int, [_P, _P, _P]),
     "sg_matchlist_group_reps": (C.c_int, [_P, _P, C.c_int32, _P]),
     "sg_row_costs": (C.c_int, [_P, _P, _P, _P]),
+    "sg_csr_rowwise_dot": (C.c_int, [_P, _P, _P, _P]),
     "sg_ctx_stats": (C.c_int, [_P, C.POINTER(SgStats)]),
 }
 
@@ -401,6 +402,13 @@ class Context:
         check(lib().sg_matchlist_build(self.h, res.h, 1 if fix_diagonal else 0, 1 if symmetrize else 0,
                                        1 if sort_by_column else 0, C.byref(out)))
         return MatchList(self, out)
+
+    def rowwise_dot(self, A: Csr, B: Csr) -> np.ndarray:
+        """sum_k A[i, k] * B[i, k] per row, in scipy/numpy's arithmetic (string_grouper.py:433-440)."""
+        r, _, _, d = A.dims()
+        out = np.zeros(max(r, 1), code_np_dtype(d))
+        check(lib().sg_csr_rowwise_dot(self.h, A.h, B.h, _ptr(out)))
+        return out[:r]
 
     def row_costs(self, A: Csr, Bt: Postings) -> np.ndarray:
         out = np.zeros(max(A.dims()[0], 1), np.int64)

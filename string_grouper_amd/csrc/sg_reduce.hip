@@ -1,5 +1,5 @@
 // K7 / K8 -- the two reductions the reference runs over the match list, on the device
-// (SURVEY.md section 8f, rows f3 and f2).  Both read the CSR-ordered match list K6 leaves in HBM and
+// (SURVEY.md section 8f, rows f3 and f2); K9 -- the row-wise similarity of dot() (row f4).  Both read the CSR-ordered match list K6 leaves in HBM and
 // return ONE int32 per string instead of the list itself.
 //
 // K7  best master per duplicate (match_most_similar):                string_grouper.py:803-807
@@ -110,29 +110,29 @@ __global__ void __launch_bounds__(256) cc_jump_kernel(int32_t *label, int64_t n,
 // fewer than 8 elements sequentially; up to 128 with eight strided partial sums combined as
 // ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)) and the tail added sequentially; longer runs split in halves
 // rounded down to a multiple of 8).  The centroid is an arg-max over these sums, so the bits matter.
-template <typename T>
-__device__ double np_pairwise_sum(const T *a, int64_t n) {
+template <typename ACC, typename T>   // ACC: the type numpy accumulates in (the array's own: float for float32)
+__device__ ACC np_pairwise_sum(const T *a, int64_t n) {
     if (n < 8) {
-        double res = 0.0;
-        for (int64_t i = 0; i < n; ++i) res = res + (double)a[i];
+        ACC res = (ACC)0;
+        for (int64_t i = 0; i < n; ++i) res = res + (ACC)a[i];
         return res;
     }
     if (n <= 128) {
-        double r[8];
+        ACC r[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) r[j] = (double)a[j];
+        for (int j = 0; j < 8; ++j) r[j] = (ACC)a[j];
         int64_t i = 8;
         for (; i < n - (n % 8); i += 8) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) r[j] = r[j] + (double)a[i + j];
+            for (int j = 0; j < 8; ++j) r[j] = r[j] + (ACC)a[i + j];
         }
-        double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
-        for (; i < n; ++i) res = res + (double)a[i];
+        ACC res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+        for (; i < n; ++i) res = res + (ACC)a[i];
         return res;
     }
     int64_t n2 = n / 2;
     n2 -= n2 % 8;
-    return np_pairwise_sum<T>(a, n2) + np_pairwise_sum<T>(a + n2, n - n2);
+    return np_pairwise_sum<ACC, T>(a, n2) + np_pairwise_sum<ACC, T>(a + n2, n - n2);
 }
 
 template <typename T>
@@ -141,7 +141,7 @@ __global__ void __launch_bounds__(256) row_weight_kernel(const int64_t *__restri
     const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n_rows) return;
     const int64_t lo = row_ptr[r], m = row_ptr[r + 1] - lo;
-    weight[r] = m == 0 ? 0.0 : (double)vals[lo] + np_pairwise_sum<T>(vals + lo + 1, m - 1);
+    weight[r] = m == 0 ? 0.0 : (double)vals[lo] + np_pairwise_sum<double, T>(vals + lo + 1, m - 1);
 }
 
 template <typename T>
@@ -163,6 +163,40 @@ __global__ void __launch_bounds__(256) rep_gather_kernel(const int32_t *__restri
                                                          const int32_t *__restrict__ group_rep, int64_t n, int32_t *out) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = group_rep[label[i]];
+}
+
+// ---------------------------------------------------------------------------------------------- K9
+// Row-wise similarity of two equally shaped matrices (StringGrouper.dot, string_grouper.py:433-440):
+//   np.asarray(master_matrix.multiply(duplicate_matrix).sum(axis=1))
+// scipy's element-wise product keeps the non-zero products of the common columns in ascending column
+// order (csr_binop_csr_canonical), rounded to T; the row sum is again np.add.reduceat: first product +
+// numpy's pairwise sum of the rest, accumulated in T.  One thread per row: the products go to a scratch
+// segment (at most the row's length in A), then the sum is taken from there.
+template <typename T>
+__global__ void __launch_bounds__(256) rowwise_dot_kernel(const int64_t *__restrict__ a_indptr, const int32_t *__restrict__ a_indices,
+                                                          const T *__restrict__ a_data, const int64_t *__restrict__ b_indptr,
+                                                          const int32_t *__restrict__ b_indices, const T *__restrict__ b_data,
+                                                          int64_t n_rows, T *scratch, T *out) {
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_rows) return;
+    int64_t pa = a_indptr[r], pb = b_indptr[r];
+    const int64_t ea = a_indptr[r + 1], eb = b_indptr[r + 1];
+    T *prod = scratch + (a_indptr[r] - a_indptr[0]);
+    int64_t m = 0;
+    while (pa < ea && pb < eb) {
+        const int32_t ka = a_indices[pa], kb = b_indices[pb];
+        if (ka == kb) {
+            const T p = a_data[pa] * b_data[pb];
+            if (p != (T)0) prod[m++] = p;
+            ++pa;
+            ++pb;
+        } else if (ka < kb) {
+            ++pa;
+        } else {
+            ++pb;
+        }
+    }
+    out[r] = m == 0 ? (T)0 : prod[0] + np_pairwise_sum<T, T>(prod + 1, m - 1);
 }
 
 // ---------------------------------------------------------------------------------------------- host
@@ -283,6 +317,40 @@ extern "C" int sg_matchlist_group_reps(sg_ctx *ctx, const sg_matchlist *ml, int3
     if (st != SG_OK) return st;
     if (e != hipSuccess) {
         sg_set_error("sg_matchlist_group_reps: %s", hipGetErrorString(e));
+        return SG_ERR_HIP;
+    }
+    return SG_OK;
+}
+
+extern "C" int sg_csr_rowwise_dot(sg_ctx *ctx, const sg_csr *A, const sg_csr *B, void *out_host) {
+    SG_REQUIRE(ctx && A && B && out_host, "null argument");
+    SG_REQUIRE(A->n_rows == B->n_rows && A->n_cols == B->n_cols, "matrices differ in shape");
+    SG_REQUIRE(A->dtype == B->dtype, "matrices differ in value type");
+    const int64_t n = A->n_rows;
+    if (n == 0) return SG_OK;
+    const size_t s = A->dtype == SG_F64 ? 8 : 4;
+    void *scratch = nullptr, *out = nullptr;
+    int st = ctx->alloc(((size_t)A->nnz + 1) * s, &scratch);
+    if (st == SG_OK) st = ctx->alloc((size_t)n * s, &out);
+    hipError_t e = hipSuccess;
+    if (st == SG_OK) {
+        if (A->dtype == SG_F64)
+            hipLaunchKernelGGL(rowwise_dot_kernel<double>, dim3(blocks_for(n)), dim3(256), 0, ctx->stream, A->d_indptr, A->d_indices,
+                               (const double *)A->d_data, B->d_indptr, B->d_indices, (const double *)B->d_data, n,
+                               (double *)scratch, (double *)out);
+        else
+            hipLaunchKernelGGL(rowwise_dot_kernel<float>, dim3(blocks_for(n)), dim3(256), 0, ctx->stream, A->d_indptr, A->d_indices,
+                               (const float *)A->d_data, B->d_indptr, B->d_indices, (const float *)B->d_data, n,
+                               (float *)scratch, (float *)out);
+        e = hipGetLastError();
+        if (e == hipSuccess) e = hipMemcpyAsync(out_host, out, (size_t)n * s, hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    }
+    ctx->release(scratch);
+    ctx->release(out);
+    if (st != SG_OK) return st;
+    if (e != hipSuccess) {
+        sg_set_error("sg_csr_rowwise_dot: %s", hipGetErrorString(e));
         return SG_ERR_HIP;
     }
     return SG_OK;

@@ -143,6 +143,10 @@ class HipEngine:
         res.free()
         return C
 
+    def rowwise_dot(self, A: DeviceMatrix, B: DeviceMatrix) -> np.ndarray:
+        """Row-wise similarity of master and duplicates (string_grouper.py:433-440) on the device (K9)."""
+        return self.ctx.rowwise_dot(A.csr, B.csr)
+
     # ------------------------------------------------------------------ fused tail of fit() (K6)
     def match_list(self, A: DeviceMatrix, B: DeviceMatrix, top_n: int, threshold: float, self_join_fix: bool,
                    keep_on_device: bool = False):

@@ -335,8 +335,13 @@ class StringGrouper(object):
         """Row-wise similarity between master and duplicates."""
         if len(self._master) != len(self._duplicates):
             raise Exception("To perform this function, both input Series must have the same length.")
-        a, b = self._get_tf_idf_matrices()
-        sims = np.asarray(a.multiply(b).sum(axis=1)).squeeze(axis=1)
+        eng = _engine_mod.get_engine()
+        if hasattr(eng, 'rowwise_dot'):      # on the device (K9): only the similarities come back
+            A, B = self._tfidf_on_engine()
+            sims = eng.rowwise_dot(A, B)
+        else:
+            a, b = self._get_tf_idf_matrices()
+            sims = np.asarray(a.multiply(b).sum(axis=1)).squeeze(axis=1)
         return pd.Series(sims, name='similarity', index=self._master.index)
 
     # ------------------------------------------------------------------ post-processing

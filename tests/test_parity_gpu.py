@@ -651,3 +651,28 @@ def test_editing_the_match_list_drops_the_device_copy(ctx):
     groups = sg.get_groups()
     reps = groups if isinstance(groups, pd.Series) else groups.iloc[:, -1]
     assert reps.iloc[1] == reps.iloc[2]
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_rowwise_dot_on_device_equals_scipy(ctx, dtype):
+    """K9 (StringGrouper.dot / compute_pairwise_similarities, string_grouper.py:433-440) against scipy's
+    multiply(...).sum(axis=1) on the same matrices: bit-identical, incl. long rows (pairwise summation)."""
+    import pandas as pd
+    import string_grouper_amd as sga
+    import string_grouper_amd.engine as E
+    from string_grouper_amd.synth import synth_names
+    E.set_engine(E.HipEngine(ctx))
+    rng = np.random.default_rng(3)
+    letters = np.array(list("ABCDEFGHIJ "))
+    left = list(_names(4000, 51)) + ["".join(rng.choice(letters, 400)) for _ in range(50)] + ["", "AB", "XYZ"]
+    other = list(synth_names(4000, seed=52))
+    right = [(left[i] + " INC" if i % 2 else left[i][:-1]) if i % 3 else other[i] for i in range(4000)]   # row-aligned edits
+    right += [s[:350] + "Q" + s[351:] for s in left[4000:4050]] + ["", "AB", "XYW"]
+    s1, s2 = pd.Series(left), pd.Series(right)
+    got = sga.compute_pairwise_similarities(s1, s2, tfidf_matrix_dtype=dtype)
+    A = _tfidf(left + right, dtype)          # same vocabulary / idf as fit on master + duplicates
+    a, b = A[:len(left)], A[len(left):]
+    want = np.asarray(a.multiply(b).sum(axis=1)).squeeze(axis=1)
+    assert got.dtype == want.dtype
+    np.testing.assert_array_equal(got.to_numpy(), want)
+    assert (got.to_numpy() > 0.5).sum() > 1000
