@@ -17,6 +17,7 @@ Differences from the reference that a caller can observe, all deliberate:
 from __future__ import annotations
 
 import functools
+import inspect
 import logging
 import multiprocessing
 import re
@@ -289,14 +290,16 @@ class StringGrouper(object):
             # symmetrise, compaction (K3 + K4 + K6); only (master_side, dupe_side, similarity) comes back
             eng = _engine_mod.get_engine()
             fix = bool(self._config.force_symmetries and self._duplicates is None)
+            keep = 'keep_on_device' in inspect.signature(eng.match_list).parameters   # engine doubles may lack it
             out = eng.match_list(master_matrix, duplicate_matrix, self._max_n_matches, self._config.min_similarity,
-                                 fix, keep_on_device=True)
+                                 fix, **({'keep_on_device': True} if keep else {}))
             rows, cols, sims, self._true_max_n_matches = out[:4]
             self._matches_list = pd.DataFrame({'master_side': rows, 'dupe_side': cols,
                                                'similarity': sims.astype(np.float64, copy=False)})
             # the same list stays in HBM for get_groups(): best master per duplicate (K7) / group
             # representatives (K8) come back as one int32 per string
-            self.__dict__['_device_matches'] = out[4]
+            if len(out) > 4:
+                self.__dict__['_device_matches'] = out[4]
             self.is_build = True
             return self
         if self._n_blocks == (1, 1):
@@ -417,7 +420,21 @@ class StringGrouper(object):
 
         def side(series, positions, default_name, drop_index, mirror):
             named = series if series.name else series.rename(default_name)
-            picked = named.iloc[positions].reset_index(drop=drop_index)
+            pos = np.asarray(positions)
+            idx = named.index
+            if drop_index or (idx.nlevels == 1 and named.name not in ('index', 'level_0')
+                              and idx.name not in (named.name,)):
+                # the common shapes, without pandas' take + reset_index (which copy every column twice
+                # at millions of rows): gather values -- and the index, as reset_index would name it --
+                # with numpy and hand the columns over as they are
+                values = pd.Series(named.array.take(pos), name=named.name, copy=False)      # keeps the dtype
+                if drop_index:
+                    return values
+                index_col = pd.Series(idx.take(pos), name='index' if idx.name is None else idx.name, copy=False)
+                cols = [values, index_col] if mirror else [index_col, values]
+                with pd.option_context("mode.copy_on_write", True):
+                    return pd.concat(cols, axis=1)
+            picked = named.iloc[pos].reset_index(drop=drop_index)
             if mirror and isinstance(picked, pd.DataFrame):
                 picked = picked[picked.columns[::-1]]
             return picked
@@ -438,7 +455,10 @@ class StringGrouper(object):
             right_id = side(right_ids, pairs.dupe_side, DEFAULT_ID_NAME, True, True)
             parts = [prefixed(left, LEFT_PREFIX), prefixed(left_id, LEFT_PREFIX), similarity,
                      prefixed(right_id, RIGHT_PREFIX), prefixed(right, RIGHT_PREFIX)]
-        return pd.concat(parts, axis=1, copy=False)
+        # copy-on-write mode makes concat keep the columns as they are (no consolidation, which at millions of
+        # rows means re-copying every object pointer); the parts are temporaries nobody else references
+        with pd.option_context("mode.copy_on_write", True):
+            return pd.concat(parts, axis=1)
 
     @validate_is_fit
     def get_groups(self, ignore_index: Optional[bool] = None,
