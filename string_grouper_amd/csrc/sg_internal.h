@@ -132,7 +132,7 @@ struct sg_postings {
     void *d_fwd = nullptr;
     uint32_t *d_fwd_ptr = nullptr;       // n_right + 1
     // 4-byte "filter postings", same order as the postings proper (only for cosine-like B):
-    //   bits [0, L) column inside the tile (L = tile_log2), [L, L+8) fq, [L+8, 32) bq   with
+    //   bits [0, L) column inside the tile (L = tile_log2), [L, 24) bq, [24, 32) fq   with
     //   b <= bq / bq_max * norm_up   and
     //   || b_j restricted to the frequent terms (list length >= freq_min) || <= fq / 255 * norm_up
     uint32_t *d_filt = nullptr;

@@ -82,7 +82,7 @@ __global__ void __launch_bounds__(256) postings_fill(const int64_t *__restrict__
             const uint32_t bq_max = (1u << (24 - tile_log2)) - 1u;   // the bits the column and fq leave
             uint32_t bq = (uint32_t)ceilf((float)data[p] * inv_norm_up * (float)bq_max * 1.000002f);
             if (bq > bq_max) bq = bq_max;
-            out_filt[pos] = col | (fq << tile_log2) | (bq << (tile_log2 + 8));
+            out_filt[pos] = col | (bq << tile_log2) | (fq << 24);   // fq in the top byte: one v_cvt_f32_ubyte3 in K4p
         }
     }
 }

@@ -20,7 +20,7 @@
 // the canonical order (score desc, column asc) and the top-n cut are applied as in K4.
 //
 // p_ij is only a filter: any upper bound will do, in any summation order.  K3 therefore writes, next
-// to the postings proper, 4-byte "filter postings" {column in tile: L bits, fq: 8, bq: 24 - L} with the
+// to the postings proper, 4-byte "filter postings" {column in tile: L bits, bq: 24 - L, fq: 8} with the
 // value b and the norm f_j quantised UPWARDS, and the kernel accumulates upper bounds of a * b in
 // 16-bit fixed point (scale 2^15) with LDS integer atomics.  That removes K4's structural cost -- one
 // wave instruction per posting segment because two segments may hit the same column -- here every
@@ -34,12 +34,12 @@
 //
 // One 64-lane wave per left row, single-wave workgroups, persistent waves fed by a global row
 // counter, as K4.  LDS per wave: the tile's 4096 u16 accumulators (two per word), row i as a term ->
-// value hash (for the exact scoring) and the survivor buffer: 10.75 KiB -> 14 waves per CU.
+// value hash (for the exact scoring) and the survivor buffer: 10 KiB -> 16 waves per CU.
 // Rows the kernel does not handle (more than 64 non-zeros) are appended to a list and processed by K4.
 #define SG_WATCH_NAME sg_debug_watch_pruned
 #include "sg_k4_device.h"
 
-#define SG_SURV_CAP 320   // survivors buffered per wave (verified 64 at a time as soon as 64 are there)
+#define SG_SURV_CAP 128   // survivors buffered per wave (verified 64 at a time as soon as 64 are there)
 
 template <typename T>
 __device__ __forceinline__ T wave_shfl(T v, int src) {
@@ -293,8 +293,8 @@ spgemm_topn_pruned_kernel(const int64_t *__restrict__ a_indptr, const int32_t *_
                 uint32_t c = 0;
                 if (bt.ok[e]) {
                     c = bt.r[e] & (uint32_t)(TILE - 1);
-                    const uint32_t x = (uint32_t)(c_a * (float)(bt.r[e] >> (TILE_LOG2 + 8))) + 1u;
-                    const uint32_t tq = (uint32_t)(t0 - c1 * (float)((bt.r[e] >> TILE_LOG2) & 0xffu));
+                    const uint32_t x = (uint32_t)(c_a * (float)((bt.r[e] >> TILE_LOG2) & ((1u << (24 - TILE_LOG2)) - 1u))) + 1u;
+                    const uint32_t tq = (uint32_t)(t0 - c1 * (float)(bt.r[e] >> 24));
                     const uint32_t sh = (c & 1u) << 4;
                     const uint32_t old = __hip_atomic_fetch_add(&tab[c >> 1], x << sh, __ATOMIC_RELAXED,
                                                                 __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -305,29 +305,23 @@ spgemm_topn_pruned_kernel(const int64_t *__restrict__ a_indptr, const int32_t *_
                 if (cm) {
                     if (cross) surv[n_surv + __popcll(cm & lanes_below)] = (t << TILE_LOG2) + (int)c;
                     n_surv += __popcll(cm);
+                    if (n_surv >= 64) {   // a full wave of survivors: score them now (the buffer holds 128)
+                        verify_chunk<T>(surv[lane], hk, ha, fwd_ptr, fwd, thr, top, lane);
+                        st_surv += 64;
+                        const uint32_t rem = n_surv - 64;   // < 64: move to the front
+                        const int keepv = (uint32_t)lane < rem ? surv[64 + lane] : 0;
+                        __builtin_amdgcn_wave_barrier();
+                        if ((uint32_t)lane < rem) surv[lane] = keepv;
+                        n_surv = rem;
+                    }
                 }
-            }
-            if (n_surv >= 64) {
-                uint32_t done = 0;
-                SG_WD_DECL(wd_d);
-                while (n_surv - done >= 64) {
-                    SG_WD(wd_d, 16, 15)
-                    verify_chunk<T>(surv[done + lane], hk, ha, fwd_ptr, fwd, thr, top, lane);
-                    done += 64;
-                    st_surv += 64;
-                }
-                const uint32_t rem = n_surv - done;   // < 64: move to the front
-                const int keepv = (uint32_t)lane < rem ? surv[done + lane] : 0;
-                __builtin_amdgcn_wave_barrier();
-                if ((uint32_t)lane < rem) surv[lane] = keepv;
-                n_surv = rem;
             }
         };
 
         // Software pipeline over the column tiles: while tile t is applied, the first batches of tiles t + 1
         // and t + 2 are in flight and the segment bound needed for tile t + 3 is being fetched (b0..b4 =
         // seg[t .. t + 4] of my term).  The multiply is bound by load latency (~1-2 us to the Infinity
-        // Cache at 14 waves per CU), not by bandwidth or issue: every level of prefetch paid off.
+        // Cache at 14 waves per CU): with one tile of prefetch instead of two the kernel takes 36.1 ms instead of 33.5.
         const uint32_t last = (uint32_t)n_tiles;
         uint32_t b0 = 0, b1 = 0, b2 = 0, b3 = 0, b4 = 0;
         if (g) {
