@@ -100,11 +100,17 @@ __global__ void __launch_bounds__(256) alphabet_kernel(const uint8_t *__restrict
 }
 
 // One wave per string: filter, n-gram, sort, run-length encode.
+// The tokeniser runs single-wave workgroups: LDS operations of one wave execute in issue order, so its
+// phases need no s_barrier (and no wait for the outstanding df atomics / token stores of the previous
+// string, which __syncthreads() implies); a compiler-level barrier keeps the LDS accesses in program order.
+__device__ __forceinline__ void wave_sync() { __builtin_amdgcn_wave_barrier(); }
+
 __global__ void __launch_bounds__(64) tokenize_kernel(const uint8_t *__restrict__ bytes,
                                                       const int64_t *__restrict__ offsets, int64_t n_rows,
                                                       TokParams p, const int64_t *__restrict__ ub_ptr,
                                                       int32_t *__restrict__ out_cnt, uint32_t *__restrict__ out_keys,
-                                                      int32_t *__restrict__ out_tf, int32_t *df_table, int32_t *err) {
+                                                      int32_t *__restrict__ out_tf, int32_t *df_table,
+                                                      int32_t df_replicas, int64_t df_stride, int32_t *err) {
     __shared__ uint32_t keys[TOK_CAP];
     __shared__ uint16_t starts[TOK_CAP + 2];
     __shared__ uint8_t chars[TOK_CHARS];
@@ -131,18 +137,18 @@ __global__ void __launch_bounds__(64) tokenize_kernel(const uint8_t *__restrict_
                 break;
             }
         }
-        __syncthreads();
+        wave_sync();
         int g = m - p.ngram + 1;   // number of n-grams
         if (g < 0) g = 0;
         if (overflow || g > TOK_CAP) {
             if (lane == 0) atomicExch(err, 1);
             if (lane == 0) out_cnt[row] = 0;
-            __syncthreads();
+            wave_sync();
             continue;
         }
         if (g == 0) {
             if (lane == 0) out_cnt[row] = 0;
-            __syncthreads();
+            wave_sync();
             continue;
         }
         // ---- pack keys
@@ -156,7 +162,7 @@ __global__ void __launch_bounds__(64) tokenize_kernel(const uint8_t *__restrict_
             }
             keys[idx] = key;
         }
-        __syncthreads();
+        wave_sync();
         // ---- bitonic sort, ascending
         for (int k = 2; k <= P; k <<= 1) {
             for (int j = k >> 1; j > 0; j >>= 1) {
@@ -169,7 +175,7 @@ __global__ void __launch_bounds__(64) tokenize_kernel(const uint8_t *__restrict_
                         keys[i + j] = a;
                     }
                 }
-                __syncthreads();
+                wave_sync();
             }
         }
         // ---- run-length encode: starts[u] = index of the first occurrence of the u-th distinct key
@@ -183,18 +189,28 @@ __global__ void __launch_bounds__(64) tokenize_kernel(const uint8_t *__restrict_
             uniq += __popcll(hm);
         }
         if (lane == 0) starts[uniq] = (uint16_t)g;
-        __syncthreads();
+        wave_sync();
         const int64_t obase = ub_ptr[row];
         for (int u = lane; u < uniq; u += 64) {
             const int s0 = starts[u];
             const uint32_t key = keys[s0];
             out_keys[obase + u] = key;
             out_tf[obase + u] = (int32_t)starts[u + 1] - s0;
-            if (df_table) atomicAdd(&df_table[key], 1);
+            // the same few n-grams ('inc', ' co') occur in a fifth of all strings: spread their atomics over
+            // several copies of the table (summed by df_reduce_kernel) instead of serialising on one address
+            if (df_table) atomicAdd(&df_table[(int64_t)(row % df_replicas) * df_stride + key], 1);
         }
         if (lane == 0) out_cnt[row] = uniq;
-        __syncthreads();
+        wave_sync();
     }
+}
+
+__global__ void __launch_bounds__(256) df_reduce_kernel(int32_t *df_table, int64_t key_space, int32_t replicas, int64_t stride) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= key_space) return;
+    int32_t s = df_table[i];
+    for (int r = 1; r < replicas; ++r) s += df_table[(int64_t)r * stride + i];
+    df_table[i] = s;
 }
 
 __global__ void __launch_bounds__(256) presence_kernel(const int32_t *__restrict__ df_table, int64_t key_space,
@@ -279,7 +295,8 @@ static void free_cache(sg_ctx *ctx, TokenCache &c) {
     c = TokenCache();
 }
 
-static int tokenize_set(sg_ctx *ctx, const sg_strings *s, const TokParams &tp, int32_t *df_table, int32_t *d_err,
+static int tokenize_set(sg_ctx *ctx, const sg_strings *s, const TokParams &tp, int32_t *df_table, int32_t df_replicas,
+                        int64_t df_stride, int32_t *d_err,
                         TokenCache *out) {
     TokenCache c;
     c.src = s;
@@ -304,7 +321,7 @@ static int tokenize_set(sg_ctx *ctx, const sg_strings *s, const TokParams &tp, i
         unsigned grid = (unsigned)ctx->num_cu * 24u;
         if ((int64_t)grid > s->n) grid = (unsigned)s->n;
         hipLaunchKernelGGL(tokenize_kernel, dim3(grid), dim3(64), 0, ctx->stream, s->d_bytes, s->d_offsets, s->n, tp,
-                           (const int64_t *)c.d_ub_ptr, c.d_cnt, c.d_keys, c.d_tf, df_table, d_err);
+                           (const int64_t *)c.d_ub_ptr, c.d_cnt, c.d_keys, c.d_tf, df_table, df_replicas, df_stride, d_err);
         if (hipGetLastError() != hipSuccess) {
             sg_set_error("tokenize_kernel launch failed");
             st = SG_ERR_HIP;
@@ -396,16 +413,22 @@ extern "C" int sg_vec_fit(sg_ctx *ctx, const sg_strings *const *sets, int32_t n_
 
     {
         SgTimer timer(ctx, SG_K_TOKENIZE);
-        st = sg_alloc(ctx, (size_t)v->key_space + 1, &im->d_df_table);
+        // df table: `replicas` copies (row mod replicas picks one) while they stay small, summed afterwards
+        const int64_t df_stride = v->key_space + 1;
+        int32_t replicas = 8;
+        if (const char *e = getenv("SG_DF_REPLICAS")) replicas = atoi(e);
+        while (replicas > 1 && df_stride * replicas > ((int64_t)1 << 25)) replicas >>= 1;   // <= 128 MiB of counters
+        if (replicas < 1) replicas = 1;
+        st = sg_alloc(ctx, (size_t)(df_stride * replicas), &im->d_df_table);
         if (st == SG_OK) st = sg_alloc(ctx, (size_t)v->key_space + 1, &v->d_key_to_col);
         if (st == SG_OK) st = sg_alloc(ctx, 4, &im->d_err);
         if (st == SG_OK) {
-            (void)hipMemsetAsync(im->d_df_table, 0, sizeof(int32_t) * (size_t)(v->key_space + 1), ctx->stream);
+            (void)hipMemsetAsync(im->d_df_table, 0, sizeof(int32_t) * (size_t)(df_stride * replicas), ctx->stream);
             (void)hipMemsetAsync(im->d_err, 0, 16, ctx->stream);
         }
         for (int i = 0; i < n_sets && st == SG_OK; ++i) {
             TokenCache c;
-            st = tokenize_set(ctx, sets[i], tp, im->d_df_table, im->d_err, &c);
+            st = tokenize_set(ctx, sets[i], tp, im->d_df_table, replicas, df_stride, im->d_err, &c);
             if (st == SG_OK) {
                 im->caches.push_back(c);
                 v->n_docs += sets[i]->n;
@@ -416,6 +439,9 @@ extern "C" int sg_vec_fit(sg_ctx *ctx, const sg_strings *const *sets, int32_t n_
         if (st == SG_OK) st = sg_alloc(ctx, 4, &d_total);
         if (st == SG_OK) {
             const unsigned grid = (unsigned)((v->key_space + 255) / 256);
+            if (replicas > 1)
+                hipLaunchKernelGGL(df_reduce_kernel, dim3(grid), dim3(256), 0, ctx->stream, im->d_df_table, v->key_space,
+                                   replicas, df_stride);
             hipLaunchKernelGGL(presence_kernel, dim3(grid), dim3(256), 0, ctx->stream, im->d_df_table, v->key_space,
                                (uint32_t *)v->d_key_to_col);
             st = sg_exclusive_scan_u32(ctx, (const uint32_t *)v->d_key_to_col, (uint32_t *)v->d_key_to_col,
@@ -540,7 +566,7 @@ extern "C" int sg_vec_transform(sg_ctx *ctx, const sg_vocab *v, const sg_strings
         SgTimer timer(ctx, SG_K_TOKENIZE);
         const TokParams tp = make_tok_params(v, im);
         (void)hipMemsetAsync(im->d_err, 0, 16, ctx->stream);
-        st = tokenize_set(ctx, strings, tp, nullptr, im->d_err, &local);
+        st = tokenize_set(ctx, strings, tp, nullptr, 1, 0, im->d_err, &local);
         if (st != SG_OK) return st;
         tc = &local;
     }
