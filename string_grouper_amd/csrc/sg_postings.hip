@@ -18,13 +18,21 @@
 
 #include "sg_internal.h"
 
+// Thread -> right-hand row.  Consecutive rows share a column tile, hence the bins of the frequent terms:
+// with thread i on row i a whole wave hammers the same counter.  Consecutive threads are therefore dealt
+// to consecutive TILES (thread g -> row (g mod n_tiles) * tile + g div n_tiles); every thread still walks
+// its own row, so nothing is lost in coalescing.
+__device__ __forceinline__ int64_t row_of_thread(int64_t g, int32_t tile_log2, int32_t n_tiles) {
+    return ((g % n_tiles) << tile_log2) | (g / n_tiles);
+}
+
 template <typename T>
 __global__ void __launch_bounds__(256) postings_count(const int64_t *__restrict__ indptr,
                                                       const int32_t *__restrict__ indices, int64_t n_rows,
                                                       int32_t tile_log2, int32_t n_tiles, uint32_t *seg_counts) {
     // one wave per 64 rows would leave lanes idle on short rows; nnz is only ~19/row, so a thread per
-    // row with a short serial loop keeps the code simple; adjacent threads touch adjacent rows.
-    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    // row with a short serial loop keeps the code simple
+    const int64_t j = row_of_thread((int64_t)blockIdx.x * blockDim.x + threadIdx.x, tile_log2, n_tiles);
     if (j >= n_rows) return;
     const int64_t lo = indptr[j], hi = indptr[j + 1];
     const uint32_t t = (uint32_t)(j >> tile_log2);
@@ -58,7 +66,7 @@ __global__ void __launch_bounds__(256) postings_fill(const int64_t *__restrict__
                                                      uint32_t *cursor, int32_t *out_rows, T *out_vals,
                                                      uint32_t *out_filt /* null: no filter postings */,
                                                      uint32_t freq_min, float inv_norm_up) {
-    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t j = row_of_thread((int64_t)blockIdx.x * blockDim.x + threadIdx.x, tile_log2, n_tiles);
     if (j >= n_rows) return;
     const int64_t lo = indptr[j], hi = indptr[j + 1];
     const uint32_t t = (uint32_t)(j >> tile_log2);
@@ -186,7 +194,8 @@ extern "C" int sg_postings_build(sg_ctx *ctx, const sg_csr *B, int32_t tile_cols
         SgTimer timer(ctx, SG_K_POSTINGS);
         SG_HIP_TRY(hipMemsetAsync(p->d_seg, 0, sizeof(uint32_t) * (size_t)(n_bins + 1), ctx->stream));
         SG_HIP_TRY(hipMemsetAsync(cursor, 0, sizeof(uint32_t) * (size_t)(n_bins + 1), ctx->stream));
-        const unsigned grid = (unsigned)((B->n_rows + 255) / 256);
+        // one thread per slot of the (tile x row-in-tile) grid: covers every row, see row_of_thread
+        const unsigned grid = (unsigned)((((int64_t)p->n_tiles << tile_log2) + 255) / 256);
         if (grid > 0) {
             if (B->dtype == SG_F64)
                 hipLaunchKernelGGL(postings_count<double>, dim3(grid), dim3(256), 0, ctx->stream, B->d_indptr,
