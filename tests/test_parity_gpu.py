@@ -676,3 +676,22 @@ def test_rowwise_dot_on_device_equals_scipy(ctx, dtype):
     assert got.dtype == want.dtype
     np.testing.assert_array_equal(got.to_numpy(), want)
     assert (got.to_numpy() > 0.5).sum() > 1000
+
+
+def test_pruned_multiply_with_unsorted_output_and_row_blocks(ctx, mats, monkeypatch):
+    """sort=False (rows re-ordered by column afterwards) and a left matrix that is a row-block view
+    (how the multi-GPU path hands out work) through the pruned kernel."""
+    monkeypatch.delenv("SG_PRUNE", raising=False)
+    A = mats[np.float32]
+    dA = ctx.csr_from_scipy(A)
+    post = ctx.postings_build(dA)
+    for lo, hi in ((0, 20000), (5000, 12345), (19990, 20000)):
+        blk = dA.row_block(lo, hi)
+        for sort in (True, False):
+            res = ctx.spgemm_topn(blk, post, 10, 0.7, sort)
+            st = ctx.stats()
+            assert st["prune_rows"] > 0
+            assert_csr_identical(res.to_scipy(), P.sp_matmul_topn_port(A[lo:hi], A.T, 10, 0.7, sort, 8), f"{lo}:{hi} sort={sort}")
+            res.free()
+        blk.free()
+    post.free()
