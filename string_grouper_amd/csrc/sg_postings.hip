@@ -58,6 +58,35 @@ __device__ __forceinline__ void store_posting<double>(int32_t *rows, double *val
     vals[pos] = v;
 }
 
+// norm of a row's frequent part (terms whose list holds >= freq_min entries), quantised upwards to 8 bits
+// relative to norm_up
+template <typename T>
+__device__ __forceinline__ uint32_t frequent_norm_q8(const int32_t *__restrict__ indices, const T *__restrict__ data,
+                                                     int64_t lo, int64_t hi, const uint32_t *__restrict__ seg, int32_t n_tiles,
+                                                     uint32_t freq_min, float inv_norm_up) {
+    double f2 = 0.0;
+    for (int64_t p = lo; p < hi; ++p) {
+        const int64_t k = indices[p];
+        if (seg[(k + 1) * n_tiles] - seg[k * n_tiles] >= freq_min) f2 += (double)data[p] * (double)data[p];
+    }
+    uint32_t fq = (uint32_t)ceilf(__double2float_ru(sqrt(f2)) * inv_norm_up * 255.0f * 1.000002f);
+    return fq > 255u ? 255u : fq;
+}
+
+// one posting (+ its filter posting) of column `col` of the tile at position `pos`
+template <typename T>
+__device__ __forceinline__ void emit_posting(int32_t *out_rows, T *out_vals, uint32_t *out_filt, uint32_t pos, uint32_t col,
+                                             T v, uint32_t fq, int32_t tile_log2, float inv_norm_up) {
+    // the multiply wants the byte offset of the accumulator inside its LDS tile, not j itself
+    store_posting<T>(out_rows, out_vals, pos, (int32_t)(col * (uint32_t)sizeof(T)), v);
+    if (out_filt) {
+        const uint32_t bq_max = (1u << (24 - tile_log2)) - 1u;   // the bits the column and fq leave
+        uint32_t bq = (uint32_t)ceilf((float)v * inv_norm_up * (float)bq_max * 1.000002f);
+        if (bq > bq_max) bq = bq_max;
+        out_filt[pos] = col | (bq << tile_log2) | (fq << 24);   // fq in the top byte: one v_cvt_f32_ubyte3 in K4p
+    }
+}
+
 template <typename T>
 __global__ void __launch_bounds__(256) postings_fill(const int64_t *__restrict__ indptr,
                                                      const int32_t *__restrict__ indices,
@@ -71,26 +100,56 @@ __global__ void __launch_bounds__(256) postings_fill(const int64_t *__restrict__
     const int64_t lo = indptr[j], hi = indptr[j + 1];
     const uint32_t t = (uint32_t)(j >> tile_log2);
     const uint32_t col = (uint32_t)(j & (((int64_t)1 << tile_log2) - 1));
-    uint32_t fq = 0;
-    if (out_filt) {   // norm of the row's frequent part, quantised upwards to 8 bits (relative to norm_up)
-        double f2 = 0.0;
-        for (int64_t p = lo; p < hi; ++p) {
-            const int64_t k = indices[p];
-            if (seg[(k + 1) * n_tiles] - seg[k * n_tiles] >= freq_min) f2 += (double)data[p] * (double)data[p];
-        }
-        fq = (uint32_t)ceilf(__double2float_ru(sqrt(f2)) * inv_norm_up * 255.0f * 1.000002f);
-        if (fq > 255u) fq = 255u;
-    }
+    const uint32_t fq = out_filt ? frequent_norm_q8<T>(indices, data, lo, hi, seg, n_tiles, freq_min, inv_norm_up) : 0u;
     for (int64_t p = lo; p < hi; ++p) {
         const int64_t bin = (int64_t)indices[p] * n_tiles + t;
         const uint32_t pos = seg[bin] + atomicAdd(&cursor[bin], 1u);
-        // the multiply wants the byte offset of the accumulator inside its LDS tile, not j itself
-        store_posting<T>(out_rows, out_vals, pos, (int32_t)(col * (uint32_t)sizeof(T)), data[p]);
-        if (out_filt) {
-            const uint32_t bq_max = (1u << (24 - tile_log2)) - 1u;   // the bits the column and fq leave
-            uint32_t bq = (uint32_t)ceilf((float)data[p] * inv_norm_up * (float)bq_max * 1.000002f);
-            if (bq > bq_max) bq = bq_max;
-            out_filt[pos] = col | (bq << tile_log2) | (fq << 24);   // fq in the top byte: one v_cvt_f32_ubyte3 in K4p
+        emit_posting<T>(out_rows, out_vals, out_filt, pos, col, data[p], fq, tile_log2, inv_norm_up);
+    }
+}
+
+// The same two passes with the tile's counters in LDS: one workgroup per column tile (its rows are
+// consecutive), a histogram / cursor array over the vocabulary in LDS (4 bytes per term), LDS atomics
+// instead of 2 x nnz global ones.  Used when the vocabulary fits (n_terms * 4 <= 120 KiB).
+template <typename T>
+__global__ void __launch_bounds__(1024) postings_count_lds(const int64_t *__restrict__ indptr,
+                                                           const int32_t *__restrict__ indices, int64_t n_rows,
+                                                           int32_t tile_log2, int32_t n_tiles, int32_t n_terms,
+                                                           uint32_t *seg_counts) {
+    extern __shared__ uint32_t hist[];
+    const int64_t t = blockIdx.x;
+    for (int k = threadIdx.x; k < n_terms; k += blockDim.x) hist[k] = 0;
+    __syncthreads();
+    const int64_t j0 = t << tile_log2;
+    int64_t j1 = j0 + ((int64_t)1 << tile_log2);
+    if (j1 > n_rows) j1 = n_rows;
+    for (int64_t j = j0 + threadIdx.x; j < j1; j += blockDim.x)
+        for (int64_t p = indptr[j]; p < indptr[j + 1]; ++p) atomicAdd(&hist[indices[p]], 1u);
+    __syncthreads();
+    for (int k = threadIdx.x; k < n_terms; k += blockDim.x) seg_counts[(int64_t)k * n_tiles + t] = hist[k];
+}
+
+template <typename T>
+__global__ void __launch_bounds__(1024) postings_fill_lds(const int64_t *__restrict__ indptr,
+                                                          const int32_t *__restrict__ indices,
+                                                          const T *__restrict__ data, int64_t n_rows, int32_t tile_log2,
+                                                          int32_t n_tiles, int32_t n_terms, const uint32_t *__restrict__ seg,
+                                                          int32_t *out_rows, T *out_vals, uint32_t *out_filt,
+                                                          uint32_t freq_min, float inv_norm_up) {
+    extern __shared__ uint32_t cursor[];   // next free slot of (term k, this tile)
+    const int64_t t = blockIdx.x;
+    for (int k = threadIdx.x; k < n_terms; k += blockDim.x) cursor[k] = seg[(int64_t)k * n_tiles + t];
+    __syncthreads();
+    const int64_t j0 = t << tile_log2;
+    int64_t j1 = j0 + ((int64_t)1 << tile_log2);
+    if (j1 > n_rows) j1 = n_rows;
+    for (int64_t j = j0 + threadIdx.x; j < j1; j += blockDim.x) {
+        const int64_t lo = indptr[j], hi = indptr[j + 1];
+        const uint32_t col = (uint32_t)(j - j0);
+        const uint32_t fq = out_filt ? frequent_norm_q8<T>(indices, data, lo, hi, seg, n_tiles, freq_min, inv_norm_up) : 0u;
+        for (int64_t p = lo; p < hi; ++p) {
+            const uint32_t pos = atomicAdd(&cursor[indices[p]], 1u);
+            emit_posting<T>(out_rows, out_vals, out_filt, pos, col, data[p], fq, tile_log2, inv_norm_up);
         }
     }
 }
@@ -196,7 +255,28 @@ extern "C" int sg_postings_build(sg_ctx *ctx, const sg_csr *B, int32_t tile_cols
         SG_HIP_TRY(hipMemsetAsync(cursor, 0, sizeof(uint32_t) * (size_t)(n_bins + 1), ctx->stream));
         // one thread per slot of the (tile x row-in-tile) grid: covers every row, see row_of_thread
         const unsigned grid = (unsigned)((((int64_t)p->n_tiles << tile_log2) + 255) / 256);
-        if (grid > 0) {
+        // the tile's counters fit in LDS: one workgroup per tile, LDS atomics (otherwise global ones)
+        const size_t lds = (size_t)B->n_cols * 4;
+        bool in_lds = B->n_rows > 0 && lds <= 120 * 1024 && lds > 0;
+        if (const char *e = getenv("SG_POSTINGS_LDS")) in_lds = in_lds && e[0] != '0';
+        const float inv_norm = p->d_filt ? 1.0f / p->norm_up : 0.f;
+        if (in_lds) {
+            static bool attr_done = false;
+            if (!attr_done) {
+                (void)hipFuncSetAttribute((const void *)postings_count_lds<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024);
+                (void)hipFuncSetAttribute((const void *)postings_count_lds<double>, hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024);
+                (void)hipFuncSetAttribute((const void *)postings_fill_lds<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024);
+                (void)hipFuncSetAttribute((const void *)postings_fill_lds<double>, hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024);
+                attr_done = true;
+            }
+            if (B->dtype == SG_F64)
+                hipLaunchKernelGGL(postings_count_lds<double>, dim3((unsigned)p->n_tiles), dim3(1024), lds, ctx->stream, B->d_indptr,
+                                   B->d_indices, B->n_rows, tile_log2, p->n_tiles, (int32_t)B->n_cols, p->d_seg);
+            else
+                hipLaunchKernelGGL(postings_count_lds<float>, dim3((unsigned)p->n_tiles), dim3(1024), lds, ctx->stream, B->d_indptr,
+                                   B->d_indices, B->n_rows, tile_log2, p->n_tiles, (int32_t)B->n_cols, p->d_seg);
+            SG_HIP_TRY(hipGetLastError());
+        } else if (grid > 0) {
             if (B->dtype == SG_F64)
                 hipLaunchKernelGGL(postings_count<double>, dim3(grid), dim3(256), 0, ctx->stream, B->d_indptr,
                                    B->d_indices, B->n_rows, tile_log2, p->n_tiles, p->d_seg);
@@ -207,17 +287,25 @@ extern "C" int sg_postings_build(sg_ctx *ctx, const sg_csr *B, int32_t tile_cols
         }
         // counts -> offsets, in place; seg[n_bins] receives the total (= nnz)
         st = sg_exclusive_scan_u32(ctx, p->d_seg, p->d_seg, n_bins, p->d_seg + n_bins);
-        if (st == SG_OK && grid > 0) {
+        if (st == SG_OK && in_lds) {
+            if (B->dtype == SG_F64)
+                hipLaunchKernelGGL(postings_fill_lds<double>, dim3((unsigned)p->n_tiles), dim3(1024), lds, ctx->stream, B->d_indptr,
+                                   B->d_indices, (const double *)B->d_data, B->n_rows, tile_log2, p->n_tiles, (int32_t)B->n_cols,
+                                   p->d_seg, p->d_rows, (double *)p->d_vals, p->d_filt, p->freq_min, inv_norm);
+            else
+                hipLaunchKernelGGL(postings_fill_lds<float>, dim3((unsigned)p->n_tiles), dim3(1024), lds, ctx->stream, B->d_indptr,
+                                   B->d_indices, (const float *)B->d_data, B->n_rows, tile_log2, p->n_tiles, (int32_t)B->n_cols,
+                                   p->d_seg, p->d_rows, (float *)p->d_vals, p->d_filt, p->freq_min, inv_norm);
+            if (hipGetLastError() != hipSuccess) st = SG_ERR_HIP;
+        } else if (st == SG_OK && grid > 0) {
             if (B->dtype == SG_F64)
                 hipLaunchKernelGGL(postings_fill<double>, dim3(grid), dim3(256), 0, ctx->stream, B->d_indptr,
                                    B->d_indices, (const double *)B->d_data, B->n_rows, tile_log2, p->n_tiles,
-                                   p->d_seg, cursor, p->d_rows, (double *)p->d_vals, p->d_filt, p->freq_min,
-                                   p->d_filt ? 1.0f / p->norm_up : 0.f);
+                                   p->d_seg, cursor, p->d_rows, (double *)p->d_vals, p->d_filt, p->freq_min, inv_norm);
             else
                 hipLaunchKernelGGL(postings_fill<float>, dim3(grid), dim3(256), 0, ctx->stream, B->d_indptr,
                                    B->d_indices, (const float *)B->d_data, B->n_rows, tile_log2, p->n_tiles,
-                                   p->d_seg, cursor, p->d_rows, (float *)p->d_vals, p->d_filt, p->freq_min,
-                                   p->d_filt ? 1.0f / p->norm_up : 0.f);
+                                   p->d_seg, cursor, p->d_rows, (float *)p->d_vals, p->d_filt, p->freq_min, inv_norm);
             if (hipGetLastError() != hipSuccess) st = SG_ERR_HIP;
         }
         if (st == SG_OK && p->d_fwd) {

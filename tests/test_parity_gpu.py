@@ -695,3 +695,22 @@ def test_pruned_multiply_with_unsorted_output_and_row_blocks(ctx, mats, monkeypa
             res.free()
         blk.free()
     post.free()
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_postings_built_with_lds_and_with_global_counters_give_the_same_multiply(ctx, mats, dtype, monkeypatch):
+    """K3 keeps a tile's counters in LDS when the vocabulary fits and in global memory otherwise; the
+    order of the entries inside a posting segment differs, the multiply's result must not."""
+    A = mats[dtype][:9000]
+    B = mats[dtype][4000:20000]
+    dA, dB = ctx.csr_from_scipy(A), ctx.csr_from_scipy(B)
+    want = P.sp_matmul_topn_port(A, B.T, 10, 0.6, True, 8)
+    for lds in ("1", "0"):
+        monkeypatch.setenv("SG_POSTINGS_LDS", lds)
+        for prune in ("1", "0"):
+            monkeypatch.setenv("SG_PRUNE", prune)
+            post = ctx.postings_build(dB)
+            res = ctx.spgemm_topn(dA, post, 10, 0.6, True)
+            assert_csr_identical(res.to_scipy(), want, f"{dtype.__name__} lds={lds} prune={prune}")
+            res.free()
+            post.free()
