@@ -294,8 +294,10 @@ class StringGrouper(object):
             out = eng.match_list(master_matrix, duplicate_matrix, self._max_n_matches, self._config.min_similarity,
                                  fix, **({'keep_on_device': True} if keep else {}))
             rows, cols, sims, self._true_max_n_matches = out[:4]
-            self._matches_list = pd.DataFrame({'master_side': rows, 'dupe_side': cols,
-                                               'similarity': sims.astype(np.float64, copy=False)})
+            with pd.option_context("mode.copy_on_write", True):     # columns kept as they are: no re-copy
+                self._matches_list = pd.concat(
+                    [pd.Series(rows, name='master_side', copy=False), pd.Series(cols, name='dupe_side', copy=False),
+                     pd.Series(sims.astype(np.float64, copy=False), name='similarity', copy=False)], axis=1)
             # the same list stays in HBM for get_groups(): best master per duplicate (K7) / group
             # representatives (K8) come back as one int32 per string
             if len(out) > 4:
