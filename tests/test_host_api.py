@@ -176,3 +176,108 @@ def test_pruned_multiply_rule_used_for_the_row_split():
     assert pruned_multiply_expected(10, 0.8)
     assert not pruned_multiply_expected(65, 0.8)
     assert not pruned_multiply_expected(10, 0.3)
+
+
+# ------------------------------------------------------------------------------------------------
+# The glue around the device reductions (K7 / K8 / K9), exercised on the CPU with an engine double whose
+# "device" list reduces with numpy: the frames built from the reduced arrays must equal the ones the
+# host formulation builds from the full match list.
+class _NumpyDeviceList:
+    def __init__(self, rows, cols, vals, n_cols):
+        self.rows, self.cols, self.vals, self.n_cols = rows, cols, vals, n_cols
+        self.freed = False
+
+    def best_master(self):
+        import numpy as np
+        best = np.full(self.n_cols, -1, np.int32)
+        order = np.lexsort((self.rows, -self.vals.astype(np.float64), self.cols))
+        cs = self.cols[order]
+        first = np.ones(len(order), bool)
+        first[1:] = cs[1:] != cs[:-1]
+        best[cs[first]] = self.rows[order][first]
+        return best
+
+    def group_reps(self, centroid):
+        import numpy as np
+        import scipy.sparse as sp
+        from scipy.sparse.csgraph import connected_components
+        n = self.n_cols
+        g = sp.csr_matrix((np.ones(len(self.rows)), (self.rows, self.cols)), shape=(n, n))
+        _, labels = connected_components(g, directed=True)
+        if centroid:
+            g.data = self.vals.astype(np.float64)
+            weight = np.asarray(g.sum(axis=1)).squeeze(axis=1)
+            order = np.lexsort((np.arange(n), -weight, labels))
+        else:
+            order = np.lexsort((np.arange(n), labels))
+        ls = labels[order]
+        head = np.ones(n, bool)
+        head[1:] = ls[1:] != ls[:-1]
+        rep_of = np.empty(labels.max() + 1, np.int64)
+        rep_of[ls[head]] = order[head]
+        return rep_of[labels].astype(np.int32)
+
+    def free(self):
+        self.freed = True
+
+
+def _engine_with_device_reductions():
+    import numpy as np
+    import scipy.sparse as sp
+    from tests._oracle_engine import OracleEngine
+
+    class Engine(OracleEngine):
+        def match_list(self, A, B, top_n, threshold, self_join_fix, keep_on_device=False):
+            import string_grouper_amd as sga
+            C = self._mul(A.m, B.m, top_n, threshold)
+            true_max = int(np.diff(C.indptr).max()) if C.shape[0] else 0
+            if self_join_fix:
+                C = sga.StringGrouper._symmetrize_matrix(sga.StringGrouper._fix_diagonal(C))
+            C = sp.csr_matrix(C)
+            rows = np.repeat(np.arange(C.shape[0], dtype=np.int64), np.diff(C.indptr))
+            cols, vals = C.indices.astype(np.int64), C.data
+            out = (rows, cols, vals, true_max)
+            return out + (_NumpyDeviceList(rows, cols, vals, B.shape[0]),) if keep_on_device else out
+
+        def rowwise_dot(self, A, B):
+            return np.asarray(A.m.multiply(B.m).sum(axis=1)).squeeze(axis=1)
+
+    return Engine(use_port=True)
+
+
+def test_get_groups_through_the_device_reductions_equals_the_host_formulation():
+    import numpy as np
+    import pandas as pd
+    import string_grouper_amd as sga
+    import string_grouper_amd.engine as E
+    from string_grouper_amd.synth import synth_names
+    old = E._engine
+    E.set_engine(_engine_with_device_reductions())
+    try:
+        names = list(synth_names(1500, 5))
+        s = pd.Series(names + [names[3]] * 7, index=np.arange(1507) * 3)
+        for rep in ("centroid", "first"):
+            sg = sga.StringGrouper(s, min_similarity=0.8, group_rep=rep).fit()
+            dml = sg.__dict__["_device_matches"]
+            on_device = sg.get_groups()
+            sg._drop_device_matches()
+            assert dml.freed
+            pd.testing.assert_frame_equal(on_device, sg.get_groups())
+        dupes = pd.Series(synth_names(700, seed=6, perturb_of=names, perturb_frac=0.7))
+        ids_m, ids_d = pd.Series(np.arange(len(s)) + 100), pd.Series(np.arange(len(dupes)) + 9000)
+        for kw in (dict(), dict(ignore_index=True)):
+            sg = sga.StringGrouper(s.reset_index(drop=True), dupes, ids_m, ids_d, min_similarity=0.7, **kw).fit()
+            on_device = sg.get_groups()
+            sg._drop_device_matches()
+            pd.testing.assert_frame_equal(on_device, sg.get_groups())
+        sg = sga.StringGrouper(s.reset_index(drop=True), dupes, min_similarity=0.7, replace_na=True).fit()
+        on_device = sg.get_groups()
+        sg._drop_device_matches()
+        pd.testing.assert_frame_equal(on_device, sg.get_groups())
+        sims = sga.compute_pairwise_similarities(pd.Series(names[:700]), dupes)
+        from oracle import oracle as O
+        (a, b), _, _ = O.tfidf_sklearn(names[:700] + list(dupes), [names[:700], list(dupes)], dtype=np.float64)
+        assert sims.name == "similarity" and len(sims) == 700
+        np.testing.assert_array_equal(sims.to_numpy(), np.asarray(a.multiply(b).sum(axis=1)).squeeze(axis=1))
+    finally:
+        E.set_engine(old)
