@@ -94,6 +94,17 @@ class StringGrouperNotFitException(Exception):
     """A result was requested before ``fit()``."""
 
 
+def _concat_columns(parts):
+    """pd.concat(parts, axis=1) that keeps the columns as they are.  Under copy-on-write concat neither
+    copies nor consolidates (consolidation re-copies every object pointer at millions of rows); the parts
+    are temporaries nobody else references.  pandas >= 3 behaves like that without the option."""
+    try:
+        with pd.option_context("mode.copy_on_write", True):
+            return pd.concat(parts, axis=1)
+    except (KeyError, ValueError):          # the option is gone: copy-on-write is the only mode
+        return pd.concat(parts, axis=1)
+
+
 def validate_is_fit(method):
     @functools.wraps(method)
     def guarded(self, *args, **kwargs):
@@ -294,10 +305,9 @@ class StringGrouper(object):
             out = eng.match_list(master_matrix, duplicate_matrix, self._max_n_matches, self._config.min_similarity,
                                  fix, **({'keep_on_device': True} if keep else {}))
             rows, cols, sims, self._true_max_n_matches = out[:4]
-            with pd.option_context("mode.copy_on_write", True):     # columns kept as they are: no re-copy
-                self._matches_list = pd.concat(
-                    [pd.Series(rows, name='master_side', copy=False), pd.Series(cols, name='dupe_side', copy=False),
-                     pd.Series(sims.astype(np.float64, copy=False), name='similarity', copy=False)], axis=1)
+            self._matches_list = _concat_columns(      # columns kept as they are: no re-copy
+                [pd.Series(rows, name='master_side', copy=False), pd.Series(cols, name='dupe_side', copy=False),
+                 pd.Series(sims.astype(np.float64, copy=False), name='similarity', copy=False)])
             # the same list stays in HBM for get_groups(): best master per duplicate (K7) / group
             # representatives (K8) come back as one int32 per string
             if len(out) > 4:
@@ -433,9 +443,7 @@ class StringGrouper(object):
                 if drop_index:
                     return values
                 index_col = pd.Series(idx.take(pos), name='index' if idx.name is None else idx.name, copy=False)
-                cols = [values, index_col] if mirror else [index_col, values]
-                with pd.option_context("mode.copy_on_write", True):
-                    return pd.concat(cols, axis=1)
+                return _concat_columns([values, index_col] if mirror else [index_col, values])
             picked = named.iloc[pos].reset_index(drop=drop_index)
             if mirror and isinstance(picked, pd.DataFrame):
                 picked = picked[picked.columns[::-1]]
@@ -457,10 +465,7 @@ class StringGrouper(object):
             right_id = side(right_ids, pairs.dupe_side, DEFAULT_ID_NAME, True, True)
             parts = [prefixed(left, LEFT_PREFIX), prefixed(left_id, LEFT_PREFIX), similarity,
                      prefixed(right_id, RIGHT_PREFIX), prefixed(right, RIGHT_PREFIX)]
-        # copy-on-write mode makes concat keep the columns as they are (no consolidation, which at millions of
-        # rows means re-copying every object pointer); the parts are temporaries nobody else references
-        with pd.option_context("mode.copy_on_write", True):
-            return pd.concat(parts, axis=1)
+        return _concat_columns(parts)
 
     @validate_is_fit
     def get_groups(self, ignore_index: Optional[bool] = None,
