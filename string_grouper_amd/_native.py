@@ -12,7 +12,9 @@ from typing import Optional
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsg_hip.so")
+# SG_HIP_LIB: diagnostic hook -- another build of the SAME library (e.g. the -DSG_WATCHDOG build scripts/ make on the
+# GPU box); never a different implementation
+LIB_PATH = os.environ.get("SG_HIP_LIB") or os.path.join(_HERE, "libsg_hip.so")
 
 SG_OK, SG_ERR_BADARG, SG_ERR_OOM, SG_ERR_OVERFLOW, SG_ERR_HIP, SG_ERR_NODEVICE, SG_ERR_UNSUPPORTED = range(7)
 SG_F32, SG_F64 = 0, 1

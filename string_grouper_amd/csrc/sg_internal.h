@@ -109,6 +109,7 @@ struct sg_csr {
     // lazily computed by sg_csr_props (sg_spgemm_pruned.hip): 0 unknown, 1 cosine-like, 2 not
     mutable int props_state = 0;
     mutable float props_max_norm2 = 0.f;
+    mutable uint32_t props_max_nnz = 0;  // longest row
 };
 
 struct sg_postings {
@@ -136,6 +137,10 @@ struct sg_postings {
     //   b <= bq / bq_max * norm_up   and
     //   || b_j restricted to the frequent terms (list length >= freq_min) || <= fq / 255 * norm_up
     uint32_t *d_filt = nullptr;
+    // per term a 16-byte aligned row of nt_pad entries: d_ends[k * nt_pad + t] = BYTE offset into d_filt of the end
+    // of segment (k, t) (entries past the last tile repeat the end of the list): one 16-byte load = four tiles
+    uint32_t *d_ends = nullptr;
+    int32_t nt_pad = 0;
     float norm_up = 0.f;                 // max ||row of B||, rounded up
     uint32_t freq_min = 0;               // list length from which a term counts as frequent
     bool cosine_like = false;            // B: values >= 0, sorted rows, row norms <= 1 (sg_csr_props)
@@ -169,11 +174,14 @@ int sg_matchlist_device_view(const sg_matchlist *ml, int64_t *n_rows, int64_t *n
                              const int64_t **row_ptr, const int32_t **cols, const void **vals);
 
 // sg_spgemm_pruned.hip
-int sg_csr_props(sg_ctx *ctx, const sg_csr *m, bool *cosine_like, float *max_norm2);
+int sg_csr_props(sg_ctx *ctx, const sg_csr *m, bool *cosine_like, float *max_norm2, uint32_t *max_nnz = nullptr);
 bool sg_pruned_supports_tile(int32_t tile_log2);
 int sg_spgemm_pruned_launch(sg_ctx *ctx, const sg_csr *A, const sg_postings *Bt, int32_t keep, sg_topn *r,
                             double threshold, double delta, uint32_t *row_counter,
                             uint32_t *flagged_count, uint32_t *flagged_rows, unsigned long long *stats);
+
+int sg_spgemm_pruned_symmetric(sg_ctx *ctx, const sg_csr *A, const sg_postings *Bt, int32_t keep, sg_topn *r,
+                               double threshold, double delta, unsigned long long *stats, bool *done);
 
 // exclusive prefix sum of n uint32 values (in place allowed); total written to *d_total if non-null
 int sg_exclusive_scan_u32(sg_ctx *ctx, const uint32_t *d_in, uint32_t *d_out, int64_t n, uint32_t *d_total);

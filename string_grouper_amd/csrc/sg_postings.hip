@@ -73,17 +73,24 @@ __device__ __forceinline__ uint32_t frequent_norm_q8(const int32_t *__restrict__
     return fq > 255u ? 255u : fq;
 }
 
-// one posting (+ its filter posting) of column `col` of the tile at position `pos`
+// one posting (+ its filter posting) of column `col` of the tile at position `pos`.
+// Filter posting (read by K4p, sg_spgemm_pruned.hip), 32 bits, AB = tile_log2 + 1:
+//   [0]        h     which 16-bit half of the accumulator word the column owns (col & 1)
+//   [1]        0
+//   [2, AB)    word  (col >> 1): bits [0, AB) masked with ~3 ARE the byte address of the accumulator word in LDS
+//   [AB, 24)   bq    value quantised upwards relative to norm_up
+//   [24, 32)   fq    norm of the row's frequent part, quantised upwards relative to norm_up
 template <typename T>
 __device__ __forceinline__ void emit_posting(int32_t *out_rows, T *out_vals, uint32_t *out_filt, uint32_t pos, uint32_t col,
                                              T v, uint32_t fq, int32_t tile_log2, float inv_norm_up) {
     // the multiply wants the byte offset of the accumulator inside its LDS tile, not j itself
     store_posting<T>(out_rows, out_vals, pos, (int32_t)(col * (uint32_t)sizeof(T)), v);
     if (out_filt) {
-        const uint32_t bq_max = (1u << (24 - tile_log2)) - 1u;   // the bits the column and fq leave
+        const int32_t ab = tile_log2 + 1;
+        const uint32_t bq_max = (1u << (24 - ab)) - 1u;   // the bits the address and fq leave
         uint32_t bq = (uint32_t)ceilf((float)v * inv_norm_up * (float)bq_max * 1.000002f);
         if (bq > bq_max) bq = bq_max;
-        out_filt[pos] = col | (bq << tile_log2) | (fq << 24);   // fq in the top byte: one v_cvt_f32_ubyte3 in K4p
+        out_filt[pos] = ((col >> 1) << 2) | (col & 1u) | (bq << ab) | (fq << 24);
     }
 }
 
@@ -174,6 +181,21 @@ __global__ void __launch_bounds__(256) fwd_pack(const int64_t *__restrict__ indp
     }
 }
 
+// segment ends of every term as byte offsets into the filter postings, rows padded to a multiple of four tiles
+__global__ void __launch_bounds__(256) pack_ends_kernel(const uint32_t *__restrict__ seg, int64_t n_terms, int32_t n_tiles,
+                                                        int32_t nt_pad, uint32_t *__restrict__ ends) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (n_terms + 1) * nt_pad) return;
+    const int64_t k = i / nt_pad;
+    if (k == n_terms) {   // one more row, all zero: the segments of a lane without a term (always empty)
+        ends[i] = 0;
+        return;
+    }
+    int32_t t = (int32_t)(i - k * nt_pad);
+    if (t >= n_tiles) t = n_tiles - 1;
+    ends[i] = seg[k * n_tiles + t + 1] << 2;
+}
+
 extern "C" int sg_postings_build(sg_ctx *ctx, const sg_csr *B, int32_t tile_cols, sg_postings **out) {
     SG_REQUIRE(ctx && B && out, "null argument");
     // cosine-like right-hand sides (non-negative, sorted rows, norms <= 1: TF-IDF) take the pruned multiply,
@@ -232,10 +254,14 @@ extern "C" int sg_postings_build(sg_ctx *ctx, const sg_csr *B, int32_t tile_cols
     if (st == SG_OK && B->dtype == SG_F64) st = sg_alloc(ctx, (size_t)B->nnz + 64, &p->d_rows);
     if (st == SG_OK) st = ctx->alloc(((size_t)B->nnz + 64) * vs, &p->d_vals);
     if (st == SG_OK) st = sg_alloc(ctx, (size_t)n_bins + 1, &cursor);
-    if (st == SG_OK && want_pruned && sg_pruned_supports_tile(tile_log2) && n_bins < ((int64_t)1 << 30)) {
+    if (st == SG_OK && want_pruned && sg_pruned_supports_tile(tile_log2) &&
+        (B->n_cols + 1) * ((n_tiles64 + 3) & ~(int64_t)3) < ((int64_t)1 << 30)) {
         st = ctx->alloc(((size_t)B->nnz + 8) * (B->dtype == SG_F64 ? 16 : 8), &p->d_fwd);
         if (st == SG_OK) st = sg_alloc(ctx, (size_t)B->n_rows + 2, &p->d_fwd_ptr);
-        if (st == SG_OK) st = sg_alloc(ctx, (size_t)B->nnz + 64, &p->d_filt);
+        // slack: the pruned multiply loads a lane's four slots of a segment unconditionally (<= 4 * 63 entries past it)
+        if (st == SG_OK) st = sg_alloc(ctx, (size_t)B->nnz + 512, &p->d_filt);
+        p->nt_pad = (int32_t)((n_tiles64 + 3) & ~(int64_t)3);
+        if (st == SG_OK) st = sg_alloc(ctx, (size_t)(B->n_cols + 1) * (size_t)p->nt_pad + 4, &p->d_ends);
         p->norm_up = __builtin_nextafterf(sqrtf(max_norm2) * 1.000001f, 2.f);
         // a term is "frequent" when it occurs in at least this share of the right-hand rows: the suffix of a
         // left row is drawn from frequent terms only, which lets the survivor test use each candidate's own
@@ -308,6 +334,12 @@ extern "C" int sg_postings_build(sg_ctx *ctx, const sg_csr *B, int32_t tile_cols
                                    p->d_seg, cursor, p->d_rows, (float *)p->d_vals, p->d_filt, p->freq_min, inv_norm);
             if (hipGetLastError() != hipSuccess) st = SG_ERR_HIP;
         }
+        if (st == SG_OK && p->d_ends && B->n_cols > 0) {
+            const int64_t cells = (B->n_cols + 1) * (int64_t)p->nt_pad;
+            hipLaunchKernelGGL(pack_ends_kernel, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, ctx->stream,
+                               (const uint32_t *)p->d_seg, B->n_cols, p->n_tiles, p->nt_pad, p->d_ends);
+            if (hipGetLastError() != hipSuccess) st = SG_ERR_HIP;
+        }
         if (st == SG_OK && p->d_fwd) {
             const unsigned g2 = (unsigned)((B->n_rows + 1 + 255) / 256);
             if (B->dtype == SG_F64)
@@ -336,6 +368,7 @@ extern "C" int sg_postings_free(sg_postings *p) {
     p->ctx->release(p->d_fwd);
     p->ctx->release(p->d_fwd_ptr);
     p->ctx->release(p->d_filt);
+    p->ctx->release(p->d_ends);
     delete p;
     return SG_OK;
 }

@@ -20,26 +20,50 @@
 // the canonical order (score desc, column asc) and the top-n cut are applied as in K4.
 //
 // p_ij is only a filter: any upper bound will do, in any summation order.  K3 therefore writes, next
-// to the postings proper, 4-byte "filter postings" {column in tile: L bits, bq: 24 - L, fq: 8} with the
+// to the postings proper, 4-byte "filter postings" {accumulator address + half, bq, fq: 8} with the
 // value b and the norm f_j quantised UPWARDS, and the kernel accumulates upper bounds of a * b in
-// 16-bit fixed point (scale 2^15) with LDS integer atomics.  That removes K4's structural cost -- one
-// wave instruction per posting segment because two segments may hit the same column -- here every
+// 16-bit fixed point (scale 2^15) with LDS integer atomics, all in integer arithmetic:
+//        x    = (CA * (bq << AB)) >> 32   >=  a * b * 2^15 - 1    CA = ceil(a * norm_b * 2^15 / bq_max * 2^(32 - AB))
+//        tq   = (T0 - C1 * fq) >> 8       <=  (thr - 1e-5) * 2^15 - 2 - ||a_S|| f_j 2^15 - |P|
+// (the |P| pays for the "- 1" of every add: a column receives at most one posting per term of P) and column j
+// survives when its accumulator reaches tq.  Because atomics tolerate collisions, every
 // lane of the wave carries a posting of whatever term: lanes are dealt to the terms of P in
-// proportion to their list lengths, lane (term g, u of G_g) walks postings lo_g + u, lo_g + u + G_g, ...
-// of the current column tile.  ds_add_rtn_u32 returns the previous value, so the lane whose add takes
-// an accumulator across its column's survivor threshold knows it (values only grow) and appends the
-// column to the wave's survivor list -- no sweep of the tile, it is just cleared.  Measured on MI355X:
-// 7.6-13 cycles per 64-lane ds_add(_rtn)_u32 per CU against 16.5 for a plain read-add-write and 212
-// for ds_add_f32 (profiles/r01_lds_atomic_microbench.log).
+// proportion to their list lengths, lane (term g, u of G_g) owns entries lo_g + u, lo_g + u + G_g, ...
+// of its term's list.  ds_add_rtn_u32 returns the previous value, so the lane whose add takes an
+// accumulator across its column's survivor threshold knows it (values only grow) and appends the column
+// to the wave's survivor list -- no sweep of the tile.  Measured on MI355X: 7.6-13 cycles per 64-lane
+// ds_add(_rtn)_u32 per CU against 16.5 for a plain read-add-write and 212 for ds_add_f32
+// (profiles/r01_lds_atomic_microbench.log).
+//
+// The column-tile loop (round 2).  Round 1's loop spent ~150 VALU + ~67 SALU wave instructions per
+// (row, tile) for ~1.5 postings per lane and ran at 94 % VALU-pipe utilisation (profiles/r01_profile_k4p.log):
+// float conversions for x and tq, a select + shift + compare per speculative load, register rotation of the
+// prefetched batches.  Now: the loop is unrolled four tiles deep with four statically named batches (the
+// batch of tile t + 3 is issued while tile t is applied -- no register moves, so no waits on loads in
+// flight); a batch is four unconditional loads at base, base + G, base + 2G, base + 3G (K3 leaves slack
+// behind the postings) plus ONE signed remainder `rem` = bytes of the segment at and after the lane's first
+// entry, slot e is valid iff e * 4G < rem; the segment ends come four tiles per 16-byte load from the
+// padded table K3 writes; x and tq are 24-bit integer multiplies (v_mul_hi_u32_u24, v_mul_i32_i24 with a
+// byte select).  ~12 VALU per round, ~2.5 rounds per tile.
+//
+// Self-join ("symmetric") mode: score(i, j) and score(j, i) are the same float (same products, same
+// ascending-k order), so when A is the matrix the postings were built from, row i only walks the tiles
+// up to its own column and scores the pairs j <= i; every pair above the threshold is appended to a
+// global list and a second pass builds both rows' candidate lists from it and takes each row's top-n
+// with the canonical order.  Half the (row, tile) visits, half the exact scorings, identical result.
 //
 // One 64-lane wave per left row, single-wave workgroups, persistent waves fed by a global row
 // counter, as K4.  LDS per wave: the tile's 4096 u16 accumulators (two per word), row i as a term ->
 // value hash (for the exact scoring) and the survivor buffer: 10 KiB -> 16 waves per CU.
-// Rows the kernel does not handle (more than 64 non-zeros) are appended to a list and processed by K4.
+// Rows the kernel does not handle (more than 64 non-zeros) are appended to a list and processed by K4
+// (in symmetric mode their presence makes the caller fall back to the one-sided form).
 #define SG_WATCH_NAME sg_debug_watch_pruned
 #include "sg_k4_device.h"
 
-#define SG_SURV_CAP 128   // survivors buffered per wave (verified 64 at a time as soon as 64 are there)
+#define SG_SURV_CAP 128   // survivors buffered per wave (scored 64 at a time as soon as 64 are there)
+
+// lane mask of a predicate as a wave-uniform scalar (s_and of the compare result, no VALU round trip)
+__device__ __forceinline__ uint64_t ballot64(bool p) { return __builtin_amdgcn_ballot_w64(p); }
 
 template <typename T>
 __device__ __forceinline__ T wave_shfl(T v, int src) {
@@ -89,11 +113,10 @@ struct FwdRound<double> {   // 8 loads x 1 entry
 // Exact score of (row i of A, row j of B) for the lanes with j >= 0: the products of the shared terms are
 // added in ascending k (B's rows are sorted), product and sum rounded separately -- the reference's
 // arithmetic.  A term row i does not have contributes a * b with a = 0: sum + 0 == sum exactly (all
-// values are non-negative), so absent terms and the padding of a round need no branch.  The hits
-// (score > threshold) go into the register top-n list.
+// values are non-negative), so absent terms and the padding of a round need no branch.
 template <typename T>
-__device__ __forceinline__ void verify_chunk(int j, const int *hk, const T *ha, const uint32_t *__restrict__ fwd_ptr,
-                                             const void *__restrict__ fwd, T thr, TopList<T> &top, int lane) {
+__device__ __forceinline__ T exact_score(int j, const int *hk, const T *ha, const uint32_t *__restrict__ fwd_ptr,
+                                         const void *__restrict__ fwd) {
     T sum = (T)0;
     if (j >= 0) {
         const uint32_t pb = fwd_ptr[j];
@@ -121,46 +144,81 @@ __device__ __forceinline__ void verify_chunk(int j, const int *hk, const T *ha, 
             }
         }
     }
-    uint64_t hm = __ballot(j >= 0 && sum > thr);
-    SG_WD_DECL(wd_h);
-    while (hm) {
-        SG_WD(wd_h, 70, 22)
-        const int src = __builtin_ctzll(hm);
-        hm &= hm - 1;
-        top.insert(wave_read<T>(sum, src), wave_read<int>(j, src), lane);
-    }
+    return sum;
 }
 
-// Four filter postings per lane of one column tile: lane (term g, u of G) holds entries idx, idx + G,
-// idx + 2G, idx + 3G of its term's segment.  The loads are unconditional (lanes without an entry re-read
-// posting 0) so that a batch can stay in flight while the previous one is applied.
-struct FiltBatch {
-    uint32_t r[4];
-    bool ok[4];
-    __device__ __forceinline__ void issue(const uint32_t *__restrict__ filt, uint32_t idx, uint32_t hi, uint32_t g) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            ok[e] = g != 0 && idx + e * g < hi;
-            const uint32_t off = (ok[e] ? idx + e * g : 0u) << 2;   // kernel-constant base + 32-bit byte offset
-            r[e] = *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(filt) + off);
+// Scores the columns in surv[0 .. min(n_surv, 64)) and moves the rest of the buffer to the front.  Deliberately
+// not inlined: the tile loop has sixteen unrolled rounds and must not carry sixteen copies of this.
+// (LDS objects are addressed through the kernel's own shared array so that they stay ds_* accesses.)
+template <typename T, bool SYM, int TILE_LOG2>
+__device__ __noinline__ TopList<T> drain_survivors(const uint32_t *fwd_ptr, const void *fwd, T thr, uint32_t row,
+                                                   uint32_t *pair_i, uint32_t *pair_j, T *pair_s,
+                                                   unsigned long long *pair_count, unsigned long long pair_cap,
+                                                   TopList<T> top, uint32_t n_surv) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int TILE = 1 << TILE_LOG2;
+    const int *hk = reinterpret_cast<const int *>(smem + TILE * 2);
+    const T *ha = reinterpret_cast<const T *>(smem + TILE * 2 + 512);
+    int *surv = reinterpret_cast<int *>(smem + TILE * 2 + 512 + 1024);
+    const int lane = threadIdx.x;
+    const int j = (uint32_t)lane < n_surv ? surv[lane] : -1;
+    const T sum = exact_score<T>(j, hk, ha, fwd_ptr, fwd);
+    uint64_t hm = __ballot(j >= 0 && sum > thr);
+    if (SYM) {
+        if (hm) {
+            const int n_hit = __popcll(hm);
+            unsigned long long base = 0;
+            if (lane == 0) base = atomicAdd(pair_count, (unsigned long long)n_hit);
+            base = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(base >> 32)) << 32) |
+                   (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)base);
+            if ((hm >> lane) & 1ull) {
+                const unsigned long long at = base + (unsigned long long)__popcll(hm & ((1ull << lane) - 1ull));
+                if (at < pair_cap) {   // past the capacity only the count grows: the caller sees it and falls back
+                    pair_i[at] = row;
+                    pair_j[at] = (uint32_t)j;
+                    pair_s[at] = sum;
+                }
+            }
+        }
+    } else {
+        SG_WD_DECL(wd_h);
+        while (hm) {
+            SG_WD(wd_h, 70, 22)
+            const int src = __builtin_ctzll(hm);
+            hm &= hm - 1;
+            top.insert(wave_read<T>(sum, src), wave_read<int>(j, src), lane);
         }
     }
-};
+    if (n_surv > 64) {   // < 64 left: move to the front
+        const uint32_t rem = n_surv - 64;
+        const int keepv = (uint32_t)lane < rem ? surv[64 + lane] : 0;
+        __builtin_amdgcn_wave_barrier();
+        if ((uint32_t)lane < rem) surv[lane] = keepv;
+    }
+    return top;
+}
 
-template <typename T, int TILE_LOG2>
-__global__ void __launch_bounds__(64)
+template <typename T, int TILE_LOG2, bool SYM>
+__global__ void __launch_bounds__(64, 4)   // 16 single-wave workgroups per CU (the LDS limit) = 4 waves per SIMD: <= 128 VGPRs
 spgemm_topn_pruned_kernel(const int64_t *__restrict__ a_indptr, const int32_t *__restrict__ a_indices,
                           const T *__restrict__ a_data, uint32_t n_left, const uint32_t *__restrict__ seg,
+                          const uint32_t *__restrict__ ends, int32_t nt_pad, uint32_t n_terms,
                           const uint32_t *__restrict__ filt, int32_t n_tiles, const uint32_t *__restrict__ fwd_ptr,
                           const void *__restrict__ fwd, int32_t keep, int32_t out_stride, T thr,
                           float s_budget /* (beta / max ||b_j||)^2, rounded down */, float norm_b /* max ||b_j||, rounded up */,
                           uint32_t freq_min /* list length from which a term may join the suffix */,
                           int32_t *__restrict__ out_cols, T *__restrict__ out_vals, int32_t *__restrict__ out_cnt,
                           uint32_t *row_counter, uint32_t *flagged_count, uint32_t *flagged_rows,
-                          unsigned long long *stats /* [0] rows [1] postings streamed [2] survivors */) {
+                          unsigned long long *stats /* [0] rows [1] postings streamed [2] survivors */,
+                          uint32_t *pair_i, uint32_t *pair_j, T *pair_s, unsigned long long *pair_count,
+                          unsigned long long pair_cap) {
     constexpr int TILE = 1 << TILE_LOG2;
+    constexpr int AB = TILE_LOG2 + 1;                          // address + half bits of a filter posting
+    constexpr uint32_t ADDR_MASK = ((1u << AB) - 1u) & ~3u;    // byte address of the accumulator word
+    constexpr uint32_t BQ_BITS = 24 - AB;
+    constexpr uint32_t BQ_MAX = (1u << BQ_BITS) - 1u;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    uint32_t *tab = reinterpret_cast<uint32_t *>(smem);                       // TILE u16 accumulators
+    // smem: TILE u16 accumulators (address 0), then
     int *hk = reinterpret_cast<int *>(smem + TILE * 2);                       // row i: hash of its terms
     T *ha = reinterpret_cast<T *>(smem + TILE * 2 + 512);                     //        and their values
     int *surv = reinterpret_cast<int *>(smem + TILE * 2 + 512 + 1024);        // SG_SURV_CAP columns
@@ -169,12 +227,22 @@ spgemm_topn_pruned_kernel(const int64_t *__restrict__ a_indptr, const int32_t *_
     for (int x = lane; x < TILE * 2 / 16; x += 64) tab_v[x] = make_uint4(0, 0, 0, 0);
     const uint64_t lanes_below = (1ull << lane) - 1ull;
     unsigned long long st_rows = 0, st_post = 0, st_surv = 0;
+    // the accumulator tile is the kernel's first LDS object (address 0): a posting's address field IS the LDS address
+    auto tab_at = [&](uint32_t byte_addr) {
+        typedef __attribute__((address_space(3))) uint32_t lds_u32;
+        return (uint32_t *)(lds_u32 *)(uintptr_t)byte_addr;
+    };
+    auto filt_at = [&](uint32_t byte_off) {   // kernel-constant base + 32-bit byte offset
+        return *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(filt) + byte_off);
+    };
 
-    // rows are handed out four at a time: one global atomic per row capped the kernel at ~88 rows/us
+    // rows are handed out four at a time: one global atomic per row capped the kernel at ~88 rows/us.
+    // Symmetric mode walks the rows from the last to the first: a row's cost grows with its index there.
     SG_WD_DECL(wd_rows);
     for (uint32_t row0 = next_row(row_counter, lane) * 4u; row0 < n_left; row0 = next_row(row_counter, lane) * 4u)
-    for (uint32_t row = row0; row < min(row0 + 4u, n_left); ++row) {
+    for (uint32_t rr = row0; rr < min(row0 + 4u, n_left); ++rr) {
         SG_WD(wd_rows, n_left + 2, 11)
+        const uint32_t row = SYM ? n_left - 1u - rr : rr;
         const int64_t rlo = a_indptr[row];
         const int nnz = __builtin_amdgcn_readfirstlane((int)(a_indptr[row + 1] - rlo));
         if (nnz > 64) {   // more non-zeros than lanes: exact kernel
@@ -185,12 +253,13 @@ spgemm_topn_pruned_kernel(const int64_t *__restrict__ a_indptr, const int32_t *_
         ++st_rows;
         int k = 0;
         T a = (T)0;
-        uint32_t df = 0;
+        uint32_t df = 0, lo_e = 0;
         if (lane < nnz) {
             k = a_indices[rlo + lane];
             a = a_data[rlo + lane];
             const uint32_t *sp = seg + (int64_t)k * n_tiles;
-            df = sp[n_tiles] - sp[0];
+            lo_e = sp[0];
+            df = sp[n_tiles] - lo_e;
         }
         // ---- suffix S: the most frequent terms while the bound on ||a_S|| holds.  cum = sum of squares of
         // the terms ordered before this lane's (list length descending, lane ascending), inclusive.
@@ -216,19 +285,22 @@ spgemm_topn_pruned_kernel(const int64_t *__restrict__ a_indptr, const int32_t *_
         bs2 = wave_read<float>(bs2, 0);     // explicitly wave-uniform: the branches below must not diverge
         dsum = wave_read<float>(dsum, 0);
         if (!(dsum > 0.f)) continue;   // every list of P is empty
-        st_post += (unsigned long long)dsum;   // statistic (float sum of the list lengths)
         const int np = __popcll(pm);
         // ---- survivor test in fixed point (scale 2^15).  q_ij accumulates UPPER bounds of the products, so
         //      p_ij * 2^15 <= q_ij; the exact kernel's float score obeys  score~ <= score + 1e-5  and
         //      score <= p_ij + ||a_S|| f_j  with  f_j <= fq_j / 255 * norm_b.  Column j survives when
-        //      q_ij >= tq_j = (thr - 1e-5) * 2^15 - c1 * fq_j - 2   (the 2 covers the float evaluation).
+        //      q_ij >= tq_j,  tq_j = floor(((T0 - C1 * fq_j)) / 256)  <=  (thr - 1e-5) * 2^15 - 2 - c1 * fq_j
+        //      (T0 = floor(t0 * 256), C1 = floor(c1 * 256) + 1; the 2 covers the float evaluation of t0, c1).
         const float b_s = sqrtf(bs2) * 1.000002f;
         const float t0 = ((float)thr - 1e-5f) * 32768.0f - 2.0f;
         const float c1 = b_s * norm_b * (32768.0f / 255.0f) * 1.000002f;
-        if (!(t0 - c1 * 255.0f >= 1.0f)) {   // delta too small for the fixed-point resolution: exact kernel
+        const int32_t T0 = (int32_t)floorf(t0 * 256.0f) - 256 * np;   // every add may fall short by < 1, |P| adds at most
+        const int32_t C1 = (int32_t)(c1 * 256.0f) + 1;
+        if (!(T0 - C1 * 255 >= 256)) {   // delta too small for the fixed-point resolution: exact kernel
             if (lane == 0) flagged_rows[atomicAdd(flagged_count, 1u)] = row;
             continue;
         }
+        const int32_t T0m = T0 - 256;    // (T0m - C1 * fq) >> 8 == tq - 1 >= 0
 
         // ---- deal the 64 lanes to the terms of P in proportion to their list lengths
         uint32_t G = in_p ? 1u + (uint32_t)((float)(64 - np) * 0.999f * ((float)df / dsum)) : 0u;
@@ -258,12 +330,20 @@ spgemm_topn_pruned_kernel(const int64_t *__restrict__ a_indptr, const int32_t *_
             }
         }
         const int my_k = wave_shfl<int>(k, src);
-        // upper bound of a * b * 2^15 from the bq of a filter posting: (uint32)(c_a * bq) + 1
-        const float c_a = (float)wave_shfl<T>(a, src) * norm_b * (32768.0f / (float)((1 << (24 - TILE_LOG2)) - 1)) * 1.000002f;
-        const uint32_t seg_off = (uint32_t)my_k * (uint32_t)n_tiles;   // < 2^30 bins (checked when the postings are built)
-        auto seg_at = [&](uint32_t i) {
-            return *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(seg) + ((seg_off + i) << 2));
+        const uint32_t my_lo = wave_shfl<uint32_t>(lo_e, src);
+        // upper bound (less one) of a * b * 2^15 from the bq field of a filter posting, left in place:
+        // x = (CA * (bq << AB)) >> 32 with CA >= c_a * 2^(32 - AB), c_a = a * norm_b * 2^15 / BQ_MAX
+        const float c_a = (float)wave_shfl<T>(a, src) * norm_b * (32768.0f / (float)BQ_MAX) * 1.000002f;
+        const uint32_t CA = (uint32_t)(c_a * (float)(1u << (32 - AB))) + 1u;   // < 2^24
+        // lane (term, u of G): byte offset of its first entry inside a segment, stride; idle lanes read the
+        // all-zero row K3 appends to the table of segment ends (empty segments, rem == 0) and entry 0
+        const uint32_t u4 = u << 2, G4 = g << 2, G8 = g << 3, G12 = 3u * G4, G16 = g << 4;
+        const uint32_t erow = (g ? (uint32_t)my_k : n_terms) * (uint32_t)nt_pad;
+        auto ends_at = [&](uint32_t group) {
+            return *reinterpret_cast<const uint4 *>(reinterpret_cast<const char *>(ends) + ((erow + (group << 2)) << 2));
         };
+        const uint32_t t_end = SYM ? (row >> TILE_LOG2) + 1u : (uint32_t)n_tiles;
+        const uint32_t last_group = (uint32_t)(nt_pad >> 2) - 1u;
 
         // ---- stage row i for the exact scoring: term -> value hash (filled by compare-and-swap, one wave)
         hk[lane] = -1;
@@ -283,93 +363,245 @@ spgemm_topn_pruned_kernel(const int64_t *__restrict__ a_indptr, const int32_t *_
         TopList<T> top;
         top.clear();
         uint32_t n_surv = 0;
-        // applies one batch to the tile's accumulators; a lane whose add takes an accumulator across tq
-        // appends the column to the survivor buffer; full waves of survivors are scored at once
-        auto apply = [&](const FiltBatch &bt, int t) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                if (e > 0 && __ballot(bt.ok[e]) == 0) break;   // a lane's entries fill its slots in order
-                bool cross = false;
-                uint32_t c = 0;
-                if (bt.ok[e]) {
-                    c = bt.r[e] & (uint32_t)(TILE - 1);
-                    const uint32_t x = (uint32_t)(c_a * (float)((bt.r[e] >> TILE_LOG2) & ((1u << (24 - TILE_LOG2)) - 1u))) + 1u;
-                    const uint32_t tq = (uint32_t)(t0 - c1 * (float)(bt.r[e] >> 24));
-                    const uint32_t sh = (c & 1u) << 4;
-                    const uint32_t old = __hip_atomic_fetch_add(&tab[c >> 1], x << sh, __ATOMIC_RELAXED,
-                                                                __HIP_MEMORY_SCOPE_WORKGROUP);
-                    const uint32_t oh = (old >> sh) & 0xffffu;
-                    cross = oh < tq && oh + x >= tq;
+
+        // One posting applied by the lanes in `valid`: the add into the 16-bit accumulator and the survivor
+        // test.  zaddr receives the accumulator's byte address (for re-zeroing).  A lane whose add takes an
+        // accumulator across tq appends the column to the survivor buffer; a full wave of survivors is scored
+        // at once.
+        // (Only the atomic is under the lane mask: everything else is side-effect free and runs for all lanes, which
+        // keeps the survivor mask a wave-uniform scalar for the compiler.)
+        auto round = [&](uint32_t r, bool valid, uint64_t valid_mask, uint32_t t, uint32_t &zaddr) {
+            zaddr = r & ADDR_MASK;
+            const uint32_t sh = r << 4;   // bit 4 = the half; shifts and bit-field offsets use 5 bits
+            const uint32_t x = (uint32_t)(((uint64_t)(r & (BQ_MAX << AB)) * (uint64_t)(CA & 0xffffffu)) >> 32);
+            const uint32_t tq1 = (uint32_t)((T0m - __mul24(C1, (int32_t)(r >> 24))) >> 8);
+            uint32_t xs;   // x << (16 * half): the hardware shift takes the low five bits of sh by itself
+            asm("v_lshlrev_b32 %0, %1, %2" : "=v"(xs) : "v"(sh), "v"(x));
+            uint32_t old;
+            asm("" : "=v"(old));   // lanes without a posting: whatever the register holds, masked below
+            if (valid)
+                old = __hip_atomic_fetch_add(tab_at(zaddr), xs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            asm volatile("" : "+v"(old));   // keep the test outside the masked region: its result is then a plain lane mask
+            const uint32_t oh = __builtin_amdgcn_ubfe(old, sh, 16u);
+            // oh < tq && oh + x >= tq  (unsigned wrap when oh >= tq); the mask of a compare ANDed with a scalar mask
+            // stays scalar (the mask of a combined predicate would be rebuilt through a VALU select)
+            uint64_t cm = ballot64(tq1 - oh < x) & valid_mask;
+            if (cm) {
+                bool cross = (cm >> lane) & 1ull;
+                const int col = (int)((t << TILE_LOG2) | (zaddr >> 1) | (r & 1u));
+                if (SYM) {
+                    cross = cross && (uint32_t)col <= row;   // the pair (i, j > i) is row j's to score
+                    cm = ballot64(cross);
                 }
-                const uint64_t cm = __ballot(cross);
-                if (cm) {
-                    if (cross) surv[n_surv + __popcll(cm & lanes_below)] = (t << TILE_LOG2) + (int)c;
-                    n_surv += __popcll(cm);
-                    if (n_surv >= 64) {   // a full wave of survivors: score them now (the buffer holds 128)
-                        verify_chunk<T>(surv[lane], hk, ha, fwd_ptr, fwd, thr, top, lane);
-                        st_surv += 64;
-                        const uint32_t rem = n_surv - 64;   // < 64: move to the front
-                        const int keepv = (uint32_t)lane < rem ? surv[64 + lane] : 0;
-                        __builtin_amdgcn_wave_barrier();
-                        if ((uint32_t)lane < rem) surv[lane] = keepv;
-                        n_surv = rem;
-                    }
+                if (cross) surv[n_surv + __popcll(cm & lanes_below)] = col;
+                n_surv += __popcll(cm);
+                if (n_surv >= 64) {
+                    top = drain_survivors<T, SYM, TILE_LOG2>(fwd_ptr, fwd, thr, row, pair_i, pair_j, pair_s, pair_count,
+                                                             pair_cap, top, n_surv);
+                    st_surv += 64;
+                    n_surv -= 64;
                 }
             }
         };
 
-        // Software pipeline over the column tiles: while tile t is applied, the first batches of tiles t + 1
-        // and t + 2 are in flight and the segment bound needed for tile t + 3 is being fetched (b0..b4 =
-        // seg[t .. t + 4] of my term).  The multiply is bound by load latency (~1-2 us to the Infinity
-        // Cache at 14 waves per CU): with one tile of prefetch instead of two the kernel takes 36.1 ms instead of 33.5.
-        const uint32_t last = (uint32_t)n_tiles;
-        uint32_t b0 = 0, b1 = 0, b2 = 0, b3 = 0, b4 = 0;
-        if (g) {
-            b0 = seg_at(0);
-            b1 = seg_at(min(1u, last));
-            b2 = seg_at(min(2u, last));
-            b3 = seg_at(min(3u, last));
-        }
-        FiltBatch cur, nx1;
-        cur.issue(filt, b0 + u, b1, g);
-        nx1.issue(filt, b1 + u, b2, g);
-        SG_WD_DECL(wd_t);
-        for (int t = 0; t < n_tiles; ++t) {
-            SG_WD(wd_t, n_tiles + 2, 13)
-            if (g) b4 = seg_at(min((uint32_t)t + 4u, last));
-            FiltBatch nx2;
-            nx2.issue(filt, b2 + u, b3, g);   // past the last tile the bounds coincide: nothing to load
-            if (__ballot(cur.ok[0]) != 0) {
-                apply(cur, t);
-                uint32_t idx = b0 + u + 4 * g;
-                if (__ballot(g != 0 && idx < b1) == 0) {
-                    // re-zero only what was touched (a few dozen of the tile's accumulators): sweeping the
-                    // tile for every row costs rows * columns * 2 B of LDS writes, 11 ms at 663 k
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        if (cur.ok[e]) tab[(cur.r[e] & (uint32_t)(TILE - 1)) >> 1] = 0u;
-                } else {
-                    SG_WD_DECL(wd_b);
-                    do {   // segments longer than the dealt lanes cover in one batch
-                        SG_WD(wd_b, 1 << 24, 14)
-                        FiltBatch more;
-                        more.issue(filt, idx, b1, g);
-                        apply(more, t);
-                        idx += 4 * g;
-                    } while (__ballot(g != 0 && idx < b1) != 0);
-                    for (int x = lane; x < TILE * 2 / 16; x += 64) tab_v[x] = make_uint4(0, 0, 0, 0);
+        // a batch = the lane's (up to) four entries of one tile's segment + what is left of the segment from the
+        // lane's first entry on, in bytes (<= 0: nothing for this lane)
+        struct Batch {
+            uint32_t r0, r1, r2, r3;
+            int32_t rem;
+            uint32_t base;
+        };
+        auto issue = [&](Batch &bt, uint32_t lo, uint32_t hi) {
+            bt.base = lo + u4;
+            bt.rem = (int32_t)(hi - bt.base);
+            bt.r0 = filt_at(bt.base);
+            bt.r1 = filt_at(bt.base + G4);
+            bt.r2 = filt_at(bt.base + G8);
+            bt.r3 = filt_at(bt.base + G12);
+        };
+        auto apply = [&](const Batch &bt, uint32_t t) {
+            const bool v0 = bt.rem > 0;
+            const uint64_t m0 = ballot64(v0);
+            if (m0 == 0) return;
+            uint32_t z0 = 0, z1 = 0, z2 = 0, z3 = 0;
+            uint64_t m1 = 0, m2 = 0, m3 = 0;
+            bool big = false;
+            round(bt.r0, v0, m0, t, z0);
+            const bool v1 = bt.rem > (int32_t)G4;
+            m1 = ballot64(v1);
+            if (m1) {
+                round(bt.r1, v1, m1, t, z1);
+                const bool v2 = bt.rem > (int32_t)G8;
+                m2 = ballot64(v2);
+                if (m2) {
+                    round(bt.r2, v2, m2, t, z2);
+                    const bool v3 = bt.rem > (int32_t)G12;
+                    m3 = ballot64(v3);
+                    if (m3) {
+                        round(bt.r3, v3, m3, t, z3);
+                        // a segment longer than four entries per lane: generic rounds, then a full clear
+                        int32_t left = bt.rem - (int32_t)G16;
+                        uint32_t at = bt.base + G16;
+                        SG_WD_DECL(wd_b);
+                        uint64_t ml;
+                        while ((ml = ballot64(left > 0)) != 0) {
+                            SG_WD(wd_b, 1 << 24, 14)
+                            uint32_t zz = 0;
+                            const uint32_t rx = filt_at(at);
+                            round(rx, left > 0, ml, t, zz);
+                            left -= (int32_t)G4;
+                            at += G4;
+                            big = true;
+                        }
+                    }
                 }
             }
-            b0 = b1;
-            b1 = b2;
-            b2 = b3;
-            b3 = b4;
-            cur = nx1;
-            nx1 = nx2;
+            if (big) {
+                for (int x = lane; x < TILE * 2 / 16; x += 64) tab_v[x] = make_uint4(0, 0, 0, 0);
+            } else {
+                // re-zero only what was touched (a few dozen of the tile's accumulators): sweeping the
+                // tile for every row costs rows * columns * 2 B of LDS writes, 11 ms at 663 k
+                if (v0) *tab_at(z0) = 0u;
+                if ((m1 >> lane) & 1ull) *tab_at(z1) = 0u;
+                if ((m2 >> lane) & 1ull) *tab_at(z2) = 0u;
+                if ((m3 >> lane) & 1ull) *tab_at(z3) = 0u;
+            }
+        };
+
+        // Software pipeline, four tiles per trip: E = segment ends of tiles 4m .. 4m + 3 (byte offsets),
+        // prev = end of tile 4m - 1 (= start of tile 4m); batch j of a trip belongs to tile 4m + j and is
+        // re-issued for tile 4m + j + 4 ... no: the batch of tile t + 3 is issued while tile t is applied.
+        uint4 E0 = ends_at(0);
+        uint4 E1 = ends_at(min(1u, last_group));
+        const uint32_t list_lo = g ? my_lo << 2 : 0u;
+        Batch b0, b1, b2, b3;
+        issue(b0, list_lo, E0.x);
+        issue(b1, E0.x, E0.y);
+        issue(b2, E0.y, E0.z);
+        SG_WD_DECL(wd_t);
+        for (uint32_t t = 0; t < t_end; t += 4) {
+            SG_WD(wd_t, n_tiles + 2, 13)
+            // tiles t .. t + 3 use E0; E1 = the next four; E2 is fetched for the trip after
+            const uint4 E2 = ends_at(min((t >> 2) + 2u, last_group));
+            issue(b3, E0.z, E0.w);
+            apply(b0, t);
+            if (t + 1 >= t_end) break;
+            issue(b0, E0.w, E1.x);
+            apply(b1, t + 1);
+            if (t + 2 >= t_end) break;
+            issue(b1, E1.x, E1.y);
+            apply(b2, t + 2);
+            if (t + 3 >= t_end) break;
+            issue(b2, E1.y, E1.z);
+            apply(b3, t + 3);
+            E0 = E1;
+            E1 = E2;
+        }
+        {   // postings streamed = entries of P's lists in the tiles visited
+            uint32_t mine = 0;
+            if (g && u == 0) {
+                const uint32_t *erp = ends + (size_t)erow;
+                mine = (erp[t_end - 1u] >> 2) - my_lo;
+            }
+#pragma unroll
+            for (int d = 32; d > 0; d >>= 1) mine += __shfl_xor(mine, d, 64);
+            st_post += (unsigned long long)wave_read<uint32_t>(mine, 0);
         }
         if (n_surv > 0) {   // fewer than 64 left
-            verify_chunk<T>((uint32_t)lane < n_surv ? surv[lane] : -1, hk, ha, fwd_ptr, fwd, thr, top, lane);
+            top = drain_survivors<T, SYM, TILE_LOG2>(fwd_ptr, fwd, thr, row, pair_i, pair_j, pair_s, pair_count, pair_cap, top,
+                                                     n_surv);
             st_surv += n_surv;
+        }
+        if (!SYM) {
+            int cnt = __popcll(__ballot(top.c != INT32_MAX));
+            if (cnt > keep) cnt = keep;
+            const size_t obase = (size_t)row * (size_t)out_stride;
+            if (lane < cnt) {
+                out_vals[obase + lane] = top.s;
+                out_cols[obase + lane] = top.c;
+            }
+            if (lane == 0) out_cnt[row] = cnt;
+        }
+    }
+    if (lane == 0) {
+        if (st_rows) atomicAdd(stats + 0, st_rows);
+        if (st_post) atomicAdd(stats + 1, st_post);
+        if (st_surv) atomicAdd(stats + 2, st_surv);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Symmetric mode, second pass: the pair list -> per-row candidate lists (both directions) -> top-n.
+__global__ void __launch_bounds__(256) pairs_count_kernel(const uint32_t *__restrict__ pi, const uint32_t *__restrict__ pj,
+                                                          const unsigned long long *__restrict__ n_pairs, uint32_t *cnt) {
+    const unsigned long long n = *n_pairs;
+    for (unsigned long long p = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; p < n;
+         p += (unsigned long long)gridDim.x * blockDim.x) {
+        const uint32_t i = pi[p], j = pj[p];
+        atomicAdd(&cnt[i], 1u);
+        if (j != i) atomicAdd(&cnt[j], 1u);
+    }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) pairs_fill_kernel(const uint32_t *__restrict__ pi, const uint32_t *__restrict__ pj,
+                                                         const T *__restrict__ ps,
+                                                         const unsigned long long *__restrict__ n_pairs,
+                                                         const uint32_t *__restrict__ ptr, uint32_t *cursor,
+                                                         int32_t *__restrict__ lcol, T *__restrict__ lval) {
+    const unsigned long long n = *n_pairs;
+    for (unsigned long long p = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; p < n;
+         p += (unsigned long long)gridDim.x * blockDim.x) {
+        const uint32_t i = pi[p], j = pj[p];
+        const T s = ps[p];
+        uint32_t at = ptr[i] + atomicAdd(&cursor[i], 1u);
+        lcol[at] = (int32_t)j;
+        lval[at] = s;
+        if (j != i) {
+            at = ptr[j] + atomicAdd(&cursor[j], 1u);
+            lcol[at] = (int32_t)i;
+            lval[at] = s;
+        }
+    }
+}
+
+// one wave per row: its candidates through the register top-n list (order of arrival is irrelevant)
+template <typename T>
+__global__ void __launch_bounds__(64) pairs_select_kernel(const uint32_t *__restrict__ ptr, const int32_t *__restrict__ lcol,
+                                                          const T *__restrict__ lval, uint32_t n_rows, int32_t keep,
+                                                          int32_t out_stride, int32_t *__restrict__ out_cols,
+                                                          T *__restrict__ out_vals, int32_t *__restrict__ out_cnt) {
+    const int lane = threadIdx.x;
+    for (uint32_t row = blockIdx.x; row < n_rows; row += gridDim.x) {
+        const uint32_t lo = ptr[row], hi = ptr[row + 1];
+        TopList<T> top;
+        top.clear();
+        if (hi - lo <= 64u) {
+            // the common case: every lane holds one candidate and ranks it against the others
+            const bool have = lo + (uint32_t)lane < hi;
+            const T s = have ? lval[lo + lane] : (T)-INFINITY;
+            const int c = have ? lcol[lo + lane] : INT32_MAX;
+            int rank = 0;
+            const int m = (int)(hi - lo);
+            for (int q = 0; q < m; ++q) {
+                const T sq = wave_read<T>(s, q);
+                const int cq = wave_read<int>(c, q);
+                rank += (sq > s || (sq == s && cq < c)) ? 1 : 0;
+            }
+            const size_t obase = (size_t)row * (size_t)out_stride;
+            if (have && rank < keep) {
+                out_vals[obase + rank] = s;
+                out_cols[obase + rank] = c;
+            }
+            if (lane == 0) out_cnt[row] = m < keep ? m : keep;
+            continue;
+        }
+        for (uint32_t base = lo; base < hi; base += 64) {
+            const bool have = base + (uint32_t)lane < hi;
+            const T s = have ? lval[base + lane] : (T)0;
+            const int c = have ? lcol[base + lane] : 0;
+            const int m = (int)min(64u, hi - base);
+            for (int q = 0; q < m; ++q) top.insert(wave_read<T>(s, q), wave_read<int>(c, q), lane);
         }
         int cnt = __popcll(__ballot(top.c != INT32_MAX));
         if (cnt > keep) cnt = keep;
@@ -380,11 +612,6 @@ spgemm_topn_pruned_kernel(const int64_t *__restrict__ a_indptr, const int32_t *_
         }
         if (lane == 0) out_cnt[row] = cnt;
     }
-    if (lane == 0) {
-        if (st_rows) atomicAdd(stats + 0, st_rows);
-        if (st_post) atomicAdd(stats + 1, st_post);
-        if (st_surv) atomicAdd(stats + 2, st_surv);
-    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -394,11 +621,12 @@ template <typename T>
 __global__ void __launch_bounds__(256) csr_props_kernel(const int64_t *__restrict__ indptr,
                                                         const int32_t *__restrict__ indices,
                                                         const T *__restrict__ data, int64_t n_rows,
-                                                        uint32_t *out /* [0] violations [1] max ||row||^2 as float bits */) {
+                                                        uint32_t *out /* [0] violations [1] max ||row||^2 as float bits [2] longest row */) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    uint32_t bad = 0;
+    uint32_t bad = 0, len = 0;
     float n2 = 0.f;
     if (i < n_rows) {
+        len = (uint32_t)(indptr[i + 1] - indptr[i]);
         double s = 0.0;
         int prev = -1;
         for (int64_t p = indptr[i]; p < indptr[i + 1]; ++p) {
@@ -415,20 +643,22 @@ __global__ void __launch_bounds__(256) csr_props_kernel(const int64_t *__restric
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) {
         nb = max(nb, (uint32_t)__shfl_xor((int)nb, d, 64));
+        len = max(len, (uint32_t)__shfl_xor((int)len, d, 64));
         bad |= (uint32_t)__shfl_xor((int)bad, d, 64);
     }
     if ((threadIdx.x & 63) == 0) {
         if (bad) atomicOr(out, 1u);
         atomicMax(out + 1, nb);
+        atomicMax(out + 2, len);
     }
 }
 
-int sg_csr_props(sg_ctx *ctx, const sg_csr *m, bool *cosine_like, float *max_norm2) {
+int sg_csr_props(sg_ctx *ctx, const sg_csr *m, bool *cosine_like, float *max_norm2, uint32_t *max_nnz) {
     if (m->props_state == 0) {
         uint32_t *d = nullptr;
-        SG_TRY(sg_alloc(ctx, (size_t)2, &d));
-        uint32_t h[2] = {0, 0};
-        hipError_t e = hipMemsetAsync(d, 0, 8, ctx->stream);
+        SG_TRY(sg_alloc(ctx, (size_t)4, &d));
+        uint32_t h[4] = {0, 0, 0, 0};
+        hipError_t e = hipMemsetAsync(d, 0, 16, ctx->stream);
         if (e == hipSuccess && m->n_rows > 0) {
             const unsigned grid = (unsigned)((m->n_rows + 255) / 256);
             if (m->dtype == SG_F64)
@@ -439,7 +669,7 @@ int sg_csr_props(sg_ctx *ctx, const sg_csr *m, bool *cosine_like, float *max_nor
                                    m->d_indices, (const float *)m->d_data, m->n_rows, d);
             e = hipGetLastError();
         }
-        if (e == hipSuccess) e = hipMemcpyAsync(h, d, 8, hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(h, d, 16, hipMemcpyDeviceToHost, ctx->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
         ctx->release(d);
         if (e != hipSuccess) {
@@ -449,18 +679,28 @@ int sg_csr_props(sg_ctx *ctx, const sg_csr *m, bool *cosine_like, float *max_nor
         float n2;
         memcpy(&n2, &h[1], 4);
         m->props_max_norm2 = n2;
+        m->props_max_nnz = h[2];
         m->props_state = (h[0] == 0 && n2 <= 1.0001f) ? 1 : 2;
     }
     *cosine_like = m->props_state == 1;
     *max_norm2 = m->props_max_norm2;
+    if (max_nnz) *max_nnz = m->props_max_nnz;
     return SG_OK;
 }
 
 // ------------------------------------------------------------------------------------------------
-template <typename T, int TILE_LOG2>
+struct PairList {   // symmetric mode: every pair (i, j <= i) above the threshold, in order of discovery
+    uint32_t *d_i = nullptr;
+    uint32_t *d_j = nullptr;
+    void *d_s = nullptr;
+    unsigned long long *d_count = nullptr;
+    unsigned long long cap = 0;
+};
+
+template <typename T, int TILE_LOG2, bool SYM>
 static int launch_pruned(sg_ctx *ctx, const sg_csr *A, const sg_postings *Bt, int32_t keep, sg_topn *r, T thr,
                          float s_budget, uint32_t *row_counter, uint32_t *flagged_count, uint32_t *flagged_rows,
-                         unsigned long long *stats) {
+                         unsigned long long *stats, const PairList &pl) {
     const size_t lds = ((size_t)2 << TILE_LOG2) + 512 + 1024 + (size_t)SG_SURV_CAP * 4;
     int waves_per_cu = (int)(ctx->lds_per_cu / lds);
     if (waves_per_cu > 32) waves_per_cu = 32;
@@ -469,24 +709,26 @@ static int launch_pruned(sg_ctx *ctx, const sg_csr *A, const sg_postings *Bt, in
         if (atoi(v) > 0) waves_per_cu = atoi(v);
     unsigned grid = (unsigned)ctx->num_cu * (unsigned)waves_per_cu;
     if ((int64_t)grid > A->n_rows) grid = (unsigned)(A->n_rows > 0 ? A->n_rows : 1);
-    hipLaunchKernelGGL((spgemm_topn_pruned_kernel<T, TILE_LOG2>), dim3(grid), dim3(64), lds, ctx->stream, A->d_indptr,
+    hipLaunchKernelGGL((spgemm_topn_pruned_kernel<T, TILE_LOG2, SYM>), dim3(grid), dim3(64), lds, ctx->stream, A->d_indptr,
                        A->d_indices, (const T *)A->d_data, (uint32_t)A->n_rows, (const uint32_t *)Bt->d_seg,
+                       (const uint32_t *)Bt->d_ends, Bt->nt_pad, (uint32_t)Bt->n_terms,
                        (const uint32_t *)Bt->d_filt, Bt->n_tiles, (const uint32_t *)Bt->d_fwd_ptr,
                        (const void *)Bt->d_fwd, keep, r->stride, thr, s_budget, Bt->norm_up, Bt->freq_min, r->d_cols,
                        (T *)r->d_vals,
-                       r->d_counts, row_counter, flagged_count, flagged_rows, stats);
+                       r->d_counts, row_counter, flagged_count, flagged_rows, stats, pl.d_i, pl.d_j, (T *)pl.d_s, pl.d_count,
+                       pl.cap);
     SG_HIP_TRY(hipGetLastError());
     return SG_OK;
 }
 
-template <typename T>
+template <typename T, bool SYM>
 static int dispatch_pruned(sg_ctx *ctx, const sg_csr *A, const sg_postings *Bt, int32_t keep, sg_topn *r, T thr,
                            float s_budget, uint32_t *row_counter, uint32_t *flagged_count, uint32_t *flagged_rows,
-                           unsigned long long *stats) {
+                           unsigned long long *stats, const PairList &pl) {
     switch (Bt->tile_log2) {
-        case 11: return launch_pruned<T, 11>(ctx, A, Bt, keep, r, thr, s_budget, row_counter, flagged_count, flagged_rows, stats);
-        case 12: return launch_pruned<T, 12>(ctx, A, Bt, keep, r, thr, s_budget, row_counter, flagged_count, flagged_rows, stats);
-        case 13: return launch_pruned<T, 13>(ctx, A, Bt, keep, r, thr, s_budget, row_counter, flagged_count, flagged_rows, stats);
+        case 11: return launch_pruned<T, 11, SYM>(ctx, A, Bt, keep, r, thr, s_budget, row_counter, flagged_count, flagged_rows, stats, pl);
+        case 12: return launch_pruned<T, 12, SYM>(ctx, A, Bt, keep, r, thr, s_budget, row_counter, flagged_count, flagged_rows, stats, pl);
+        case 13: return launch_pruned<T, 13, SYM>(ctx, A, Bt, keep, r, thr, s_budget, row_counter, flagged_count, flagged_rows, stats, pl);
         default:
             sg_set_error("postings tile of 2^%d columns is not supported by the pruned multiply (2^11..2^13)", Bt->tile_log2);
             return SG_ERR_UNSUPPORTED;
@@ -495,17 +737,139 @@ static int dispatch_pruned(sg_ctx *ctx, const sg_csr *A, const sg_postings *Bt, 
 
 bool sg_pruned_supports_tile(int32_t tile_log2) { return tile_log2 >= 11 && tile_log2 <= 13; }
 
-int sg_spgemm_pruned_launch(sg_ctx *ctx, const sg_csr *A, const sg_postings *Bt, int32_t keep, sg_topn *r,
-                            double threshold, double delta, uint32_t *row_counter, uint32_t *flagged_count,
-                            uint32_t *flagged_rows, unsigned long long *stats) {
+static float prune_budget(const sg_postings *Bt, double threshold, double delta) {
     // beta = threshold - delta bounds ||a_S|| * max ||b_j||; the kernel compares sums of squares of a
     const double nb = (double)Bt->norm_up;
     const double beta = threshold - delta;
     const double budget = (beta / nb) * (beta / nb) * (1.0 - 1e-6);
-    const float s_budget = __builtin_nextafterf((float)budget, 0.f);
+    return __builtin_nextafterf((float)budget, 0.f);
+}
+
+int sg_spgemm_pruned_launch(sg_ctx *ctx, const sg_csr *A, const sg_postings *Bt, int32_t keep, sg_topn *r,
+                            double threshold, double delta, uint32_t *row_counter, uint32_t *flagged_count,
+                            uint32_t *flagged_rows, unsigned long long *stats) {
+    const float s_budget = prune_budget(Bt, threshold, delta);
+    PairList none;
     if (A->dtype == SG_F64)
-        return dispatch_pruned<double>(ctx, A, Bt, keep, r, (double)threshold, s_budget, row_counter, flagged_count,
-                                       flagged_rows, stats);
-    return dispatch_pruned<float>(ctx, A, Bt, keep, r, (float)threshold, s_budget, row_counter, flagged_count,
-                                  flagged_rows, stats);
+        return dispatch_pruned<double, false>(ctx, A, Bt, keep, r, (double)threshold, s_budget, row_counter, flagged_count,
+                                              flagged_rows, stats, none);
+    return dispatch_pruned<float, false>(ctx, A, Bt, keep, r, (float)threshold, s_budget, row_counter, flagged_count,
+                                         flagged_rows, stats, none);
+}
+
+// Self-join form: pass 1 (the pruned kernel over the pairs j <= i) + the decision whether its pair list is
+// complete (one host round trip: pair count, rows the kernel could not handle) + pass 2 (lists, top-n).
+// *done == false: nothing usable was produced (too many pairs for the list, or rows for the exact kernel) and
+// the caller runs the one-sided form; the result object and the statistics words are untouched then.
+int sg_spgemm_pruned_symmetric(sg_ctx *ctx, const sg_csr *A, const sg_postings *Bt, int32_t keep, sg_topn *r,
+                               double threshold, double delta, unsigned long long *stats, bool *done) {
+    *done = false;
+    const size_t vs = A->dtype == SG_F64 ? 8 : 4;
+    const int64_t n = A->n_rows;
+    PairList pl;
+    // a name list has a few matches per row; hubs of identical names can have far more -> fall back then
+    int64_t cap = 8 * n + ((int64_t)1 << 20);
+    if (const char *v = getenv("SG_SYM_PAIR_CAP"))
+        if (atoll(v) > 0) cap = atoll(v);
+    if (2 * cap >= ((int64_t)1 << 32)) cap = ((int64_t)1 << 31) - 1;   // list offsets are 32-bit
+    pl.cap = (unsigned long long)cap;
+    uint32_t *words = nullptr;   // [0] row counter [1] flagged count [2..3] pair count (64-bit)
+    uint32_t *cnt = nullptr, *cursor = nullptr;
+    int32_t *lcol = nullptr;
+    void *lval = nullptr;
+    uint32_t *flagged_rows = nullptr;
+    int st = sg_alloc(ctx, (size_t)8, &words);
+    if (st == SG_OK) st = sg_alloc(ctx, (size_t)cap, &pl.d_i);
+    if (st == SG_OK) st = sg_alloc(ctx, (size_t)cap, &pl.d_j);
+    if (st == SG_OK) st = ctx->alloc((size_t)cap * vs, &pl.d_s);
+    if (st == SG_OK) st = sg_alloc(ctx, (size_t)n + 2, &cnt);
+    if (st == SG_OK) st = sg_alloc(ctx, (size_t)n + 2, &cursor);
+    if (st == SG_OK) st = sg_alloc(ctx, (size_t)n + 2, &flagged_rows);
+    unsigned long long *h = (unsigned long long *)ctx->h_stat_words;   // pinned; read before anything else uses it
+    auto cleanup = [&]() {
+        ctx->release(words);
+        ctx->release(pl.d_i);
+        ctx->release(pl.d_j);
+        ctx->release(pl.d_s);
+        ctx->release(cnt);
+        ctx->release(cursor);
+        ctx->release(flagged_rows);
+        ctx->release(lcol);
+        ctx->release(lval);
+    };
+    if (st != SG_OK) {
+        cleanup();
+        return st;
+    }
+    pl.d_count = (unsigned long long *)(words + 2);
+    unsigned long long *d_stats3 = nullptr;   // this pass's own statistics: they only count when the pass does
+    st = sg_alloc(ctx, (size_t)4, &d_stats3);
+    hipError_t e = hipSuccess;
+    if (st == SG_OK) {
+        e = hipMemsetAsync(words, 0, 8 * sizeof(uint32_t), ctx->stream);
+        if (e == hipSuccess) e = hipMemsetAsync(d_stats3, 0, 4 * sizeof(unsigned long long), ctx->stream);
+        if (e == hipSuccess) e = hipMemsetAsync(cnt, 0, sizeof(uint32_t) * (size_t)(n + 2), ctx->stream);
+        if (e == hipSuccess) e = hipMemsetAsync(cursor, 0, sizeof(uint32_t) * (size_t)(n + 2), ctx->stream);
+        if (e != hipSuccess) st = SG_ERR_HIP;
+    }
+    const float s_budget = prune_budget(Bt, threshold, delta);
+    if (st == SG_OK) {
+        if (A->dtype == SG_F64)
+            st = dispatch_pruned<double, true>(ctx, A, Bt, keep, r, (double)threshold, s_budget, words, words + 1, flagged_rows,
+                                               d_stats3, pl);
+        else
+            st = dispatch_pruned<float, true>(ctx, A, Bt, keep, r, (float)threshold, s_budget, words, words + 1, flagged_rows,
+                                              d_stats3, pl);
+    }
+    if (st == SG_OK) {
+        // h[0] = {row counter, flagged}, h[1] = pair count
+        e = hipMemcpyAsync(h, words, 16, hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) {
+            sg_set_error("symmetric multiply: %s", hipGetErrorString(e));
+            st = SG_ERR_HIP;
+        }
+    }
+    if (st != SG_OK) {
+        ctx->release(d_stats3);
+        cleanup();
+        return st;
+    }
+    const uint32_t flagged = (uint32_t)(h[0] >> 32);
+    const unsigned long long n_pairs = h[1];
+    if (flagged != 0 || n_pairs > pl.cap) {
+        ctx->release(d_stats3);
+        cleanup();
+        return SG_OK;   // *done stays false
+    }
+    // ---- pass 2
+    const unsigned pgrid = (unsigned)(n_pairs == 0 ? 1 : (n_pairs + 255) / 256 > 4096 ? 4096 : (n_pairs + 255) / 256);
+    hipLaunchKernelGGL(pairs_count_kernel, dim3(pgrid), dim3(256), 0, ctx->stream, pl.d_i, pl.d_j, pl.d_count, cnt);
+    st = sg_exclusive_scan_u32(ctx, cnt, cnt, n + 1, nullptr);   // cnt becomes ptr (n + 1 entries)
+    const size_t n_list = (size_t)(2 * n_pairs + 64);
+    if (st == SG_OK) st = sg_alloc(ctx, n_list, &lcol);
+    if (st == SG_OK) st = ctx->alloc(n_list * vs, &lval);
+    if (st == SG_OK) {
+        unsigned sgrid = (unsigned)(n < 256 * 64 ? (n > 0 ? n : 1) : 256 * 64);
+        if (A->dtype == SG_F64) {
+            hipLaunchKernelGGL(pairs_fill_kernel<double>, dim3(pgrid), dim3(256), 0, ctx->stream, pl.d_i, pl.d_j,
+                               (const double *)pl.d_s, pl.d_count, cnt, cursor, lcol, (double *)lval);
+            hipLaunchKernelGGL(pairs_select_kernel<double>, dim3(sgrid), dim3(64), 0, ctx->stream, cnt, lcol, (const double *)lval,
+                               (uint32_t)n, keep, r->stride, r->d_cols, (double *)r->d_vals, r->d_counts);
+        } else {
+            hipLaunchKernelGGL(pairs_fill_kernel<float>, dim3(pgrid), dim3(256), 0, ctx->stream, pl.d_i, pl.d_j,
+                               (const float *)pl.d_s, pl.d_count, cnt, cursor, lcol, (float *)lval);
+            hipLaunchKernelGGL(pairs_select_kernel<float>, dim3(sgrid), dim3(64), 0, ctx->stream, cnt, lcol, (const float *)lval,
+                               (uint32_t)n, keep, r->stride, r->d_cols, (float *)r->d_vals, r->d_counts);
+        }
+        if (hipGetLastError() != hipSuccess) st = SG_ERR_HIP;
+        // the statistics of the pass that counted
+        if (st == SG_OK && hipMemcpyAsync(stats, d_stats3, 3 * sizeof(unsigned long long), hipMemcpyDeviceToDevice,
+                                          ctx->stream) != hipSuccess)
+            st = SG_ERR_HIP;
+    }
+    ctx->release(d_stats3);
+    cleanup();
+    if (st == SG_OK) *done = true;
+    return st;
 }

@@ -574,7 +574,7 @@ extern "C" int sg_spgemm_topn(sg_ctx *ctx, const sg_csr *A, const sg_postings *B
 
     // ---- pruned multiply (sg_spgemm_pruned.hip) when both sides are cosine-like and one register list
     //      holds the row's result; its survivor threshold needs some room below the threshold
-    bool prune = false;
+    bool prune = false, symmetric = false;
     double delta = 0.0;
     {
         const char *pr = getenv("SG_PRUNE");
@@ -585,12 +585,18 @@ extern "C" int sg_spgemm_topn(sg_ctx *ctx, const sg_csr *A, const sg_postings *B
             if (delta < 0.02) delta = 0.02;
             bool a_ok = false;
             float a_n2 = 0.f;
-            const int pst = sg_csr_props(ctx, A, &a_ok, &a_n2);
+            uint32_t a_max_nnz = 0;
+            const int pst = sg_csr_props(ctx, A, &a_ok, &a_n2, &a_max_nnz);
             if (pst != SG_OK) {
                 sg_topn_free(r);
                 return pst;
             }
             prune = a_ok;
+            // self-join (A is the matrix the postings were built from) whose rows all fit the pruned kernel:
+            // score every pair once, from the row with the larger index (sg_spgemm_pruned.hip, symmetric mode)
+            const char *sy = getenv("SG_SYM");
+            symmetric = prune && !(sy && sy[0] == '0') && A->n_rows == Bt->n_right && A->d_indptr == Bt->b_indptr &&
+                        A->d_indices == Bt->b_indices && A->d_data == Bt->b_data && a_max_nnz <= 64;
         }
     }
 
@@ -612,11 +618,15 @@ extern "C" int sg_spgemm_topn(sg_ctx *ctx, const sg_csr *A, const sg_postings *B
             hipMemsetAsync(r->d_counts, 0, sizeof(int32_t) * (size_t)A->n_rows, ctx->stream) != hipSuccess ||
             hipMemsetAsync(ctx->d_stat_words + 2, 0, 4 * sizeof(int64_t), ctx->stream) != hipSuccess)
             st = SG_ERR_HIP;
-        if (prune && st == SG_OK)
+        bool sym_done = false;
+        if (symmetric && st == SG_OK)
+            st = sg_spgemm_pruned_symmetric(ctx, A, Bt, stride, r, threshold, delta,
+                                            (unsigned long long *)(ctx->d_stat_words + 2), &sym_done);
+        if (prune && !sym_done && st == SG_OK)
             st = sg_spgemm_pruned_launch(ctx, A, Bt, stride, r, threshold, delta, counters + n_launch + 1,
                                          handed_count, handed_rows, (unsigned long long *)(ctx->d_stat_words + 2));
         int li = 0;
-        for (int pass = 0; pass < n_pass && st == SG_OK && A->n_rows > 0; ++pass) {
+        for (int pass = 0; pass < n_pass && st == SG_OK && A->n_rows > 0 && !sym_done; ++pass) {
             const int pass_off = pass * SG_TOPN_LANES;
             const int keep = stride - pass_off < SG_TOPN_LANES ? stride - pass_off : SG_TOPN_LANES;
             for (int g = 0; g < n_groups && st == SG_OK; ++g, ++li) {

@@ -1,6 +1,6 @@
 """The pruning rule of the pruned multiply (string_grouper_amd/csrc/sg_spgemm_pruned.hip), restated in
-numpy with the kernel's arithmetic (float32 bound, upward-quantised filter postings, 2^15 fixed point,
-the same slack terms)
+numpy with the kernel's arithmetic (float32 bound, upward-quantised filter postings, 2^15 fixed point in
+24-bit integer multiplies, the same slack terms)
 and checked against the oracle: every pair the oracle keeps must be among the kernel's survivors.
 This pins the MATH of the filter on the CPU; the kernel itself is compared bit for bit with the
 oracle by the GPU parity tests."""
@@ -11,11 +11,13 @@ from oracle import oracle as O
 from string_grouper_amd.synth import synth_names
 
 f32 = np.float32
+AB = 13                      # address + half bits of a filter posting at tile_log2 = 12
+BQ_MAX = (1 << (24 - AB)) - 1
 
 
 def quantise_right(m, mt, freq_min, norm_up):
-    """K3's filter postings: per right row fq (8 bits, frequent-part norm) and per posting bq (12 bits),
-    both rounded up relative to norm_up (sg_postings.hip, postings_fill)."""
+    """K3's filter postings: per right row fq (8 bits, frequent-part norm) and per posting bq (11 bits at the
+    default tile of 4096 columns), both rounded up relative to norm_up (sg_postings.hip, emit_posting)."""
     df = np.diff(mt.indptr)
     inv = f32(1.0) / f32(norm_up)
     frequent = df[m.indices] >= freq_min
@@ -23,7 +25,7 @@ def quantise_right(m, mt, freq_min, norm_up):
     np.add.at(f2, np.repeat(np.arange(m.shape[0]), np.diff(m.indptr))[frequent],
               m.data[frequent].astype(np.float64) ** 2)
     fq = np.minimum(255, np.ceil(np.nextafter(np.sqrt(f2).astype(f32), f32(2)) * inv * f32(255.0) * f32(1.000002)))
-    bq_t = np.minimum(4095, np.ceil(mt.data.astype(f32) * inv * f32(4095.0) * f32(1.000002)))
+    bq_t = np.minimum(BQ_MAX, np.ceil(mt.data.astype(f32) * inv * f32(BQ_MAX) * f32(1.000002)))
     return fq.astype(np.int64), bq_t.astype(np.int64)
 
 
@@ -49,18 +51,23 @@ def survivors_of_row(a_idx, a_val, Bt_indptr, Bt_rows, bq_t, fq, thr, delta, nor
     b_s = f32(f32(np.sqrt(bs2)) * f32(1.000002))
     t0 = f32(f32(f32(thr) - f32(1e-5)) * f32(32768.0)) - f32(2.0)
     c1 = f32(f32(f32(b_s * f32(norm_up)) * f32(32768.0 / 255.0)) * f32(1.000002))
-    assert t0 - c1 * f32(255.0) >= 1.0
+    n_p = int(in_p.sum())
+    T0 = int(np.floor(f32(t0 * f32(256.0)))) - 256 * n_p
+    C1 = int(f32(c1 * f32(256.0))) + 1
+    assert T0 - C1 * 255 >= 256
     q = {}
     streamed = 0
     for t in np.nonzero(in_p)[0]:
         lo, hi = Bt_indptr[a_idx[t]], Bt_indptr[a_idx[t] + 1]
-        c_a = f32(f32(f32(f32(a_val[t]) * f32(norm_up)) * f32(32768.0 / 4095.0)) * f32(1.000002))
-        x = (c_a * bq_t[lo:hi].astype(f32)).astype(f32).astype(np.uint32) + 1   # truncation, then + 1
+        c_a = f32(f32(f32(f32(a_val[t]) * f32(norm_up)) * f32(32768.0 / BQ_MAX)) * f32(1.000002))
+        CA = int(f32(c_a * f32(1 << (32 - AB)))) + 1
+        assert CA < (1 << 24)
+        x = (CA * (bq_t[lo:hi].astype(np.int64) << AB)) >> 32      # v_mul_hi_u32_u24
         streamed += hi - lo
         for j, xv in zip(Bt_rows[lo:hi], x):
             q[j] = q.get(j, 0) + int(xv)
     assert max(q.values()) < 65536
-    surv = np.array(sorted(j for j, v in q.items() if v >= np.uint32(t0 - c1 * f32(fq[j]))), dtype=np.int64)
+    surv = np.array(sorted(j for j, v in q.items() if v >= ((T0 - C1 * int(fq[j])) >> 8)), dtype=np.int64)
     return surv, streamed
 
 
