@@ -167,6 +167,7 @@ struct sg_vocab {
     uint64_t *d_keys = nullptr;          // n_terms: key of column i (ascending)
     int32_t *d_df = nullptr;             // n_terms
     void *d_idf = nullptr;               // n_terms, params.dtype; null until sg_vocab_set_idf
+    struct VocabImpl *impl = nullptr;    // tokeniser state (sg_vectorize.hip): token caches, character coding, df table
 };
 
 // sg_matchlist.hip

@@ -364,10 +364,26 @@ spgemm_topn_pruned_kernel(const int64_t *__restrict__ a_indptr, const int32_t *_
         top.clear();
         uint32_t n_surv = 0;
 
-        // One posting applied by the lanes in `valid`: the add into the 16-bit accumulator and the survivor
-        // test.  zaddr receives the accumulator's byte address (for re-zeroing).  A lane whose add takes an
-        // accumulator across tq appends the column to the survivor buffer; a full wave of survivors is scored
-        // at once.
+        // The survivors of one slot of a tile (rare: a few per row): append the crossing lanes' columns, score a
+        // full wave of them at once.
+        auto collect = [&](uint64_t cm, uint32_t r, uint32_t t) {
+            bool cross = (cm >> lane) & 1ull;
+            const int col = (int)((t << TILE_LOG2) | ((r & ADDR_MASK) >> 1) | (r & 1u));
+            if (SYM) {
+                cross = cross && (uint32_t)col <= row;   // the pair (i, j > i) is row j's to score
+                cm = ballot64(cross);
+            }
+            if (cross) surv[n_surv + __popcll(cm & lanes_below)] = col;
+            n_surv += __popcll(cm);
+            if (n_surv >= 64) {
+                top = drain_survivors<T, SYM, TILE_LOG2>(fwd_ptr, fwd, thr, row, pair_i, pair_j, pair_s, pair_count, pair_cap,
+                                                         top, n_surv);
+                st_surv += 64;
+                n_surv -= 64;
+            }
+        };
+        // One posting applied by the lanes in `valid`, waiting for its result (the slot-by-slot form, used for tiles
+        // with more than four postings per lane): the add into the 16-bit accumulator and the survivor test.
         // (Only the atomic is under the lane mask: everything else is side-effect free and runs for all lanes, which
         // keeps the survivor mask a wave-uniform scalar for the compiler.)
         auto round = [&](uint32_t r, bool valid, uint64_t valid_mask, uint32_t t, uint32_t &zaddr) {
@@ -385,23 +401,8 @@ spgemm_topn_pruned_kernel(const int64_t *__restrict__ a_indptr, const int32_t *_
             const uint32_t oh = __builtin_amdgcn_ubfe(old, sh, 16u);
             // oh < tq && oh + x >= tq  (unsigned wrap when oh >= tq); the mask of a compare ANDed with a scalar mask
             // stays scalar (the mask of a combined predicate would be rebuilt through a VALU select)
-            uint64_t cm = ballot64(tq1 - oh < x) & valid_mask;
-            if (cm) {
-                bool cross = (cm >> lane) & 1ull;
-                const int col = (int)((t << TILE_LOG2) | (zaddr >> 1) | (r & 1u));
-                if (SYM) {
-                    cross = cross && (uint32_t)col <= row;   // the pair (i, j > i) is row j's to score
-                    cm = ballot64(cross);
-                }
-                if (cross) surv[n_surv + __popcll(cm & lanes_below)] = col;
-                n_surv += __popcll(cm);
-                if (n_surv >= 64) {
-                    top = drain_survivors<T, SYM, TILE_LOG2>(fwd_ptr, fwd, thr, row, pair_i, pair_j, pair_s, pair_count,
-                                                             pair_cap, top, n_surv);
-                    st_surv += 64;
-                    n_surv -= 64;
-                }
-            }
+            const uint64_t cm = ballot64(tq1 - oh < x) & valid_mask;
+            if (cm) collect(cm, r, t);
         };
 
         // a batch = the lane's (up to) four entries of one tile's segment + what is left of the segment from the
@@ -419,52 +420,79 @@ spgemm_topn_pruned_kernel(const int64_t *__restrict__ a_indptr, const int32_t *_
             bt.r2 = filt_at(bt.base + G8);
             bt.r3 = filt_at(bt.base + G12);
         };
+        // What one slot adds and what its accumulator must reach: side-effect free, computed for all lanes.
+        struct Slot {
+            uint32_t z, sh, x, xs, tq1;
+        };
+        auto prep = [&](uint32_t r) {
+            Slot s;
+            s.z = r & ADDR_MASK;
+            s.sh = r << 4;   // bit 4 = the half; shifts and bit-field offsets use 5 bits
+            s.x = (uint32_t)(((uint64_t)(r & (BQ_MAX << AB)) * (uint64_t)(CA & 0xffffffu)) >> 32);
+            s.tq1 = (uint32_t)((T0m - __mul24(C1, (int32_t)(r >> 24))) >> 8);
+            // x << (16 * half): the hardware shift takes the low five bits of sh by itself
+            asm("v_lshlrev_b32 %0, %1, %2" : "=v"(s.xs) : "v"(s.sh), "v"(s.x));
+            return s;
+        };
+        // One tile: the (up to) four postings of every lane.  All four adds and the four re-zeroing stores are
+        // issued back to back -- DS operations of a wave execute in order, so an add's returned value reflects
+        // every earlier add and the stores land after all of them -- and the wave waits ONCE for the returns
+        // (round 2's first version waited per slot: 2.5 LDS round trips per tile made the loop latency-bound,
+        // profiles/r02_sessionA_*.log).  Everything but the LDS operations runs for all lanes.
         auto apply = [&](const Batch &bt, uint32_t t) {
-            const bool v0 = bt.rem > 0;
+            const bool v0 = bt.rem > 0, v1 = bt.rem > (int32_t)G4, v2 = bt.rem > (int32_t)G8, v3 = bt.rem > (int32_t)G12;
             const uint64_t m0 = ballot64(v0);
             if (m0 == 0) return;
-            uint32_t z0 = 0, z1 = 0, z2 = 0, z3 = 0;
-            uint64_t m1 = 0, m2 = 0, m3 = 0;
-            bool big = false;
-            round(bt.r0, v0, m0, t, z0);
-            const bool v1 = bt.rem > (int32_t)G4;
-            m1 = ballot64(v1);
-            if (m1) {
-                round(bt.r1, v1, m1, t, z1);
-                const bool v2 = bt.rem > (int32_t)G8;
-                m2 = ballot64(v2);
-                if (m2) {
-                    round(bt.r2, v2, m2, t, z2);
-                    const bool v3 = bt.rem > (int32_t)G12;
-                    m3 = ballot64(v3);
-                    if (m3) {
-                        round(bt.r3, v3, m3, t, z3);
-                        // a segment longer than four entries per lane: generic rounds, then a full clear
-                        int32_t left = bt.rem - (int32_t)G16;
-                        uint32_t at = bt.base + G16;
-                        SG_WD_DECL(wd_b);
-                        uint64_t ml;
-                        while ((ml = ballot64(left > 0)) != 0) {
-                            SG_WD(wd_b, 1 << 24, 14)
-                            uint32_t zz = 0;
-                            const uint32_t rx = filt_at(at);
-                            round(rx, left > 0, ml, t, zz);
-                            left -= (int32_t)G4;
-                            at += G4;
-                            big = true;
-                        }
-                    }
+            if (ballot64(bt.rem > (int32_t)G16)) {
+                // a segment longer than four entries per lane (rare): slot by slot, then a full clear
+                uint32_t zz = 0;
+                round(bt.r0, v0, m0, t, zz);
+                round(bt.r1, v1, ballot64(v1), t, zz);
+                round(bt.r2, v2, ballot64(v2), t, zz);
+                round(bt.r3, v3, ballot64(v3), t, zz);
+                int32_t left = bt.rem - (int32_t)G16;
+                uint32_t at = bt.base + G16;
+                SG_WD_DECL(wd_b);
+                uint64_t ml;
+                while ((ml = ballot64(left > 0)) != 0) {
+                    SG_WD(wd_b, 1 << 24, 14)
+                    const uint32_t rx = filt_at(at);
+                    round(rx, left > 0, ml, t, zz);
+                    left -= (int32_t)G4;
+                    at += G4;
                 }
-            }
-            if (big) {
                 for (int x = lane; x < TILE * 2 / 16; x += 64) tab_v[x] = make_uint4(0, 0, 0, 0);
-            } else {
-                // re-zero only what was touched (a few dozen of the tile's accumulators): sweeping the
-                // tile for every row costs rows * columns * 2 B of LDS writes, 11 ms at 663 k
-                if (v0) *tab_at(z0) = 0u;
-                if ((m1 >> lane) & 1ull) *tab_at(z1) = 0u;
-                if ((m2 >> lane) & 1ull) *tab_at(z2) = 0u;
-                if ((m3 >> lane) & 1ull) *tab_at(z3) = 0u;
+                return;
+            }
+            const uint64_t m1 = ballot64(v1), m2 = ballot64(v2), m3 = ballot64(v3);
+            const Slot s0 = prep(bt.r0), s1 = prep(bt.r1), s2 = prep(bt.r2), s3 = prep(bt.r3);
+            uint32_t o0, o1, o2, o3;
+            asm("" : "=v"(o0));   // lanes without a posting: whatever the register holds, masked below
+            asm("" : "=v"(o1));
+            asm("" : "=v"(o2));
+            asm("" : "=v"(o3));
+            if (v0) o0 = __hip_atomic_fetch_add(tab_at(s0.z), s0.xs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (v1) o1 = __hip_atomic_fetch_add(tab_at(s1.z), s1.xs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (v2) o2 = __hip_atomic_fetch_add(tab_at(s2.z), s2.xs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (v3) o3 = __hip_atomic_fetch_add(tab_at(s3.z), s3.xs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            // re-zero only what was touched (a few dozen of the tile's accumulators): sweeping the tile for every
+            // row costs rows * columns * 2 B of LDS writes, 11 ms at 663 k
+            if (v0) *tab_at(s0.z) = 0u;
+            if (v1) *tab_at(s1.z) = 0u;
+            if (v2) *tab_at(s2.z) = 0u;
+            if (v3) *tab_at(s3.z) = 0u;
+            asm volatile("" : "+v"(o0), "+v"(o1), "+v"(o2), "+v"(o3));   // the one wait; the tests below stay outside the masks
+            // oh < tq && oh + x >= tq  (unsigned wrap when oh >= tq); the mask of a compare ANDed with a scalar mask
+            // stays scalar (the mask of a combined predicate would be rebuilt through a VALU select)
+            const uint64_t c0 = ballot64(s0.tq1 - __builtin_amdgcn_ubfe(o0, s0.sh, 16u) < s0.x) & m0;
+            const uint64_t c1m = ballot64(s1.tq1 - __builtin_amdgcn_ubfe(o1, s1.sh, 16u) < s1.x) & m1;
+            const uint64_t c2 = ballot64(s2.tq1 - __builtin_amdgcn_ubfe(o2, s2.sh, 16u) < s2.x) & m2;
+            const uint64_t c3 = ballot64(s3.tq1 - __builtin_amdgcn_ubfe(o3, s3.sh, 16u) < s3.x) & m3;
+            if (c0 | c1m | c2 | c3) {
+                if (c0) collect(c0, bt.r0, t);
+                if (c1m) collect(c1m, bt.r1, t);
+                if (c2) collect(c2, bt.r2, t);
+                if (c3) collect(c3, bt.r3, t);
             }
         };
 

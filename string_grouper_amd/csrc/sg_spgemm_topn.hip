@@ -9,10 +9,12 @@
 // no barriers anywhere, LDS is allocated in wave-sized grains, and up to 160 KiB / (TILE * s) waves
 // are resident per CU).  For every column tile t of the right-hand side and every non-zero (k, a) of
 // row i IN ASCENDING k, the wave streams segment (k, t) of the inverted index (sg_postings.hip) with
-// coalesced loads -- lane l takes posting slo + l -- and issues one LDS atomic add per lane:
+// coalesced loads -- lane l takes posting slo + l -- and does a plain LDS read-add-write per lane
+// (LDS float atomics cost ~190 cycles per wave instruction here and were dropped after v2):
 //         acc[j - t*TILE] += a * b            (product rounded, then sum rounded: no FMA)
 // All j inside one segment are distinct, so one wave instruction never carries two updates of the
-// same accumulator, and DS instructions of one wave execute in issue order, so every accumulator
+// same accumulator (the read-add-write is race-free), and DS instructions of one wave execute in issue
+// order, so every accumulator
 // receives its products in ascending k: the same order scipy / sparse_dot_topn use, hence bit-equal
 // scores (a requirement for bit-equal match indices next to the threshold and at the top-n cut).
 // After the last k the wave sweeps its tile with 16-byte LDS reads (re-zeroing as it goes), finds
@@ -817,11 +819,17 @@ extern "C" int sg_topn_zip(sg_ctx *ctx, const sg_topn *const *parts, const int64
         return st;
     }
     (void)s;
-    SG_HIP_TRY(hipMemcpyAsync(d_desc, host_desc.data(), host_desc.size(), hipMemcpyHostToDevice, ctx->stream));
-    SG_HIP_TRY(hipStreamSynchronize(ctx->stream));   // host_desc is a local
+    hipError_t he = hipMemcpyAsync(d_desc, host_desc.data(), host_desc.size(), hipMemcpyHostToDevice, ctx->stream);
+    if (he == hipSuccess) he = hipStreamSynchronize(ctx->stream);   // host_desc is a local
+    if (he == hipSuccess) he = hipMemsetAsync(r->d_counts, 0, sizeof(int32_t) * (size_t)n_rows, ctx->stream);
+    if (he != hipSuccess) {
+        sg_set_error("sg_topn_zip: %s", hipGetErrorString(he));
+        ctx->release(d_desc);
+        sg_topn_free(r);
+        return he == hipErrorOutOfMemory ? SG_ERR_OOM : SG_ERR_HIP;
+    }
     {
         SgTimer timer(ctx, SG_K_ZIP);
-        SG_HIP_TRY(hipMemsetAsync(r->d_counts, 0, sizeof(int32_t) * (size_t)n_rows, ctx->stream));
         const int n_pass = (stride + SG_TOPN_LANES - 1) / SG_TOPN_LANES;
         unsigned grid = (unsigned)(n_rows < 256 * 32 ? (n_rows > 0 ? n_rows : 1) : 256 * 32);
         for (int pass = 0; pass < n_pass && n_rows > 0; ++pass) {

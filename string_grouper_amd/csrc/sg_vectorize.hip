@@ -51,16 +51,7 @@ struct VocabImpl {
     int32_t *d_err = nullptr;      // [0] != 0: a string exceeded TOK_CAP
 };
 
-// sg_vocab (sg_internal.h) carries an opaque pointer to this through d_key_to_col's owner; we keep a
-// side table keyed by the vocab address to avoid widening the shared struct.
-static std::mutex g_impl_mu;
-static std::map<const sg_vocab *, VocabImpl *> g_impl;
-
-static VocabImpl *impl_of(const sg_vocab *v) {
-    std::lock_guard<std::mutex> g(g_impl_mu);
-    auto it = g_impl.find(v);
-    return it == g_impl.end() ? nullptr : it->second;
-}
+static VocabImpl *impl_of(const sg_vocab *v) { return v ? v->impl : nullptr; }
 
 struct TokParams {
     int32_t ngram;
@@ -356,13 +347,14 @@ extern "C" int sg_vec_fit(sg_ctx *ctx, const sg_strings *const *sets, int32_t n_
 
     sg_vocab *v = new (std::nothrow) sg_vocab();
     VocabImpl *im = new (std::nothrow) VocabImpl();
-    if (!v || !im) return SG_ERR_OOM;
+    if (!v || !im) {
+        delete v;
+        delete im;
+        return SG_ERR_OOM;
+    }
     v->ctx = ctx;
     v->params = *params;
-    {
-        std::lock_guard<std::mutex> g(g_impl_mu);
-        g_impl[v] = im;
-    }
+    v->impl = im;
     int st = SG_OK;
     // ---- character coding: raw 7 bits when the key space stays small, else ranks of the bytes present
     for (int c = 0; c < 128; ++c) {
@@ -527,15 +519,8 @@ extern "C" int sg_vocab_set_idf(sg_ctx *ctx, sg_vocab *v, const void *idf, int32
 
 extern "C" int sg_vocab_free(sg_vocab *v) {
     if (!v) return SG_OK;
-    VocabImpl *im = nullptr;
-    {
-        std::lock_guard<std::mutex> g(g_impl_mu);
-        auto it = g_impl.find(v);
-        if (it != g_impl.end()) {
-            im = it->second;
-            g_impl.erase(it);
-        }
-    }
+    VocabImpl *im = v->impl;
+    v->impl = nullptr;
     sg_ctx *ctx = v->ctx;
     if (im) {
         for (auto &c : im->caches) free_cache(ctx, c);

@@ -69,15 +69,22 @@ def broadcast_csr(indptr, indices, data, shape, src: int = 0, device=None, group
 
 
 def gather_counts(local_counts, n_total: int, group=None):
-    """All ranks' per-row match counts, concatenated in rank order (row blocks are contiguous)."""
+    """All ranks' per-row match counts, concatenated in rank order (row blocks are contiguous).  The block
+    sizes are exchanged first: the cuts may be the balanced ones of ``row_block`` or cost-weighted
+    (``weighted_row_blocks``), and only the owning rank knows which."""
     world = dist.get_world_size(group)
-    sizes = [row_block(r, world, n_total) for r in range(world)]
-    longest = max(hi - lo for lo, hi in sizes)
+    mine = torch.tensor([int(local_counts.numel())], dtype=torch.int64, device=local_counts.device)
+    sizes = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(sizes, mine, group=group)
+    sizes = [int(s.item()) for s in sizes]
+    if sum(sizes) != n_total:
+        raise ValueError(f"row blocks of the ranks hold {sum(sizes)} rows, expected {n_total}")
+    longest = max(max(sizes), 1)
     padded = torch.zeros(longest, dtype=local_counts.dtype, device=local_counts.device)
     padded[: local_counts.numel()] = local_counts
     out = [torch.empty_like(padded) for _ in range(world)]
     dist.all_gather(out, padded, group=group)
-    return torch.cat([o[: hi - lo] for o, (lo, hi) in zip(out, sizes)])
+    return torch.cat([o[:n] for o, n in zip(out, sizes)])
 
 
 class DeviceTensorView:

@@ -185,6 +185,14 @@ class StringGrouper(object):
         if dml is not None:
             dml.free()
 
+    def __getstate__(self):
+        """Pickle / deepcopy like the reference's plain-Python object: device handles (the vectoriser's
+        vocabulary, the device-resident match list) stay behind; the copy reduces on the host."""
+        state = dict(self.__dict__)
+        state.pop('_device_matches', None)
+        state['_vectorizer'] = None
+        return state
+
     # ------------------------------------------------------------------ data / options
     def _set_data(self, master, duplicates=None, master_id=None, duplicates_id=None):
         self.master = master
@@ -302,8 +310,24 @@ class StringGrouper(object):
             eng = _engine_mod.get_engine()
             fix = bool(self._config.force_symmetries and self._duplicates is None)
             keep = 'keep_on_device' in inspect.signature(eng.match_list).parameters   # engine doubles may lack it
-            out = eng.match_list(master_matrix, duplicate_matrix, self._max_n_matches, self._config.min_similarity,
-                                 fix, **({'keep_on_device': True} if keep else {}))
+            try:
+                out = eng.match_list(master_matrix, duplicate_matrix, self._max_n_matches, self._config.min_similarity,
+                                     fix, **({'keep_on_device': True} if keep else {}))
+            except OverflowError:
+                # the one exception the reference's fit() handles (string_grouper.py:397-413): fall back to the
+                # block-wise multiply with the reference's own guess of the split
+                logger.warning("An OverflowError occurred but is being handled: the input is split into "
+                               "n_blocks = (%d, %d) and processed block-wise", guess[0], guess[1])
+                out = None
+            if out is None:
+                self._n_blocks_guessed = False
+                matches = self._build_matches(master_matrix, duplicate_matrix, guess if guess != (1, 1) else (2, 1))
+                self._true_max_n_matches = int(np.diff(matches.indptr).max()) if matches.shape[0] else 0
+                if fix:
+                    matches = StringGrouper._symmetrize_matrix(StringGrouper._fix_diagonal(matches))
+                self._matches_list = self._get_matches_list(matches)
+                self.is_build = True
+                return self
             rows, cols, sims, self._true_max_n_matches = out[:4]
             self._matches_list = _concat_columns(      # columns kept as they are: no re-copy
                 [pd.Series(rows, name='master_side', copy=False), pd.Series(cols, name='dupe_side', copy=False),

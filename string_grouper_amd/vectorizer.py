@@ -170,7 +170,6 @@ class HipTfidfVectorizer:
         self._ctx = ctx
         self._vocab: Optional[N.Vocab] = None
         self._fit_sets: List[PreparedStrings] = []
-        self._fit_ids: List[int] = []
         self._keys = None
         self._df = None
         self.idf_ = None
@@ -214,19 +213,16 @@ class HipTfidfVectorizer:
 
     # ------------------------------------------------------------------ sklearn-shaped API (seam b1)
     def fit(self, raw_documents, y=None):
-        p = self.prepare(raw_documents)
-        self._fit_ids = [id(raw_documents)]
-        return self.fit_prepared([p])
+        return self.fit_prepared([self.prepare(raw_documents)])
 
     def transform(self, raw_documents):
-        if self._fit_ids == [id(raw_documents)] and len(self._fit_sets) == 1:
-            p = self._fit_sets[0]                       # same object that was fitted: reuse its tokens
-        else:
-            p = self.prepare(raw_documents)
-        return self.transform_prepared(p).to_scipy()
+        """Always re-reads ``raw_documents`` (as sklearn does): the tokens of fit() are only reused through the
+        explicit handles (``prepare`` / ``fit_prepared`` / ``transform_prepared``, or ``fit_transform``)."""
+        return self.transform_prepared(self.prepare(raw_documents)).to_scipy()
 
     def fit_transform(self, raw_documents, y=None):
-        return self.fit(raw_documents).transform(raw_documents)
+        p = self.prepare(raw_documents)
+        return self.fit_prepared([p]).transform_prepared(p).to_scipy()      # one tokenisation pass
 
     @property
     def vocabulary_(self) -> Dict[str, int]:
