@@ -188,6 +188,53 @@ def test_100k_selfjoin_matches_port(ctx):
     assert (np.abs(d[d > 0] - 1) < 1e-5).all()
 
 
+def test_headline_663k_selfjoin_every_row_equals_sklearn_and_the_port(ctx):
+    """BASELINE.json's headline configuration (configs[2] on the SynthNames-v1 stand-in): 663 000 names,
+    3-grams, ntop=10, min_sim=0.8, fp32.  The device TF-IDF matrix against sklearn driven as the reference
+    drives it, and ALL rows of the multiply (pruned kernel, symmetric mode -- the path bench.py times) against
+    the C restatement of sp_matmul_topn; then the one-sided pruned kernel and the size-independent properties."""
+    import os
+    from string_grouper_amd.vectorizer import HipTfidfVectorizer
+    n = 663000
+    names = _names(n)
+    vec = HipTfidfVectorizer(dtype=np.float32, ctx=ctx)
+    prepared = vec.prepare(names)
+    vec.fit_prepared([prepared])
+    dA = vec.transform_prepared(prepared)
+    A_dev = dA.to_scipy()
+    A_ref = _tfidf(names, np.float32)
+    assert_csr_identical(A_dev, A_ref, "tf-idf at 663k")
+    threads = max(1, min(64, len(os.sched_getaffinity(0))))
+    C_ref = P.sp_matmul_topn_port(A_ref, A_ref.T, 10, 0.8, True, threads)
+    post = ctx.postings_build(dA)
+    res = ctx.spgemm_topn(dA, post, 10, 0.8, True)
+    st = ctx.stats()
+    C_sym = res.to_scipy()
+    res.free()
+    assert st["prune_rows"] > 0 and st["exact_rows"] == 0
+    assert_csr_identical(C_sym, C_ref, "663k self-join, symmetric pruned multiply")
+    assert st["prune_postings"] < 0.06 * st["macs"]       # the symmetric pass streams half of the one-sided 8 %
+    os.environ["SG_SYM"] = "0"
+    try:
+        res = ctx.spgemm_topn(dA, post, 10, 0.8, True)
+        C_one = res.to_scipy()
+        res.free()
+    finally:
+        os.environ.pop("SG_SYM")
+    assert_csr_identical(C_one, C_ref, "663k self-join, one-sided pruned multiply")
+    post.free()
+    # properties that hold at any size: every non-empty row finds itself with a score of 1 (+- rounding), rows are
+    # ordered by (score desc, column asc), scores are in (0.8, 1 + eps]
+    nnz_row = np.diff(A_ref.indptr) > 0
+    d = C_sym.diagonal()
+    assert (np.abs(d[nnz_row] - 1) < 1e-5).all() and (d[~nnz_row] == 0).all()
+    assert (C_sym.data > np.float32(0.8)).all() and (C_sym.data < 1.0001).all()
+    rows = np.repeat(np.arange(n), np.diff(C_sym.indptr))
+    same_row = rows[1:] == rows[:-1]
+    ok = (C_sym.data[:-1] > C_sym.data[1:]) | ((C_sym.data[:-1] == C_sym.data[1:]) & (C_sym.indices[:-1] < C_sym.indices[1:]))
+    assert ok[same_row].all()
+
+
 def test_public_api_golden_cases_on_gpu(ctx):
     """The reference's golden vectors (tests/golden, made by the unmodified reference) through the
     drop-in API with the HIP engine: match frames, groups, most-similar, known answers."""
