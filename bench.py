@@ -3,21 +3,27 @@
 
 One "step" = one pass of the hot path over one batch of synthetic input that is already resident
 in HBM: n-gram tokenise + vocabulary/df (K1), tf-idf weight + L2 normalise (K2), inverted index (K3),
-thresholded sparse top-n multiply (K4).  Workload at N=1: the configuration BASELINE.json's metric
+thresholded sparse top-n multiply (K4p / K4).  Workload at N=1: the configuration BASELINE.json's metric
 is quoted on -- 663k-name self-join, 3-grams, ntop=10, min_sim=0.8, fp32 -- on SynthNames-v1
 (the sec__edgar list is not distributable; see string_grouper_amd/synth.py).
 
     python bench.py --gpus N --steps K --warmup W
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-N > 1 is strong scaling of the same workload: rank 0's string column is broadcast once over RCCL,
-every rank vectorises and multiplies its contiguous block of left rows
-(string_grouper_amd/distributed.py).
+``--gpus N`` with N > 1 and no rank environment re-executes itself under ``torch.distributed.run`` (N ranks,
+one per GPU, RCCL); launched BY torch.distributed.run it reads RANK / LOCAL_RANK / WORLD_SIZE.  N > 1 is strong
+scaling of the same workload: left rows in N contiguous blocks (string_grouper_amd/distributed.py).
 
-Prints ONE JSON line (rank 0) with ``roofline`` (the multiply kernel of the step -- the pruned kernel
-K4p on this workload -- live HIP-event time on the library's stream, priced on its own algorithmic
-bytes), ``exact_kernel`` (K4 timed live on the same input; results compared bit for bit) and
-``cpu_baseline`` (the C/OpenMP port of sparse_dot_topn on a bounded row sample, rank 0, N=1).
+Prints ONE JSON line (rank 0):
+  value / ms_per_step   the hot path, inputs in HBM (the contract's metric)
+  roofline              the multiply kernel of the step, live HIP-event time on the library's stream, priced on its
+                        own algorithmic bytes
+  exact_kernel          K4 timed live on the same input; results compared bit for bit
+  end_to_end            wall-clock of the PUBLIC match_strings() incl. host string preparation, PCIe both ways, the
+                        device match list (K6) and the pandas frames, fp32 and fp64, with the split -- this is what
+                        BASELINE.json's "match_strings wall-clock" target refers to; never `value`
+  cpu_baseline          the reference's match_strings call sequence (oracle/ref_pipeline.py: sklearn + the C port of
+                        sparse_dot_topn) on 4 host cores in a child process, bounded sample (oracle/baseline.py);
+                        all_cores: the multiply leg on every core
 """
 from __future__ import annotations
 
@@ -47,12 +53,27 @@ def parse_args():
     ap.add_argument("--cpu-sample-rows", type=int, default=0, help="left rows of the CPU baseline (0 = auto)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-exact-kernel", action="store_true", help="skip the live run of the exact kernel K4")
-    ap.add_argument("--end-to-end", action="store_true", help="also time match_strings() incl. PCIe and pandas")
+    ap.add_argument("--no-end-to-end", action="store_true", help="skip the match_strings() wall-clock runs (fp32 + fp64)")
+    ap.add_argument("--end-to-end", action="store_true", help=argparse.SUPPRESS)      # round-1 flag: now the default
+    ap.add_argument("--cpu-cores", type=int, default=4, help="cores of the reference CPU leg (README: 4)")
     return ap.parse_args()
+
+
+def respawn_under_torchrun(args) -> None:
+    """``python bench.py --gpus N`` (N > 1) outside a launcher: become ``torch.distributed.run`` with N ranks."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    os.execv(sys.executable, cmd)
 
 
 def main():
     args = parse_args()
+    if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
+        respawn_under_torchrun(args)
     # RCCL prints a version banner to stdout when the first communicator is created; the contract is ONE
     # JSON line on stdout, so everything else this process (and its libraries) writes goes to stderr
     sys.stdout.flush()
@@ -80,25 +101,37 @@ def main():
 
     names = synth_names(args.rows, 1234)
     make_vec = lambda: HipTfidfVectorizer(dtype=dtype, ctx=ctx)  # noqa: E731
-    prepared = make_vec().prepare(names) if (rank == 0 or not distributed) else None   # strings -> HBM (untimed)
+    dist_mode = os.environ.get("SG_BENCH_DIST_MODE", "sharded")
+    whole_column_here = (not distributed) or (rank == 0 and dist_mode != "sharded")
+    prepared = make_vec().prepare(names) if whole_column_here else None   # strings -> HBM (untimed)
 
+    # N > 1: every rank holds ITS block of the string column in HBM before the timed region starts (the list is
+    # generated identically on every rank; only the block is uploaded).  SG_BENCH_DIST_MODE=strings|csr selects
+    # round 1's forms (whole column broadcast from rank 0 and vectorised everywhere / CSR broadcast).
     dev_strings = (None, None)
-    if distributed and rank == 0:
-        from string_grouper_amd.distributed import strings_to_device_tensors
-        dev_strings = strings_to_device_tensors(prepared, torch.device("cuda", local_rank))   # HBM-resident input
+    local_block = ops = None
+    if distributed:
+        from string_grouper_amd import distributed as D
+        if dist_mode == "sharded":
+            lo, hi = D.row_block(rank, world, args.rows)
+            local_block = make_vec().prepare(names[lo:hi])
+            ops = D.HipOps(ctx, make_vec)
+        elif rank == 0:
+            dev_strings = D.strings_to_device_tensors(prepared, torch.device("cuda", local_rank))   # HBM-resident input
 
     def step():
         if distributed:
-            # the one exchange: rank 0's string column (bytes + offsets, resident in HBM) goes to every rank
-            # over RCCL; then each rank vectorises and multiplies its block of left rows, no further collective
-            from string_grouper_amd.distributed import broadcast_strings, sharded_self_join_replicated
-            mode = os.environ.get("SG_BENCH_DIST_MODE", "strings")
-            if mode == "csr":
-                from string_grouper_amd.distributed import sharded_self_join
-                res, _, _ = sharded_self_join(ctx, prepared, make_vec, args.top_n, args.min_similarity)
+            if dist_mode == "sharded":
+                # tokenise the local block, all-reduce the document frequencies, weight the local block, all-gather
+                # the CSR blocks, build the inverted index, multiply the local rows; results stay on the rank
+                res, _ = D.distributed_self_join(ops, local_block, args.top_n, args.min_similarity)
+                ctx.sync()
                 return res
-            local = broadcast_strings(ctx, *dev_strings)
-            res, _, _ = sharded_self_join_replicated(ctx, local, make_vec, args.top_n, args.min_similarity)
+            if dist_mode == "csr":
+                res, _, _ = D.sharded_self_join(ctx, prepared, make_vec, args.top_n, args.min_similarity)
+                return res
+            local, _, _ = D.broadcast_strings(ctx, *dev_strings)
+            res, _, _ = D.sharded_self_join_replicated(ctx, local, make_vec, args.top_n, args.min_similarity)
             return res
         vec = make_vec()
         vec.fit_prepared([prepared])
@@ -148,6 +181,7 @@ def main():
     ms_per_step = elapsed / args.steps * 1e3
     k4_avg_ms = float(np.mean(k4_ms))
     pruned = stats["prune_rows"] > 0
+    symmetric = bool(stats.get("prune_symmetric"))
     # dominant kernel of the step.  Pruned multiply: ITS OWN algorithmic bytes (4 B per filter posting it
     # streams + one packed row of B per pair it scores exactly + A + out), not the bytes of the products it
     # proved unnecessary.  Exact multiply: the stream model, (4+s) B per intermediate product + A + out.
@@ -169,12 +203,16 @@ def main():
         "data": "synthetic (SynthNames-v1 seed 1234; sec__edgar names are not distributable)",
         "config": {"workload": f"{args.rows}-name self-join (BASELINE.json configs[2] on the synthetic stand-in)",
                    "ngram_size": 3, "max_n_matches": args.top_n, "min_similarity": args.min_similarity,
-                   "parallelism": "single GPU" if world == 1 else f"left rows in {world} contiguous blocks, one per GPU; string column broadcast once over RCCL, each rank vectorises"},
+                   "parallelism": "single GPU" if world == 1 else
+                   f"{world} GPUs, one process each: rows of the string column in {world} contiguous blocks; tokenise local "
+                   f"block -> all-reduce df table -> weight local block -> all-gather CSR -> inverted index + multiply of "
+                   f"the local rows; no collective in the multiply ({dist_mode})"},
         "kernels_ms": {k[3:]: round(v, 4) for k, v in stats.items() if k.startswith("ms_")},
         "matches": int(job_nnz),
         "macs": int(job_macs),
         "roofline": {"bound": "hbm",
-                     "kernel": "spgemm_topn_pruned_kernel (K4p)" if pruned else "spgemm_topn_kernel (K4)",
+                     "kernel": ("spgemm_topn_pruned_kernel<SYM> + pair-list pass (K4p, self-join form)" if symmetric else
+                                "spgemm_topn_pruned_kernel (K4p)") if pruned else "spgemm_topn_kernel (K4)",
                      "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
                      "traffic": None, "algorithmic_bytes_per_launch": int(k4_bytes), "avg_ms": k4_avg_ms,
                      "note": ("algorithmic = 4 B per filter posting streamed + (8 + mean packed row) B per pair scored "
@@ -185,14 +223,14 @@ def main():
     if pruned:
         result["pruning"] = {"rows": stats["prune_rows"], "postings_streamed": stats["prune_postings"],
                              "of_intermediate_products": stats["macs"], "pairs_scored_exactly": stats["prune_survivors"],
-                             "rows_handed_to_exact_kernel": stats["exact_rows"]}
+                             "rows_handed_to_exact_kernel": stats["exact_rows"], "self_join_form": symmetric}
 
     # measured HBM-side traffic of the same kernel on the same workload, from the committed PMC passes
     try:
         with open(os.path.join(ROOT, "profiles", "k4_traffic.json")) as f:
             tr = json.load(f)
         if (tr.get("workload_rows") == args.rows and tr.get("dtype") == args.dtype and world == 1
-                and tr.get("kernel", "K4") == ("K4p" if pruned else "K4")):
+                and tr.get("kernel", "K4") == (("K4p-sym" if symmetric else "K4p") if pruned else "K4")):
             result["roofline"]["traffic"] = tr["traffic_bytes_per_launch_raw"]
             result["roofline"]["traffic_note"] = tr["source"] + "; " + tr["note"]
     except Exception:
@@ -231,60 +269,104 @@ def main():
                                   "pruned_result_identical": identical,
                                   "note": "stream model (4+s) B per intermediate product + A + out"}
 
-    if world == 1 and not args.no_cpu_baseline:
-        from oracle import oracle as O
-        from oracle import port as P
-        cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-        threads = max(1, min(cores, 64))
-        # bounded sample: TF-IDF of the whole list is needed as the right-hand side; build it with the GPU
-        # path (already parity-checked) so the CPU leg spends its budget on the multiply it is about.
-        vec = make_vec()
-        vec.fit_prepared([prepared])
-        A_host = vec.transform_prepared(prepared).to_scipy()
-        if args.cpu_sample_rows:
-            sample = min(args.rows, args.cpu_sample_rows)
-        else:   # size the sample for ~15 s of CPU work from a 1000-row probe
-            t0 = time.perf_counter()
-            P.sp_matmul_topn_port(A_host[:1000], A_host.T, args.top_n, args.min_similarity, True, threads)
-            probe = time.perf_counter() - t0
-            sample = int(min(args.rows, max(2000, 1000 * 15.0 / max(probe, 1e-3))))
-        t0 = time.perf_counter()
-        C_cpu = P.sp_matmul_topn_port(A_host[:sample], A_host.T, args.top_n, args.min_similarity, True, threads)
-        t_cpu = time.perf_counter() - t0
-        n_vec = min(args.rows, 50000)
-        t0 = time.perf_counter()
-        O.tfidf_sklearn(names[:n_vec], [names[:n_vec]], dtype=dtype)      # fit + transform = 2 tokenisation passes
-        t_vec = time.perf_counter() - t0
-        pass_per_row = t_vec / (2.0 * n_vec)
-        # the reference tokenises the master column three times per match_strings (ctor, fit, transform:
-        # string_grouper.py:267, :687, :689), single-threaded, then multiplies with n_threads
-        per_row = 3.0 * pass_per_row + t_cpu / sample
-        result["cpu_baseline"] = {
-            "value": 1.0 / per_row, "unit": "rows/s", "cores": threads, "kind": "port",
-            "sample": f"multiply: first {sample} left rows x all {args.rows} right rows with oracle/sdtn_port.c "
-                      f"({threads} OpenMP threads, {t_cpu:.2f} s); vectorise: sklearn TfidfVectorizer driven as the "
-                      f"reference does on {n_vec} names (1 thread, {t_vec:.2f} s for fit+transform), scaled to the "
-                      f"reference's three passes",
-            "multiply_rows_per_s": sample / t_cpu, "vectorise_rows_per_s_per_pass": 1.0 / pass_per_row,
-        }
-        # the sampled CPU rows must equal the GPU rows (parity on the bench workload itself)
-        r = step()
-        C_gpu = r.to_scipy()[:sample]
-        r.free()
-        same = (np.array_equal(C_gpu.indptr, C_cpu.indptr) and np.array_equal(C_gpu.indices, C_cpu.indices)
-                and np.array_equal(C_gpu.data, C_cpu.data))
-        result["parity_on_sample"] = bool(same)
-
-    if args.end_to_end and world == 1:
+    if world == 1 and not args.no_end_to_end:
+        # the public API end to end: pandas Series in, match frame out (host preparation, PCIe, K1-K4p, K6, frames)
         import pandas as pd
         import string_grouper_amd as sga
         import string_grouper_amd.engine as E
-        E.set_engine(E.HipEngine(ctx))
-        s = pd.Series(names)
-        t0 = time.perf_counter()
-        df = sga.match_strings(s, max_n_matches=args.top_n, min_similarity=args.min_similarity, tfidf_matrix_dtype=dtype)
-        result["end_to_end_match_strings_s"] = time.perf_counter() - t0
-        result["end_to_end_rows"] = len(df)
+        eng = E.HipEngine(ctx)
+        E.set_engine(eng)
+        series = pd.Series(names)
+        result["end_to_end"] = {"what": "wall-clock of string_grouper_amd.match_strings(pd.Series) -> DataFrame, best of 3 "
+                                        "after one warm-up call; includes host string preparation, H2D, the device hot "
+                                        "path, the device match list (K6), D2H and the pandas frames"}
+        for dname, dt in (("f32", np.float32), ("f64", np.float64)):
+            best, split, n_match = None, None, 0
+            for rep in range(4):
+                t0 = time.perf_counter()
+                df = sga.match_strings(series, max_n_matches=args.top_n, min_similarity=args.min_similarity,
+                                       tfidf_matrix_dtype=dt)
+                t = time.perf_counter() - t0
+                n_match = len(df)
+                if rep > 0 and (best is None or t < best):
+                    best = t
+                    split = dict(eng.timings)
+                del df
+            device = split.get("vectorise_s", 0.0) + split.get("multiply_s", 0.0) + split.get("match_list_and_download_s", 0.0)
+            split["validation_and_frames_s"] = best - device - split.get("prepare_and_upload_s", 0.0)
+            result["end_to_end"][dname] = {"seconds": best, "rows_per_s": args.rows / best, "match_rows": n_match,
+                                           "split": {k: round(v, 5) for k, v in split.items()}}
+
+    if world == 1 and not args.no_cpu_baseline:
+        # the reference's CPU path on this box's host cores, in a child process pinned to --cpu-cores CPUs
+        # (oracle/baseline.py).  The child gets the full TF-IDF matrix from this process (built by the GPU path,
+        # parity-checked by the tests) so that its budget goes into what it measures.
+        import subprocess
+        import tempfile
+        from oracle import port as P
+        vec = make_vec()
+        vec.fit_prepared([prepared])
+        A_dev = vec.transform_prepared(prepared)
+        A_host = A_dev.to_scipy()
+        A_dev.free()
+        tmp = tempfile.mkdtemp(prefix="sg_bench_")
+        mpath = os.path.join(tmp, "A.npz")
+        np.savez(mpath, indptr=A_host.indptr.astype(np.int64), indices=A_host.indices, data=A_host.data,
+                 shape=np.array(A_host.shape))
+        common = [sys.executable, "-m", "oracle.baseline", "--matrix", mpath, "--rows", str(args.rows), "--top-n",
+                  str(args.top_n), "--min-similarity", str(args.min_similarity), "--dtype", args.dtype,
+                  "--matches-full", str(result.get("end_to_end", {}).get(args.dtype, {}).get("match_rows", 0))]
+        all_cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+        try:
+            r4 = subprocess.run(common + ["--cores", str(args.cpu_cores), "--multiply-seconds", "10"], cwd=ROOT,
+                                capture_output=True, text=True, timeout=600)
+            base = json.loads(r4.stdout.strip().splitlines()[-1])
+            rall = subprocess.run(common + ["--cores", str(min(all_cores, 64)), "--multiply-seconds", "6",
+                                            "--multiply-only"], cwd=ROOT, capture_output=True, text=True, timeout=600)
+            ball = json.loads(rall.stdout.strip().splitlines()[-1])
+            vec_s = base["vectorise"]["seconds_full_estimate"]
+            tail_s = base["tail"]["seconds_full_estimate"]
+            all_total = vec_s + ball["multiply"]["seconds_full_estimate"] + tail_s
+            result["cpu_baseline"] = {
+                "value": base["value"], "unit": "rows/s", "cores": base["cores"], "kind": "port",
+                "cpu_model": base["cpu_model"], "seconds_full_estimate": base["seconds_full_estimate"],
+                "sample": (f"reference match_strings call sequence restated on sklearn + oracle/sdtn_port.c "
+                           f"(oracle/ref_pipeline.py; the Python reference cannot travel to the GPU box), child process "
+                           f"pinned to {base['cores']} cores, number_of_processes={base['cores']}: full pipeline on "
+                           f"{base['small_run']['rows']} names ({base['small_run']['seconds']:.2f} s) for the three "
+                           f"single-threaded tokenisation passes and the lil/frames tail, scaled by rows / match rows; "
+                           f"multiply = the reference's own block split n_blocks={tuple(base['multiply']['n_blocks'])} "
+                           f"of the full problem for the first {base['multiply']['sample_left_rows']} left rows "
+                           f"({base['multiply']['seconds_sample']:.2f} s), scan part scaled by exact MAC count"),
+                "split_seconds_full_estimate": {"vectorise_3_passes": vec_s,
+                                                "multiply": base["multiply"]["seconds_full_estimate"], "tail": tail_s},
+                "all_cores": {"cores": ball["cores"], "multiply_seconds_full_estimate": ball["multiply"]["seconds_full_estimate"],
+                              "value": args.rows / all_total, "unit": "rows/s",
+                              "note": "same composition with the multiply leg on every core (tokenisation stays single-threaded in the reference)"},
+            }
+        except Exception as e:       # a baseline failure must not lose the GPU line
+            result["cpu_baseline"] = {"error": repr(e)[:300]}
+        finally:
+            try:
+                os.remove(mpath)
+                os.rmdir(tmp)
+            except OSError:
+                pass
+        # the first rows of the C port must equal the GPU rows (parity on the bench workload itself; the
+        # whole 663k x 663k comparison is tests/test_parity_gpu.py::test_headline_663k_...)
+        sample = min(args.rows, 30000)
+        C_cpu = P.sp_matmul_topn_port(A_host[:sample], A_host.T, args.top_n, args.min_similarity, True, min(all_cores, 64))
+        r = step()
+        C_gpu = r.to_scipy()[:sample]
+        r.free()
+        result["parity_on_sample"] = bool(np.array_equal(C_gpu.indptr, C_cpu.indptr) and
+                                          np.array_equal(C_gpu.indices, C_cpu.indices) and
+                                          np.array_equal(C_gpu.data, C_cpu.data))
+        if "value" in result.get("cpu_baseline", {}) and "end_to_end" in result:
+            e2e = result["end_to_end"].get(args.dtype, {})
+            if e2e.get("seconds"):
+                result["end_to_end"]["speedup_vs_cpu_baseline_4_cores"] = \
+                    result["cpu_baseline"]["seconds_full_estimate"] / e2e["seconds"]
 
     sys.stdout.flush()
     os.write(json_fd, (json.dumps(result) + "\n").encode())

@@ -90,6 +90,16 @@ typedef struct {
  * Returns SG_ERR_BADARG with "empty vocabulary" if no n-gram exists at all. */
 int sg_vec_fit(sg_ctx *ctx, const sg_strings *const *sets, int32_t n_sets, const sg_vec_params *params,
                sg_vocab **out);
+/* The two halves of sg_vec_fit, for a caller that shards the strings over several GPUs: every rank tokenises ITS
+ * block (begin), the dense document-frequency tables are summed across ranks (sg_vocab_df_table gives the device
+ * pointer: key_space int32 counters, e.g. for an RCCL all-reduce), and every rank derives the same vocabulary
+ * from the summed table (end; n_docs_total = documents over all ranks, it enters the idf).
+ * *shareable == 0: the keys are coded with the alphabet of the local strings (ngram_size > 3) and the table
+ * must not be combined with another rank's -- fit on the whole column instead. */
+int sg_vec_fit_begin(sg_ctx *ctx, const sg_strings *const *sets, int32_t n_sets, const sg_vec_params *params,
+                     sg_vocab **out);
+int sg_vocab_df_table(sg_vocab *v, int32_t **d_table, int64_t *n_entries, int32_t *shareable);
+int sg_vec_fit_end(sg_ctx *ctx, sg_vocab *v, int64_t n_docs_total);
 int sg_vocab_size(const sg_vocab *v, int64_t *n_terms, int64_t *n_docs);
 /* keys[i]: the n-gram of column i, bytes packed big-endian 7 bits each; df[i]: its document count. */
 int sg_vocab_to_host(sg_ctx *ctx, const sg_vocab *v, uint64_t *keys, int64_t *df);
@@ -186,7 +196,7 @@ int sg_matchlist_group_reps(sg_ctx *ctx, const sg_matchlist *ml, int32_t centroi
 int sg_row_costs(sg_ctx *ctx, const sg_csr *A, const sg_postings *Bt, int64_t *out_cost);
 
 /* ------------------------------------------------------------------ measurement */
-enum { SG_K_TOKENIZE = 0, SG_K_WEIGHT = 1, SG_K_POSTINGS = 2, SG_K_SPGEMM = 3, SG_K_ZIP = 4, SG_K_COUNT = 5 };
+enum { SG_K_TOKENIZE = 0, SG_K_WEIGHT = 1, SG_K_POSTINGS = 2, SG_K_SPGEMM = 3, SG_K_ZIP = 4, SG_K_VOCAB = 5, SG_K_COUNT = 6 };
 typedef struct {
     float ms[SG_K_COUNT];     /* HIP-event time of the most recent launch group of each kernel      */
     int64_t macs;             /* intermediate products of the most recent sg_spgemm_topn            */
@@ -199,6 +209,8 @@ typedef struct {
     int64_t exact_rows;       /* left rows it handed to the exact kernel                            */
     int64_t prune_bytes;      /* its algorithmic bytes: 4 per posting streamed + one packed row of  */
                               /* B (and its two row pointers) per survivor + A + out    */
+    int64_t prune_symmetric;  /* != 0: self-join form (every pair scored once, from the row with    */
+                              /* the larger index, then both rows' lists built from the pair list)  */
 } sg_stats;
 /* Waits for the recorded events, so it is a synchronisation point. */
 int sg_ctx_stats(sg_ctx *ctx, sg_stats *out);

@@ -18,8 +18,8 @@ LIB_PATH = os.environ.get("SG_HIP_LIB") or os.path.join(_HERE, "libsg_hip.so")
 
 SG_OK, SG_ERR_BADARG, SG_ERR_OOM, SG_ERR_OVERFLOW, SG_ERR_HIP, SG_ERR_NODEVICE, SG_ERR_UNSUPPORTED = range(7)
 SG_F32, SG_F64 = 0, 1
-SG_K_TOKENIZE, SG_K_WEIGHT, SG_K_POSTINGS, SG_K_SPGEMM, SG_K_ZIP, SG_K_COUNT = range(6)
-KERNEL_NAMES = ("tokenize", "weight", "postings", "spgemm_topn", "zip")
+SG_K_TOKENIZE, SG_K_WEIGHT, SG_K_POSTINGS, SG_K_SPGEMM, SG_K_ZIP, SG_K_VOCAB, SG_K_COUNT = range(7)
+KERNEL_NAMES = ("tokenize", "weight", "postings", "spgemm_topn", "zip", "vocab")
 
 
 class SgVecParams(C.Structure):
@@ -30,7 +30,8 @@ class SgVecParams(C.Structure):
 class SgStats(C.Structure):
     _fields_ = [("ms", C.c_float * SG_K_COUNT), ("macs", C.c_int64), ("spgemm_bytes", C.c_int64),
                 ("out_nnz", C.c_int64), ("prune_rows", C.c_int64), ("prune_postings", C.c_int64),
-                ("prune_survivors", C.c_int64), ("exact_rows", C.c_int64), ("prune_bytes", C.c_int64)]
+                ("prune_survivors", C.c_int64), ("exact_rows", C.c_int64), ("prune_bytes", C.c_int64),
+                ("prune_symmetric", C.c_int64)]
 
 
 # every symbol include/sg_hip.h declares: name -> (restype, argtypes)
@@ -48,6 +49,9 @@ ABI = {
     "sg_strings_from_device": (C.c_int, [_P, _P, _P, C.c_int64, C.c_int64, _PP]),
     "sg_strings_free": (C.c_int, [_P]),
     "sg_vec_fit": (C.c_int, [_P, _PP, C.c_int32, C.POINTER(SgVecParams), _PP]),
+    "sg_vec_fit_begin": (C.c_int, [_P, _PP, C.c_int32, C.POINTER(SgVecParams), _PP]),
+    "sg_vocab_df_table": (C.c_int, [_P, _PP, C.POINTER(C.c_int64), C.POINTER(C.c_int32)]),
+    "sg_vec_fit_end": (C.c_int, [_P, _P, C.c_int64]),
     "sg_vocab_size": (C.c_int, [_P, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "sg_vocab_to_host": (C.c_int, [_P, _P, _P, _P]),
     "sg_vocab_set_idf": (C.c_int, [_P, _P, _P, C.c_int32]),
@@ -314,7 +318,7 @@ class Context:
         d.update(macs=int(st.macs), spgemm_bytes=int(st.spgemm_bytes), out_nnz=int(st.out_nnz),
                  prune_rows=int(st.prune_rows), prune_postings=int(st.prune_postings),
                  prune_survivors=int(st.prune_survivors), exact_rows=int(st.exact_rows),
-                 prune_bytes=int(st.prune_bytes))
+                 prune_bytes=int(st.prune_bytes), prune_symmetric=int(st.prune_symmetric))
         return d
 
     # ---- strings
@@ -343,6 +347,22 @@ class Context:
         out = C.c_void_p()
         check(lib().sg_vec_fit(self.h, arr, len(sets), C.byref(params), C.byref(out)))
         return Vocab(self, out)
+
+    def vec_fit_begin(self, sets, params: SgVecParams) -> Vocab:
+        """Tokenise + document frequencies of the LOCAL strings; the vocabulary is finished by ``vec_fit_end``."""
+        arr = (C.c_void_p * len(sets))(*[s.h for s in sets])
+        out = C.c_void_p()
+        check(lib().sg_vec_fit_begin(self.h, arr, len(sets), C.byref(params), C.byref(out)))
+        return Vocab(self, out)
+
+    def vocab_df_table(self, v: Vocab):
+        """(device pointer, entries, shareable) of the dense int32 document-frequency table."""
+        p, n, ok = C.c_void_p(), C.c_int64(), C.c_int32()
+        check(lib().sg_vocab_df_table(v.h, C.byref(p), C.byref(n), C.byref(ok)))
+        return p.value, n.value, bool(ok.value)
+
+    def vec_fit_end(self, v: Vocab, n_docs_total: int = 0):
+        check(lib().sg_vec_fit_end(self.h, v.h, int(n_docs_total)))
 
     def vocab_size(self, v: Vocab):
         a, b = C.c_int64(), C.c_int64()

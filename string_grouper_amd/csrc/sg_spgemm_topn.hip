@@ -624,6 +624,7 @@ extern "C" int sg_spgemm_topn(sg_ctx *ctx, const sg_csr *A, const sg_postings *B
         if (symmetric && st == SG_OK)
             st = sg_spgemm_pruned_symmetric(ctx, A, Bt, stride, r, threshold, delta,
                                             (unsigned long long *)(ctx->d_stat_words + 2), &sym_done);
+        ctx->prune_symmetric = sym_done;
         if (prune && !sym_done && st == SG_OK)
             st = sg_spgemm_pruned_launch(ctx, A, Bt, stride, r, threshold, delta, counters + n_launch + 1,
                                          handed_count, handed_rows, (unsigned long long *)(ctx->d_stat_words + 2));

@@ -31,6 +31,8 @@
 #include "sg_internal.h"
 
 #define TOK_CAP 1024            // n-grams per string the device tokeniser handles
+#define SG_KEY_OOV 0xFFFFFFFEu   // key of an n-gram that contains such a character (sorts behind every real key)
+#define SG_CHAR_ABSENT 0xFF     // character code of a byte that did not occur at fit(): its n-grams are out of vocabulary
 #define TOK_CHARS (TOK_CAP + 16)
 
 struct TokenCache {             // tokenised strings in the padded layout
@@ -49,6 +51,7 @@ struct VocabImpl {
     uint8_t byte_of_rank[128];
     int32_t *d_df_table = nullptr; // key_space
     int32_t *d_err = nullptr;      // [0] != 0: a string exceeded TOK_CAP
+    bool local_alphabet = false;   // characters coded by rank among the bytes seen at fit() (ngram_size > 3)
 };
 
 static VocabImpl *impl_of(const sg_vocab *v) { return v ? v->impl : nullptr; }
@@ -149,7 +152,13 @@ __global__ void __launch_bounds__(64) tokenize_kernel(const uint8_t *__restrict_
             uint32_t key = 0xFFFFFFFFu;
             if (idx < g) {
                 key = 0;
-                for (int q = 0; q < p.ngram; ++q) key = (key << p.bits) | chars[idx + q];
+                bool absent = false;   // a character that did not occur at fit(): the n-gram is out of vocabulary
+                for (int q = 0; q < p.ngram; ++q) {
+                    const uint32_t ch = chars[idx + q];
+                    absent |= ch == SG_CHAR_ABSENT;
+                    key = (key << p.bits) | ch;
+                }
+                if (absent) key = SG_KEY_OOV;
             }
             keys[idx] = key;
         }
@@ -189,7 +198,7 @@ __global__ void __launch_bounds__(64) tokenize_kernel(const uint8_t *__restrict_
             out_tf[obase + u] = (int32_t)starts[u + 1] - s0;
             // the same few n-grams ('inc', ' co') occur in a fifth of all strings: spread their atomics over
             // several copies of the table (summed by df_reduce_kernel) instead of serialising on one address
-            if (df_table) atomicAdd(&df_table[(int64_t)(row % df_replicas) * df_stride + key], 1);
+            if (df_table && key != SG_KEY_OOV) atomicAdd(&df_table[(int64_t)(row % df_replicas) * df_stride + key], 1);
         }
         if (lane == 0) out_cnt[row] = uniq;
         wave_sync();
@@ -236,7 +245,10 @@ __global__ void __launch_bounds__(256) kept_count_kernel(const int64_t *__restri
     const int64_t b = ub_ptr[i];
     const int c = cnt[i];
     int k = 0;
-    for (int q = 0; q < c; ++q) k += key_to_col[keys[b + q]] >= 0;
+    for (int q = 0; q < c; ++q) {
+        const uint32_t key = keys[b + q];
+        k += key != SG_KEY_OOV && key_to_col[key] >= 0;
+    }
     kept[i] = k;
 }
 
@@ -264,7 +276,8 @@ __global__ void __launch_bounds__(256) weight_normalize_kernel(const int64_t *__
     const int64_t o0 = o;
     double acc = 0.0;
     for (int q = 0; q < c; ++q) {   // ascending key == ascending column
-        const int32_t col = key_to_col[keys[b + q]];
+        const uint32_t key = keys[b + q];
+        const int32_t col = key != SG_KEY_OOV ? key_to_col[key] : -1;
         if (col < 0) continue;       // out-of-vocabulary n-gram of a string that was not part of fit()
         const T w = tmul<T>((T)tf[b + q], idf[col]);
         out_idx[o] = col;
@@ -338,8 +351,11 @@ static TokParams make_tok_params(const sg_vocab *v, const VocabImpl *im) {
     return tp;
 }
 
-extern "C" int sg_vec_fit(sg_ctx *ctx, const sg_strings *const *sets, int32_t n_sets, const sg_vec_params *params,
-                          sg_vocab **out) {
+// fit = begin (tokenise, count document frequencies into the dense key table) + end (vocabulary from the table).
+// The two halves are separate entry points so that a multi-GPU caller can all-reduce the table in between
+// (one rank tokenises one block of the strings; every rank then derives the SAME vocabulary and idf).
+extern "C" int sg_vec_fit_begin(sg_ctx *ctx, const sg_strings *const *sets, int32_t n_sets, const sg_vec_params *params,
+                                sg_vocab **out) {
     SG_REQUIRE(ctx && sets && params && out && n_sets >= 1, "null argument");
     SG_REQUIRE(params->ngram_size >= 1 && params->ngram_size <= 9, "ngram_size must be in [1, 9]");
     SG_REQUIRE(params->dtype == SG_F32 || params->dtype == SG_F64, "dtype must be SG_F32 or SG_F64");
@@ -379,6 +395,9 @@ extern "C" int sg_vec_fit(sg_ctx *ctx, const sg_strings *const *sets, int32_t n_
         }
         ctx->release(d_present);
         if (st == SG_OK) {
+            // bytes that do not occur get the out-of-alphabet code: an n-gram containing one (only possible in a
+            // later transform() of strings that were not part of fit()) is not in the vocabulary and is skipped
+            for (int c = 0; c < 128; ++c) im->rank_of_byte[c] = SG_CHAR_ABSENT;
             int sigma = 0;
             for (int c = 0; c < 128; ++c)
                 if ((present[c >> 5] >> (c & 31)) & 1u) {
@@ -389,6 +408,7 @@ extern "C" int sg_vec_fit(sg_ctx *ctx, const sg_strings *const *sets, int32_t n_
             int bits = 1;
             while ((1 << bits) < sigma) ++bits;
             v->bits_per_char = bits;
+            im->local_alphabet = true;
             if (bits * params->ngram_size > 30) {
                 sg_set_error("n-gram key space 2^%d (alphabet of %d characters, ngram_size %d) is too large for the "
                              "device vocabulary table", bits * params->ngram_size, sigma, params->ngram_size);
@@ -426,14 +446,44 @@ extern "C" int sg_vec_fit(sg_ctx *ctx, const sg_strings *const *sets, int32_t n_
                 v->n_docs += sets[i]->n;
             }
         }
+        if (st == SG_OK && replicas > 1) {
+            const unsigned grid = (unsigned)((v->key_space + 255) / 256);
+            hipLaunchKernelGGL(df_reduce_kernel, dim3(grid), dim3(256), 0, ctx->stream, im->d_df_table, v->key_space,
+                               replicas, df_stride);
+            if (hipGetLastError() != hipSuccess) st = SG_ERR_HIP;
+        }
+    }
+    if (st != SG_OK) {
+        sg_vocab_free(v);
+        return st;
+    }
+    *out = v;
+    return SG_OK;
+}
+
+extern "C" int sg_vocab_df_table(sg_vocab *v, int32_t **d_table, int64_t *n_entries, int32_t *shareable) {
+    SG_REQUIRE(v && v->impl && d_table && n_entries, "null argument");
+    SG_REQUIRE(v->n_terms == 0, "the vocabulary is already finished");
+    *d_table = v->impl->d_df_table;
+    *n_entries = v->key_space;
+    // a table coded with the alphabet of the LOCAL strings (ngram_size > 3) means something else on every rank
+    if (shareable) *shareable = v->impl->local_alphabet ? 0 : 1;
+    return SG_OK;
+}
+
+extern "C" int sg_vec_fit_end(sg_ctx *ctx, sg_vocab *v, int64_t n_docs_total) {
+    SG_REQUIRE(ctx && v && v->impl, "null argument");
+    SG_REQUIRE(v->n_terms == 0, "the vocabulary is already finished");
+    VocabImpl *im = v->impl;
+    if (n_docs_total > 0) v->n_docs = n_docs_total;
+    int st = SG_OK;
+    {
+        SgTimer timer(ctx, SG_K_VOCAB);
         // ---- vocabulary = keys with df > 0, column id = rank
         uint32_t *d_total = nullptr;
-        if (st == SG_OK) st = sg_alloc(ctx, 4, &d_total);
+        st = sg_alloc(ctx, 4, &d_total);
         if (st == SG_OK) {
             const unsigned grid = (unsigned)((v->key_space + 255) / 256);
-            if (replicas > 1)
-                hipLaunchKernelGGL(df_reduce_kernel, dim3(grid), dim3(256), 0, ctx->stream, im->d_df_table, v->key_space,
-                                   replicas, df_stride);
             hipLaunchKernelGGL(presence_kernel, dim3(grid), dim3(256), 0, ctx->stream, im->d_df_table, v->key_space,
                                (uint32_t *)v->d_key_to_col);
             st = sg_exclusive_scan_u32(ctx, (const uint32_t *)v->d_key_to_col, (uint32_t *)v->d_key_to_col,
@@ -469,6 +519,15 @@ extern "C" int sg_vec_fit(sg_ctx *ctx, const sg_strings *const *sets, int32_t n_
             if (hipGetLastError() != hipSuccess) st = SG_ERR_HIP;
         }
     }
+    return st;
+}
+
+extern "C" int sg_vec_fit(sg_ctx *ctx, const sg_strings *const *sets, int32_t n_sets, const sg_vec_params *params,
+                          sg_vocab **out) {
+    SG_REQUIRE(out != nullptr, "null argument");
+    sg_vocab *v = nullptr;
+    SG_TRY(sg_vec_fit_begin(ctx, sets, n_sets, params, &v));
+    const int st = sg_vec_fit_end(ctx, v, 0);
     if (st != SG_OK) {
         sg_vocab_free(v);
         return st;

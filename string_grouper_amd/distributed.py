@@ -1,20 +1,31 @@
 """Multi-GPU execution of the hot path: one process per GPU, ``torch.distributed`` over RCCL/xGMI.
 
 The rows of ``C = topn(A . B^T)`` are independent and the top-n is taken per LEFT row
-(string_grouper/string_grouper.py:728-729), so the left matrix is cut into contiguous row blocks,
-one per rank (this is the reference's ``n_blocks[0]`` / ``vstack``, :734 and :750 -- concatenation,
-no merge).  The right-hand matrix is needed by every rank: rank 0 vectorises and its CSR is
-broadcast ONCE (three tensors) -- the only collective on the data path; every rank then builds the
-inverted index locally (K3, a few ms) and multiplies its block (K4).  Results stay on the owning
-rank; ``gather_counts`` collects the per-row match counts for reporting.
+(string_grouper/string_grouper.py:728-729), so the left matrix is cut into contiguous row blocks, one per
+rank (the reference's ``n_blocks[0]`` / ``vstack``, :734 and :750 -- concatenation, no merge), and every rank
+needs the whole right-hand matrix.  Round 2 shards the vectoriser as well (round 1 replicated it, which
+bounded strong scaling at ~4x on 8 GPUs):
 
-PyTorch is plumbing here: device tensors to broadcast into, and the process group.  The
-orchestration below is backend-agnostic (tensors in, tensors out) so that the world_size-2 ``gloo``
-tests on CPU exercise the same code path with host tensors.
+  1. every rank tokenises ITS block of every string column (K1) and counts document frequencies into the dense
+     key table;
+  2. ONE all-reduce (sum) of that table (8 MiB of int32 for 3-grams) + the document count: every rank now derives
+     the same vocabulary and idf (string_grouper.py:699-707 fits on master + duplicates);
+  3. every rank weights + normalises its block (K2) -> its rows of the TF-IDF matrices;
+  4. ONE all-gather of the right-hand side's CSR blocks (self-join: of the matrix itself) -> every rank builds
+     the inverted index (K3) and multiplies its left block (K4p / K4);
+  5. results stay on the owning rank (``bench.py``), or the fixed-stride blocks are all-gathered and concatenated
+     on the host for the public API (``DistributedHipEngine`` in engine.py; the north star's "per-block COO results
+     concatenated on host").
+No collective in the steady state of the multiply.  The self-join form of the pruned kernel (every pair scored
+once) is a single-GPU optimisation: with a row block on the left the one-sided kernel runs.
+
+The orchestration below talks to the device through an ``ops`` object (``HipOps`` here; the world_size-2 gloo
+tests on CPU pass a numpy-backed double with the same methods), so the code that shards, reduces, gathers and
+concatenates is the same in both.  PyTorch is plumbing: tensors that alias library memory, and the process group.
 """
 from __future__ import annotations
 
-from typing import Optional, Tuple
+from typing import List, Optional, Sequence, Tuple
 
 import numpy as np
 
@@ -26,6 +37,7 @@ except Exception:  # pragma: no cover - torch is part of the image
     dist = None
 
 
+# ---------------------------------------------------------------------------------------------- row blocks
 def row_block(rank: int, world: int, n_rows: int) -> Tuple[int, int]:
     """Contiguous, balanced row range of ``rank`` (sizes differ by at most one row)."""
     base, extra = divmod(n_rows, world)
@@ -43,6 +55,37 @@ def weighted_row_blocks(row_cost: np.ndarray, world: int) -> np.ndarray:
         cuts.append(int(np.searchsorted(c, total * r / world)))
     cuts.append(len(c))
     return np.maximum.accumulate(np.asarray(cuts, dtype=np.int64))
+
+
+# ---------------------------------------------------------------------------------------------- collectives
+def _all_sizes(n: int, device, group=None) -> List[int]:
+    world = dist.get_world_size(group)
+    mine = torch.tensor([int(n)], dtype=torch.int64, device=device)
+    sizes = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(sizes, mine, group=group)
+    return [int(s.item()) for s in sizes]
+
+
+def all_gather_ragged(t, group=None) -> list:
+    """All ranks' 1-d tensors (different lengths, same dtype) as a list in rank order: one exchange of the
+    lengths, one padded all-gather of the payload."""
+    sizes = _all_sizes(t.numel(), t.device, group)
+    longest = max(max(sizes), 1)
+    padded = torch.zeros(longest, dtype=t.dtype, device=t.device)
+    padded[: t.numel()] = t
+    out = [torch.empty_like(padded) for _ in sizes]
+    dist.all_gather(out, padded, group=group)
+    return [o[:n] for o, n in zip(out, sizes)]
+
+
+def gather_counts(local_counts, n_total: int, group=None):
+    """All ranks' per-row match counts, concatenated in rank order (row blocks are contiguous).  The block
+    sizes are exchanged first: the cuts may be the balanced ones of ``row_block`` or cost-weighted
+    (``weighted_row_blocks``), and only the owning rank knows which."""
+    parts = all_gather_ragged(local_counts, group)
+    if sum(p.numel() for p in parts) != n_total:
+        raise ValueError(f"row blocks of the ranks hold {sum(p.numel() for p in parts)} rows, expected {n_total}")
+    return torch.cat(parts)
 
 
 def broadcast_csr(indptr, indices, data, shape, src: int = 0, device=None, group=None):
@@ -68,25 +111,89 @@ def broadcast_csr(indptr, indices, data, shape, src: int = 0, device=None, group
     return indptr, indices, data, (n_rows, n_cols)
 
 
-def gather_counts(local_counts, n_total: int, group=None):
-    """All ranks' per-row match counts, concatenated in rank order (row blocks are contiguous).  The block
-    sizes are exchanged first: the cuts may be the balanced ones of ``row_block`` or cost-weighted
-    (``weighted_row_blocks``), and only the owning rank knows which."""
-    world = dist.get_world_size(group)
-    mine = torch.tensor([int(local_counts.numel())], dtype=torch.int64, device=local_counts.device)
-    sizes = [torch.zeros_like(mine) for _ in range(world)]
-    dist.all_gather(sizes, mine, group=group)
-    sizes = [int(s.item()) for s in sizes]
-    if sum(sizes) != n_total:
-        raise ValueError(f"row blocks of the ranks hold {sum(sizes)} rows, expected {n_total}")
-    longest = max(max(sizes), 1)
-    padded = torch.zeros(longest, dtype=local_counts.dtype, device=local_counts.device)
-    padded[: local_counts.numel()] = local_counts
-    out = [torch.empty_like(padded) for _ in range(world)]
-    dist.all_gather(out, padded, group=group)
-    return torch.cat([o[:n] for o, n in zip(out, sizes)])
+def all_gather_csr(indptr, indices, data, n_cols: int, group=None):
+    """Concatenate the ranks' CSR row blocks (rank order = row order): returns (indptr, indices, data, shape) of
+    the whole matrix on every rank.  Row pointers are exchanged as row lengths and rebuilt by a prefix sum."""
+    lens = all_gather_ragged((indptr[1:] - indptr[:-1]).to(torch.int64), group)
+    idx = all_gather_ragged(indices, group)
+    val = all_gather_ragged(data, group)
+    row_len = torch.cat(lens)
+    full_ptr = torch.zeros(row_len.numel() + 1, dtype=torch.int64, device=indptr.device)
+    torch.cumsum(row_len, 0, out=full_ptr[1:])
+    return full_ptr, torch.cat(idx), torch.cat(val), (int(row_len.numel()), int(n_cols))
 
 
+# ---------------------------------------------------------------------------------------------- the sharded path
+def sharded_tfidf(ops, local_sets: Sequence, group=None):
+    """Steps 1-3: TF-IDF of the LOCAL blocks of every string column with the vocabulary / idf of ALL ranks' strings
+    (TfidfVectorizer.fit(concat(all strings)) + transform, string_grouper.py:685-707).
+    ``local_sets``: this rank's block of each column, e.g. [master block] or [master block, duplicates block].
+    Returns (fit state, [local CSR of each set])."""
+    state = ops.fit_begin(local_sets)
+    df = ops.df_tensor(state)                                   # dense int32 table over the n-gram key space
+    n_docs = torch.tensor([sum(ops.n_strings(s) for s in local_sets)], dtype=torch.int64, device=df.device)
+    if dist.get_world_size(group) > 1:
+        if not ops.df_shareable(state):
+            raise NotImplementedError("ngram_size > 3 codes characters by their rank among the LOCAL strings; "
+                                      "the sharded vectoriser needs the shared 7-bit coding (ngram_size <= 3)")
+        dist.all_reduce(df, op=dist.ReduceOp.SUM, group=group)
+        dist.all_reduce(n_docs, op=dist.ReduceOp.SUM, group=group)
+    ops.fit_end(state, int(n_docs.item()))
+    return state, [ops.transform(state, s) for s in local_sets]
+
+
+def replicate_csr(ops, local_csr, group=None):
+    """Step 4a: the whole matrix on every rank from the ranks' row blocks."""
+    if dist.get_world_size(group) == 1:
+        return local_csr
+    ip, ix, d = ops.csr_tensors(local_csr)
+    n_cols = ops.csr_shape(local_csr)[1]
+    return ops.csr_from_tensors(*all_gather_csr(ip, ix, d, n_cols, group))
+
+
+def sharded_topn(ops, left_local, right_full, top_n: int, threshold: float, tile_cols: int = 0):
+    """Step 4b: inverted index of the whole right-hand side, multiply of the local left rows."""
+    post = ops.postings(right_full, tile_cols)
+    res = ops.multiply(left_local, post, top_n, threshold)
+    ops.keep_alive(res, post, left_local, right_full)
+    return res
+
+
+def gather_topn(ops, res, group=None):
+    """Step 5 for the public API: every rank's fixed-stride block, all-gathered and concatenated in row order
+    on the HOST (the reference's vstack, string_grouper.py:750).  Returns (cols [n, stride], vals [n, stride],
+    counts [n]) as numpy arrays, identical on every rank."""
+    cols, vals, counts = ops.topn_tensors(res)
+    stride = cols.shape[1] if cols.dim() == 2 else 1
+    if dist.get_world_size(group) > 1:
+        strides = _all_sizes(stride, counts.device, group)
+        if len(set(strides)) != 1:
+            raise RuntimeError(f"ranks disagree on the result stride: {strides}")
+        cols = torch.cat(all_gather_ragged(cols.reshape(-1), group)).reshape(-1, stride)
+        vals = torch.cat(all_gather_ragged(vals.reshape(-1), group)).reshape(-1, stride)
+        counts = torch.cat(all_gather_ragged(counts, group))
+    return cols.cpu().numpy(), vals.cpu().numpy(), counts.cpu().numpy()
+
+
+def distributed_self_join(ops, local_block, top_n: int, threshold: float, group=None, tile_cols: int = 0):
+    """Self-join of a string column of which this rank holds ``local_block`` (rows in rank order).
+    Returns (TopN of the local rows -- columns index the WHOLE column --, fit state)."""
+    state, (A_local,) = sharded_tfidf(ops, [local_block], group)
+    A_full = replicate_csr(ops, A_local, group)
+    return sharded_topn(ops, A_local, A_full, top_n, threshold, tile_cols), state
+
+
+def distributed_match(ops, master_block, duplicates_block, top_n: int, threshold: float, group=None,
+                      tile_cols: int = 0):
+    """master x duplicates (BASELINE.json configs[4]; string_grouper.py:286-290, :728-729: rows = master): this rank
+    holds a block of BOTH columns; the vocabulary is fitted on all of both; the master block stays where it is,
+    the duplicates' rows are replicated; every rank multiplies its master rows with all duplicates."""
+    state, (A_local, B_local) = sharded_tfidf(ops, [master_block, duplicates_block], group)
+    B_full = replicate_csr(ops, B_local, group)
+    return sharded_topn(ops, A_local, B_full, top_n, threshold, tile_cols), state
+
+
+# ---------------------------------------------------------------------------------------------- HIP adapter
 class DeviceTensorView:
     """Zero-copy torch view of library-owned device memory (``__cuda_array_interface__``)."""
 
@@ -109,13 +216,86 @@ def csr_as_torch(csr) -> tuple:
 
 
 def csr_from_torch(ctx, indptr, indices, data, shape):
-    """Wrap broadcast tensors as a device CSR of the HIP library (no copy; tensors are kept alive)."""
+    """Wrap tensors as a device CSR of the HIP library (no copy; tensors are kept alive)."""
     nnz = int(indices.numel())
     dtype = np.float64 if data.dtype == torch.float64 else np.float32
+    indptr, indices, data = indptr.contiguous(), indices.contiguous(), data.contiguous()
     return ctx.csr_from_device(shape[0], shape[1], nnz, indptr.data_ptr(), indices.data_ptr() if nnz else 0,
                                data.data_ptr() if nnz else 0, dtype, keepalive=(indptr, indices, data))
 
 
+class HipOps:
+    """The device side of the sharded path on the MI355X library."""
+
+    def __init__(self, ctx, vectorizer_factory):
+        self.ctx = ctx
+        self.make_vec = vectorizer_factory
+        self.device = torch.device("cuda", ctx.device)
+
+    def _sync(self):
+        # the library launches on its own stream (or torch's current one): hand-offs between the two are ordered
+        # by a full synchronisation -- a handful per fit(), each a few microseconds when nothing is pending
+        self.ctx.sync()
+        torch.cuda.current_stream(self.device).synchronize()
+
+    def n_strings(self, prepared) -> int:
+        return prepared.n
+
+    def fit_begin(self, local_sets):
+        vec = self.make_vec()
+        vec.fit_begin_prepared(list(local_sets))
+        return vec
+
+    def df_tensor(self, vec):
+        ptr, n, _ = vec.df_table()
+        self._sync()
+        return torch.as_tensor(DeviceTensorView(ptr, n, "<i4"), device=self.device)
+
+    def df_shareable(self, vec) -> bool:
+        return vec.df_table()[2]
+
+    def fit_end(self, vec, n_docs_total: int):
+        self._sync()
+        vec.fit_end(n_docs_total)
+
+    def transform(self, vec, prepared):
+        return vec.transform_prepared(prepared)
+
+    def csr_tensors(self, csr):
+        self._sync()
+        return csr_as_torch(csr)
+
+    def csr_shape(self, csr):
+        return csr.dims()[:2]
+
+    def csr_from_tensors(self, indptr, indices, data, shape):
+        self._sync()
+        return csr_from_torch(self.ctx, indptr, indices, data, shape)
+
+    def postings(self, csr, tile_cols: int = 0):
+        return self.ctx.postings_build(csr, tile_cols)
+
+    def multiply(self, left, post, top_n, threshold):
+        return self.ctx.spgemm_topn(left, post, top_n, threshold, True)
+
+    def keep_alive(self, res, *objs):
+        res._keep = objs
+
+    def topn_tensors(self, res):
+        import ctypes as C
+        from . import _native as N
+        r, s, d, _ = res.dims()
+        pc, pv, pn = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        N.check(N.lib().sg_topn_device_ptrs(res.h, C.byref(pc), C.byref(pv), C.byref(pn)))
+        self._sync()
+        cols = torch.as_tensor(DeviceTensorView(pc.value, max(r * s, 1), "<i4"), device=self.device)[:r * s].reshape(r, s)
+        vals = torch.as_tensor(DeviceTensorView(pv.value, max(r * s, 1), "<f8" if d == N.SG_F64 else "<f4"),
+                               device=self.device)[:r * s].reshape(r, s)
+        counts = torch.as_tensor(DeviceTensorView(pn.value, max(r, 1), "<i4"), device=self.device)[:r]
+        return cols, vals, counts
+
+
+# ---------------------------------------------------------------------------------------------- string exchange
 def strings_to_device_tensors(prepared, device):
     """(bytes, offsets) of a PreparedStrings as torch tensors on ``device`` (done once, outside any
     timed region; the tensors own the HBM copy that ``broadcast_strings`` sends)."""
@@ -125,13 +305,30 @@ def strings_to_device_tensors(prepared, device):
     return t_bytes, t_offs
 
 
+def _wrap_device_strings(ctx, t_bytes, t_offs, n: int, total: int):
+    from .vectorizer import PreparedStrings
+    p = object.__new__(PreparedStrings)
+    p.data, p.offsets, p.n = None, None, n
+    p.dev = ctx.strings_from_device(t_bytes.data_ptr(), t_offs.data_ptr(), n, total, keepalive=(t_bytes, t_offs))
+    return p
+
+
+def local_string_block(ctx, t_bytes, t_offs, rank: int, world: int):
+    """This rank's contiguous block of a string column that is resident in HBM (bytes + int64 offsets tensors of the
+    WHOLE column): a view, offsets rebased on the device.  Returns (PreparedStrings of the block, (lo, hi))."""
+    n = int(t_offs.numel()) - 1
+    lo, hi = row_block(rank, world, n)
+    b0, b1 = int(t_offs[lo].item()), int(t_offs[hi].item())
+    offs = (t_offs[lo:hi + 1] - b0).contiguous()
+    bytes_ = t_bytes[b0:max(b1, b0 + 1)].contiguous() if b1 > b0 else torch.zeros(1, dtype=torch.uint8, device=t_bytes.device)
+    torch.cuda.current_stream(t_bytes.device).synchronize()
+    return _wrap_device_strings(ctx, bytes_, offs, hi - lo, b1 - b0), (lo, hi)
+
+
 def broadcast_strings(ctx, t_bytes, t_offs, src: int = 0, group=None):
     """Broadcast a string column that is resident in HBM on ``src`` (UTF-8 bytes uint8 tensor + int64
-    offsets tensor; other ranks pass None, None) to every rank over RCCL and wrap it as device strings
-    of the HIP library (no copy).  This is the one exchange step of the sharded path: the strings are
-    ~5x smaller than the TF-IDF CSR (21 MB vs 105 MB at 663 k), and every rank can then vectorise by
-    itself instead of waiting for rank ``src``."""
-    from .vectorizer import PreparedStrings
+    offsets tensor; other ranks pass None, None) to every rank over RCCL.  Returns (PreparedStrings of the whole
+    column, bytes tensor, offsets tensor).  21 MB at 663 k names -- a fifth of the TF-IDF CSR."""
     rank = dist.get_rank(group)
     dev = torch.device("cuda", ctx.device)
     header = torch.zeros(2, dtype=torch.int64, device=dev)
@@ -146,12 +343,10 @@ def broadcast_strings(ctx, t_bytes, t_offs, src: int = 0, group=None):
     dist.broadcast(t_bytes, src=src, group=group)
     dist.broadcast(t_offs, src=src, group=group)
     torch.cuda.current_stream(dev).synchronize()
-    p = object.__new__(PreparedStrings)
-    p.data, p.offsets, p.n = None, None, n
-    p.dev = ctx.strings_from_device(t_bytes.data_ptr(), t_offs.data_ptr(), n, total, keepalive=(t_bytes, t_offs))
-    return p
+    return _wrap_device_strings(ctx, t_bytes, t_offs, n, total), t_bytes, t_offs
 
 
+# ---------------------------------------------------------------------------------------------- round-1 forms
 def pruned_multiply_expected(top_n: int, threshold: float) -> bool:
     """The library's rule for taking the pruned multiply on TF-IDF input (sg_spgemm_topn).
     Its cost per left row is nearly uniform (the column-tile loop dominates), whereas the exact kernel's
@@ -164,14 +359,11 @@ def pruned_multiply_expected(top_n: int, threshold: float) -> bool:
 
 def sharded_self_join_replicated(ctx, prepared_dev, vectorizer_factory, top_n: int, threshold: float,
                                  group=None, tile_cols: int = 0, balance: Optional[bool] = None):
-    """Strong-scaled self-join when every rank holds the string column in HBM (after
-    ``broadcast_strings``): each rank vectorises (K1 + K2, ~4 ms at 663 k -- cheaper than receiving the
-    CSR), builds the postings (K3) and multiplies ITS contiguous block of left rows (K4).  No collective
-    inside.  ``balance``: cut the rows so that every rank gets the same number of intermediate products
-    (sg_row_costs) instead of the same number of rows -- matters for the exact kernel when the input is
-    sorted; default: only when the exact kernel will run (the pruned kernel's cost per row is uniform and
-    the cost pass + its host round trip would cost more than they save).  Returns (TopN of the local
-    block, (row_lo, row_hi), n_rows_total)."""
+    """Round 1's form: every rank holds the whole string column, vectorises ALL of it (replicated K1 + K2), builds
+    the postings and multiplies its block of left rows.  No collective inside; kept for ngram_size > 3 (whose
+    character coding cannot be shared) and for cost-balanced cuts with the exact kernel.  ``balance``: cut the rows
+    so that every rank gets the same number of intermediate products (sg_row_costs) instead of the same number of
+    rows.  Returns (TopN of the local block, (row_lo, row_hi), n_rows_total)."""
     rank, world = dist.get_rank(group), dist.get_world_size(group)
     if balance is None:
         balance = not pruned_multiply_expected(top_n, threshold)
@@ -195,10 +387,9 @@ def sharded_self_join_replicated(ctx, prepared_dev, vectorizer_factory, top_n: i
 
 def sharded_self_join(ctx, prepared_strings_or_none, vectorizer_factory, top_n: int, threshold: float,
                       group=None, tile_cols: int = 0):
-    """Strong-scaled self-join, CSR-broadcast form (BASELINE.json's description of the path).
-
-    Rank 0 vectorises (``prepared_strings_or_none`` is its PreparedStrings, other ranks pass None),
-    broadcasts the TF-IDF CSR over RCCL, every rank builds the postings and multiplies its row block.
+    """Strong-scaled self-join, CSR-broadcast form (BASELINE.json's literal description of the path): rank 0
+    vectorises (``prepared_strings_or_none`` is its PreparedStrings, other ranks pass None), broadcasts the TF-IDF
+    CSR over RCCL, every rank builds the postings and multiplies its row block.
     Returns (TopN result of the local block, (row_lo, row_hi), n_rows_total)."""
     rank, world = dist.get_rank(group), dist.get_world_size(group)
     dev = torch.device("cuda", ctx.device)

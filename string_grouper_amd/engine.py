@@ -8,6 +8,7 @@ engine in this package and ``get_engine()`` raises if the HIP library cannot be 
 """
 from __future__ import annotations
 
+import time
 from typing import List, Optional, Sequence, Tuple
 
 import numpy as np
@@ -66,6 +67,14 @@ class HipEngine:
 
     def __init__(self, ctx: Optional[N.Context] = None):
         self._ctx = ctx
+        # wall-clock split of the most recent fit() through this engine (seconds): host string preparation +
+        # upload, device vectorise, device multiply + match list, download.  Read by bench.py (end_to_end).
+        self.timings = {}
+
+    def _tick(self, name: str, t0: float) -> float:
+        now = time.perf_counter()
+        self.timings[name] = self.timings.get(name, 0.0) + now - t0
+        return now
 
     @property
     def ctx(self) -> N.Context:
@@ -79,14 +88,18 @@ class HipEngine:
         tokenisation pass per series: transform reuses the tokens of fit."""
         vec = HipTfidfVectorizer(ngram_size=ngram_size, regex=regex, ignore_case=ignore_case,
                                  normalize_to_ascii=normalize_to_ascii, dtype=dtype, ctx=self.ctx)
+        self.timings = {}
+        t = time.perf_counter()
         pm = vec.prepare(master)
         sets = [pm]
         if duplicates is not None:
             pd_ = vec.prepare(duplicates)
             sets.append(pd_)
+        t = self._tick("prepare_and_upload_s", t)
         vec.fit_prepared(sets)
         A = DeviceMatrix(vec.transform_prepared(pm))
         B = A if duplicates is None else DeviceMatrix(vec.transform_prepared(sets[1]))
+        self._tick("vectorise_s", t)             # fit_prepared reads the vocabulary back: a synchronisation point
         return A, B, vec
 
     def wrap(self, m) -> DeviceMatrix:
@@ -154,18 +167,25 @@ class HipEngine:
         similarity, true_max_n_matches).  ``self_join_fix``: set the diagonal to 1 and symmetrise
         (string_grouper.py:419-427); the rows then come back sorted by column.  ``keep_on_device``: a fifth
         element, the device-resident list (``DeviceMatchList``), for the reductions over it (K7, K8)."""
+        t = time.perf_counter()
         res = self._topn_device(A, B, top_n, threshold)
+        return self._match_list_from_topn(res, A.dtype, B.shape[0], self_join_fix, keep_on_device, t)
+
+    def _match_list_from_topn(self, res: "N.TopN", dtype, n_cols: int, self_join_fix: bool, keep_on_device: bool,
+                              t: float):
         cnt = res.counts()
         true_max = int(cnt.max()) if len(cnt) else 0
+        t = self._tick("multiply_s", t)           # counts() waits for the multiply
         # the reference up-casts a float32 result to float64 through scipy (vstack(dtype=float64), :750),
         # which re-sorts every row by column; a float64 result keeps the multiply's score-descending order
         ml = self.ctx.matchlist_build(res, self_join_fix, self_join_fix,
-                                      sort_by_column=(not self_join_fix) and A.dtype == np.float32)
+                                      sort_by_column=(not self_join_fix) and dtype == np.float32)
         row_ptr, cols, vals = ml.to_host()
+        t = self._tick("match_list_and_download_s", t)
         res.free()
         rows = np.repeat(np.arange(len(row_ptr) - 1, dtype=np.int64), np.diff(row_ptr))
         if keep_on_device:
-            return rows, cols.astype(np.int64), vals, true_max, DeviceMatchList(ml, B.shape[0])
+            return rows, cols.astype(np.int64), vals, true_max, DeviceMatchList(ml, n_cols)
         ml.free()
         return rows, cols.astype(np.int64), vals, true_max
 
@@ -200,6 +220,104 @@ class HipEngine:
         if not stacked:
             return sp.csr_matrix((A.shape[0], B.shape[0]), dtype=np.float64)
         return sp.vstack(stacked, dtype=np.float64).tocsr()
+
+
+class ShardedMatrix(DeviceMatrix):
+    """This rank's contiguous row block of a TF-IDF matrix whose other rows live on the other ranks.  ``shape`` is
+    the shape of the WHOLE matrix (what the front end reasons about); ``csr`` holds rows [lo, hi)."""
+
+    def __init__(self, csr: "N.Csr", n_total: int, row_range: Tuple[int, int], ops, group):
+        super().__init__(csr)
+        self.local_shape = self.shape
+        self.shape = (n_total, self.shape[1])
+        self.row_range = row_range
+        self._ops, self._group = ops, group
+        self._full: Optional["N.Csr"] = None
+
+    def full(self) -> "N.Csr":
+        """The whole matrix on this rank (one all-gather of the ranks' blocks, cached)."""
+        if self._full is None:
+            from . import distributed as D
+            self._full = D.replicate_csr(self._ops, self.csr, self._group)
+        return self._full
+
+    def to_scipy(self) -> sp.csr_matrix:
+        if self._host is None:
+            self._host = self.full().to_scipy()
+        return self._host
+
+
+class DistributedHipEngine(HipEngine):
+    """The engine behind ``fit()`` when the process is one rank of a ``torch.distributed`` group (one process per
+    GPU, RCCL): every rank runs the SAME script on the SAME input Series and gets the SAME results.  The ranks split
+    the rows of every string column (vectorise), all-reduce the document frequencies, all-gather the right-hand
+    TF-IDF rows, multiply their block of left rows and all-gather the fixed-stride results, which are concatenated
+    on the host (string_grouper.py:750 vstack) -- string_grouper_amd/distributed.py.  The tail of fit() (match
+    list, groups) then runs on every rank's GPU over the whole result, as on one GPU."""
+    name = "hip-distributed"
+
+    def __init__(self, ctx: Optional[N.Context] = None, group=None):
+        super().__init__(ctx)
+        self.group = group
+
+    def tfidf(self, master, duplicates, ngram_size, regex, ignore_case, normalize_to_ascii, dtype):
+        import torch.distributed as dist
+        from . import distributed as D
+        rank, world = dist.get_rank(self.group), dist.get_world_size(self.group)
+
+        def factory():
+            return HipTfidfVectorizer(ngram_size=ngram_size, regex=regex, ignore_case=ignore_case,
+                                      normalize_to_ascii=normalize_to_ascii, dtype=dtype, ctx=self.ctx)
+        ops = D.HipOps(self.ctx, factory)
+        self.timings = {}
+        t = time.perf_counter()
+        probe = factory()
+        ranges, blocks = [], []
+        for series in ([master] if duplicates is None else [master, duplicates]):
+            lo, hi = D.row_block(rank, world, len(series))
+            ranges.append((lo, hi))
+            blocks.append(probe.prepare(series.iloc[lo:hi] if hasattr(series, "iloc") else series[lo:hi]))
+        t = self._tick("prepare_and_upload_s", t)
+        vec, mats = D.sharded_tfidf(ops, blocks, self.group)
+        self._tick("vectorise_s", t)
+        A = ShardedMatrix(mats[0], len(master), ranges[0], ops, self.group)
+        B = A if duplicates is None else ShardedMatrix(mats[1], len(duplicates), ranges[1], ops, self.group)
+        return A, B, vec
+
+    def _topn_device(self, A, B, top_n: int, threshold: float) -> "N.TopN":
+        if not isinstance(A, ShardedMatrix):
+            return super()._topn_device(A, B, top_n, threshold)      # replicated inputs: every rank does it all
+        from . import distributed as D
+        right = B.full() if isinstance(B, ShardedMatrix) else B.csr
+        res_local = D.sharded_topn(A._ops, A.csr, right, top_n, threshold)
+        cols, vals, counts = D.gather_topn(A._ops, res_local, self.group)
+        res_local.free()
+        return self.ctx.topn_from_host(cols, vals, counts, B.shape[0])
+
+    def rowwise_dot(self, A, B) -> np.ndarray:
+        """Row-wise similarity: local rows on the device (K9), the ranks' pieces concatenated."""
+        if not isinstance(A, ShardedMatrix):
+            return super().rowwise_dot(A, B)
+        import torch
+        from . import distributed as D
+        local = self.ctx.rowwise_dot(A.csr, B.csr)
+        parts = D.all_gather_ragged(torch.from_numpy(np.ascontiguousarray(local)).to(A._ops.device), self.group)
+        return torch.cat(parts).cpu().numpy()
+
+    def topn_multiply_blocked(self, A, B, n_blocks, top_n, threshold):
+        if isinstance(A, ShardedMatrix):          # explicit n_blocks only cut the work differently: same result
+            return self.topn_multiply(A, B, top_n, threshold).astype(np.float64)
+        return super().topn_multiply_blocked(A, B, n_blocks, top_n, threshold)
+
+
+def enable_distributed(group=None, ctx: Optional[N.Context] = None) -> "HipEngine":
+    """Make fit() of this process use all ranks of the (already initialised) ``torch.distributed`` process group.
+    Call on every rank after ``dist.init_process_group("nccl")`` and ``torch.cuda.set_device(local_rank)``."""
+    import torch.distributed as dist
+    N.lib()
+    eng = DistributedHipEngine(ctx, group) if dist.is_initialized() and dist.get_world_size(group) > 1 else HipEngine(ctx)
+    set_engine(eng)
+    return eng
 
 
 _engine = None

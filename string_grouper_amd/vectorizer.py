@@ -206,6 +206,27 @@ class HipTfidfVectorizer:
         self._vocabulary = None
         return self
 
+    # ---- the two halves of fit for a caller that shards the strings over several GPUs (distributed.py)
+    def fit_begin_prepared(self, sets: Sequence[PreparedStrings]) -> "HipTfidfVectorizer":
+        """Tokenise the LOCAL sets and count their document frequencies; ``df_table()`` is then summed across
+        ranks and ``fit_end`` finishes the vocabulary + idf identically on every rank."""
+        self._vocab = self.ctx.vec_fit_begin([s.dev for s in sets], self._params)
+        self._fit_sets = list(sets)
+        return self
+
+    def df_table(self):
+        """(device pointer, entries, shareable) of the dense int32 document-frequency table of ``fit_begin``."""
+        return self.ctx.vocab_df_table(self._vocab)
+
+    def fit_end(self, n_docs_total: int = 0) -> "HipTfidfVectorizer":
+        self.ctx.vec_fit_end(self._vocab, n_docs_total)
+        n_terms, n_docs = self.ctx.vocab_size(self._vocab)
+        self._keys, self._df = self.ctx.vocab_to_host(self._vocab)
+        self.idf_ = idf_from_df(self._df, n_docs, self.dtype)
+        self.ctx.vocab_set_idf(self._vocab, self.idf_)
+        self._vocabulary = None
+        return self
+
     def transform_prepared(self, s: PreparedStrings) -> N.Csr:
         if self._vocab is None:
             raise RuntimeError("vectoriser is not fitted")

@@ -1,0 +1,112 @@
+"""numpy / oracle double of ``string_grouper_amd.distributed.HipOps`` for the world_size-2 gloo tests on CPU: same
+methods, CPU torch tensors, the oracle's arithmetic.  TEST INFRASTRUCTURE ONLY.  The code under test is the
+orchestration in string_grouper_amd/distributed.py (sharding, the df all-reduce, the ragged all-gathers, the
+concatenation), which is the same code the GPU path runs."""
+import numpy as np
+import scipy.sparse as sp
+import torch
+
+from oracle import oracle as O
+from oracle import port as P
+
+KEY_BITS = 7
+NGRAM = 3
+KEY_SPACE = 1 << (KEY_BITS * NGRAM)
+
+
+def _keys_of(strings):
+    """Per string the packed keys of its 3-grams (the device's coding: 7 bits per character, big-endian)."""
+    out = []
+    for s in strings:
+        grams = O.ngrams(s, NGRAM)
+        out.append(np.array([(ord(g[0]) << 14) | (ord(g[1]) << 7) | ord(g[2]) for g in grams], dtype=np.int64))
+    return out
+
+
+class _State:
+    def __init__(self, dtype):
+        self.dtype = dtype
+        self.df = torch.zeros(KEY_SPACE, dtype=torch.int32)
+        self.keys_of_set = {}
+        self.key_to_col = None
+        self.idf = None
+
+
+class NumpyOps:
+    device = torch.device("cpu")
+
+    def __init__(self, dtype=np.float32):
+        self.dtype = dtype
+
+    def n_strings(self, strings):
+        return len(strings)
+
+    def fit_begin(self, local_sets):
+        st = _State(self.dtype)
+        df = np.zeros(KEY_SPACE, np.int32)
+        for s in local_sets:
+            ks = _keys_of(s)
+            st.keys_of_set[id(s)] = ks
+            for k in ks:
+                df[np.unique(k)] += 1
+        st.df = torch.from_numpy(df)
+        return st
+
+    def df_tensor(self, st):
+        return st.df
+
+    def df_shareable(self, st):
+        return True
+
+    def fit_end(self, st, n_docs_total):
+        df = st.df.numpy()
+        present = np.flatnonzero(df > 0)
+        st.key_to_col = np.full(KEY_SPACE, -1, np.int64)
+        st.key_to_col[present] = np.arange(len(present))
+        st.idf = O.idf_vector(df[present], n_docs_total, self.dtype)
+
+    def transform(self, st, strings):
+        ks = st.keys_of_set.get(id(strings)) or _keys_of(strings)
+        indptr, indices, data = [0], [], []
+        for k in ks:
+            cols = st.key_to_col[k]
+            cols = cols[cols >= 0]
+            u, c = np.unique(cols, return_counts=True)
+            indices.extend(u.tolist())
+            data.extend(c.tolist())
+            indptr.append(len(indices))
+        X = sp.csr_matrix((np.asarray(data, dtype=self.dtype), np.asarray(indices, np.int32), np.asarray(indptr, np.int32)),
+                          shape=(len(ks), len(st.idf)))
+        return O.tfidf_weight_normalize(X, st.idf)
+
+    def csr_tensors(self, m):
+        return (torch.from_numpy(m.indptr.astype(np.int64)), torch.from_numpy(m.indices.astype(np.int32)),
+                torch.from_numpy(np.ascontiguousarray(m.data)))
+
+    def csr_shape(self, m):
+        return m.shape
+
+    def csr_from_tensors(self, indptr, indices, data, shape):
+        return sp.csr_matrix((data.numpy(), indices.numpy(), indptr.numpy()), shape=shape)
+
+    def postings(self, m, tile_cols=0):
+        return m
+
+    def multiply(self, left, right, top_n, threshold):
+        C = P.sp_matmul_topn_port(left, right.T, top_n, threshold, True, 2)
+        stride = max(1, min(top_n, right.shape[0]))
+        n = left.shape[0]
+        cols = np.zeros((n, stride), np.int32)
+        vals = np.zeros((n, stride), self.dtype)
+        cnt = np.diff(C.indptr).astype(np.int32)
+        for i in range(n):
+            lo, hi = C.indptr[i], C.indptr[i + 1]
+            cols[i, :hi - lo] = C.indices[lo:hi]
+            vals[i, :hi - lo] = C.data[lo:hi]
+        return cols, vals, cnt
+
+    def keep_alive(self, res, *objs):
+        pass
+
+    def topn_tensors(self, res):
+        return torch.from_numpy(res[0]), torch.from_numpy(res[1]), torch.from_numpy(res[2])

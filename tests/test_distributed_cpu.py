@@ -78,3 +78,84 @@ def test_broadcast_shard_gather_world2():
     ret = mgr.dict()
     mp.spawn(_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
     assert dict(ret) == {0: True, 1: True}
+
+
+def _expected(names_m, names_d, top_n, thr, dtype):
+    from oracle import oracle as O
+    from oracle import port as P
+    if names_d is None:
+        (A,), _, _ = O.tfidf_sklearn(names_m, [names_m], dtype=dtype)
+        B = A
+    else:
+        (A, B), _, _ = O.tfidf_sklearn(names_m + names_d, [names_m, names_d], dtype=dtype)
+    return A, B, P.sp_matmul_topn_port(A, B.T, top_n, thr, True, 2)
+
+
+def _csr_of(cols, vals, counts, n_cols):
+    indptr = np.zeros(len(counts) + 1, np.int64)
+    np.cumsum(counts, out=indptr[1:])
+    mask = np.arange(cols.shape[1])[None, :] < counts[:, None]
+    return sp.csr_matrix((vals[mask], cols[mask], indptr), shape=(len(counts), n_cols))
+
+
+def _sharded_worker(rank, world, port, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from string_grouper_amd.synth import synth_names
+        from tests._numpy_ops import NumpyOps
+        ops = NumpyOps(np.float32)
+        ok = {}
+        # ---- self-join: every rank tokenises its block, df all-reduce, CSR all-gather, local multiply, result gather
+        names = synth_names(2501, 42) + ["", "AB", "ACME HOLDINGS INC"] * 3          # odd size: uneven blocks
+        lo, hi = D.row_block(rank, world, len(names))
+        res, state = D.distributed_self_join(ops, names[lo:hi], 10, 0.8)
+        cols, vals, counts = D.gather_topn(ops, res)
+        A, _, C = _expected(names, None, 10, 0.8, np.float32)
+        got = _csr_of(cols, vals, counts, len(names))
+        ok["selfjoin_counts"] = np.array_equal(np.diff(got.indptr), np.diff(C.indptr))
+        ok["selfjoin_indices"] = np.array_equal(got.indices, C.indices)
+        ok["selfjoin_scores"] = np.array_equal(got.data, C.data)
+        ok["idf"] = np.array_equal(state.idf, O_idf(names, np.float32))
+        # the replicated matrix equals the single-process TF-IDF matrix bit for bit
+        full = D.replicate_csr(ops, ops.transform(state, names[lo:hi]))
+        ok["replicated_matrix"] = (np.array_equal(full.indptr, A.indptr) and np.array_equal(full.indices, A.indices)
+                                   and np.array_equal(full.data, A.data))
+        # ---- master x duplicates (configs[4]): both columns sharded, vocabulary from both, duplicates replicated
+        master = synth_names(1800, 7)
+        dups = synth_names(901, 8, perturb_of=master, perturb_frac=0.5)
+        mlo, mhi = D.row_block(rank, world, len(master))
+        dlo, dhi = D.row_block(rank, world, len(dups))
+        res, _ = D.distributed_match(ops, master[mlo:mhi], dups[dlo:dhi], 20, 0.7)
+        cols, vals, counts = D.gather_topn(ops, res)
+        _, _, C = _expected(master, dups, 20, 0.7, np.float32)
+        got = _csr_of(cols, vals, counts, len(dups))
+        ok["match_counts"] = np.array_equal(np.diff(got.indptr), np.diff(C.indptr))
+        ok["match_indices"] = np.array_equal(got.indices, C.indices)
+        ok["match_scores"] = np.array_equal(got.data, C.data)
+        # ---- gather_counts with cost-weighted (uneven) cuts
+        cuts = D.weighted_row_blocks(np.arange(1, 101) ** 2, world)
+        mine = torch.arange(int(cuts[rank]), int(cuts[rank + 1]), dtype=torch.int32)
+        ok["weighted_gather"] = D.gather_counts(mine, 100).tolist() == list(range(100))
+        ret[rank] = ok
+    finally:
+        dist.destroy_process_group()
+
+
+def O_idf(names, dtype):
+    from oracle import oracle as O
+    _, _, idf = O.tfidf_sklearn(names, [names], dtype=dtype)
+    return idf
+
+
+@pytest.mark.timeout(600)
+def test_sharded_vectoriser_gather_and_match_world2():
+    """The round-2 sharded path on 2 gloo ranks: df all-reduce, CSR all-gather, self-join and master x duplicates,
+    concatenation on the host -- bit-identical to the single-process oracle."""
+    world = 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_sharded_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
+    for r in range(world):
+        assert all(ret[r].values()), (r, dict(ret[r]))

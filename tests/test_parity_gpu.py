@@ -303,10 +303,48 @@ def test_device_resident_inputs_and_rccl_plumbing(ctx):
         assert counts.cpu().numpy().tolist() == np.diff(C_ref.indptr).tolist()
         # string-broadcast form (what bench.py uses for N > 1)
         tb, to = D.strings_to_device_tensors(p, torch.device("cuda", 0))
-        local = D.broadcast_strings(ctx, tb, to)
+        local, tb2, to2 = D.broadcast_strings(ctx, tb, to)
         res2, blk, n2 = D.sharded_self_join_replicated(ctx, local, lambda: HipTfidfVectorizer(dtype=np.float32, ctx=ctx), 10, 0.8)
         assert blk == (0, len(names)) and n2 == len(names)
         assert_csr_identical(res2.to_scipy(), C_ref)
+        # round 2's sharded form on the one rank: local block = everything; the df table, the CSR and the result are
+        # handed to torch as zero-copy views, pushed through the (1-rank) RCCL collectives and wrapped again
+        ops = D.HipOps(ctx, lambda: HipTfidfVectorizer(dtype=np.float32, ctx=ctx))
+        block, (lo, hi) = D.local_string_block(ctx, tb2, to2, 0, 1)
+        assert (lo, hi) == (0, len(names))
+        res3, vec3 = D.distributed_self_join(ops, block, 10, 0.8)
+        assert_csr_identical(res3.to_scipy(), C_ref)
+        np.testing.assert_array_equal(vec3.idf_, O.tfidf_sklearn(names, [names], dtype=np.float32)[2])
+        cols, vals, counts = D.gather_topn(ops, res3)
+        assert counts.tolist() == np.diff(C_ref.indptr).tolist()
+        ipg, ixg, dg, shp = D.all_gather_csr(*D.csr_as_torch(A), A.dims()[1])     # the collective form, explicitly
+        A3 = ops.csr_from_tensors(ipg, ixg, dg, shp)
+        assert_csr_identical(A3.to_scipy(), sp.csr_matrix(A_ref))
+        # master x duplicates through the same path
+        dups = _names(2500, seed=12)
+        pd_ = vec.prepare(dups)
+        res4, _ = D.distributed_match(ops, p, pd_, 20, 0.7)
+        (Am, Bd), _, _ = O.tfidf_sklearn(names + dups, [names, dups], dtype=np.float32)
+        assert_csr_identical(res4.to_scipy(), P.sp_matmul_topn_port(Am, Bd.T, 20, 0.7, True, 4))
+        # and behind the public API: the distributed engine on a 1-rank group must give what the plain engine gives
+        import pandas as pd
+        import string_grouper_amd as sga
+        import string_grouper_amd.engine as E
+        old = E._engine
+        try:
+            s_m, s_d = pd.Series(names[:3000], name="name"), pd.Series(dups[:1000], name="dup")
+            E.set_engine(E.HipEngine(ctx))
+            want = [sga.match_strings(s_m, min_similarity=0.8, max_n_matches=10, tfidf_matrix_dtype=np.float32),
+                    sga.match_strings(s_m, s_d, min_similarity=0.7), sga.group_similar_strings(s_m, min_similarity=0.8),
+                    sga.match_most_similar(s_m, s_d, min_similarity=0.7)]
+            E.set_engine(E.DistributedHipEngine(ctx))
+            got = [sga.match_strings(s_m, min_similarity=0.8, max_n_matches=10, tfidf_matrix_dtype=np.float32),
+                   sga.match_strings(s_m, s_d, min_similarity=0.7), sga.group_similar_strings(s_m, min_similarity=0.8),
+                   sga.match_most_similar(s_m, s_d, min_similarity=0.7)]
+            for w, g in zip(want, got):
+                pd.testing.assert_frame_equal(pd.DataFrame(w), pd.DataFrame(g))
+        finally:
+            E.set_engine(old)
     finally:
         dist.destroy_process_group()
 
