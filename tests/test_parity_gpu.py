@@ -167,6 +167,22 @@ def test_vectoriser_unicode_case_and_ngram_sizes(ctx):
         assert_csr_identical(m_dev, sp.csr_matrix(m_ref), str(kw))
 
 
+def test_transform_of_strings_with_characters_unseen_at_fit(ctx):
+    """sklearn's transform() drops the n-grams it has not seen at fit(); with ngram_size >= 4 the device codes
+    characters by their rank among the bytes seen at fit(), so an unseen character needs its own code."""
+    from sklearn.feature_extraction.text import TfidfVectorizer
+    from string_grouper_amd.vectorizer import HipTfidfVectorizer
+    fit_on = ["abcdefgh ijkl", "abcd efgh", "hgfedcba lkji", "abcabcabc"] * 5
+    later = ["abcdefgh", "abcdxefgh", "zzzzzzzz", "abcd1234efgh", "ABCDEFGH-QRSTUVWXYZ", "", "a", "abcdefg hijklm nopq"]
+    for n in (3, 4, 5, 6):
+        for dtype in (np.float32, np.float64):
+            ref = TfidfVectorizer(min_df=1, analyzer=lambda s, n=n: O.ngrams(s, n), dtype=dtype).fit(fit_on)
+            vec = HipTfidfVectorizer(ngram_size=n, dtype=dtype, ctx=ctx).fit(fit_on)
+            assert vec.vocabulary_ == ref.vocabulary_
+            assert_csr_identical(vec.transform(later), sp.csr_matrix(ref.transform(later)), f"n={n}")
+            assert_csr_identical(vec.transform(fit_on), sp.csr_matrix(ref.transform(fit_on)), f"n={n} fit set")
+
+
 def test_run_twice_is_bitwise_identical(ctx, mats):
     """Determinism: per-row independence + fixed summation order (no race shows up as a diff)."""
     from string_grouper_amd.sparse_dot_topn import sp_matmul_topn
