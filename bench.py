@@ -340,7 +340,11 @@ def main():
                            f"({base['multiply']['seconds_sample']:.2f} s), scan part scaled by exact MAC count"),
                 "split_seconds_full_estimate": {"vectorise_3_passes": vec_s,
                                                 "multiply": base["multiply"]["seconds_full_estimate"], "tail": tail_s},
-                "all_cores": {"cores": ball["cores"], "multiply_seconds_full_estimate": ball["multiply"]["seconds_full_estimate"],
+                "all_cores": {"cores": ball["cores"], "cpus_in_affinity_mask": ball.get("cpus_in_affinity_mask"),
+                              "cgroup_cpu_quota": ball.get("cgroup_cpu_quota"),
+                              "multiply_sample_left_rows": ball["multiply"]["sample_left_rows"],
+                              "multiply_seconds_sample": ball["multiply"]["seconds_sample"],
+                              "multiply_seconds_full_estimate": ball["multiply"]["seconds_full_estimate"],
                               "value": args.rows / all_total, "unit": "rows/s",
                               "note": "same composition with the multiply leg on every core (tokenisation stays single-threaded in the reference)"},
             }

@@ -42,6 +42,18 @@ def cpu_model() -> str:
     return "unknown"
 
 
+def cpu_quota():
+    """CPUs the cgroup grants this process (None: unlimited / unknown) -- the affinity mask alone can overstate it."""
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            q, period = f.read().split()
+        if q != "max":
+            return max(1, int(int(q) / int(period)))
+    except (OSError, ValueError):
+        pass
+    return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--matrix", required=True, help="npz with the full TF-IDF CSR (indptr, indices, data, shape)")
@@ -58,9 +70,11 @@ def main():
     args = ap.parse_args()
 
     allowed = sorted(os.sched_getaffinity(0))
-    cores = max(1, min(args.cores, len(allowed)))
+    quota = cpu_quota()
+    cores = max(1, min(args.cores, len(allowed), quota or len(allowed)))   # never more threads than the cgroup grants
     os.sched_setaffinity(0, set(allowed[:cores]))
     os.environ["OMP_NUM_THREADS"] = str(cores)
+    os.environ["OMP_WAIT_POLICY"] = "passive"      # 166 short parallel regions per pass: no spinning at their barriers
 
     import numpy as np
     import pandas as pd
@@ -75,7 +89,8 @@ def main():
     z = np.load(args.matrix)
     A = sp.csr_matrix((z["data"], z["indices"], z["indptr"]), shape=tuple(z["shape"]))
     n = A.shape[0]
-    out = {"cores": cores, "cpu_model": cpu_model(), "kind": "port", "rows": n}
+    out = {"cores": cores, "cpu_model": cpu_model(), "kind": "port", "rows": n, "cpus_in_affinity_mask": len(allowed),
+           "cgroup_cpu_quota": quota}
 
     # ---- multiply: the reference's own block split of the full problem, first S left rows
     n_blocks = O.guess_n_blocks(n, n)

@@ -1,6 +1,7 @@
 // Context, scratch pool, object plumbing and the prefix-sum utility of libsg_hip.so.
 // gfx950 (MI355X) only; no CPU fallback lives in this library.
 #include <stdarg.h>
+#include <stdlib.h>
 
 #include "sg_internal.h"
 
@@ -30,6 +31,14 @@ extern "C" int sg_device_count(int *count) {
 }
 
 // ------------------------------------------------------------------------------------ pool
+// SG_POISON_ALLOC=1 (test hook): every block handed out is filled with 0xFF bytes (NaN as a float, -1 as an index)
+// first, so that a kernel reading memory it never wrote shows up as a wrong result instead of depending on what
+// the pool happened to hold (tests/test_parity_gpu.py::test_results_do_not_depend_on_uninitialised_memory).
+static bool poison_allocations() {
+    const char *v = getenv("SG_POISON_ALLOC");
+    return v && v[0] == '1';
+}
+
 int sg_ctx::alloc(size_t bytes, void **out) {
     if (bytes == 0) bytes = 256;
     bytes = (bytes + 255) & ~(size_t)255;
@@ -38,8 +47,10 @@ int sg_ctx::alloc(size_t bytes, void **out) {
         auto it = free_blocks.lower_bound(bytes);
         if (it != free_blocks.end() && it->first <= bytes + bytes / 2 + 4096) {
             *out = it->second;
+            const size_t have = it->first;
             live_blocks[it->second] = it->first;
             free_blocks.erase(it);
+            if (poison_allocations()) (void)hipMemsetAsync(*out, 0xFF, have, stream);
             return SG_OK;
         }
     }
@@ -55,6 +66,7 @@ int sg_ctx::alloc(size_t bytes, void **out) {
             return SG_ERR_OOM;
         }
     }
+    if (poison_allocations()) (void)hipMemsetAsync(p, 0xFF, bytes, stream);
     std::lock_guard<std::mutex> g(mu);
     live_blocks[p] = bytes;
     *out = p;

@@ -341,6 +341,12 @@ extern "C" int sg_postings_build(sg_ctx *ctx, const sg_csr *B, int32_t tile_cols
             if (hipGetLastError() != hipSuccess) st = SG_ERR_HIP;
         }
         if (st == SG_OK && p->d_fwd) {
+            // the exact scoring reads packed rows in rounds of eight entries and multiplies the slots past a row's end by
+            // a = 0: the pad behind the LAST row must hold finite values (0 * NaN would poison that row's score)
+            const size_t es = B->dtype == SG_F64 ? 16 : 8;
+            if (hipMemsetAsync((char *)p->d_fwd + (size_t)B->nnz * es, 0, 8 * es, ctx->stream) != hipSuccess) st = SG_ERR_HIP;
+        }
+        if (st == SG_OK && p->d_fwd) {
             const unsigned g2 = (unsigned)((B->n_rows + 1 + 255) / 256);
             if (B->dtype == SG_F64)
                 hipLaunchKernelGGL(fwd_pack<double>, dim3(g2), dim3(256), 0, ctx->stream, B->d_indptr, B->d_indices,

@@ -251,6 +251,53 @@ def test_headline_663k_selfjoin_every_row_equals_sklearn_and_the_port(ctx):
     assert ok[same_row].all()
 
 
+def test_results_do_not_depend_on_uninitialised_memory(ctx, monkeypatch):
+    """With SG_POISON_ALLOC=1 the library fills every block it hands out with 0xFF bytes (NaN / -1) first.  Round 2's
+    663k test found a score that was multiplied with the uninitialised pad behind the last packed row (0 * NaN);
+    this runs the whole path -- odd sizes, self-join and two series, both dtypes, both forms of the pruned kernel,
+    the exact kernel, the fused tail and the reductions -- on poisoned memory against the oracle."""
+    import pandas as pd
+    import string_grouper_amd as sga
+    import string_grouper_amd.engine as E
+    from string_grouper_amd.vectorizer import HipTfidfVectorizer
+    monkeypatch.setenv("SG_POISON_ALLOC", "1")
+    ctx.trim()                                   # nothing cached from earlier tests
+    for n, dtype in ((4097, np.float32), (5001, np.float64), (12289, np.float32)):
+        names = _names(n, seed=n)
+        A_ref = _tfidf(names, dtype)
+        C_ref = P.sp_matmul_topn_port(A_ref, A_ref.T, 10, 0.8, True, 8)
+        for env in ({}, {"SG_SYM": "0"}, {"SG_PRUNE": "0"}):
+            for k, v in env.items():
+                monkeypatch.setenv(k, v)
+            vec = HipTfidfVectorizer(dtype=dtype, ctx=ctx)
+            p = vec.prepare(names)
+            vec.fit_prepared([p])
+            dA = vec.transform_prepared(p)
+            assert_csr_identical(dA.to_scipy(), A_ref, f"tf-idf n={n}")
+            post = ctx.postings_build(dA)
+            res = ctx.spgemm_topn(dA, post, 10, 0.8, True)
+            assert_csr_identical(res.to_scipy(), C_ref, f"n={n} {dtype.__name__} {env}")
+            res.free()
+            post.free()
+            dA.free()
+            for k in env:
+                monkeypatch.delenv(k)
+    old = E._engine
+    E.set_engine(E.HipEngine(ctx))
+    try:
+        from tests import _golden as G
+        G.run_api_checks(sga)
+        s = pd.Series(_names(3001, seed=3))
+        a = sga.group_similar_strings(s, min_similarity=0.8)
+        b = sga.match_most_similar(s, pd.Series(_names(1001, seed=4)), min_similarity=0.7)
+        monkeypatch.delenv("SG_POISON_ALLOC")
+        pd.testing.assert_frame_equal(pd.DataFrame(a), pd.DataFrame(sga.group_similar_strings(s, min_similarity=0.8)))
+        pd.testing.assert_frame_equal(pd.DataFrame(b), pd.DataFrame(sga.match_most_similar(s, pd.Series(_names(1001, seed=4)),
+                                                                                        min_similarity=0.7)))
+    finally:
+        E.set_engine(old)
+
+
 def test_public_api_golden_cases_on_gpu(ctx):
     """The reference's golden vectors (tests/golden, made by the unmodified reference) through the
     drop-in API with the HIP engine: match frames, groups, most-similar, known answers."""
