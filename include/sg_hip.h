@@ -73,6 +73,15 @@ int sg_strings_from_host(sg_ctx *ctx, const uint8_t *bytes, const int64_t *offse
                          sg_strings **out);
 int sg_strings_from_device(sg_ctx *ctx, const uint8_t *d_bytes, const int64_t *d_offsets, int64_t n,
                            int64_t total_bytes, sg_strings **out);
+/* A column whose characters the host has already lower-cased, regex-deleted and ranked into the alphabet of the fit
+ * (n-grams over non-ASCII code points: normalize_to_ascii=False, string_grouper.py:202, :373-374): symbols[i] is the
+ * rank of a character in the sorted alphabet of alphabet_size characters, 0xFFFF = "not in the alphabet" (only in a
+ * later transform); offsets count symbols.  All columns of one fit must share the alphabet. */
+int sg_strings_from_host_symbols(sg_ctx *ctx, const uint16_t *symbols, const int64_t *offsets, int64_t n,
+                                 int32_t alphabet_size, sg_strings **out);
+/* Byte column: the host has already applied str.lower() (rows with non-ASCII characters go through the host, whose
+ * NFKD step can produce upper-case ASCII that must stay: 'TM' from U+2122); the device then leaves A-Z alone. */
+int sg_strings_set_prelowered(sg_strings *s, int32_t prelowered);
 int sg_strings_free(sg_strings *s);
 
 /* ------------------------------------------------------------------ seam b1: vectoriser */
@@ -101,8 +110,14 @@ int sg_vec_fit_begin(sg_ctx *ctx, const sg_strings *const *sets, int32_t n_sets,
 int sg_vocab_df_table(sg_vocab *v, int32_t **d_table, int64_t *n_entries, int32_t *shareable);
 int sg_vec_fit_end(sg_ctx *ctx, sg_vocab *v, int64_t n_docs_total);
 int sg_vocab_size(const sg_vocab *v, int64_t *n_terms, int64_t *n_docs);
-/* keys[i]: the n-gram of column i, bytes packed big-endian 7 bits each; df[i]: its document count. */
+/* How the keys of this vocabulary are coded: bits per character; != 0 if fitted on symbol columns; != 0 if the
+ * vocabulary is the sorted key array (keys wider than 30 bits) instead of the dense table. */
+int sg_vocab_coding(const sg_vocab *v, int32_t *bits_per_char, int32_t *symbols, int32_t *sorted_mode);
+/* keys[i]: the n-gram of column i, its character codes packed big-endian bits_per_char bits each (sg_vocab_coding);
+ * a code is the rank of a symbol in the caller's alphabet (symbol columns) or indexes sg_vocab_byte_alphabet (byte
+ * columns: the identity for n-grams of up to 3 characters).  df[i]: its document count. */
 int sg_vocab_to_host(sg_ctx *ctx, const sg_vocab *v, uint64_t *keys, int64_t *df);
+int sg_vocab_byte_alphabet(const sg_vocab *v, uint8_t *byte_of_code /* 128 */, int32_t *n_codes);
 /* idf is computed by the caller from df (numpy, sklearn's exact op sequence text.py:1664-1679,
  * so that log() is bit-identical) and installed here; dtype must match params.dtype. */
 int sg_vocab_set_idf(sg_ctx *ctx, sg_vocab *v, const void *idf, int32_t dtype);

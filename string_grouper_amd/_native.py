@@ -47,13 +47,17 @@ ABI = {
     "sg_ctx_trim": (C.c_int, [_P]),
     "sg_strings_from_host": (C.c_int, [_P, _P, _P, C.c_int64, _PP]),
     "sg_strings_from_device": (C.c_int, [_P, _P, _P, C.c_int64, C.c_int64, _PP]),
+    "sg_strings_from_host_symbols": (C.c_int, [_P, _P, _P, C.c_int64, C.c_int32, _PP]),
+    "sg_strings_set_prelowered": (C.c_int, [_P, C.c_int32]),
     "sg_strings_free": (C.c_int, [_P]),
     "sg_vec_fit": (C.c_int, [_P, _PP, C.c_int32, C.POINTER(SgVecParams), _PP]),
     "sg_vec_fit_begin": (C.c_int, [_P, _PP, C.c_int32, C.POINTER(SgVecParams), _PP]),
     "sg_vocab_df_table": (C.c_int, [_P, _PP, C.POINTER(C.c_int64), C.POINTER(C.c_int32)]),
     "sg_vec_fit_end": (C.c_int, [_P, _P, C.c_int64]),
     "sg_vocab_size": (C.c_int, [_P, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "sg_vocab_coding": (C.c_int, [_P, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "sg_vocab_to_host": (C.c_int, [_P, _P, _P, _P]),
+    "sg_vocab_byte_alphabet": (C.c_int, [_P, _P, C.POINTER(C.c_int32)]),
     "sg_vocab_set_idf": (C.c_int, [_P, _P, _P, C.c_int32]),
     "sg_vocab_free": (C.c_int, [_P]),
     "sg_vec_transform": (C.c_int, [_P, _P, _P, _PP]),
@@ -332,6 +336,26 @@ class Context:
         s.n = n
         return s
 
+    def strings_from_host_symbols(self, symbols: np.ndarray, offsets: np.ndarray, alphabet_size: int) -> Strings:
+        """A symbol column: uint16 ranks in the fit's alphabet (0xFFFF = not in it), offsets in symbols."""
+        symbols = np.ascontiguousarray(symbols, dtype=np.uint16)
+        offsets = np.ascontiguousarray(offsets, dtype=np.int64)
+        out = C.c_void_p()
+        n = len(offsets) - 1
+        check(lib().sg_strings_from_host_symbols(self.h, _ptr(symbols), _ptr(offsets), n, int(alphabet_size), C.byref(out)))
+        s = Strings(self, out)
+        s.n = n
+        return s
+
+    def strings_set_prelowered(self, s: Strings, prelowered: bool):
+        check(lib().sg_strings_set_prelowered(s.h, 1 if prelowered else 0))
+
+    def vocab_coding(self, v: "Vocab"):
+        """(bits per character, fitted on symbol columns, sorted vocabulary)"""
+        b, sy, so = C.c_int32(), C.c_int32(), C.c_int32()
+        check(lib().sg_vocab_coding(v.h, C.byref(b), C.byref(sy), C.byref(so)))
+        return b.value, bool(sy.value), bool(so.value)
+
     def strings_from_device(self, d_bytes: int, d_offsets: int, n: int, total_bytes: int, keepalive=None) -> Strings:
         out = C.c_void_p()
         check(lib().sg_strings_from_device(self.h, C.c_void_p(d_bytes), C.c_void_p(d_offsets), n, total_bytes,
@@ -375,6 +399,13 @@ class Context:
         df = np.empty(max(n_terms, 1), np.int64)
         check(lib().sg_vocab_to_host(self.h, v.h, _ptr(keys), _ptr(df)))
         return keys[:n_terms], df[:n_terms]
+
+    def vocab_byte_alphabet(self, v: Vocab) -> np.ndarray:
+        """byte value of every character code of a vocabulary fitted on byte columns"""
+        out = np.zeros(128, np.uint8)
+        n = C.c_int32()
+        check(lib().sg_vocab_byte_alphabet(v.h, _ptr(out), C.byref(n)))
+        return out[:n.value]
 
     def vocab_set_idf(self, v: Vocab, idf: np.ndarray):
         idf = np.ascontiguousarray(idf)

@@ -220,6 +220,52 @@ extern "C" int sg_strings_from_host(sg_ctx *ctx, const uint8_t *bytes, const int
     return SG_OK;
 }
 
+extern "C" int sg_strings_from_host_symbols(sg_ctx *ctx, const uint16_t *symbols, const int64_t *offsets, int64_t n,
+                                            int32_t alphabet_size, sg_strings **out) {
+    SG_REQUIRE(ctx && offsets && out && n >= 0, "null argument");
+    SG_REQUIRE(alphabet_size >= 1 && alphabet_size <= 65535, "alphabet_size must be in [1, 65535]");
+    const int64_t total = offsets[n] - offsets[0];
+    SG_REQUIRE(total >= 0 && (total == 0 || symbols != nullptr), "bad offsets");
+    SG_REQUIRE(offsets[0] == 0, "offsets must start at 0");
+    sg_strings *s = new (std::nothrow) sg_strings();
+    if (!s) return SG_ERR_OOM;
+    s->ctx = ctx;
+    s->n = n;
+    s->total_bytes = total;
+    s->owned = true;
+    s->sym_width = 2;
+    s->alphabet = alphabet_size;
+    s->prelowered = true;
+    uint16_t *db = nullptr;
+    int64_t *doff = nullptr;
+    int st = sg_alloc(ctx, (size_t)total + 16, &db);
+    if (st == SG_OK) st = sg_alloc(ctx, (size_t)n + 1, &doff);
+    if (st != SG_OK) {
+        ctx->release(db);
+        delete s;
+        return st;
+    }
+    s->d_bytes = (const uint8_t *)db;
+    s->d_offsets = doff;
+    hipError_t e = hipSuccess;
+    if (total > 0) e = hipMemcpyAsync(db, symbols, (size_t)total * 2, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(doff, offsets, sizeof(int64_t) * (size_t)(n + 1), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);   // host buffers may be pageable / reused
+    if (e != hipSuccess) {
+        sg_set_error("sg_strings_from_host_symbols: %s", hipGetErrorString(e));
+        sg_strings_free(s);
+        return SG_ERR_HIP;
+    }
+    *out = s;
+    return SG_OK;
+}
+
+extern "C" int sg_strings_set_prelowered(sg_strings *s, int32_t prelowered) {
+    SG_REQUIRE(s != nullptr, "strings are null");
+    s->prelowered = prelowered != 0;
+    return SG_OK;
+}
+
 extern "C" int sg_strings_from_device(sg_ctx *ctx, const uint8_t *d_bytes, const int64_t *d_offsets, int64_t n,
                                       int64_t total_bytes, sg_strings **out) {
     SG_REQUIRE(ctx && d_offsets && out && n >= 0 && total_bytes >= 0, "null argument");

@@ -95,8 +95,13 @@ struct sg_strings {
     const uint8_t *d_bytes = nullptr;
     const int64_t *d_offsets = nullptr;
     int64_t n = 0;
-    int64_t total_bytes = 0;
+    int64_t total_bytes = 0;             // bytes, or symbols of a symbol column
     bool owned = false;
+    // kind of column (string_grouper_amd/strprep.py): UTF-8 bytes the tokeniser filters itself, or uint16 symbols that
+    // the host has already lower-cased, regex-deleted and ranked into the fit's alphabet (0xFFFF = not in it)
+    int32_t sym_width = 1;               // 1: d_bytes are bytes; 2: d_bytes are uint16 symbols, offsets count symbols
+    int32_t alphabet = 0;                // symbol columns: number of symbols of the alphabet
+    bool prelowered = false;             // byte columns: the host applied str.lower() already, leave A-Z alone
 };
 
 struct sg_csr {
@@ -163,8 +168,11 @@ struct sg_vocab {
     sg_vec_params params;
     int32_t bits_per_char = 7;
     int64_t n_terms = 0, n_docs = 0;
-    int64_t key_space = 0;               // 2^(bits_per_char * ngram_size)
-    int32_t *d_key_to_col = nullptr;     // key_space entries, -1 = not in vocabulary
+    int64_t key_space = 0;               // dense mode: 2^(bits_per_char * ngram_size)
+    // dense mode (bits_per_char * ngram_size <= 30): 32-bit keys, a table over the whole key space;
+    // sorted mode (up to 64 bits): 64-bit keys, the vocabulary is the sorted array d_keys, columns by binary search
+    bool sorted_mode = false;
+    int32_t *d_key_to_col = nullptr;     // dense mode: key_space entries, -1 = not in vocabulary
     uint64_t *d_keys = nullptr;          // n_terms: key of column i (ascending)
     int32_t *d_df = nullptr;             // n_terms
     void *d_idf = nullptr;               // n_terms, params.dtype; null until sg_vocab_set_idf
@@ -184,6 +192,9 @@ int sg_spgemm_pruned_launch(sg_ctx *ctx, const sg_csr *A, const sg_postings *Bt,
 
 int sg_spgemm_pruned_symmetric(sg_ctx *ctx, const sg_csr *A, const sg_postings *Bt, int32_t keep, sg_topn *r,
                                double threshold, double delta, unsigned long long *stats, bool *done);
+
+// sg_sortvocab.hip: ascending distinct values of d_keys[0 .. n) and how often each occurs (d_keys is overwritten)
+int sg_sort_unique_u64(sg_ctx *ctx, uint64_t *d_keys, int64_t n, uint64_t *d_unique, int32_t *d_counts, int64_t *n_unique);
 
 // exclusive prefix sum of n uint32 values (in place allowed); total written to *d_total if non-null
 int sg_exclusive_scan_u32(sg_ctx *ctx, const uint32_t *d_in, uint32_t *d_out, int64_t n, uint32_t *d_total);

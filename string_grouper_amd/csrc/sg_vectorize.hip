@@ -26,14 +26,37 @@
 // sequentially in column order, w = (T)((double)w / sqrt(acc)); rows with acc == 0 are left alone.
 // This op order reproduces sklearn bit for bit (tests/test_parity_gpu.py).
 //
+// Domain (round 2).  Strings of any length: one wave sorts up to 1024 n-grams in LDS, longer strings go to a
+// workgroup-per-string kernel with its keys in global scratch.  Keys of up to 30 bits index a dense table (3-grams over
+// 7-bit ASCII: 2 M counters); wider ones (long n-grams, large alphabets; up to 63 bits) are 64-bit and the vocabulary
+// is the sorted array of the distinct keys (sg_sortvocab.hip), looked up by binary search.  Columns whose n-grams are
+// over non-ASCII code points arrive as SYMBOL columns: uint16 ranks in the alphabet of the fit, prepared on the host
+// (string_grouper_amd/strprep.py).
+//
 // Bound: HBM.  Algorithmic bytes = sum(len) + 8n (read strings) + nnz*(4+s) + 8(n+1) (write CSR)
 // + the key-space tables (4 * 2^(bits*n) for df and rank).
+#include <type_traits>
+
 #include "sg_internal.h"
 
-#define TOK_CAP 1024            // n-grams per string the device tokeniser handles
-#define SG_KEY_OOV 0xFFFFFFFEu   // key of an n-gram that contains such a character (sorts behind every real key)
-#define SG_CHAR_ABSENT 0xFF     // character code of a byte that did not occur at fit(): its n-grams are out of vocabulary
+#define TOK_CAP 1024            // n-grams per string of the one-wave-per-string tokeniser; longer strings: tokenize_long_kernel
+#define SG_KEY_OOV32 0xFFFFFFFEu            // key of an n-gram with a character that is not in the fit's alphabet
+#define SG_KEY_OOV64 0xFFFFFFFFFFFFFFFEull  // (sorts behind every real key; never in the vocabulary)
+#define SG_CHAR_ABSENT 0xFFFFu  // code of such a character
 #define TOK_CHARS (TOK_CAP + 16)
+
+template <typename KeyT>
+struct KeyTraits;
+template <>
+struct KeyTraits<uint32_t> {
+    static constexpr uint32_t OOV = SG_KEY_OOV32;
+    static constexpr uint32_t PAD = 0xFFFFFFFFu;
+};
+template <>
+struct KeyTraits<uint64_t> {
+    static constexpr uint64_t OOV = SG_KEY_OOV64;
+    static constexpr uint64_t PAD = 0xFFFFFFFFFFFFFFFFull;
+};
 
 struct TokenCache {             // tokenised strings in the padded layout
     const sg_strings *src = nullptr;
@@ -41,27 +64,28 @@ struct TokenCache {             // tokenised strings in the padded layout
     int64_t cap_total = 0;
     int64_t *d_ub_ptr = nullptr;   // n + 1: start of row i's slots
     int32_t *d_cnt = nullptr;      // n: distinct n-grams of row i
-    uint32_t *d_keys = nullptr;    // cap_total
+    void *d_keys = nullptr;        // cap_total keys (uint32 in dense mode, uint64 in sorted mode)
     int32_t *d_tf = nullptr;       // cap_total
 };
 
 struct VocabImpl {
     std::vector<TokenCache> caches;
-    uint8_t rank_of_byte[128];     // byte -> compact character code
+    uint16_t rank_of_byte[128];    // byte -> compact character code (SG_CHAR_ABSENT: did not occur at fit())
     uint8_t byte_of_rank[128];
-    int32_t *d_df_table = nullptr; // key_space
-    int32_t *d_err = nullptr;      // [0] != 0: a string exceeded TOK_CAP
-    bool local_alphabet = false;   // characters coded by rank among the bytes seen at fit() (ngram_size > 3)
+    int32_t *d_df_table = nullptr; // dense mode: key_space counters
+    bool local_alphabet = false;   // byte columns coded by rank among the bytes seen at fit() (7 * ngram_size > 24)
+    bool symbols = false;          // the fit's columns are symbol columns (sg_strings_from_host_symbols)
+    int32_t alphabet = 0;          // their alphabet size
 };
 
 static VocabImpl *impl_of(const sg_vocab *v) { return v ? v->impl : nullptr; }
 
 struct TokParams {
     int32_t ngram;
-    int32_t ascii_lower;
+    int32_t lower;                 // byte columns: map A-Z to a-z
     int32_t bits;
     uint32_t del_mask[4];          // bit c set: ASCII byte c is deleted
-    uint8_t rank_of_byte[128];
+    uint16_t rank_of_byte[128];
 };
 
 // -------------------------------------------------------------------------------------------------
@@ -69,10 +93,9 @@ __global__ void __launch_bounds__(256) ub_count_kernel(const int64_t *__restrict
                                                        int32_t *ub) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const int64_t len = offsets[i + 1] - offsets[i];
+    const int64_t len = offsets[i + 1] - offsets[i];      // bytes or symbols: an upper bound of the characters kept
     int64_t g = len - ngram + 1;
     if (g < 0) g = 0;
-    if (g > TOK_CAP) g = TOK_CAP;   // longer rows are reported through the error word by the tokeniser
     ub[i] = (int32_t)g;
 }
 
@@ -85,12 +108,27 @@ __global__ void __launch_bounds__(256) alphabet_kernel(const uint8_t *__restrict
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         uint32_t c = bytes[i];
         if (c >= 0x80) continue;
-        if (p.ascii_lower && c >= 'A' && c <= 'Z') c += 32;
+        if (p.lower && c >= 'A' && c <= 'Z') c += 32;
         if ((p.del_mask[c >> 5] >> (c & 31)) & 1u) continue;
         atomicOr(&local[c >> 5], 1u << (c & 31));
     }
     __syncthreads();
     if (threadIdx.x < 4 && local[threadIdx.x]) atomicOr(&present[threadIdx.x], local[threadIdx.x]);
+}
+
+// The character code of a byte (byte columns: filter, lower, delete, rank) or of a symbol (symbol columns: as it is).
+// Returns false when the character is dropped.
+template <bool SYMBOLS>
+__device__ __forceinline__ bool char_code(const void *chars, int64_t at, const TokParams &p, uint32_t *code) {
+    if (SYMBOLS) {
+        *code = reinterpret_cast<const uint16_t *>(chars)[at];
+        return true;
+    }
+    uint32_t c = reinterpret_cast<const uint8_t *>(chars)[at];
+    if (p.lower && c >= 'A' && c <= 'Z') c += 32;
+    if (c >= 0x80 || ((p.del_mask[(c & 127) >> 5] >> (c & 31)) & 1u)) return false;
+    *code = p.rank_of_byte[c];
+    return true;
 }
 
 // One wave per string: filter, n-gram, sort, run-length encode.
@@ -99,15 +137,17 @@ __global__ void __launch_bounds__(256) alphabet_kernel(const uint8_t *__restrict
 // string, which __syncthreads() implies); a compiler-level barrier keeps the LDS accesses in program order.
 __device__ __forceinline__ void wave_sync() { __builtin_amdgcn_wave_barrier(); }
 
-__global__ void __launch_bounds__(64) tokenize_kernel(const uint8_t *__restrict__ bytes,
+template <typename KeyT, bool SYMBOLS>
+__global__ void __launch_bounds__(64) tokenize_kernel(const void *__restrict__ chars_in,
                                                       const int64_t *__restrict__ offsets, int64_t n_rows,
                                                       TokParams p, const int64_t *__restrict__ ub_ptr,
-                                                      int32_t *__restrict__ out_cnt, uint32_t *__restrict__ out_keys,
+                                                      int32_t *__restrict__ out_cnt, KeyT *__restrict__ out_keys,
                                                       int32_t *__restrict__ out_tf, int32_t *df_table,
-                                                      int32_t df_replicas, int64_t df_stride, int32_t *err) {
-    __shared__ uint32_t keys[TOK_CAP];
+                                                      int32_t df_replicas, int64_t df_stride,
+                                                      uint32_t *long_count, uint32_t *long_rows) {
+    __shared__ KeyT keys[TOK_CAP];
     __shared__ uint16_t starts[TOK_CAP + 2];
-    __shared__ uint8_t chars[TOK_CHARS];
+    __shared__ uint16_t chars[TOK_CHARS];
     const int lane = threadIdx.x;
     const uint64_t lt_mask = ((uint64_t)1 << lane) - 1;
 
@@ -118,13 +158,11 @@ __global__ void __launch_bounds__(64) tokenize_kernel(const uint8_t *__restrict_
         int m = 0;   // surviving characters
         bool overflow = false;
         for (int64_t base = 0; base < len; base += 64) {
-            uint32_t c = 0xFF;
-            if (base + lane < len) c = bytes[b0 + base + lane];
-            if (p.ascii_lower && c >= 'A' && c <= 'Z') c += 32;
-            const bool keep = c < 0x80 && !((p.del_mask[(c & 127) >> 5] >> (c & 31)) & 1u);
+            uint32_t code = 0;
+            const bool keep = base + lane < len && char_code<SYMBOLS>(chars_in, b0 + base + lane, p, &code);
             const uint64_t km = __ballot(keep);
             const int pos = m + __popcll(km & lt_mask);
-            if (keep && pos < TOK_CHARS) chars[pos] = p.rank_of_byte[c];
+            if (keep && pos < TOK_CHARS) chars[pos] = (uint16_t)code;
             m += __popcll(km);
             if (m > TOK_CHARS) {
                 overflow = true;
@@ -134,9 +172,11 @@ __global__ void __launch_bounds__(64) tokenize_kernel(const uint8_t *__restrict_
         wave_sync();
         int g = m - p.ngram + 1;   // number of n-grams
         if (g < 0) g = 0;
-        if (overflow || g > TOK_CAP) {
-            if (lane == 0) atomicExch(err, 1);
-            if (lane == 0) out_cnt[row] = 0;
+        if (overflow || g > TOK_CAP) {   // a long string: the workgroup-per-string kernel takes it
+            if (lane == 0) {
+                long_rows[atomicAdd(long_count, 1u)] = (uint32_t)row;
+                out_cnt[row] = 0;
+            }
             wave_sync();
             continue;
         }
@@ -149,16 +189,16 @@ __global__ void __launch_bounds__(64) tokenize_kernel(const uint8_t *__restrict_
         int P = 64;
         while (P < g) P <<= 1;
         for (int idx = lane; idx < P; idx += 64) {
-            uint32_t key = 0xFFFFFFFFu;
+            KeyT key = KeyTraits<KeyT>::PAD;
             if (idx < g) {
                 key = 0;
-                bool absent = false;   // a character that did not occur at fit(): the n-gram is out of vocabulary
+                bool absent = false;   // a character that is not in the alphabet of fit(): the n-gram is out of vocabulary
                 for (int q = 0; q < p.ngram; ++q) {
                     const uint32_t ch = chars[idx + q];
                     absent |= ch == SG_CHAR_ABSENT;
-                    key = (key << p.bits) | ch;
+                    key = (key << p.bits) | (KeyT)ch;
                 }
-                if (absent) key = SG_KEY_OOV;
+                if (absent) key = KeyTraits<KeyT>::OOV;
             }
             keys[idx] = key;
         }
@@ -168,7 +208,7 @@ __global__ void __launch_bounds__(64) tokenize_kernel(const uint8_t *__restrict_
             for (int j = k >> 1; j > 0; j >>= 1) {
                 for (int idx = lane; idx < (P >> 1); idx += 64) {
                     const int i = ((idx & ~(j - 1)) << 1) | (idx & (j - 1));
-                    const uint32_t a = keys[i], b = keys[i + j];
+                    const KeyT a = keys[i], b = keys[i + j];
                     const bool up = (i & k) == 0;
                     if ((a > b) == up) {
                         keys[i] = b;
@@ -193,16 +233,124 @@ __global__ void __launch_bounds__(64) tokenize_kernel(const uint8_t *__restrict_
         const int64_t obase = ub_ptr[row];
         for (int u = lane; u < uniq; u += 64) {
             const int s0 = starts[u];
-            const uint32_t key = keys[s0];
+            const KeyT key = keys[s0];
             out_keys[obase + u] = key;
             out_tf[obase + u] = (int32_t)starts[u + 1] - s0;
             // the same few n-grams ('inc', ' co') occur in a fifth of all strings: spread their atomics over
             // several copies of the table (summed by df_reduce_kernel) instead of serialising on one address
-            if (df_table && key != SG_KEY_OOV) atomicAdd(&df_table[(int64_t)(row % df_replicas) * df_stride + key], 1);
+            if (df_table && key != KeyTraits<KeyT>::OOV)
+                atomicAdd(&df_table[(int64_t)(row % df_replicas) * df_stride + (int64_t)key], 1);
         }
         if (lane == 0) out_cnt[row] = uniq;
         wave_sync();
     }
+}
+
+// A string with more n-grams than one wave sorts in LDS (an address line, a description, a whole document): one
+// 256-thread workgroup per string, characters and keys in global scratch (L2-resident), bitonic sort with workgroup
+// barriers.  Rare, so it favours simplicity over speed.  scratch layout per long string e: chars at
+// lchars + coff[e] (its byte / symbol length), keys at lkeys + koff[e] (the next power of two of that length).
+template <typename KeyT, bool SYMBOLS>
+__global__ void __launch_bounds__(256) tokenize_long_kernel(const void *__restrict__ chars_in,
+                                                            const int64_t *__restrict__ offsets, TokParams p,
+                                                            const uint32_t *__restrict__ long_rows,
+                                                            const int64_t *__restrict__ coff, const int64_t *__restrict__ koff,
+                                                            uint16_t *lchars, KeyT *lkeys,
+                                                            const int64_t *__restrict__ ub_ptr, int32_t *__restrict__ out_cnt,
+                                                            KeyT *__restrict__ out_keys, int32_t *__restrict__ out_tf,
+                                                            int32_t *df_table, int32_t df_replicas, int64_t df_stride) {
+    __shared__ int32_t wave_tot[4];
+    __shared__ int32_t carry;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int64_t row = long_rows[blockIdx.x];
+    const int64_t b0 = offsets[row];
+    const int64_t len = offsets[row + 1] - b0;
+    uint16_t *ch = lchars + coff[blockIdx.x];
+    KeyT *keys = lkeys + koff[blockIdx.x];
+    const int64_t P = koff[blockIdx.x + 1] - koff[blockIdx.x];
+    if (tid == 0) carry = 0;
+    __syncthreads();
+    // ---- filter + compact (block-wide, 256 characters per step)
+    for (int64_t base = 0; base < len; base += 256) {
+        uint32_t code = 0;
+        const bool keep = base + tid < len && char_code<SYMBOLS>(chars_in, b0 + base + tid, p, &code);
+        const uint64_t km = __ballot(keep);
+        if (lane == 0) wave_tot[wv] = __popcll(km);
+        __syncthreads();
+        int before = carry;
+        for (int w = 0; w < wv; ++w) before += wave_tot[w];
+        if (keep) ch[before + __popcll(km & (((uint64_t)1 << lane) - 1))] = (uint16_t)code;
+        __syncthreads();
+        if (tid == 0) carry += wave_tot[0] + wave_tot[1] + wave_tot[2] + wave_tot[3];
+        __syncthreads();
+    }
+    const int64_t m = carry;
+    int64_t g = m - p.ngram + 1;
+    if (g < 0) g = 0;
+    // ---- keys, padded to the power of two
+    for (int64_t idx = tid; idx < P; idx += 256) {
+        KeyT key = KeyTraits<KeyT>::PAD;
+        if (idx < g) {
+            key = 0;
+            bool absent = false;
+            for (int q = 0; q < p.ngram; ++q) {
+                const uint32_t c = ch[idx + q];
+                absent |= c == SG_CHAR_ABSENT;
+                key = (key << p.bits) | (KeyT)c;
+            }
+            if (absent) key = KeyTraits<KeyT>::OOV;
+        }
+        keys[idx] = key;
+    }
+    __syncthreads();
+    for (int64_t k = 2; k <= P; k <<= 1) {
+        for (int64_t j = k >> 1; j > 0; j >>= 1) {
+            for (int64_t idx = tid; idx < (P >> 1); idx += 256) {
+                const int64_t i = ((idx & ~(j - 1)) << 1) | (idx & (j - 1));
+                const KeyT a = keys[i], b = keys[i + j];
+                const bool up = (i & k) == 0;
+                if ((a > b) == up) {
+                    keys[i] = b;
+                    keys[i + j] = a;
+                }
+            }
+            __syncthreads();
+        }
+    }
+    // ---- run-length encode into the string's slots (block-wide, 256 keys per step)
+    const int64_t obase = ub_ptr[row];
+    __syncthreads();
+    if (tid == 0) carry = 0;   // distinct keys so far
+    __syncthreads();
+    for (int64_t base = 0; base < g; base += 256) {
+        const int64_t idx = base + tid;
+        const bool head = idx < g && (idx == 0 || keys[idx] != keys[idx - 1]);
+        const uint64_t hm = __ballot(head);
+        if (lane == 0) wave_tot[wv] = __popcll(hm);
+        __syncthreads();
+        int before = carry;
+        for (int w = 0; w < wv; ++w) before += wave_tot[w];
+        if (head) {
+            const int64_t u = before + __popcll(hm & (((uint64_t)1 << lane) - 1));
+            const KeyT key = keys[idx];
+            int64_t e = idx + 1;      // the run's end: a scan forward (a run = the occurrences of one n-gram in one string)
+            while (e < g && keys[e] == key) ++e;
+            out_keys[obase + u] = key;
+            out_tf[obase + u] = (int32_t)(e - idx);
+            if (df_table && key != KeyTraits<KeyT>::OOV)
+                atomicAdd(&df_table[(int64_t)(row % df_replicas) * df_stride + (int64_t)key], 1);
+        }
+        __syncthreads();
+        if (tid == 0) carry += wave_tot[0] + wave_tot[1] + wave_tot[2] + wave_tot[3];
+        __syncthreads();
+    }
+    if (tid == 0) out_cnt[row] = carry;
+}
+
+__global__ void __launch_bounds__(256) long_sizes_kernel(const int64_t *__restrict__ offsets, const uint32_t *__restrict__ long_rows,
+                                                         uint32_t n_long, int64_t *sizes) {
+    const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < n_long) sizes[e] = offsets[long_rows[e] + 1] - offsets[long_rows[e]];
 }
 
 __global__ void __launch_bounds__(256) df_reduce_kernel(int32_t *df_table, int64_t key_space, int32_t replicas, int64_t stride) {
@@ -235,21 +383,48 @@ __global__ void __launch_bounds__(256) vocab_finalize_kernel(const int32_t *__re
     }
 }
 
+// column of a key: dense mode = table lookup, sorted mode = binary search in the ascending vocabulary
+struct DenseLookup {
+    const int32_t *key_to_col;
+    __device__ __forceinline__ int32_t operator()(uint32_t key) const { return key == SG_KEY_OOV32 ? -1 : key_to_col[key]; }
+};
+struct SortedLookup {
+    const uint64_t *vocab;
+    int64_t n_terms;
+    __device__ __forceinline__ int32_t operator()(uint64_t key) const {
+        int64_t lo = 0, hi = n_terms;
+        while (lo < hi) {
+            const int64_t mid = (lo + hi) >> 1;
+            if (vocab[mid] < key) lo = mid + 1;
+            else hi = mid;
+        }
+        return (lo < n_terms && vocab[lo] == key) ? (int32_t)lo : -1;
+    }
+};
+
+template <typename KeyT, typename Lookup>
 __global__ void __launch_bounds__(256) kept_count_kernel(const int64_t *__restrict__ ub_ptr,
                                                          const int32_t *__restrict__ cnt,
-                                                         const uint32_t *__restrict__ keys,
-                                                         const int32_t *__restrict__ key_to_col, int64_t n,
+                                                         const KeyT *__restrict__ keys, Lookup lookup, int64_t n,
                                                          int32_t *kept) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const int64_t b = ub_ptr[i];
     const int c = cnt[i];
     int k = 0;
-    for (int q = 0; q < c; ++q) {
-        const uint32_t key = keys[b + q];
-        k += key != SG_KEY_OOV && key_to_col[key] >= 0;
-    }
+    for (int q = 0; q < c; ++q) k += lookup(keys[b + q]) >= 0;
     kept[i] = k;
+}
+
+// all (row, distinct n-gram) keys of a token cache, back to back (input of the sorted vocabulary)
+__global__ void __launch_bounds__(256) gather_keys_kernel(const int64_t *__restrict__ ub_ptr, const int32_t *__restrict__ cnt,
+                                                          const uint64_t *__restrict__ keys, const int64_t *__restrict__ dst_ptr,
+                                                          int64_t n, uint64_t *__restrict__ dst) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int64_t b = ub_ptr[i], d = dst_ptr[i];
+    const int c = cnt[i];
+    for (int q = 0; q < c; ++q) dst[d + q] = keys[b + q];
 }
 
 template <typename T>
@@ -259,12 +434,11 @@ __device__ __forceinline__ float tmul<float>(float a, float b) { return __fmul_r
 template <>
 __device__ __forceinline__ double tmul<double>(double a, double b) { return __dmul_rn(a, b); }
 
-template <typename T>
+template <typename T, typename KeyT, typename Lookup>
 __global__ void __launch_bounds__(256) weight_normalize_kernel(const int64_t *__restrict__ ub_ptr,
                                                                const int32_t *__restrict__ cnt,
-                                                               const uint32_t *__restrict__ keys,
-                                                               const int32_t *__restrict__ tf,
-                                                               const int32_t *__restrict__ key_to_col,
+                                                               const KeyT *__restrict__ keys,
+                                                               const int32_t *__restrict__ tf, Lookup lookup,
                                                                const T *__restrict__ idf, int64_t n,
                                                                const int64_t *__restrict__ indptr,
                                                                int32_t *__restrict__ out_idx, T *__restrict__ out_val) {
@@ -276,8 +450,7 @@ __global__ void __launch_bounds__(256) weight_normalize_kernel(const int64_t *__
     const int64_t o0 = o;
     double acc = 0.0;
     for (int q = 0; q < c; ++q) {   // ascending key == ascending column
-        const uint32_t key = keys[b + q];
-        const int32_t col = key != SG_KEY_OOV ? key_to_col[key] : -1;
+        const int32_t col = lookup(keys[b + q]);
         if (col < 0) continue;       // out-of-vocabulary n-gram of a string that was not part of fit()
         const T w = tmul<T>((T)tf[b + q], idf[col]);
         out_idx[o] = col;
@@ -299,16 +472,32 @@ static void free_cache(sg_ctx *ctx, TokenCache &c) {
     c = TokenCache();
 }
 
-static int tokenize_set(sg_ctx *ctx, const sg_strings *s, const TokParams &tp, int32_t *df_table, int32_t df_replicas,
-                        int64_t df_stride, int32_t *d_err,
-                        TokenCache *out) {
+static TokParams make_tok_params(const sg_vocab *v, const VocabImpl *im, const sg_strings *s) {
+    TokParams tp;
+    memset(&tp, 0, sizeof(tp));
+    tp.ngram = v->params.ngram_size;
+    tp.lower = (v->params.ascii_lower && !(s && s->prelowered)) ? 1 : 0;
+    tp.bits = v->bits_per_char;
+    for (int c = 0; c < 128; ++c)
+        if (v->params.delete_table[c]) tp.del_mask[c >> 5] |= 1u << (c & 31);
+    memcpy(tp.rank_of_byte, im->rank_of_byte, sizeof(tp.rank_of_byte));
+    return tp;
+}
+
+// K1 over one string column: the one-wave-per-string kernel, then the workgroup-per-string kernel for the strings it
+// handed over (one small host round trip: how many there are and how long they are).
+template <typename KeyT, bool SYMBOLS>
+static int tokenize_set_t(sg_ctx *ctx, const sg_strings *s, const TokParams &tp, int32_t *df_table, int32_t df_replicas,
+                          int64_t df_stride, TokenCache *out) {
     TokenCache c;
     c.src = s;
     c.n = s->n;
     int32_t *ub = nullptr;
+    uint32_t *longs = nullptr;   // [0] count, then the rows
     int st = sg_alloc(ctx, (size_t)s->n + 1, &ub);
     if (st == SG_OK) st = sg_alloc(ctx, (size_t)s->n + 1, &c.d_ub_ptr);
     if (st == SG_OK) st = sg_alloc(ctx, (size_t)s->n + 1, &c.d_cnt);
+    if (st == SG_OK) st = sg_alloc(ctx, (size_t)s->n + 2, &longs);
     if (st == SG_OK && s->n > 0) {
         hipLaunchKernelGGL(ub_count_kernel, dim3((unsigned)((s->n + 255) / 256)), dim3(256), 0, ctx->stream,
                            s->d_offsets, s->n, tp.ngram, ub);
@@ -317,20 +506,78 @@ static int tokenize_set(sg_ctx *ctx, const sg_strings *s, const TokParams &tp, i
         if (hipMemsetAsync(c.d_ub_ptr, 0, sizeof(int64_t), ctx->stream) != hipSuccess) st = SG_ERR_HIP;
     }
     ctx->release(ub);
-    // every row of L bytes has at most L - n + 1 n-grams, so total_bytes bounds the padded size
+    // every row of L characters has at most L - n + 1 n-grams, so the total length bounds the padded size
     c.cap_total = s->total_bytes + 1;
-    if (st == SG_OK) st = sg_alloc(ctx, (size_t)c.cap_total, &c.d_keys);
+    KeyT *keys = nullptr;
+    if (st == SG_OK) st = sg_alloc(ctx, (size_t)c.cap_total, &keys);
+    c.d_keys = keys;
     if (st == SG_OK) st = sg_alloc(ctx, (size_t)c.cap_total, &c.d_tf);
+    uint32_t n_long = 0;
     if (st == SG_OK && s->n > 0) {
+        hipError_t e = hipMemsetAsync(longs, 0, 4, ctx->stream);
         unsigned grid = (unsigned)ctx->num_cu * 24u;
         if ((int64_t)grid > s->n) grid = (unsigned)s->n;
-        hipLaunchKernelGGL(tokenize_kernel, dim3(grid), dim3(64), 0, ctx->stream, s->d_bytes, s->d_offsets, s->n, tp,
-                           (const int64_t *)c.d_ub_ptr, c.d_cnt, c.d_keys, c.d_tf, df_table, df_replicas, df_stride, d_err);
-        if (hipGetLastError() != hipSuccess) {
-            sg_set_error("tokenize_kernel launch failed");
+        hipLaunchKernelGGL((tokenize_kernel<KeyT, SYMBOLS>), dim3(grid), dim3(64), 0, ctx->stream, (const void *)s->d_bytes,
+                           s->d_offsets, s->n, tp, (const int64_t *)c.d_ub_ptr, c.d_cnt, keys, c.d_tf, df_table, df_replicas,
+                           df_stride, longs, longs + 1);
+        if (e == hipSuccess) e = hipGetLastError();
+        if (e == hipSuccess) e = hipMemcpyAsync(&n_long, longs, 4, hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) {
+            sg_set_error("tokenize_kernel: %s", hipGetErrorString(e));
             st = SG_ERR_HIP;
         }
     }
+    if (st == SG_OK && n_long > 0) {
+        // sizes of the long strings -> scratch offsets (characters: the length; keys: the next power of two)
+        int64_t *d_sizes = nullptr, *d_coff = nullptr, *d_koff = nullptr;
+        std::vector<int64_t> sizes(n_long), coff(n_long + 1, 0), koff(n_long + 1, 0);
+        st = sg_alloc(ctx, (size_t)n_long, &d_sizes);
+        if (st == SG_OK) st = sg_alloc(ctx, (size_t)n_long + 1, &d_coff);
+        if (st == SG_OK) st = sg_alloc(ctx, (size_t)n_long + 1, &d_koff);
+        hipError_t e = hipSuccess;
+        if (st == SG_OK) {
+            hipLaunchKernelGGL(long_sizes_kernel, dim3((n_long + 255) / 256), dim3(256), 0, ctx->stream, s->d_offsets,
+                               (const uint32_t *)(longs + 1), n_long, d_sizes);
+            e = hipMemcpyAsync(sizes.data(), d_sizes, sizeof(int64_t) * n_long, hipMemcpyDeviceToHost, ctx->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        }
+        uint16_t *lchars = nullptr;
+        KeyT *lkeys = nullptr;
+        if (st == SG_OK && e == hipSuccess) {
+            for (uint32_t i = 0; i < n_long; ++i) {
+                int64_t p2 = 64;
+                while (p2 < sizes[i]) p2 <<= 1;
+                coff[i + 1] = coff[i] + sizes[i] + 8;
+                koff[i + 1] = koff[i] + p2;
+            }
+            st = sg_alloc(ctx, (size_t)coff[n_long] + 8, &lchars);
+            if (st == SG_OK) st = sg_alloc(ctx, (size_t)koff[n_long] + 8, &lkeys);
+            if (st == SG_OK) {
+                e = hipMemcpyAsync(d_coff, coff.data(), sizeof(int64_t) * (n_long + 1), hipMemcpyHostToDevice, ctx->stream);
+                if (e == hipSuccess)
+                    e = hipMemcpyAsync(d_koff, koff.data(), sizeof(int64_t) * (n_long + 1), hipMemcpyHostToDevice, ctx->stream);
+                if (e == hipSuccess) {
+                    hipLaunchKernelGGL((tokenize_long_kernel<KeyT, SYMBOLS>), dim3(n_long), dim3(256), 0, ctx->stream,
+                                       (const void *)s->d_bytes, s->d_offsets, tp, (const uint32_t *)(longs + 1),
+                                       (const int64_t *)d_coff, (const int64_t *)d_koff, lchars, lkeys,
+                                       (const int64_t *)c.d_ub_ptr, c.d_cnt, keys, c.d_tf, df_table, df_replicas, df_stride);
+                    e = hipGetLastError();
+                }
+                if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);   // coff / koff are locals
+            }
+        }
+        ctx->release(d_sizes);
+        ctx->release(d_coff);
+        ctx->release(d_koff);
+        ctx->release(lchars);
+        ctx->release(lkeys);
+        if (st == SG_OK && e != hipSuccess) {
+            sg_set_error("tokenize_long_kernel: %s", hipGetErrorString(e));
+            st = SG_ERR_HIP;
+        }
+    }
+    ctx->release(longs);
     if (st != SG_OK) {
         free_cache(ctx, c);
         return st;
@@ -339,28 +586,30 @@ static int tokenize_set(sg_ctx *ctx, const sg_strings *s, const TokParams &tp, i
     return SG_OK;
 }
 
-static TokParams make_tok_params(const sg_vocab *v, const VocabImpl *im) {
-    TokParams tp;
-    memset(&tp, 0, sizeof(tp));
-    tp.ngram = v->params.ngram_size;
-    tp.ascii_lower = v->params.ascii_lower;
-    tp.bits = v->bits_per_char;
-    for (int c = 0; c < 128; ++c)
-        if (v->params.delete_table[c]) tp.del_mask[c >> 5] |= 1u << (c & 31);
-    memcpy(tp.rank_of_byte, im->rank_of_byte, 128);
-    return tp;
+static int tokenize_set(sg_ctx *ctx, const sg_vocab *v, const sg_strings *s, int32_t *df_table, int32_t df_replicas,
+                        int64_t df_stride, TokenCache *out) {
+    const TokParams tp = make_tok_params(v, v->impl, s);
+    const bool sym = s->sym_width == 2;
+    if (v->sorted_mode)
+        return sym ? tokenize_set_t<uint64_t, true>(ctx, s, tp, df_table, df_replicas, df_stride, out)
+                   : tokenize_set_t<uint64_t, false>(ctx, s, tp, df_table, df_replicas, df_stride, out);
+    return sym ? tokenize_set_t<uint32_t, true>(ctx, s, tp, df_table, df_replicas, df_stride, out)
+               : tokenize_set_t<uint32_t, false>(ctx, s, tp, df_table, df_replicas, df_stride, out);
 }
 
-// fit = begin (tokenise, count document frequencies into the dense key table) + end (vocabulary from the table).
-// The two halves are separate entry points so that a multi-GPU caller can all-reduce the table in between
-// (one rank tokenises one block of the strings; every rank then derives the SAME vocabulary and idf).
+// fit = begin (tokenise, count document frequencies) + end (vocabulary).  The two halves are separate entry points so
+// that a multi-GPU caller can all-reduce the dense document-frequency table in between (one rank tokenises one block of
+// the strings; every rank then derives the SAME vocabulary and idf).
 extern "C" int sg_vec_fit_begin(sg_ctx *ctx, const sg_strings *const *sets, int32_t n_sets, const sg_vec_params *params,
                                 sg_vocab **out) {
     SG_REQUIRE(ctx && sets && params && out && n_sets >= 1, "null argument");
-    SG_REQUIRE(params->ngram_size >= 1 && params->ngram_size <= 9, "ngram_size must be in [1, 9]");
+    SG_REQUIRE(params->ngram_size >= 1 && params->ngram_size <= 64, "ngram_size must be in [1, 64]");
     SG_REQUIRE(params->dtype == SG_F32 || params->dtype == SG_F64, "dtype must be SG_F32 or SG_F64");
-    for (int i = 0; i < n_sets; ++i) SG_REQUIRE(sets[i] != nullptr, "null string set");
-
+    for (int i = 0; i < n_sets; ++i) {
+        SG_REQUIRE(sets[i] != nullptr, "null string set");
+        SG_REQUIRE(sets[i]->sym_width == sets[0]->sym_width && sets[i]->alphabet == sets[0]->alphabet,
+                   "the string columns of one fit must be all byte columns or all symbol columns of one alphabet");
+    }
     sg_vocab *v = new (std::nothrow) sg_vocab();
     VocabImpl *im = new (std::nothrow) VocabImpl();
     if (!v || !im) {
@@ -372,27 +621,41 @@ extern "C" int sg_vec_fit_begin(sg_ctx *ctx, const sg_strings *const *sets, int3
     v->params = *params;
     v->impl = im;
     int st = SG_OK;
-    // ---- character coding: raw 7 bits when the key space stays small, else ranks of the bytes present
+    const int n = params->ngram_size;
+    // ---- character coding
     for (int c = 0; c < 128; ++c) {
-        im->rank_of_byte[c] = (uint8_t)c;
+        im->rank_of_byte[c] = (uint16_t)c;
         im->byte_of_rank[c] = (uint8_t)c;
     }
     v->bits_per_char = 7;
-    TokParams tp = make_tok_params(v, im);
-    if (7 * params->ngram_size > 24) {
+    if (sets[0]->sym_width == 2) {
+        // symbol columns: the host ranked the characters into the alphabet of this fit (+ one code for "not in it")
+        im->symbols = true;
+        im->alphabet = sets[0]->alphabet;
+        int bits = 1;
+        while ((1 << bits) < im->alphabet) ++bits;
+        v->bits_per_char = bits;
+        im->local_alphabet = true;
+    } else if (7 * n > 24) {
+        // byte columns, long n-grams: ranks of the bytes that occur instead of the raw 7 bits
+        bool lower_any = false;
+        for (int i = 0; i < n_sets; ++i) lower_any |= params->ascii_lower && !sets[i]->prelowered;
         uint32_t *d_present = nullptr;
         st = sg_alloc(ctx, 4, &d_present);
         uint32_t present[4] = {0, 0, 0, 0};
         if (st == SG_OK) {
             (void)hipMemsetAsync(d_present, 0, 16, ctx->stream);
             for (int i = 0; i < n_sets; ++i)
-                if (sets[i]->total_bytes > 0)
+                if (sets[i]->total_bytes > 0) {
+                    const TokParams tp = make_tok_params(v, im, sets[i]);
                     hipLaunchKernelGGL(alphabet_kernel, dim3(1024), dim3(256), 0, ctx->stream, sets[i]->d_bytes,
                                        sets[i]->total_bytes, tp, d_present);
+                }
             if (hipMemcpyAsync(present, d_present, 16, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
                 hipStreamSynchronize(ctx->stream) != hipSuccess)
                 st = SG_ERR_HIP;
         }
+        (void)lower_any;
         ctx->release(d_present);
         if (st == SG_OK) {
             // bytes that do not occur get the out-of-alphabet code: an n-gram containing one (only possible in a
@@ -401,7 +664,7 @@ extern "C" int sg_vec_fit_begin(sg_ctx *ctx, const sg_strings *const *sets, int3
             int sigma = 0;
             for (int c = 0; c < 128; ++c)
                 if ((present[c >> 5] >> (c & 31)) & 1u) {
-                    im->rank_of_byte[c] = (uint8_t)sigma;
+                    im->rank_of_byte[c] = (uint16_t)sigma;
                     im->byte_of_rank[sigma] = (uint8_t)c;
                     ++sigma;
                 }
@@ -409,44 +672,50 @@ extern "C" int sg_vec_fit_begin(sg_ctx *ctx, const sg_strings *const *sets, int3
             while ((1 << bits) < sigma) ++bits;
             v->bits_per_char = bits;
             im->local_alphabet = true;
-            if (bits * params->ngram_size > 30) {
-                sg_set_error("n-gram key space 2^%d (alphabet of %d characters, ngram_size %d) is too large for the "
-                             "device vocabulary table", bits * params->ngram_size, sigma, params->ngram_size);
-                st = SG_ERR_UNSUPPORTED;
-            }
-            tp = make_tok_params(v, im);
         }
+    }
+    if (st == SG_OK) {
+        const int key_bits = v->bits_per_char * n;
+        if (key_bits > 63) {
+            sg_set_error("n-grams of %d characters over an alphabet of 2^%d need %d-bit keys; the device vocabulary holds 63",
+                         n, v->bits_per_char, key_bits);
+            st = SG_ERR_UNSUPPORTED;
+        }
+        v->sorted_mode = key_bits > 30;
+        if (const char *e = getenv("SG_VOCAB_SORTED"))      // test hook: the sorted vocabulary at any size
+            if (e[0] == '1') v->sorted_mode = true;
+        v->key_space = v->sorted_mode ? 0 : (int64_t)1 << key_bits;
     }
     if (st != SG_OK) {
         sg_vocab_free(v);
         return st;
     }
-    v->key_space = (int64_t)1 << (v->bits_per_char * params->ngram_size);
 
     {
         SgTimer timer(ctx, SG_K_TOKENIZE);
-        // df table: `replicas` copies (row mod replicas picks one) while they stay small, summed afterwards
-        const int64_t df_stride = v->key_space + 1;
-        int32_t replicas = 8;
-        if (const char *e = getenv("SG_DF_REPLICAS")) replicas = atoi(e);
-        while (replicas > 1 && df_stride * replicas > ((int64_t)1 << 25)) replicas >>= 1;   // <= 128 MiB of counters
-        if (replicas < 1) replicas = 1;
-        st = sg_alloc(ctx, (size_t)(df_stride * replicas), &im->d_df_table);
-        if (st == SG_OK) st = sg_alloc(ctx, (size_t)v->key_space + 1, &v->d_key_to_col);
-        if (st == SG_OK) st = sg_alloc(ctx, 4, &im->d_err);
-        if (st == SG_OK) {
-            (void)hipMemsetAsync(im->d_df_table, 0, sizeof(int32_t) * (size_t)(df_stride * replicas), ctx->stream);
-            (void)hipMemsetAsync(im->d_err, 0, 16, ctx->stream);
+        int32_t replicas = 1;
+        int64_t df_stride = 0;
+        if (!v->sorted_mode) {
+            // df table: `replicas` copies (row mod replicas picks one) while they stay small, summed afterwards
+            df_stride = v->key_space + 1;
+            replicas = 8;
+            if (const char *e = getenv("SG_DF_REPLICAS")) replicas = atoi(e);
+            while (replicas > 1 && df_stride * replicas > ((int64_t)1 << 25)) replicas >>= 1;   // <= 128 MiB of counters
+            if (replicas < 1) replicas = 1;
+            st = sg_alloc(ctx, (size_t)(df_stride * replicas), &im->d_df_table);
+            if (st == SG_OK) st = sg_alloc(ctx, (size_t)v->key_space + 1, &v->d_key_to_col);
+            if (st == SG_OK)
+                (void)hipMemsetAsync(im->d_df_table, 0, sizeof(int32_t) * (size_t)(df_stride * replicas), ctx->stream);
         }
         for (int i = 0; i < n_sets && st == SG_OK; ++i) {
             TokenCache c;
-            st = tokenize_set(ctx, sets[i], tp, im->d_df_table, replicas, df_stride, im->d_err, &c);
+            st = tokenize_set(ctx, v, sets[i], im->d_df_table, replicas, df_stride, &c);
             if (st == SG_OK) {
                 im->caches.push_back(c);
                 v->n_docs += sets[i]->n;
             }
         }
-        if (st == SG_OK && replicas > 1) {
+        if (st == SG_OK && !v->sorted_mode && replicas > 1) {
             const unsigned grid = (unsigned)((v->key_space + 255) / 256);
             hipLaunchKernelGGL(df_reduce_kernel, dim3(grid), dim3(256), 0, ctx->stream, im->d_df_table, v->key_space,
                                replicas, df_stride);
@@ -464,10 +733,67 @@ extern "C" int sg_vec_fit_begin(sg_ctx *ctx, const sg_strings *const *sets, int3
 extern "C" int sg_vocab_df_table(sg_vocab *v, int32_t **d_table, int64_t *n_entries, int32_t *shareable) {
     SG_REQUIRE(v && v->impl && d_table && n_entries, "null argument");
     SG_REQUIRE(v->n_terms == 0, "the vocabulary is already finished");
-    *d_table = v->impl->d_df_table;
+    *d_table = v->impl->d_df_table;      // null in sorted mode
     *n_entries = v->key_space;
-    // a table coded with the alphabet of the LOCAL strings (ngram_size > 3) means something else on every rank
-    if (shareable) *shareable = v->impl->local_alphabet ? 0 : 1;
+    // a table coded with the alphabet of the LOCAL strings (ngram_size > 3, symbol columns) means something else on
+    // every rank; a sorted vocabulary has no table at all
+    if (shareable) *shareable = (v->impl->local_alphabet || v->sorted_mode) ? 0 : 1;
+    return SG_OK;
+}
+
+// sorted mode: vocabulary = sorted distinct keys of all columns of the fit, df = their run lengths
+static int finish_sorted_vocabulary(sg_ctx *ctx, sg_vocab *v) {
+    VocabImpl *im = v->impl;
+    int64_t total = 0;
+    std::vector<int64_t *> dst_ptrs;
+    std::vector<int64_t> totals;
+    int st = SG_OK;
+    for (auto &c : im->caches) {   // where every row's keys go in the gathered array
+        int64_t *d = nullptr;
+        st = sg_alloc(ctx, (size_t)c.n + 1, &d);
+        if (st != SG_OK) break;
+        dst_ptrs.push_back(d);
+        int64_t t = 0;
+        if (c.n > 0) {
+            st = sg_exclusive_scan_i32_to_i64(ctx, c.d_cnt, d, c.n);
+            if (st == SG_OK && (hipMemcpyAsync(&t, d + c.n, sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+                                hipStreamSynchronize(ctx->stream) != hipSuccess))
+                st = SG_ERR_HIP;
+        }
+        if (st != SG_OK) break;
+        totals.push_back(t);
+        total += t;
+    }
+    uint64_t *all = nullptr;
+    if (st == SG_OK) st = sg_alloc(ctx, (size_t)total + 1, &all);
+    if (st == SG_OK) st = sg_alloc(ctx, (size_t)total + 1, &v->d_keys);
+    if (st == SG_OK) st = sg_alloc(ctx, (size_t)total + 1, &v->d_df);
+    int64_t at = 0;
+    for (size_t i = 0; i < im->caches.size() && st == SG_OK; ++i) {
+        const TokenCache &c = im->caches[i];
+        if (c.n > 0 && totals[i] > 0) {
+            hipLaunchKernelGGL(gather_keys_kernel, dim3((unsigned)((c.n + 255) / 256)), dim3(256), 0, ctx->stream,
+                               (const int64_t *)c.d_ub_ptr, (const int32_t *)c.d_cnt, (const uint64_t *)c.d_keys,
+                               (const int64_t *)dst_ptrs[i], c.n, all + at);
+            if (hipGetLastError() != hipSuccess) st = SG_ERR_HIP;
+        }
+        at += totals[i];
+    }
+    int64_t n_unique = 0;
+    if (st == SG_OK) st = sg_sort_unique_u64(ctx, all, total, v->d_keys, v->d_df, &n_unique);
+    for (int64_t *d : dst_ptrs) ctx->release(d);
+    ctx->release(all);
+    if (st != SG_OK) return st;
+    // an out-of-alphabet key cannot occur at fit (the alphabet comes from these very strings), but a symbol column may
+    // carry the code on purpose: it sorts last and is not a term
+    if (n_unique > 0) {
+        uint64_t last = 0;
+        if (hipMemcpyAsync(&last, v->d_keys + (n_unique - 1), 8, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+            hipStreamSynchronize(ctx->stream) != hipSuccess)
+            return SG_ERR_HIP;
+        if (last == SG_KEY_OOV64) --n_unique;
+    }
+    v->n_terms = n_unique;
     return SG_OK;
 }
 
@@ -479,44 +805,45 @@ extern "C" int sg_vec_fit_end(sg_ctx *ctx, sg_vocab *v, int64_t n_docs_total) {
     int st = SG_OK;
     {
         SgTimer timer(ctx, SG_K_VOCAB);
-        // ---- vocabulary = keys with df > 0, column id = rank
-        uint32_t *d_total = nullptr;
-        st = sg_alloc(ctx, 4, &d_total);
-        if (st == SG_OK) {
-            const unsigned grid = (unsigned)((v->key_space + 255) / 256);
-            hipLaunchKernelGGL(presence_kernel, dim3(grid), dim3(256), 0, ctx->stream, im->d_df_table, v->key_space,
-                               (uint32_t *)v->d_key_to_col);
-            st = sg_exclusive_scan_u32(ctx, (const uint32_t *)v->d_key_to_col, (uint32_t *)v->d_key_to_col,
-                                       v->key_space, d_total);
-        }
-        uint32_t host_words[2] = {0, 0};
-        if (st == SG_OK) {
-            if (hipMemcpyAsync(&host_words[0], d_total, 4, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
-                hipMemcpyAsync(&host_words[1], im->d_err, 4, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
-                hipStreamSynchronize(ctx->stream) != hipSuccess) {
-                sg_set_error("reading the vocabulary size failed: %s", hipGetErrorString(hipGetLastError()));
-                st = SG_ERR_HIP;
+        if (v->sorted_mode) {
+            st = finish_sorted_vocabulary(ctx, v);
+        } else {
+            // ---- vocabulary = keys with df > 0, column id = rank
+            uint32_t *d_total = nullptr;
+            st = sg_alloc(ctx, 4, &d_total);
+            if (st == SG_OK) {
+                const unsigned grid = (unsigned)((v->key_space + 255) / 256);
+                hipLaunchKernelGGL(presence_kernel, dim3(grid), dim3(256), 0, ctx->stream, im->d_df_table, v->key_space,
+                                   (uint32_t *)v->d_key_to_col);
+                st = sg_exclusive_scan_u32(ctx, (const uint32_t *)v->d_key_to_col, (uint32_t *)v->d_key_to_col,
+                                           v->key_space, d_total);
+            }
+            uint32_t n_terms = 0;
+            if (st == SG_OK) {
+                if (hipMemcpyAsync(&n_terms, d_total, 4, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+                    hipStreamSynchronize(ctx->stream) != hipSuccess) {
+                    sg_set_error("reading the vocabulary size failed: %s", hipGetErrorString(hipGetLastError()));
+                    st = SG_ERR_HIP;
+                }
+            }
+            ctx->release(d_total);
+            if (st == SG_OK) {
+                v->n_terms = n_terms;
+                if (v->n_terms > 0) {
+                    st = sg_alloc(ctx, (size_t)v->n_terms + 1, &v->d_keys);
+                    if (st == SG_OK) st = sg_alloc(ctx, (size_t)v->n_terms + 1, &v->d_df);
+                    if (st == SG_OK) {
+                        const unsigned grid = (unsigned)((v->key_space + 255) / 256);
+                        hipLaunchKernelGGL(vocab_finalize_kernel, dim3(grid), dim3(256), 0, ctx->stream, im->d_df_table,
+                                           v->key_space, v->d_key_to_col, v->d_keys, v->d_df);
+                        if (hipGetLastError() != hipSuccess) st = SG_ERR_HIP;
+                    }
+                }
             }
         }
-        ctx->release(d_total);
-        if (st == SG_OK && host_words[1] != 0) {
-            sg_set_error("a string has more than %d n-grams; the device tokeniser does not handle it", TOK_CAP);
-            st = SG_ERR_UNSUPPORTED;
-        }
-        if (st == SG_OK) {
-            v->n_terms = host_words[0];
-            if (v->n_terms == 0) {
-                sg_set_error("empty vocabulary; perhaps the documents only contain stop words");
-                st = SG_ERR_BADARG;
-            }
-        }
-        if (st == SG_OK) st = sg_alloc(ctx, (size_t)v->n_terms + 1, &v->d_keys);
-        if (st == SG_OK) st = sg_alloc(ctx, (size_t)v->n_terms + 1, &v->d_df);
-        if (st == SG_OK) {
-            const unsigned grid = (unsigned)((v->key_space + 255) / 256);
-            hipLaunchKernelGGL(vocab_finalize_kernel, dim3(grid), dim3(256), 0, ctx->stream, im->d_df_table,
-                               v->key_space, v->d_key_to_col, v->d_keys, v->d_df);
-            if (hipGetLastError() != hipSuccess) st = SG_ERR_HIP;
+        if (st == SG_OK && v->n_terms == 0) {
+            sg_set_error("empty vocabulary; perhaps the documents only contain stop words");
+            st = SG_ERR_BADARG;
         }
     }
     return st;
@@ -543,6 +870,14 @@ extern "C" int sg_vocab_size(const sg_vocab *v, int64_t *n_terms, int64_t *n_doc
     return SG_OK;
 }
 
+extern "C" int sg_vocab_coding(const sg_vocab *v, int32_t *bits_per_char, int32_t *symbols, int32_t *sorted_mode) {
+    SG_REQUIRE(v && v->impl, "vocab is null");
+    if (bits_per_char) *bits_per_char = v->bits_per_char;
+    if (symbols) *symbols = v->impl->symbols ? 1 : 0;
+    if (sorted_mode) *sorted_mode = v->sorted_mode ? 1 : 0;
+    return SG_OK;
+}
+
 extern "C" int sg_vocab_to_host(sg_ctx *ctx, const sg_vocab *v, uint64_t *keys, int64_t *df) {
     SG_REQUIRE(ctx && v && keys && df, "null argument");
     const VocabImpl *im = impl_of(v);
@@ -551,18 +886,16 @@ extern "C" int sg_vocab_to_host(sg_ctx *ctx, const sg_vocab *v, uint64_t *keys, 
     SG_HIP_TRY(hipMemcpyAsync(keys, v->d_keys, sizeof(uint64_t) * (size_t)v->n_terms, hipMemcpyDeviceToHost, ctx->stream));
     SG_HIP_TRY(hipMemcpyAsync(hdf.data(), v->d_df, sizeof(int32_t) * (size_t)v->n_terms, hipMemcpyDeviceToHost, ctx->stream));
     SG_HIP_TRY(hipStreamSynchronize(ctx->stream));
-    const int n = v->params.ngram_size, bits = v->bits_per_char;
-    for (int64_t i = 0; i < v->n_terms; ++i) {
-        df[i] = hdf[(size_t)i];
-        // re-pack the compact character codes as 7-bit ASCII, big-endian
-        const uint64_t k = keys[i];
-        uint64_t out = 0;
-        for (int q = 0; q < n; ++q) {
-            const uint32_t code = (uint32_t)(k >> (bits * (n - 1 - q))) & ((1u << bits) - 1);
-            out = (out << 7) | im->byte_of_rank[code & 127];
-        }
-        keys[i] = out;
-    }
+    for (int64_t i = 0; i < v->n_terms; ++i) df[i] = hdf[(size_t)i];
+    return SG_OK;
+}
+
+extern "C" int sg_vocab_byte_alphabet(const sg_vocab *v, uint8_t *byte_of_code, int32_t *n_codes) {
+    SG_REQUIRE(v && v->impl && byte_of_code && n_codes, "null argument");
+    SG_REQUIRE(!v->impl->symbols, "the vocabulary was fitted on symbol columns: the caller holds their alphabet");
+    *n_codes = 1 << v->bits_per_char;
+    if (*n_codes > 128) *n_codes = 128;
+    memcpy(byte_of_code, v->impl->byte_of_rank, (size_t)*n_codes);
     return SG_OK;
 }
 
@@ -584,7 +917,6 @@ extern "C" int sg_vocab_free(sg_vocab *v) {
     if (im) {
         for (auto &c : im->caches) free_cache(ctx, c);
         ctx->release(im->d_df_table);
-        ctx->release(im->d_err);
         delete im;
     }
     ctx->release(v->d_key_to_col);
@@ -595,11 +927,21 @@ extern "C" int sg_vocab_free(sg_vocab *v) {
     return SG_OK;
 }
 
+template <typename T, typename KeyT, typename Lookup>
+static void launch_weight(sg_ctx *ctx, const TokenCache *tc, Lookup lookup, const sg_vocab *v, int64_t n, const int64_t *indptr,
+                          int32_t *idx, void *val) {
+    hipLaunchKernelGGL((weight_normalize_kernel<T, KeyT, Lookup>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream,
+                       (const int64_t *)tc->d_ub_ptr, (const int32_t *)tc->d_cnt, (const KeyT *)tc->d_keys,
+                       (const int32_t *)tc->d_tf, lookup, (const T *)v->d_idf, n, indptr, idx, (T *)val);
+}
+
 extern "C" int sg_vec_transform(sg_ctx *ctx, const sg_vocab *v, const sg_strings *strings, sg_csr **out) {
     SG_REQUIRE(ctx && v && strings && out, "null argument");
     SG_REQUIRE(v->d_idf != nullptr, "sg_vocab_set_idf has not been called");
     VocabImpl *im = impl_of(v);
     SG_REQUIRE(im != nullptr, "unknown vocab");
+    SG_REQUIRE((strings->sym_width == 2) == im->symbols && (!im->symbols || strings->alphabet == im->alphabet),
+               "the strings are not of the kind (bytes / symbols of this alphabet) the vocabulary was fitted on");
     // tokens: reuse the pass made by fit() when these strings were part of it
     TokenCache local;
     const TokenCache *tc = nullptr;
@@ -608,9 +950,7 @@ extern "C" int sg_vec_transform(sg_ctx *ctx, const sg_vocab *v, const sg_strings
     int st = SG_OK;
     if (!tc) {
         SgTimer timer(ctx, SG_K_TOKENIZE);
-        const TokParams tp = make_tok_params(v, im);
-        (void)hipMemsetAsync(im->d_err, 0, 16, ctx->stream);
-        st = tokenize_set(ctx, strings, tp, nullptr, 1, 0, im->d_err, &local);
+        st = tokenize_set(ctx, v, strings, nullptr, 1, 0, &local);
         if (st != SG_OK) return st;
         tc = &local;
     }
@@ -624,29 +964,31 @@ extern "C" int sg_vec_transform(sg_ctx *ctx, const sg_vocab *v, const sg_strings
     m->owned = true;
     int32_t *kept = nullptr;
     int64_t *indptr = nullptr;
-    int32_t host_err = 0;
     int64_t nnz = 0;
+    const DenseLookup dense{v->d_key_to_col};
+    const SortedLookup sorted{v->d_keys, v->n_terms};
     {
         SgTimer timer(ctx, SG_K_WEIGHT);
         st = sg_alloc(ctx, (size_t)n + 1, &kept);
         if (st == SG_OK) st = sg_alloc(ctx, (size_t)n + 1, &indptr);
         if (st == SG_OK && n > 0) {
-            hipLaunchKernelGGL(kept_count_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream,
-                               (const int64_t *)tc->d_ub_ptr, (const int32_t *)tc->d_cnt,
-                               (const uint32_t *)tc->d_keys, (const int32_t *)v->d_key_to_col, n, kept);
+            const unsigned grid = (unsigned)((n + 255) / 256);
+            if (v->sorted_mode)
+                hipLaunchKernelGGL((kept_count_kernel<uint64_t, SortedLookup>), dim3(grid), dim3(256), 0, ctx->stream,
+                                   (const int64_t *)tc->d_ub_ptr, (const int32_t *)tc->d_cnt, (const uint64_t *)tc->d_keys,
+                                   sorted, n, kept);
+            else
+                hipLaunchKernelGGL((kept_count_kernel<uint32_t, DenseLookup>), dim3(grid), dim3(256), 0, ctx->stream,
+                                   (const int64_t *)tc->d_ub_ptr, (const int32_t *)tc->d_cnt, (const uint32_t *)tc->d_keys,
+                                   dense, n, kept);
             st = sg_exclusive_scan_i32_to_i64(ctx, kept, indptr, n);
         } else if (st == SG_OK) {
             (void)hipMemsetAsync(indptr, 0, sizeof(int64_t), ctx->stream);
         }
         if (st == SG_OK) {
             if (hipMemcpyAsync(&nnz, indptr + n, sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
-                hipMemcpyAsync(&host_err, im->d_err, 4, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
                 hipStreamSynchronize(ctx->stream) != hipSuccess)
                 st = SG_ERR_HIP;
-        }
-        if (st == SG_OK && host_err != 0) {
-            sg_set_error("a string has more than %d n-grams; the device tokeniser does not handle it", TOK_CAP);
-            st = SG_ERR_UNSUPPORTED;
         }
         int32_t *idx = nullptr;
         void *val = nullptr;
@@ -658,19 +1000,13 @@ extern "C" int sg_vec_transform(sg_ctx *ctx, const sg_vocab *v, const sg_strings
         m->d_data = val;
         m->nnz = nnz;
         if (st == SG_OK && n > 0) {
-            const unsigned grid = (unsigned)((n + 255) / 256);
-            if (m->dtype == SG_F64)
-                hipLaunchKernelGGL(weight_normalize_kernel<double>, dim3(grid), dim3(256), 0, ctx->stream,
-                                   (const int64_t *)tc->d_ub_ptr, (const int32_t *)tc->d_cnt,
-                                   (const uint32_t *)tc->d_keys, (const int32_t *)tc->d_tf,
-                                   (const int32_t *)v->d_key_to_col, (const double *)v->d_idf, n,
-                                   (const int64_t *)indptr, idx, (double *)val);
-            else
-                hipLaunchKernelGGL(weight_normalize_kernel<float>, dim3(grid), dim3(256), 0, ctx->stream,
-                                   (const int64_t *)tc->d_ub_ptr, (const int32_t *)tc->d_cnt,
-                                   (const uint32_t *)tc->d_keys, (const int32_t *)tc->d_tf,
-                                   (const int32_t *)v->d_key_to_col, (const float *)v->d_idf, n,
-                                   (const int64_t *)indptr, idx, (float *)val);
+            if (v->sorted_mode) {
+                if (m->dtype == SG_F64) launch_weight<double, uint64_t>(ctx, tc, sorted, v, n, indptr, idx, val);
+                else launch_weight<float, uint64_t>(ctx, tc, sorted, v, n, indptr, idx, val);
+            } else {
+                if (m->dtype == SG_F64) launch_weight<double, uint32_t>(ctx, tc, dense, v, n, indptr, idx, val);
+                else launch_weight<float, uint32_t>(ctx, tc, dense, v, n, indptr, idx, val);
+            }
             if (hipGetLastError() != hipSuccess) st = SG_ERR_HIP;
         }
     }

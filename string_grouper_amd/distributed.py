@@ -306,9 +306,9 @@ def strings_to_device_tensors(prepared, device):
 
 
 def _wrap_device_strings(ctx, t_bytes, t_offs, n: int, total: int):
-    from .vectorizer import PreparedStrings
-    p = object.__new__(PreparedStrings)
-    p.data, p.offsets, p.n = None, None, n
+    from .strprep import StringColumn
+    p = StringColumn("bytes", None, np.zeros(n + 1, np.int64))       # the bytes live in HBM only
+    p.offsets = None
     p.dev = ctx.strings_from_device(t_bytes.data_ptr(), t_offs.data_ptr(), n, total, keepalive=(t_bytes, t_offs))
     return p
 

@@ -4,141 +4,41 @@ Mirrors how the reference builds and drives its vectoriser
 (string_grouper/string_grouper.py:306 ``TfidfVectorizer(min_df=1, analyzer=self.n_grams, dtype=...)``,
 ``.fit`` at :706, ``.transform`` at :689/:692) and the analyzer ``StringGrouper.n_grams`` (:365-378).
 
-Host work is limited to what the reference also does on the host per string and what has no
-byte-level definition: Unicode ``str.lower()`` / NFKD for the (few) strings that contain non-ASCII
-characters, and ``re.sub`` when the regex is not a plain character class.  Everything else --
-ASCII lower-casing, character deletion, n-gramming, vocabulary, counts, idf weighting,
+Host work is limited to what has no byte-level definition -- Unicode ``str.lower()`` / NFKD for strings with
+non-ASCII characters and ``re.sub`` for a regex that is not a plain character class -- and is vectorised
+(string_grouper_amd/strprep.py: numpy over code points, Python's own semantics consulted once per distinct code
+point).  Everything else -- ASCII lower-casing, character deletion, n-gramming, vocabulary, counts, idf weighting,
 L2 normalisation -- runs on the GPU.  There is no CPU tokeniser fallback.
+
+Two kinds of columns reach the device (strprep.StringColumn): BYTE columns (ASCII after the host step; the default
+``normalize_to_ascii=True`` always ends here) and SYMBOL columns (``normalize_to_ascii=False`` with non-ASCII
+characters: uint16 ranks in the alphabet of the fit, which is the sorted set of the code points of all columns of
+that fit -- so that the packed keys still sort like sklearn's vocabulary).
 """
 from __future__ import annotations
 
-import re
 from typing import Dict, List, Optional, Sequence
-from unicodedata import normalize as _ucd_normalize
 
 import numpy as np
 
 from . import _native as N
-
-try:                                   # Python >= 3.11
-    import re._parser as _sre_parse    # type: ignore
-    import re._constants as _sre_c     # type: ignore
-except ImportError:                    # Python 3.10
-    import sre_parse as _sre_parse     # type: ignore
-    import sre_constants as _sre_c     # type: ignore
+from . import strprep as SP
+from .strprep import StringColumn, delete_table_for, regex_is_char_class   # noqa: F401  (re-exported)
 
 DEFAULT_REGEX = r'[,-./]|\s'
+SYMBOL_ABSENT = 0xFFFF
+
+PreparedStrings = StringColumn      # round-1 name
 
 
-def regex_is_char_class(pattern: str) -> bool:
-    """True when every match of ``pattern`` is exactly one character chosen independently of
-    context (a literal, a set, a category such as \\s, or an alternation of those), so that
-    ``re.sub(pattern, '', s)`` deletes exactly the characters c with ``re.fullmatch(pattern, c)``."""
-    try:
-        parsed = _sre_parse.parse(pattern)
-    except Exception:
-        return False
-    single = (_sre_c.LITERAL, _sre_c.NOT_LITERAL, _sre_c.IN, _sre_c.CATEGORY, _sre_c.ANY)
-
-    def one_char(seq) -> bool:
-        items = list(seq)
-        if len(items) != 1:
-            return False
-        op, arg = items[0]
-        if op in single:
-            return True
-        if op is _sre_c.BRANCH:
-            return all(one_char(alt) for alt in arg[1])
-        if op is _sre_c.SUBPATTERN:
-            return one_char(arg[-1])
-        return False
-
-    if parsed.state.flags & (re.IGNORECASE | re.LOCALE):
-        return False
-    return one_char(parsed)
-
-
-def delete_table_for(pattern: str) -> np.ndarray:
-    rx = re.compile(pattern)
-    return np.array([1 if rx.fullmatch(chr(c)) else 0 for c in range(128)], dtype=np.uint8)
-
-
-class PreparedStrings:
-    """A string column as Arrow large_string buffers (contiguous UTF-8 bytes + int64 offsets),
-    after the host-side Unicode step; ``dev`` is its device-resident copy."""
-
-    def __init__(self, data: np.ndarray, offsets: np.ndarray):
-        self.data = data
-        self.offsets = offsets
-        self.n = len(offsets) - 1
-        self.dev: Optional[N.Strings] = None
-
-
-def _to_arrow_buffers(strings) -> (np.ndarray, np.ndarray):
-    import pyarrow as pa
-    if hasattr(strings, "array") and hasattr(strings.array, "_pa_array"):       # pandas ArrowExtensionArray
-        arr = strings.array._pa_array.combine_chunks()
-        arr = arr.cast(pa.large_string())
-    else:
-        values = strings.to_numpy() if hasattr(strings, "to_numpy") else np.asarray(strings, dtype=object)
-        arr = pa.array(values, type=pa.large_string())
-    if arr.null_count:
-        raise TypeError("input contains null values; only strings are accepted")
-    bufs = arr.buffers()
-    offsets = np.frombuffer(bufs[1], dtype=np.int64, count=len(arr) + 1 + arr.offset)[arr.offset:]
-    data = np.frombuffer(bufs[2], dtype=np.uint8) if bufs[2] is not None else np.zeros(0, np.uint8)
-    if offsets[0] != 0:
-        data = data[offsets[0]:offsets[-1]]
-        offsets = offsets - offsets[0]
-    else:
-        data = data[:offsets[-1]]
-    return data, np.ascontiguousarray(offsets)
-
-
-def prepare_strings(strings, ignore_case: bool, normalize_to_ascii: bool, regex: Optional[str]) -> PreparedStrings:
-    """Host step of n_grams (string_grouper.py:372-376) for what cannot be done bytewise.
-
-    ``regex`` not None: apply ``re.sub(regex, '', s)`` on the host (pattern is not a character class)."""
-    data, offsets = _to_arrow_buffers(strings)
-    needs_unicode = data.size > 0 and int(data.max()) >= 0x80
-    if not needs_unicode and regex is None:
-        return PreparedStrings(data, offsets)
-    # rows that need the Python string semantics
-    if needs_unicode:
-        hi = np.flatnonzero(data >= 0x80)
-        rows = np.unique(np.searchsorted(offsets, hi, side="right") - 1)
-        if not normalize_to_ascii:
-            raise NotImplementedError(
-                "normalize_to_ascii=False with non-ASCII input is not supported by the device tokeniser")
-    else:
-        rows = np.zeros(0, np.int64)
-    values = list(strings)
-    if regex is not None:
-        rows = np.arange(len(values))
-        rx = re.compile(regex)
-    fixed = {}
-    for r in rows:
-        s = values[r]
-        if ignore_case:
-            s = s.lower()
-        if normalize_to_ascii:
-            s = _ucd_normalize('NFKD', s).encode('ASCII', 'ignore').decode()
-        if regex is not None:
-            s = rx.sub('', s)
-        fixed[int(r)] = s
-    for r, s in fixed.items():
-        values[r] = s
-    data, offsets = _to_arrow_buffers(np.asarray(values, dtype=object))
-    if data.size and int(data.max()) >= 0x80:
-        raise NotImplementedError("non-ASCII characters survive preprocessing; not supported on the device")
-    return PreparedStrings(data, offsets)
-
-
-def keys_to_terms(keys: np.ndarray, ngram_size: int) -> List[str]:
+def keys_to_terms(keys: np.ndarray, ngram_size: int, bits: int = 7, alphabet: Optional[np.ndarray] = None) -> List[str]:
+    """The n-gram strings of packed keys: ``bits`` per character code, big-endian; ``alphabet[code]`` = code point of a
+    character code (None: the code is the code point)."""
     out = []
+    mask = (1 << bits) - 1
     for k in keys.tolist():
-        chars = [(k >> (7 * (ngram_size - 1 - q))) & 0x7F for q in range(ngram_size)]
-        out.append(bytes(chars).decode('ascii'))
+        codes = [(k >> (bits * (ngram_size - 1 - q))) & mask for q in range(ngram_size)]
+        out.append("".join(chr(int(alphabet[c])) if alphabet is not None else chr(c) for c in codes))
     return out
 
 
@@ -156,7 +56,7 @@ def idf_from_df(df: np.ndarray, n_docs: int, dtype) -> np.ndarray:
 class HipTfidfVectorizer:
     """fit / transform with the semantics of the reference's TfidfVectorizer instance.
 
-    ``transform`` returns a scipy CSR (host) for the drop-in seam; ``transform_device`` keeps the
+    ``transform`` returns a scipy CSR (host) for the drop-in seam; ``transform_prepared`` keeps the
     matrix in HBM for the fused path."""
 
     def __init__(self, ngram_size: int = 3, regex: str = DEFAULT_REGEX, ignore_case: bool = True,
@@ -169,19 +69,20 @@ class HipTfidfVectorizer:
         N.np_dtype_code(self.dtype)
         self._ctx = ctx
         self._vocab: Optional[N.Vocab] = None
-        self._fit_sets: List[PreparedStrings] = []
+        self._fit_sets: List[StringColumn] = []
         self._keys = None
         self._df = None
         self.idf_ = None
         self._vocabulary: Optional[Dict[str, int]] = None
-        self._host_regex = None if regex_is_char_class(regex) else regex
-        table = np.zeros(128, np.uint8) if self._host_regex is not None else delete_table_for(regex)
+        self._alphabet: Optional[np.ndarray] = None        # symbol fits: sorted code points, rank = symbol
+        # a regex that is not a character class is applied on the host (strprep): nothing left for the device to delete
+        self._delete_table = delete_table_for(regex) if regex_is_char_class(regex) else np.zeros(128, np.uint8)
         self._params = N.SgVecParams()
         self._params.ngram_size = self.ngram_size
         self._params.ascii_lower = 1 if self.ignore_case else 0
         self._params.dtype = N.np_dtype_code(self.dtype)
         for c in range(128):
-            self._params.delete_table[c] = int(table[c])
+            self._params.delete_table[c] = int(self._delete_table[c])
 
     @property
     def ctx(self) -> N.Context:
@@ -190,15 +91,64 @@ class HipTfidfVectorizer:
         return self._ctx
 
     # ------------------------------------------------------------------ device-level API
-    def prepare(self, strings) -> PreparedStrings:
-        p = prepare_strings(strings, self.ignore_case, self.normalize_to_ascii, self._host_regex)
-        p.dev = self.ctx.strings_from_host(p.data, p.offsets)
-        return p
+    def prepare(self, strings) -> StringColumn:
+        """Host step + upload of one string column.  Byte columns go to HBM right away; a symbol column is uploaded
+        when its alphabet is known (at fit, or against the fitted alphabet at transform)."""
+        col = SP.prepare_column(strings, self.ignore_case, self.normalize_to_ascii, self.regex)
+        if col.kind == "bytes":
+            self._upload_bytes(col)
+        return col
 
-    def fit_prepared(self, sets: Sequence[PreparedStrings]) -> "HipTfidfVectorizer":
+    def _upload_bytes(self, col: StringColumn):
+        col.dev = self.ctx.strings_from_host(col.data, col.offsets)
+        if col.prelowered:
+            self.ctx.strings_set_prelowered(col.dev, True)
+
+    def _as_symbols(self, col: StringColumn) -> StringColumn:
+        return col if col.kind == "symbols" else SP.bytes_column_to_symbols(col, self.ignore_case, self._delete_table)
+
+    def _upload_symbols(self, col: StringColumn, alphabet: np.ndarray) -> StringColumn:
+        """Rank the code points of a symbol column in ``alphabet`` (sorted) and upload the ranks."""
+        at = np.searchsorted(alphabet, col.data)
+        at_c = np.minimum(at, len(alphabet) - 1)
+        known = alphabet[at_c] == col.data if len(alphabet) else np.zeros(len(col.data), bool)
+        ranks = np.where(known, at_c, SYMBOL_ABSENT).astype(np.uint16)
+        out = StringColumn("symbols", col.data, col.offsets, prelowered=True)
+        out.dev = self.ctx.strings_from_host_symbols(ranks, col.offsets, len(alphabet))
+        return out
+
+    def _device_sets(self, sets: Sequence[StringColumn]) -> List[StringColumn]:
+        """The columns of one fit as the device wants them: all byte columns, or -- as soon as one of them carries
+        non-ASCII symbols -- all symbol columns over one shared alphabet."""
+        if all(s.kind == "bytes" for s in sets):
+            self._alphabet = None
+            for s in sets:
+                if s.dev is None:
+                    self._upload_bytes(s)
+            return list(sets)
+        syms = [self._as_symbols(s) for s in sets]
+        alphabet = np.unique(np.concatenate([s.data for s in syms])) if syms else np.zeros(0, np.uint32)
+        if len(alphabet) == 0:
+            raise ValueError("empty vocabulary; perhaps the documents only contain stop words")
+        if len(alphabet) >= SYMBOL_ABSENT:
+            raise NotImplementedError(f"{len(alphabet)} distinct characters; the device codes symbols in 16 bits")
+        self._alphabet = alphabet.astype(np.uint32)
+        return [self._upload_symbols(s, self._alphabet) for s in syms]
+
+    def fit_prepared(self, sets: Sequence[StringColumn]) -> "HipTfidfVectorizer":
         """TfidfVectorizer.fit(concat(sets)) (string_grouper.py:699-707)."""
-        self._vocab = self.ctx.vec_fit([s.dev for s in sets], self._params)
-        self._fit_sets = list(sets)
+        dev_sets = self._device_sets(sets)
+        self._vocab = self.ctx.vec_fit([s.dev for s in dev_sets], self._params)
+        self._remember(sets, dev_sets)
+        return self._finish_fit()
+
+    def _remember(self, sets, dev_sets):
+        # transform_prepared() of a column that was part of the fit must reuse the fit's tokens: the library
+        # recognises the device handle, so keep the (possibly converted) device column of every input column
+        self._fit_sets = list(dev_sets)
+        self._dev_of = {id(s): d for s, d in zip(sets, dev_sets)}
+
+    def _finish_fit(self) -> "HipTfidfVectorizer":
         n_terms, n_docs = self.ctx.vocab_size(self._vocab)
         self._keys, self._df = self.ctx.vocab_to_host(self._vocab)
         self.idf_ = idf_from_df(self._df, n_docs, self.dtype)
@@ -207,11 +157,12 @@ class HipTfidfVectorizer:
         return self
 
     # ---- the two halves of fit for a caller that shards the strings over several GPUs (distributed.py)
-    def fit_begin_prepared(self, sets: Sequence[PreparedStrings]) -> "HipTfidfVectorizer":
+    def fit_begin_prepared(self, sets: Sequence[StringColumn]) -> "HipTfidfVectorizer":
         """Tokenise the LOCAL sets and count their document frequencies; ``df_table()`` is then summed across
         ranks and ``fit_end`` finishes the vocabulary + idf identically on every rank."""
-        self._vocab = self.ctx.vec_fit_begin([s.dev for s in sets], self._params)
-        self._fit_sets = list(sets)
+        dev_sets = self._device_sets(sets)
+        self._vocab = self.ctx.vec_fit_begin([s.dev for s in dev_sets], self._params)
+        self._remember(sets, dev_sets)
         return self
 
     def df_table(self):
@@ -220,17 +171,25 @@ class HipTfidfVectorizer:
 
     def fit_end(self, n_docs_total: int = 0) -> "HipTfidfVectorizer":
         self.ctx.vec_fit_end(self._vocab, n_docs_total)
-        n_terms, n_docs = self.ctx.vocab_size(self._vocab)
-        self._keys, self._df = self.ctx.vocab_to_host(self._vocab)
-        self.idf_ = idf_from_df(self._df, n_docs, self.dtype)
-        self.ctx.vocab_set_idf(self._vocab, self.idf_)
-        self._vocabulary = None
-        return self
+        return self._finish_fit()
 
-    def transform_prepared(self, s: PreparedStrings) -> N.Csr:
+    def transform_prepared(self, s: StringColumn) -> N.Csr:
         if self._vocab is None:
             raise RuntimeError("vectoriser is not fitted")
-        return self.ctx.vec_transform(self._vocab, s.dev)
+        dev = getattr(self, "_dev_of", {}).get(id(s))
+        if dev is None:
+            if self._alphabet is not None:
+                dev = self._upload_symbols(self._as_symbols(s), self._alphabet)
+            elif s.kind == "bytes":
+                if s.dev is None:
+                    self._upload_bytes(s)
+                dev = s
+            else:
+                raise NotImplementedError(
+                    "transform() of strings with non-ASCII characters (normalize_to_ascii=False) on a vocabulary that "
+                    "was fitted on ASCII-only strings: fit on a corpus that contains the characters, as StringGrouper "
+                    "does (it fits on master + duplicates)")
+        return self.ctx.vec_transform(self._vocab, dev.dev)
 
     # ------------------------------------------------------------------ sklearn-shaped API (seam b1)
     def fit(self, raw_documents, y=None):
@@ -245,13 +204,18 @@ class HipTfidfVectorizer:
         p = self.prepare(raw_documents)
         return self.fit_prepared([p]).transform_prepared(p).to_scipy()      # one tokenisation pass
 
+    def _terms(self) -> List[str]:
+        bits, symbols, _ = self.ctx.vocab_coding(self._vocab)
+        alphabet = self._alphabet if symbols else self.ctx.vocab_byte_alphabet(self._vocab)
+        return keys_to_terms(self._keys, self.ngram_size, bits, alphabet)
+
     @property
     def vocabulary_(self) -> Dict[str, int]:
         if self._vocabulary is None:
             if self._keys is None:
                 raise AttributeError("vocabulary_ is available after fit()")
-            self._vocabulary = {t: i for i, t in enumerate(keys_to_terms(self._keys, self.ngram_size))}
+            self._vocabulary = {t: i for i, t in enumerate(self._terms())}
         return self._vocabulary
 
     def get_feature_names_out(self):
-        return np.asarray(keys_to_terms(self._keys, self.ngram_size), dtype=object)
+        return np.asarray(self._terms(), dtype=object)

@@ -167,6 +167,108 @@ def test_vectoriser_unicode_case_and_ngram_sizes(ctx):
         assert_csr_identical(m_dev, sp.csr_matrix(m_ref), str(kw))
 
 
+UNICODE_NAMES = ["Ünïcödé Straße GmbH", "™ TRADEMARK Co", "№ 5 ℡ 12 ㎆", "İstanbul ISTANBUL ıi", "ΟΔΥΣΣΕΥΣ ΣΟΦΟΣ Σ", "ὈΔΥΣΣΕΎΣ",
+                 "ﬁne ﬂour ﬃ Ⅻ ½", "ＦＵＬＬ　ｗｉｄｔｈ", "東京 Holdings 株式会社", "東京ホールディングス株式会社", "😀 emoji 𝔘𝔫𝔦", "ẞ ß SS",
+                 "Crème Brûlée Holdings", "CREME BRULEE HOLDINGS", "Łódź Fabryka SA", "", "ab", "ACME Inc.", "acme, inc"]
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_vectoriser_covers_the_analyzers_whole_domain(ctx, dtype):
+    """Every option combination of the analyzer (string_grouper.py:365-378) on names with non-ASCII characters:
+    normalize_to_ascii on / off (off = n-grams over code points: symbol columns, the alphabet of the fit),
+    ignore_case on / off, character-class and general regexes, several n-gram sizes -- vocabulary and matrix equal to
+    sklearn driven with the reference's analyzer."""
+    from string_grouper_amd.vectorizer import HipTfidfVectorizer
+    names = UNICODE_NAMES * 2 + _names(300, seed=5)
+    for norm in (True, False):
+        for case in (True, False):
+            for kw in (dict(), dict(ngram_size=2), dict(ngram_size=4), dict(regex=r"[aeiouéß]"), dict(regex=r"inc\.?|\s")):
+                kw = dict(kw, normalize_to_ascii=norm, ignore_case=case)
+                (m_ref,), vocab, idf = O.tfidf_sklearn(names, [names], dtype=dtype, **kw)
+                vec = HipTfidfVectorizer(dtype=dtype, ctx=ctx, **kw)
+                m_dev = vec.fit_transform(names)
+                assert vec.vocabulary_ == vocab, kw
+                assert_csr_identical(m_dev, sp.csr_matrix(m_ref), str(kw))
+    # master + duplicates where only ONE of the two columns has non-ASCII characters: one alphabet for both
+    master, dups = _names(200, seed=6), UNICODE_NAMES
+    (a_ref, b_ref), vocab, _ = O.tfidf_sklearn(master + dups, [master, dups], dtype=dtype, normalize_to_ascii=False)
+    vec = HipTfidfVectorizer(dtype=dtype, ctx=ctx, normalize_to_ascii=False)
+    pm, pdu = vec.prepare(master), vec.prepare(dups)
+    vec.fit_prepared([pm, pdu])
+    assert vec.vocabulary_ == vocab
+    assert_csr_identical(vec.transform_prepared(pm).to_scipy(), sp.csr_matrix(a_ref))
+    assert_csr_identical(vec.transform_prepared(pdu).to_scipy(), sp.csr_matrix(b_ref))
+
+
+def test_vectoriser_strings_of_any_length(ctx):
+    """Strings with more n-grams than one wave sorts in LDS (1024) take the workgroup-per-string kernel; the reference
+    has no length limit (a description or address column among the names must not abort the job)."""
+    from string_grouper_amd.vectorizer import HipTfidfVectorizer
+    rng = np.random.default_rng(3)
+    words = _names(400, seed=9)
+
+    def text(n_chars):
+        out = []
+        while sum(len(w) + 1 for w in out) < n_chars:
+            out.append(words[int(rng.integers(len(words)))])
+        return " ".join(out)[:n_chars]
+    names = _names(500, seed=8) + [text(1023), text(1026), text(1500), text(5000), text(70000), "é" + text(2000) + "Ü", "x" * 3000,
+                                    text(1025).lower()]
+    for dtype in (np.float32, np.float64):
+        for kw in (dict(), dict(ngram_size=5), dict(normalize_to_ascii=False)):
+            (m_ref,), vocab, _ = O.tfidf_sklearn(names, [names], dtype=dtype, **kw)
+            vec = HipTfidfVectorizer(dtype=dtype, ctx=ctx, **kw)
+            m_dev = vec.fit_transform(names)
+            assert vec.vocabulary_ == vocab, kw
+            assert_csr_identical(m_dev, sp.csr_matrix(m_ref), str(kw))
+            assert_csr_identical(vec.transform(names[-9:]), sp.csr_matrix(m_ref[-9:]), "transform of the long strings alone")
+
+
+def test_vectoriser_wide_keys_take_the_sorted_vocabulary(ctx, monkeypatch):
+    """n-gram keys wider than 30 bits (long n-grams, large alphabets) cannot index a dense table: 64-bit keys, the
+    vocabulary is the sorted array of the distinct keys.  Also forced on ordinary 3-grams (SG_VOCAB_SORTED=1)."""
+    from string_grouper_amd.vectorizer import HipTfidfVectorizer
+    names = _names(3000, seed=13) + UNICODE_NAMES
+    cases = [dict(ngram_size=6), dict(ngram_size=8), dict(ngram_size=10), dict(ngram_size=3, normalize_to_ascii=False),
+             dict(ngram_size=4, normalize_to_ascii=False, ignore_case=False)]
+    for dtype in (np.float32, np.float64):
+        for kw in cases:
+            (m_ref,), vocab, _ = O.tfidf_sklearn(names, [names], dtype=dtype, **kw)
+            vec = HipTfidfVectorizer(dtype=dtype, ctx=ctx, **kw)
+            m_dev = vec.fit_transform(names)
+            assert vec.vocabulary_ == vocab, kw
+            assert_csr_identical(m_dev, sp.csr_matrix(m_ref), str(kw))
+    monkeypatch.setenv("SG_VOCAB_SORTED", "1")
+    (m_ref,), vocab, _ = O.tfidf_sklearn(names, [names], dtype=np.float32)
+    vec = HipTfidfVectorizer(dtype=np.float32, ctx=ctx)
+    assert ctx.vocab_coding(vec.fit(names)._vocab)[2] is True
+    assert vec.vocabulary_ == vocab
+    assert_csr_identical(vec.transform(names), sp.csr_matrix(m_ref))
+
+
+def test_public_api_on_code_point_ngrams(ctx):
+    """match_strings / group_similar_strings with normalize_to_ascii=False (string_grouper.py:202) on names with
+    non-ASCII characters: the HIP engine against the host mirror on the oracle engine."""
+    import pandas as pd
+    import string_grouper_amd as sga
+    import string_grouper_amd.engine as E
+    from tests._oracle_engine import OracleEngine
+    names = pd.Series(UNICODE_NAMES * 3 + _names(2000, seed=21) + ["東京ホールディングス", "東京ホールディングス株式", "Crème Brûlée Holding"], name="name")
+    old = E._engine
+    try:
+        out = {}
+        for label, eng in (("hip", E.HipEngine(ctx)), ("oracle", OracleEngine(use_port=True))):
+            E.set_engine(eng)
+            out[label] = [sga.match_strings(names, normalize_to_ascii=False, min_similarity=0.6),
+                          sga.match_strings(names, normalize_to_ascii=False, ignore_case=False, min_similarity=0.6,
+                                            tfidf_matrix_dtype=np.float32),
+                          sga.group_similar_strings(names, normalize_to_ascii=False, min_similarity=0.6)]
+        for a, b in zip(out["hip"], out["oracle"]):
+            pd.testing.assert_frame_equal(pd.DataFrame(a), pd.DataFrame(b))
+    finally:
+        E.set_engine(old)
+
+
 def test_transform_of_strings_with_characters_unseen_at_fit(ctx):
     """sklearn's transform() drops the n-grams it has not seen at fit(); with ngram_size >= 4 the device codes
     characters by their rank among the bytes seen at fit(), so an unseen character needs its own code."""
@@ -339,7 +441,7 @@ def test_device_resident_inputs_and_rccl_plumbing(ctx):
     t_bytes = torch.from_numpy(p.data.copy()).cuda()
     t_offs = torch.from_numpy(p.offsets.copy()).cuda()
     torch.cuda.synchronize()
-    p2 = type(p)(p.data, p.offsets)
+    p2 = type(p)("bytes", p.data, p.offsets)
     p2.dev = ctx.strings_from_device(t_bytes.data_ptr(), t_offs.data_ptr(), p.n, int(p.offsets[-1]), keepalive=(t_bytes, t_offs))
     vec.fit_prepared([p2])
     A = vec.transform_prepared(p2)
