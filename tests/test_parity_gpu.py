@@ -230,7 +230,8 @@ def test_vectoriser_wide_keys_take_the_sorted_vocabulary(ctx, monkeypatch):
     from string_grouper_amd.vectorizer import HipTfidfVectorizer
     names = _names(3000, seed=13) + UNICODE_NAMES
     cases = [dict(ngram_size=6), dict(ngram_size=8), dict(ngram_size=10), dict(ngram_size=3, normalize_to_ascii=False),
-             dict(ngram_size=4, normalize_to_ascii=False, ignore_case=False)]
+             dict(ngram_size=4, normalize_to_ascii=False, ignore_case=False), dict(ngram_size=5, normalize_to_ascii=False),
+             dict(ngram_size=8, normalize_to_ascii=False, ignore_case=False)]
     for dtype in (np.float32, np.float64):
         for kw in cases:
             (m_ref,), vocab, _ = O.tfidf_sklearn(names, [names], dtype=dtype, **kw)
