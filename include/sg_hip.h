@@ -211,7 +211,9 @@ int sg_matchlist_group_reps(sg_ctx *ctx, const sg_matchlist *ml, int32_t centroi
 int sg_row_costs(sg_ctx *ctx, const sg_csr *A, const sg_postings *Bt, int64_t *out_cost);
 
 /* ------------------------------------------------------------------ measurement */
-enum { SG_K_TOKENIZE = 0, SG_K_WEIGHT = 1, SG_K_POSTINGS = 2, SG_K_SPGEMM = 3, SG_K_ZIP = 4, SG_K_VOCAB = 5, SG_K_COUNT = 6 };
+enum { SG_K_TOKENIZE = 0, SG_K_WEIGHT = 1, SG_K_POSTINGS = 2, SG_K_SPGEMM = 3 /* the multiply's whole launch group */,
+       SG_K_ZIP = 4, SG_K_VOCAB = 5, SG_K_SPGEMM_KERNEL = 6 /* its dominant kernel alone (pruned: the pruned kernel without
+       the pair-list pass; exact: the exact launches) */, SG_K_COUNT = 7 };
 typedef struct {
     float ms[SG_K_COUNT];     /* HIP-event time of the most recent launch group of each kernel      */
     int64_t macs;             /* intermediate products of the most recent sg_spgemm_topn            */

@@ -18,8 +18,8 @@ LIB_PATH = os.environ.get("SG_HIP_LIB") or os.path.join(_HERE, "libsg_hip.so")
 
 SG_OK, SG_ERR_BADARG, SG_ERR_OOM, SG_ERR_OVERFLOW, SG_ERR_HIP, SG_ERR_NODEVICE, SG_ERR_UNSUPPORTED = range(7)
 SG_F32, SG_F64 = 0, 1
-SG_K_TOKENIZE, SG_K_WEIGHT, SG_K_POSTINGS, SG_K_SPGEMM, SG_K_ZIP, SG_K_VOCAB, SG_K_COUNT = range(7)
-KERNEL_NAMES = ("tokenize", "weight", "postings", "spgemm_topn", "zip", "vocab")
+SG_K_TOKENIZE, SG_K_WEIGHT, SG_K_POSTINGS, SG_K_SPGEMM, SG_K_ZIP, SG_K_VOCAB, SG_K_SPGEMM_KERNEL, SG_K_COUNT = range(8)
+KERNEL_NAMES = ("tokenize", "weight", "postings", "spgemm_topn", "zip", "vocab", "spgemm_kernel")
 
 
 class SgVecParams(C.Structure):

@@ -63,6 +63,7 @@ struct sg_ctx {
     int64_t spgemm_fixed_bytes = 0;              // its algorithmic bytes that do not scale with MACs
     double prune_row_bytes = 0.0;                // pruned multiply: bytes read per survivor (row pointers + mean packed row)
     bool prune_symmetric = false;                // the most recent multiply took the self-join form of the pruned kernel
+    double pilot_ms_pruned = 0.0, pilot_ms_exact = 0.0;   // the most recent pruned-or-exact pilot's two estimates (0: none ran)
     int64_t *d_stat_words = nullptr;             // [0]=macs [1]=out_nnz [2..4]=pruned rows/postings/survivors [5]=rows handed to K4
     int64_t *h_stat_words = nullptr;             // pinned mirror
 

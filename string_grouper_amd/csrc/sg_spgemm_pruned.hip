@@ -842,6 +842,7 @@ int sg_spgemm_pruned_symmetric(sg_ctx *ctx, const sg_csr *A, const sg_postings *
     }
     const float s_budget = prune_budget(Bt, threshold, delta);
     if (st == SG_OK) {
+        SgTimer kt(ctx, SG_K_SPGEMM_KERNEL);   // the kernel alone (the launch group's timer also covers the second pass)
         if (A->dtype == SG_F64)
             st = dispatch_pruned<double, true>(ctx, A, Bt, keep, r, (double)threshold, s_budget, words, words + 1, flagged_rows,
                                                d_stats3, pl);

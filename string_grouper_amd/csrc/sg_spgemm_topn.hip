@@ -528,6 +528,59 @@ static int topn_alloc(sg_ctx *ctx, int64_t n_rows, int64_t n_cols, int32_t strid
     return SG_OK;
 }
 
+// Three blocks of 512 left rows (start, middle, end) through the one-sided pruned kernel: what the filter passes per
+// row, extrapolated, priced against the exact kernel.  One host round trip.
+static int prune_pilot(sg_ctx *ctx, const sg_csr *A, const sg_postings *Bt, int32_t stride, double threshold, double delta,
+                       bool symmetric, bool *keep_pruned) {
+    *keep_pruned = true;
+    const int64_t block = 512;
+    sg_topn *scratch = nullptr;
+    SG_TRY(topn_alloc(ctx, block, Bt->n_right, stride, A->dtype, &scratch));
+    uint32_t *words = nullptr;            // [0] row counter [1] flagged count, then flagged rows
+    unsigned long long *d_stats = nullptr;   // [0] rows [1] postings [2] survivors [3] MACs of the whole multiply
+    int st = sg_alloc(ctx, (size_t)block + 8, &words);
+    if (st == SG_OK) st = sg_alloc(ctx, (size_t)4, &d_stats);
+    hipError_t e = hipSuccess;
+    if (st == SG_OK) e = hipMemsetAsync(d_stats, 0, 4 * sizeof(unsigned long long), ctx->stream);
+    const int64_t starts[3] = {0, (A->n_rows - block) / 2, A->n_rows - block};
+    for (int b = 0; b < 3 && st == SG_OK && e == hipSuccess; ++b) {
+        sg_csr view = *A;
+        view.n_rows = block;
+        view.d_indptr = A->d_indptr + starts[b];
+        view.owned = false;
+        e = hipMemsetAsync(words, 0, 8 * sizeof(uint32_t), ctx->stream);
+        if (e == hipSuccess) e = hipMemsetAsync(scratch->d_counts, 0, sizeof(int32_t) * (size_t)block, ctx->stream);
+        if (e == hipSuccess)
+            st = sg_spgemm_pruned_launch(ctx, &view, Bt, stride, scratch, threshold, delta, words, words + 1, words + 8, d_stats);
+    }
+    if (st == SG_OK && e == hipSuccess) {
+        hipLaunchKernelGGL(count_macs_kernel, dim3(1024), dim3(256), 0, ctx->stream, A->d_indptr, A->d_indices, A->n_rows,
+                           (const uint32_t *)Bt->d_seg, Bt->n_tiles, d_stats + 3);
+        e = hipGetLastError();
+    }
+    unsigned long long h[4] = {0, 0, 0, 0};
+    if (st == SG_OK && e == hipSuccess) e = hipMemcpyAsync(h, d_stats, sizeof(h), hipMemcpyDeviceToHost, ctx->stream);
+    if (st == SG_OK && e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    ctx->release(words);
+    ctx->release(d_stats);
+    sg_topn_free(scratch);
+    if (st != SG_OK) return st;
+    if (e != hipSuccess) {
+        sg_set_error("pruning pilot: %s", hipGetErrorString(e));
+        return SG_ERR_HIP;
+    }
+    const double s = A->dtype == SG_F64 ? 8.0 : 4.0;
+    const double rows = (double)A->n_rows, sampled = h[0] > 0 ? (double)h[0] : 1.0;
+    const double candidates = (double)h[2] * rows / sampled;
+    double ms_pruned = rows * (double)Bt->n_tiles * 2.5e-7 + candidates * 5.5e-8;
+    if (symmetric) ms_pruned = 0.62 * ms_pruned + 0.9;
+    const double ms_exact = (double)h[3] * (4.0 + s) / 3.7e9;
+    *keep_pruned = ms_pruned <= ms_exact;
+    ctx->pilot_ms_pruned = ms_pruned;
+    ctx->pilot_ms_exact = ms_exact;
+    return SG_OK;
+}
+
 extern "C" int sg_spgemm_topn(sg_ctx *ctx, const sg_csr *A, const sg_postings *Bt, int32_t top_n, double threshold,
                               int32_t sort, sg_topn **out) {
     SG_REQUIRE(ctx && A && Bt && out, "null argument");
@@ -597,9 +650,29 @@ extern "C" int sg_spgemm_topn(sg_ctx *ctx, const sg_csr *A, const sg_postings *B
             // self-join (A is the matrix the postings were built from) whose rows all fit the pruned kernel:
             // score every pair once, from the row with the larger index (sg_spgemm_pruned.hip, symmetric mode)
             const char *sy = getenv("SG_SYM");
+            // ... from the size at which halving the (row, tile) visits outweighs the second pass over the pair list
+            // and its host round trip (~1 ms): 4.0 vs 3.4 ms at 200 k rows, 17.7 vs 26.9 ms at 663 k
+            // (profiles/r02_profile_k4p_v9b_sym.log)
             symmetric = prune && !(sy && sy[0] == '0') && A->n_rows == Bt->n_right && A->d_indptr == Bt->b_indptr &&
-                        A->d_indices == Bt->b_indices && A->d_data == Bt->b_data && a_max_nnz <= 64;
+                        A->d_indices == Bt->b_indices && A->d_data == Bt->b_data && a_max_nnz <= 64 &&
+                        (A->n_rows >= (int64_t)env_int("SG_SYM_MIN_ROWS", 320000) || (sy && sy[0] == '1'));
         }
+    }
+    // ---- pruned or exact?  On a vocabulary that is small next to the rows (2-grams: a row holds 2 % of all terms) the
+    //      filter passes thousands of candidates per row and scoring them exactly costs more than the whole exact
+    //      multiply (119 vs 84 ms at 200 k 2-grams).  Nothing cheap predicts the candidates, so on such inputs three
+    //      blocks of 512 left rows are run through the pruned kernel first and the two costs are priced from what
+    //      they did (fitted on profiles/r02_profile_k4p_v9b_sym.log: 0.25 ns per (row, tile), 0.055 ns per candidate;
+    //      the exact kernel: its stream model at the 3.7 TB/s it reaches).
+    if (prune && A->n_rows >= 32768 && A->nnz > 0 && Bt->n_terms > 0 &&
+        (double)A->nnz / (double)A->n_rows > 0.004 * (double)Bt->n_terms && env_int("SG_PRUNE_PILOT", 1) != 0) {
+        bool keep_pruned = true;
+        const int pst = prune_pilot(ctx, A, Bt, stride, threshold, delta, symmetric, &keep_pruned);
+        if (pst != SG_OK) {
+            sg_topn_free(r);
+            return pst;
+        }
+        if (!keep_pruned) prune = symmetric = false;
     }
 
     // counters: [0, n_launch] row counters of the exact launches; then the pruned kernel's row counter, the
@@ -625,9 +698,12 @@ extern "C" int sg_spgemm_topn(sg_ctx *ctx, const sg_csr *A, const sg_postings *B
             st = sg_spgemm_pruned_symmetric(ctx, A, Bt, stride, r, threshold, delta,
                                             (unsigned long long *)(ctx->d_stat_words + 2), &sym_done);
         ctx->prune_symmetric = sym_done;
-        if (prune && !sym_done && st == SG_OK)
+        if (prune && !sym_done && st == SG_OK) {
+            SgTimer kt(ctx, SG_K_SPGEMM_KERNEL);
             st = sg_spgemm_pruned_launch(ctx, A, Bt, stride, r, threshold, delta, counters + n_launch + 1,
                                          handed_count, handed_rows, (unsigned long long *)(ctx->d_stat_words + 2));
+        }
+        SgTimer *exact_timer = (!prune && !sym_done) ? new (std::nothrow) SgTimer(ctx, SG_K_SPGEMM_KERNEL) : nullptr;
         int li = 0;
         for (int pass = 0; pass < n_pass && st == SG_OK && A->n_rows > 0 && !sym_done; ++pass) {
             const int pass_off = pass * SG_TOPN_LANES;
@@ -643,6 +719,7 @@ extern "C" int sg_spgemm_topn(sg_ctx *ctx, const sg_csr *A, const sg_postings *B
                                                 counters + li, grid, prune ? handed_rows : nullptr, handed_count);
             }
         }
+        delete exact_timer;   // stop event of the exact kernel's launches
         if (prune && st == SG_OK &&
             hipMemcpyAsync(ctx->d_stat_words + 5, handed_count, 4, hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess)
             st = SG_ERR_HIP;

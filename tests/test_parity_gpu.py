@@ -370,7 +370,7 @@ def test_results_do_not_depend_on_uninitialised_memory(ctx, monkeypatch):
         names = _names(n, seed=n)
         A_ref = _tfidf(names, dtype)
         C_ref = P.sp_matmul_topn_port(A_ref, A_ref.T, 10, 0.8, True, 8)
-        for env in ({}, {"SG_SYM": "0"}, {"SG_PRUNE": "0"}):
+        for env in ({}, {"SG_SYM": "1"}, {"SG_PRUNE": "0"}):
             for k, v in env.items():
                 monkeypatch.setenv(k, v)
             vec = HipTfidfVectorizer(dtype=dtype, ctx=ctx)
@@ -703,9 +703,12 @@ def test_oversized_right_hand_side_is_split_and_zipped(ctx, mats, monkeypatch):
 # The pruned multiply (K4p, sg_spgemm_pruned.hip) must be indistinguishable from the exact kernel (K4)
 # and from the oracle: same entries, same bits, same order.
 def _multiply_both_ways(ctx, dA, dB, top_n, thr, monkeypatch, **env):
+    """pruned ("1"), exact ("0") and -- self-joins -- the pruned kernel's self-join form forced at any size ("sym":
+    by default it only runs from SG_SYM_MIN_ROWS rows on)."""
     out = {}
-    for prune in ("1", "0"):
-        monkeypatch.setenv("SG_PRUNE", prune)
+    for prune in ("1", "0") + (("sym",) if dA is dB else ()):
+        monkeypatch.setenv("SG_PRUNE", "1" if prune == "sym" else prune)
+        monkeypatch.setenv("SG_SYM", "1" if prune == "sym" else "0")
         for k, v in env.items():
             monkeypatch.setenv(k, str(v))
         post = ctx.postings_build(dB)
@@ -714,7 +717,42 @@ def _multiply_both_ways(ctx, dA, dB, top_n, thr, monkeypatch, **env):
         out[prune] = (res.to_scipy(), st)
         res.free()
         post.free()
+    monkeypatch.delenv("SG_SYM")
+    if "sym" in out:
+        assert_csr_identical(out["sym"][0], out["0"][0], "self-join form vs exact")
+        if out["1"][1]["prune_rows"] > 0 and out["1"][1]["exact_rows"] == 0:
+            assert out["sym"][1]["prune_symmetric"] == 1
     return out
+
+
+def test_pruned_or_exact_is_decided_by_a_pilot_on_dense_vocabularies(ctx, monkeypatch):
+    """2-grams: 875 terms, a row holds 2 % of the vocabulary -- the filter passes thousands of candidates per row and the
+    exact kernel is the faster one; the library prices both from a pilot (three blocks of 512 rows).  Whatever it picks,
+    the result is the oracle's."""
+    from string_grouper_amd.vectorizer import HipTfidfVectorizer
+    names = _names(40000, seed=31)
+    (A_ref,), _, _ = O.tfidf_sklearn(names, [names], dtype=np.float32, ngram_size=2)
+    C_ref = P.sp_matmul_topn_port(A_ref, A_ref.T, 10, 0.8, True, 8)
+    vec = HipTfidfVectorizer(dtype=np.float32, ctx=ctx, ngram_size=2)
+    p = vec.prepare(names)
+    vec.fit_prepared([p])
+    dA = vec.transform_prepared(p)
+    post = ctx.postings_build(dA)
+    picked = {}
+    for label, env in (("pilot", {}), ("forced pruned", {"SG_PRUNE_PILOT": "0"}), ("forced self-join form", {"SG_PRUNE_PILOT": "0", "SG_SYM": "1"})):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        res = ctx.spgemm_topn(dA, post, 10, 0.8, True)
+        picked[label] = ctx.stats()
+        assert_csr_identical(res.to_scipy(), C_ref, label)
+        res.free()
+        for k in env:
+            monkeypatch.delenv(k)
+    assert picked["forced pruned"]["prune_rows"] > 0 and picked["forced self-join form"]["prune_symmetric"] == 1
+    # the pilot's choice must be the cheaper of the two on this input
+    t_pruned, t_pilot = picked["forced pruned"]["ms_spgemm_topn"], picked["pilot"]["ms_spgemm_topn"]
+    assert t_pilot <= 1.25 * t_pruned + 0.5, (t_pilot, t_pruned)
+    post.free()
 
 
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
