@@ -725,6 +725,37 @@ def _multiply_both_ways(ctx, dA, dB, top_n, thr, monkeypatch, **env):
     return out
 
 
+@pytest.mark.parametrize("family", ["4-grams", "master x duplicates", "low threshold", "short numeric strings"])
+def test_pruned_multiply_keeps_its_lead_on_other_data_families(ctx, family, monkeypatch):
+    """Performance guard outside the 663 k headline (kernel times from sg_stats; scripts/family_sweep.py has the full
+    table): on these families the pruned multiply is 3-8 x faster than the exact kernel -- a regression of the filter
+    (or a tuning that only fits SynthNames 3-grams) shows up here as a lost lead.  Results are compared as well."""
+    from string_grouper_amd.vectorizer import HipTfidfVectorizer
+    kw, top_n, thr = {}, 10, 0.8
+    if family == "4-grams":
+        master, dups, kw = _names(150000, seed=41), None, dict(ngram_size=4)
+    elif family == "master x duplicates":
+        master = _names(200000, seed=42)
+        from string_grouper_amd.synth import synth_names
+        dups, top_n, thr = synth_names(60000, 43, perturb_of=master, perturb_frac=0.5), 20, 0.7
+    elif family == "low threshold":
+        master, dups, top_n, thr = _names(150000, seed=44), None, 20, 0.6
+    else:
+        rng = np.random.default_rng(45)
+        master, dups = ["%09d" % int(x) for x in rng.integers(0, 10 ** 9, 150000)], None
+    vec = HipTfidfVectorizer(dtype=np.float32, ctx=ctx, **kw)
+    pm = vec.prepare(master)
+    sets = [pm] + ([vec.prepare(dups)] if dups is not None else [])
+    vec.fit_prepared(sets)
+    dA = vec.transform_prepared(pm)
+    dB = dA if dups is None else vec.transform_prepared(sets[1])
+    out = _multiply_both_ways(ctx, dA, dB, top_n, thr, monkeypatch)
+    assert_csr_identical(out["1"][0], out["0"][0], family)
+    t_pruned, t_exact = out["1"][1]["ms_spgemm_topn"], out["0"][1]["ms_spgemm_topn"]
+    assert out["1"][1]["prune_rows"] > 0, family
+    assert t_pruned < 0.6 * t_exact, (family, t_pruned, t_exact)
+
+
 def test_pruned_or_exact_is_decided_by_a_pilot_on_dense_vocabularies(ctx, monkeypatch):
     """2-grams: 875 terms, a row holds 2 % of the vocabulary -- the filter passes thousands of candidates per row and the
     exact kernel is the faster one; the library prices both from a pilot (three blocks of 512 rows).  Whatever it picks,
