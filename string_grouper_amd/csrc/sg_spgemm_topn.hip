@@ -572,9 +572,14 @@ static int prune_pilot(sg_ctx *ctx, const sg_csr *A, const sg_postings *Bt, int3
     const double s = A->dtype == SG_F64 ? 8.0 : 4.0;
     const double rows = (double)A->n_rows, sampled = h[0] > 0 ? (double)h[0] : 1.0;
     const double candidates = (double)h[2] * rows / sampled;
-    double ms_pruned = rows * (double)Bt->n_tiles * 2.5e-7 + candidates * 5.5e-8;
+    // fitted on scripts/family_sweep.py (profiles/r02_profile_k4p_v9b_sym.log): the pruned kernel pays per (row, tile)
+    // visit and per candidate it scores exactly (a candidate costs one walk over a right-hand row); the exact kernel
+    // pays its stream model (long lists stream at ~6 TB/s, the 3.7 TB/s of name data include its per-visit overhead)
+    // plus its own per-visit cost
+    const double row_len = Bt->n_right > 0 ? (double)Bt->nnz / (double)Bt->n_right : 0.0;
+    double ms_pruned = rows * (double)Bt->n_tiles * 2.0e-7 + candidates * 2.9e-9 * row_len;
     if (symmetric) ms_pruned = 0.62 * ms_pruned + 0.9;
-    const double ms_exact = (double)h[3] * (4.0 + s) / 3.7e9;
+    const double ms_exact = (double)h[3] * (4.0 + s) * 0.6 / 3.7e9 + rows * (double)Bt->n_tiles * 8.0e-7;
     *keep_pruned = ms_pruned <= ms_exact;
     ctx->pilot_ms_pruned = ms_pruned;
     ctx->pilot_ms_exact = ms_exact;
@@ -662,8 +667,7 @@ extern "C" int sg_spgemm_topn(sg_ctx *ctx, const sg_csr *A, const sg_postings *B
     //      filter passes thousands of candidates per row and scoring them exactly costs more than the whole exact
     //      multiply (119 vs 84 ms at 200 k 2-grams).  Nothing cheap predicts the candidates, so on such inputs three
     //      blocks of 512 left rows are run through the pruned kernel first and the two costs are priced from what
-    //      they did (fitted on profiles/r02_profile_k4p_v9b_sym.log: 0.25 ns per (row, tile), 0.055 ns per candidate;
-    //      the exact kernel: its stream model at the 3.7 TB/s it reaches).
+    //      they did (prune_pilot; constants fitted on the family sweep in profiles/r02_profile_k4p_v9b_sym.log).
     if (prune && A->n_rows >= 32768 && A->nnz > 0 && Bt->n_terms > 0 &&
         (double)A->nnz / (double)A->n_rows > 0.004 * (double)Bt->n_terms && env_int("SG_PRUNE_PILOT", 1) != 0) {
         bool keep_pruned = true;
