@@ -55,8 +55,9 @@
 // One 64-lane wave per left row, single-wave workgroups, persistent waves fed by a global row
 // counter, as K4.  LDS per wave: the tile's 4096 u16 accumulators (two per word), row i as a term ->
 // value hash (for the exact scoring) and the survivor buffer: 10 KiB -> 16 waves per CU.
-// Rows the kernel does not handle (more than 64 non-zeros) are appended to a list and processed by K4
-// (in symmetric mode their presence makes the caller fall back to the one-sided form).
+// Rows with 65 .. 128 non-zeros are appended to a list and taken by a second launch of the same kernel that stages two
+// terms per lane (WIDE); what that one cannot take either (more than 128 non-zeros, more than 64 prefix terms) goes to
+// K4 (in symmetric mode the presence of such a row makes the caller fall back to the one-sided form).
 #define SG_WATCH_NAME sg_debug_watch_pruned
 #include "sg_k4_device.h"
 
@@ -110,12 +111,37 @@ struct FwdRound<double> {   // 8 loads x 1 entry
     }
 };
 
+// Value of term `key` in row i as staged in LDS.  Rows of up to 64 terms: a 128-slot open-addressing hash (hk, ha).
+// Wide rows (65 .. 128 terms): the row's sorted terms and values (hk = terms, ha = values), binary search -- a full
+// 128-slot hash has no empty slot to stop a probe and a larger one does not fit beside the accumulator tile.
+template <typename T, bool WIDE>
+__device__ __forceinline__ T row_value(const int *hk, const T *ha, int key, int nnz) {
+    if (WIDE) {
+        int lo = 0, hi = nnz;
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (hk[mid] < key) lo = mid + 1;
+            else hi = mid;
+        }
+        return (lo < nnz && hk[lo] == key) ? ha[lo] : (T)0;
+    }
+    uint32_t h = term_hash(key);
+    int got = hk[h];
+    SG_WD_DECL(wd_p);
+    while (got != key && got != -1) {
+        SG_WD(wd_p, SG_HASH_SLOTS + 2, 23)
+        h = (h + 1) & (SG_HASH_SLOTS - 1);
+        got = hk[h];
+    }
+    return got == key ? ha[h] : (T)0;
+}
+
 // Exact score of (row i of A, row j of B) for the lanes with j >= 0: the products of the shared terms are
 // added in ascending k (B's rows are sorted), product and sum rounded separately -- the reference's
 // arithmetic.  A term row i does not have contributes a * b with a = 0: sum + 0 == sum exactly (all
 // values are non-negative), so absent terms and the padding of a round need no branch.
-template <typename T>
-__device__ __forceinline__ T exact_score(int j, const int *hk, const T *ha, const uint32_t *__restrict__ fwd_ptr,
+template <typename T, bool WIDE>
+__device__ __forceinline__ T exact_score(int j, const int *hk, const T *ha, int nnz, const uint32_t *__restrict__ fwd_ptr,
                                          const void *__restrict__ fwd) {
     T sum = (T)0;
     if (j >= 0) {
@@ -129,17 +155,7 @@ __device__ __forceinline__ T exact_score(int j, const int *hk, const T *ha, cons
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 T a = (T)0;
-                if (q + e >= pb && q + e < pe) {
-                    uint32_t h = term_hash(r.k[e]);
-                    int key = hk[h];
-                    SG_WD_DECL(wd_p);
-                    while (key != r.k[e] && key != -1) {
-                        SG_WD(wd_p, SG_HASH_SLOTS + 2, 23)
-                        h = (h + 1) & (SG_HASH_SLOTS - 1);
-                        key = hk[h];
-                    }
-                    if (key == r.k[e]) a = ha[h];
-                }
+                if (q + e >= pb && q + e < pe) a = row_value<T, WIDE>(hk, ha, r.k[e], nnz);
                 sum = add_rn<T>(sum, mul_rn<T>(a, r.v[e]));
             }
         }
@@ -150,8 +166,8 @@ __device__ __forceinline__ T exact_score(int j, const int *hk, const T *ha, cons
 // Scores the columns in surv[0 .. min(n_surv, 64)) and moves the rest of the buffer to the front.  Deliberately
 // not inlined: the tile loop has sixteen unrolled rounds and must not carry sixteen copies of this.
 // (LDS objects are addressed through the kernel's own shared array so that they stay ds_* accesses.)
-template <typename T, bool SYM, int TILE_LOG2>
-__device__ __noinline__ TopList<T> drain_survivors(const uint32_t *fwd_ptr, const void *fwd, T thr, uint32_t row,
+template <typename T, bool SYM, int TILE_LOG2, bool WIDE>
+__device__ __noinline__ TopList<T> drain_survivors(int nnz, const uint32_t *fwd_ptr, const void *fwd, T thr, uint32_t row,
                                                    uint32_t *pair_i, uint32_t *pair_j, T *pair_s,
                                                    unsigned long long *pair_count, unsigned long long pair_cap,
                                                    TopList<T> top, uint32_t n_surv) {
@@ -162,7 +178,7 @@ __device__ __noinline__ TopList<T> drain_survivors(const uint32_t *fwd_ptr, cons
     int *surv = reinterpret_cast<int *>(smem + TILE * 2 + 512 + 1024);
     const int lane = threadIdx.x;
     const int j = (uint32_t)lane < n_surv ? surv[lane] : -1;
-    const T sum = exact_score<T>(j, hk, ha, fwd_ptr, fwd);
+    const T sum = exact_score<T, WIDE>(j, hk, ha, nnz, fwd_ptr, fwd);
     uint64_t hm = __ballot(j >= 0 && sum > thr);
     if (SYM) {
         if (hm) {
@@ -198,7 +214,9 @@ __device__ __noinline__ TopList<T> drain_survivors(const uint32_t *fwd_ptr, cons
     return top;
 }
 
-template <typename T, int TILE_LOG2, bool SYM>
+// WIDE: the second launch, over the rows the first one could not take because they have 65 .. 128 non-zeros: every lane
+// stages two of the row's terms; still one posting list per lane, so the row's prefix P must fit 64 lanes.
+template <typename T, int TILE_LOG2, bool SYM, bool WIDE>
 __global__ void __launch_bounds__(64, 4)   // 16 single-wave workgroups per CU (the LDS limit) = 4 waves per SIMD: <= 128 VGPRs
 spgemm_topn_pruned_kernel(const int64_t *__restrict__ a_indptr, const int32_t *__restrict__ a_indices,
                           const T *__restrict__ a_data, uint32_t n_left, const uint32_t *__restrict__ seg,
@@ -211,8 +229,10 @@ spgemm_topn_pruned_kernel(const int64_t *__restrict__ a_indptr, const int32_t *_
                           uint32_t *row_counter, uint32_t *flagged_count, uint32_t *flagged_rows,
                           unsigned long long *stats /* [0] rows [1] postings streamed [2] survivors */,
                           uint32_t *pair_i, uint32_t *pair_j, T *pair_s, unsigned long long *pair_count,
-                          unsigned long long pair_cap) {
+                          unsigned long long pair_cap,
+                          const uint32_t *__restrict__ row_list /* WIDE: the rows to process */, const uint32_t *row_list_len) {
     constexpr int TILE = 1 << TILE_LOG2;
+    constexpr int SLOTS = WIDE ? 2 : 1;   // row terms staged per lane
     constexpr int AB = TILE_LOG2 + 1;                          // address + half bits of a filter posting
     constexpr uint32_t ADDR_MASK = ((1u << AB) - 1u) & ~3u;    // byte address of the accumulator word
     constexpr uint32_t BQ_BITS = 24 - AB;
@@ -239,44 +259,76 @@ spgemm_topn_pruned_kernel(const int64_t *__restrict__ a_indptr, const int32_t *_
     // rows are handed out four at a time: one global atomic per row capped the kernel at ~88 rows/us.
     // Symmetric mode walks the rows from the last to the first: a row's cost grows with its index there.
     SG_WD_DECL(wd_rows);
-    for (uint32_t row0 = next_row(row_counter, lane) * 4u; row0 < n_left; row0 = next_row(row_counter, lane) * 4u)
-    for (uint32_t rr = row0; rr < min(row0 + 4u, n_left); ++rr) {
+    const uint32_t n_here = WIDE ? (uint32_t)__builtin_amdgcn_readfirstlane((int)*row_list_len) : n_left;
+    for (uint32_t row0 = next_row(row_counter, lane) * 4u; row0 < n_here; row0 = next_row(row_counter, lane) * 4u)
+    for (uint32_t rr = row0; rr < min(row0 + 4u, n_here); ++rr) {
         SG_WD(wd_rows, n_left + 2, 11)
-        const uint32_t row = SYM ? n_left - 1u - rr : rr;
+        const uint32_t row = WIDE ? (uint32_t)__builtin_amdgcn_readfirstlane((int)row_list[rr]) : (SYM ? n_left - 1u - rr : rr);
         const int64_t rlo = a_indptr[row];
         const int nnz = __builtin_amdgcn_readfirstlane((int)(a_indptr[row + 1] - rlo));
-        if (nnz > 64) {   // more non-zeros than lanes: exact kernel
+        if (nnz > 64 * SLOTS) {   // more non-zeros than this launch stages: the wide launch, or the exact kernel
             if (lane == 0) flagged_rows[atomicAdd(flagged_count, 1u)] = row;
             continue;
         }
         if (nnz == 0) continue;   // out_cnt is zero-initialised
-        ++st_rows;
-        int k = 0;
-        T a = (T)0;
-        uint32_t df = 0, lo_e = 0;
-        if (lane < nnz) {
-            k = a_indices[rlo + lane];
-            a = a_data[rlo + lane];
-            const uint32_t *sp = seg + (int64_t)k * n_tiles;
-            lo_e = sp[0];
-            df = sp[n_tiles] - lo_e;
+        int k[SLOTS];
+        T a[SLOTS];
+        uint32_t df[SLOTS], lo_e[SLOTS];
+        float w[SLOTS], cum[SLOTS];
+#pragma unroll
+        for (int sl = 0; sl < SLOTS; ++sl) {
+            k[sl] = 0;
+            a[sl] = (T)0;
+            df[sl] = lo_e[sl] = 0;
+            if (lane + 64 * sl < nnz) {
+                k[sl] = a_indices[rlo + lane + 64 * sl];
+                a[sl] = a_data[rlo + lane + 64 * sl];
+                const uint32_t *sp = seg + (int64_t)k[sl] * n_tiles;
+                lo_e[sl] = sp[0];
+                df[sl] = sp[n_tiles] - lo_e[sl];
+            }
+            // rounded up: covers the float sums below
+            w[sl] = lane + 64 * sl < nnz ? (float)a[sl] * (float)a[sl] * 1.00001f : 0.f;
+            cum[sl] = 0.f;
         }
         // ---- suffix S: the most frequent terms while the bound on ||a_S|| holds.  cum = sum of squares of
-        // the terms ordered before this lane's (list length descending, lane ascending), inclusive.
-        const float w = lane < nnz ? (float)a * (float)a * 1.00001f : 0.f;   // rounded up: covers the float sums below
-        float cum = 0.f;
+        // the terms ordered before this one (list length descending, position ascending), inclusive.
         for (int q = 0; q < nnz; ++q) {
-            const uint32_t dq = wave_read<uint32_t>(df, q);
-            const float wq = wave_read<float>(w, q);
-            const bool before = dq > df || (dq == df && q <= lane);
-            cum += before ? wq : 0.f;
+            uint32_t dq;
+            float wq;
+            if (SLOTS == 1 || q < 64) {
+                dq = wave_read<uint32_t>(df[0], q);
+                wq = wave_read<float>(w[0], q);
+            } else {
+                dq = wave_read<uint32_t>(df[SLOTS - 1], q - 64);
+                wq = wave_read<float>(w[SLOTS - 1], q - 64);
+            }
+#pragma unroll
+            for (int sl = 0; sl < SLOTS; ++sl) {
+                const bool before = dq > df[sl] || (dq == df[sl] && q <= lane + 64 * sl);
+                cum[sl] += before ? wq : 0.f;
+            }
         }
-        const bool in_s = lane < nnz && cum <= s_budget && df >= freq_min;   // a prefix of the (df desc) order
-        const bool in_p = lane < nnz && !in_s;
-        const uint64_t pm = __ballot(in_p);
-        if (pm == 0) continue;   // ||a|| * max ||b|| <= beta < threshold: no match possible
-        float bs2 = in_s ? cum : 0.f;
-        float dsum = in_p ? (float)df : 0.f;
+        bool in_p[SLOTS];
+        uint64_t pm[SLOTS];
+        float bs2 = 0.f, dsum = 0.f;
+        int np = 0;
+#pragma unroll
+        for (int sl = 0; sl < SLOTS; ++sl) {
+            const bool have = lane + 64 * sl < nnz;
+            const bool in_s = have && cum[sl] <= s_budget && df[sl] >= freq_min;   // a prefix of the (df desc) order
+            in_p[sl] = have && !in_s;
+            pm[sl] = __ballot(in_p[sl]);
+            np += __popcll(pm[sl]);
+            bs2 = fmaxf(bs2, in_s ? cum[sl] : 0.f);
+            dsum += in_p[sl] ? (float)df[sl] : 0.f;
+        }
+        if (np == 0) continue;   // ||a|| * max ||b|| <= beta < threshold: no match possible
+        if (np > 64) {           // (wide rows only) more prefix terms than lanes: exact kernel
+            if (lane == 0) flagged_rows[atomicAdd(flagged_count, 1u)] = row;
+            continue;
+        }
+        ++st_rows;
 #pragma unroll
         for (int d = 32; d > 0; d >>= 1) {
             bs2 = fmaxf(bs2, __shfl_xor(bs2, d, 64));
@@ -285,7 +337,6 @@ spgemm_topn_pruned_kernel(const int64_t *__restrict__ a_indptr, const int32_t *_
         bs2 = wave_read<float>(bs2, 0);     // explicitly wave-uniform: the branches below must not diverge
         dsum = wave_read<float>(dsum, 0);
         if (!(dsum > 0.f)) continue;   // every list of P is empty
-        const int np = __popcll(pm);
         // ---- survivor test in fixed point (scale 2^15).  q_ij accumulates UPPER bounds of the products, so
         //      p_ij * 2^15 <= q_ij; the exact kernel's float score obeys  score~ <= score + 1e-5  and
         //      score <= p_ij + ||a_S|| f_j  with  f_j <= fq_j / 255 * norm_b.  Column j survives when
@@ -303,37 +354,56 @@ spgemm_topn_pruned_kernel(const int64_t *__restrict__ a_indptr, const int32_t *_
         const int32_t T0m = T0 - 256;    // (T0m - C1 * fq) >> 8 == tq - 1 >= 0
 
         // ---- deal the 64 lanes to the terms of P in proportion to their list lengths
-        uint32_t G = in_p ? 1u + (uint32_t)((float)(64 - np) * 0.999f * ((float)df / dsum)) : 0u;
-        uint32_t start = G;   // inclusive scan, made exclusive below
+        uint32_t G[SLOTS], start[SLOTS];
+        uint32_t before_slot = 0;
 #pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const uint32_t o = __shfl_up(start, d, 64);
-            if (lane >= d) start += o;
+        for (int sl = 0; sl < SLOTS; ++sl) {
+            G[sl] = in_p[sl] ? 1u + (uint32_t)((float)(64 - np) * 0.999f * ((float)df[sl] / dsum)) : 0u;
+            uint32_t inc = G[sl];   // inclusive scan, made exclusive below
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const uint32_t o = __shfl_up(inc, d, 64);
+                if (lane >= d) inc += o;
+            }
+            start[sl] = before_slot + inc - G[sl];
+            before_slot += wave_read<uint32_t>(inc, 63);
         }
-        start -= G;
-        int src = 0;
+        int src = 0, src_slot = 0;
         uint32_t u = 0, g = 0;
-        {
-            uint64_t m = pm;
+#pragma unroll
+        for (int sl = 0; sl < SLOTS; ++sl) {
+            uint64_t m = pm[sl];
             SG_WD_DECL(wd_a);
             while (m) {
                 SG_WD(wd_a, 70, 12)
                 const int f = __builtin_ctzll(m);
                 m &= m - 1;
-                const uint32_t sf = wave_read<uint32_t>(start, f), gf = wave_read<uint32_t>(G, f);
+                const uint32_t sf = wave_read<uint32_t>(start[sl], f), gf = wave_read<uint32_t>(G[sl], f);
                 const uint32_t d = (uint32_t)lane - sf;
                 if (d < gf) {
                     src = f;
+                    src_slot = sl;
                     u = d;
                     g = gf;
                 }
             }
         }
-        const int my_k = wave_shfl<int>(k, src);
-        const uint32_t my_lo = wave_shfl<uint32_t>(lo_e, src);
+        int my_k = wave_shfl<int>(k[0], src);
+        uint32_t my_lo = wave_shfl<uint32_t>(lo_e[0], src);
+        T my_a = wave_shfl<T>(a[0], src);
+        if (SLOTS > 1) {
+            const int k1 = wave_shfl<int>(k[SLOTS - 1], src);
+            const uint32_t lo1 = wave_shfl<uint32_t>(lo_e[SLOTS - 1], src);
+            const T a1 = wave_shfl<T>(a[SLOTS - 1], src);
+            if (src_slot) {
+                my_k = k1;
+                my_lo = lo1;
+                my_a = a1;
+            }
+        }
         // upper bound (less one) of a * b * 2^15 from the bq field of a filter posting, left in place:
         // x = (CA * (bq << AB)) >> 32 with CA >= c_a * 2^(32 - AB), c_a = a * norm_b * 2^15 / BQ_MAX
-        const float c_a = (float)wave_shfl<T>(a, src) * norm_b * (32768.0f / (float)BQ_MAX) * 1.000002f;
+        const float c_a = (float)my_a * norm_b * (32768.0f / (float)BQ_MAX) * 1.000002f;
         const uint32_t CA = (uint32_t)(c_a * (float)(1u << (32 - AB))) + 1u;   // < 2^24
         // lane (term, u of G): byte offset of its first entry inside a segment, stride; idle lanes read the
         // all-zero row K3 appends to the table of segment ends (empty segments, rem == 0) and entry 0
@@ -345,20 +415,29 @@ spgemm_topn_pruned_kernel(const int64_t *__restrict__ a_indptr, const int32_t *_
         const uint32_t t_end = SYM ? (row >> TILE_LOG2) + 1u : (uint32_t)n_tiles;
         const uint32_t last_group = (uint32_t)(nt_pad >> 2) - 1u;
 
-        // ---- stage row i for the exact scoring: term -> value hash (filled by compare-and-swap, one wave)
-        hk[lane] = -1;
-        hk[lane + 64] = -1;
-        __builtin_amdgcn_wave_barrier();
-        if (lane < nnz) {
-            uint32_t h = term_hash(k);
-            SG_WD_DECL(wd_i);
-            while (atomicCAS(&hk[h], -1, k) != -1) {
-                SG_WD(wd_i, SG_HASH_SLOTS + 2, 16)
-                h = (h + 1) & (SG_HASH_SLOTS - 1);
+        // ---- stage row i for the exact scoring
+        if (WIDE) {   // the sorted row itself: terms in hk, values in ha (binary search, row_value)
+#pragma unroll
+            for (int sl = 0; sl < SLOTS; ++sl) {
+                hk[lane + 64 * sl] = lane + 64 * sl < nnz ? k[sl] : INT32_MAX;
+                ha[lane + 64 * sl] = a[sl];
             }
-            ha[h] = a;
+            __builtin_amdgcn_wave_barrier();
+        } else {      // term -> value hash (filled by compare-and-swap, one wave)
+            hk[lane] = -1;
+            hk[lane + 64] = -1;
+            __builtin_amdgcn_wave_barrier();
+            if (lane < nnz) {
+                uint32_t h = term_hash(k[0]);
+                SG_WD_DECL(wd_i);
+                while (atomicCAS(&hk[h], -1, k[0]) != -1) {
+                    SG_WD(wd_i, SG_HASH_SLOTS + 2, 16)
+                    h = (h + 1) & (SG_HASH_SLOTS - 1);
+                }
+                ha[h] = a[0];
+            }
+            __builtin_amdgcn_wave_barrier();
         }
-        __builtin_amdgcn_wave_barrier();
 
         TopList<T> top;
         top.clear();
@@ -376,7 +455,7 @@ spgemm_topn_pruned_kernel(const int64_t *__restrict__ a_indptr, const int32_t *_
             if (cross) surv[n_surv + __popcll(cm & lanes_below)] = col;
             n_surv += __popcll(cm);
             if (n_surv >= 64) {
-                top = drain_survivors<T, SYM, TILE_LOG2>(fwd_ptr, fwd, thr, row, pair_i, pair_j, pair_s, pair_count, pair_cap,
+                top = drain_survivors<T, SYM, TILE_LOG2, WIDE>(nnz, fwd_ptr, fwd, thr, row, pair_i, pair_j, pair_s, pair_count, pair_cap,
                                                          top, n_surv);
                 st_surv += 64;
                 n_surv -= 64;
@@ -536,7 +615,7 @@ spgemm_topn_pruned_kernel(const int64_t *__restrict__ a_indptr, const int32_t *_
             st_post += (unsigned long long)wave_read<uint32_t>(mine, 0);
         }
         if (n_surv > 0) {   // fewer than 64 left
-            top = drain_survivors<T, SYM, TILE_LOG2>(fwd_ptr, fwd, thr, row, pair_i, pair_j, pair_s, pair_count, pair_cap, top,
+            top = drain_survivors<T, SYM, TILE_LOG2, WIDE>(nnz, fwd_ptr, fwd, thr, row, pair_i, pair_j, pair_s, pair_count, pair_cap, top,
                                                      n_surv);
             st_surv += n_surv;
         }
@@ -725,10 +804,10 @@ struct PairList {   // symmetric mode: every pair (i, j <= i) above the threshol
     unsigned long long cap = 0;
 };
 
-template <typename T, int TILE_LOG2, bool SYM>
+template <typename T, int TILE_LOG2, bool SYM, bool WIDE>
 static int launch_pruned(sg_ctx *ctx, const sg_csr *A, const sg_postings *Bt, int32_t keep, sg_topn *r, T thr,
                          float s_budget, uint32_t *row_counter, uint32_t *flagged_count, uint32_t *flagged_rows,
-                         unsigned long long *stats, const PairList &pl) {
+                         unsigned long long *stats, const PairList &pl, const uint32_t *row_list, const uint32_t *row_list_len) {
     const size_t lds = ((size_t)2 << TILE_LOG2) + 512 + 1024 + (size_t)SG_SURV_CAP * 4;
     int waves_per_cu = (int)(ctx->lds_per_cu / lds);
     if (waves_per_cu > 32) waves_per_cu = 32;
@@ -737,16 +816,43 @@ static int launch_pruned(sg_ctx *ctx, const sg_csr *A, const sg_postings *Bt, in
         if (atoi(v) > 0) waves_per_cu = atoi(v);
     unsigned grid = (unsigned)ctx->num_cu * (unsigned)waves_per_cu;
     if ((int64_t)grid > A->n_rows) grid = (unsigned)(A->n_rows > 0 ? A->n_rows : 1);
-    hipLaunchKernelGGL((spgemm_topn_pruned_kernel<T, TILE_LOG2, SYM>), dim3(grid), dim3(64), lds, ctx->stream, A->d_indptr,
+    if (WIDE && grid > (unsigned)ctx->num_cu * 4u) grid = (unsigned)ctx->num_cu * 4u;   // few rows, if any: idle waves leave at once
+    hipLaunchKernelGGL((spgemm_topn_pruned_kernel<T, TILE_LOG2, SYM, WIDE>), dim3(grid), dim3(64), lds, ctx->stream, A->d_indptr,
                        A->d_indices, (const T *)A->d_data, (uint32_t)A->n_rows, (const uint32_t *)Bt->d_seg,
                        (const uint32_t *)Bt->d_ends, Bt->nt_pad, (uint32_t)Bt->n_terms,
                        (const uint32_t *)Bt->d_filt, Bt->n_tiles, (const uint32_t *)Bt->d_fwd_ptr,
                        (const void *)Bt->d_fwd, keep, r->stride, thr, s_budget, Bt->norm_up, Bt->freq_min, r->d_cols,
                        (T *)r->d_vals,
                        r->d_counts, row_counter, flagged_count, flagged_rows, stats, pl.d_i, pl.d_j, (T *)pl.d_s, pl.d_count,
-                       pl.cap);
+                       pl.cap, row_list, row_list_len);
     SG_HIP_TRY(hipGetLastError());
     return SG_OK;
+}
+
+// Both launches of one multiply: every row through the 64-term kernel; the rows it passes on (65 .. 128 non-zeros)
+// through the wide one; what THAT passes on (more than 128 non-zeros, more than 64 prefix terms, delta too small for
+// the fixed point) lands in (flagged_count, flagged_rows) for the exact kernel.
+template <typename T, int TILE_LOG2, bool SYM>
+static int launch_both(sg_ctx *ctx, const sg_csr *A, const sg_postings *Bt, int32_t keep, sg_topn *r, T thr,
+                       float s_budget, uint32_t *row_counter, uint32_t *flagged_count, uint32_t *flagged_rows,
+                       unsigned long long *stats, const PairList &pl) {
+    uint32_t *l1 = nullptr;
+    SG_TRY(sg_alloc(ctx, (size_t)A->n_rows + 8, &l1));
+    int st = hipMemsetAsync(l1, 0, 4 * sizeof(uint32_t), ctx->stream) == hipSuccess ? SG_OK : SG_ERR_HIP;
+    if (st == SG_OK)
+        st = launch_pruned<T, TILE_LOG2, SYM, false>(ctx, A, Bt, keep, r, thr, s_budget, row_counter, l1, l1 + 4, stats, pl,
+                                                     nullptr, nullptr);
+    if (st == SG_OK && !(getenv("SG_PRUNE_WIDE") && getenv("SG_PRUNE_WIDE")[0] == '0'))
+        st = launch_pruned<T, TILE_LOG2, SYM, true>(ctx, A, Bt, keep, r, thr, s_budget, l1 + 1, flagged_count, flagged_rows, stats,
+                                                    pl, l1 + 4, l1);
+    else if (st == SG_OK) {   // SG_PRUNE_WIDE=0: the first launch's list goes to the exact kernel as it is
+        if (hipMemcpyAsync(flagged_count, l1, 4, hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess ||
+            hipMemcpyAsync(flagged_rows, l1 + 4, sizeof(uint32_t) * (size_t)A->n_rows, hipMemcpyDeviceToDevice, ctx->stream) !=
+                hipSuccess)
+            st = SG_ERR_HIP;
+    }
+    ctx->release(l1);   // stream-ordered: the pool hands it out again only to work queued behind these launches
+    return st;
 }
 
 template <typename T, bool SYM>
@@ -754,9 +860,9 @@ static int dispatch_pruned(sg_ctx *ctx, const sg_csr *A, const sg_postings *Bt, 
                            float s_budget, uint32_t *row_counter, uint32_t *flagged_count, uint32_t *flagged_rows,
                            unsigned long long *stats, const PairList &pl) {
     switch (Bt->tile_log2) {
-        case 11: return launch_pruned<T, 11, SYM>(ctx, A, Bt, keep, r, thr, s_budget, row_counter, flagged_count, flagged_rows, stats, pl);
-        case 12: return launch_pruned<T, 12, SYM>(ctx, A, Bt, keep, r, thr, s_budget, row_counter, flagged_count, flagged_rows, stats, pl);
-        case 13: return launch_pruned<T, 13, SYM>(ctx, A, Bt, keep, r, thr, s_budget, row_counter, flagged_count, flagged_rows, stats, pl);
+        case 11: return launch_both<T, 11, SYM>(ctx, A, Bt, keep, r, thr, s_budget, row_counter, flagged_count, flagged_rows, stats, pl);
+        case 12: return launch_both<T, 12, SYM>(ctx, A, Bt, keep, r, thr, s_budget, row_counter, flagged_count, flagged_rows, stats, pl);
+        case 13: return launch_both<T, 13, SYM>(ctx, A, Bt, keep, r, thr, s_budget, row_counter, flagged_count, flagged_rows, stats, pl);
         default:
             sg_set_error("postings tile of 2^%d columns is not supported by the pruned multiply (2^11..2^13)", Bt->tile_log2);
             return SG_ERR_UNSUPPORTED;

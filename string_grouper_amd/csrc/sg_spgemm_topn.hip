@@ -659,7 +659,7 @@ extern "C" int sg_spgemm_topn(sg_ctx *ctx, const sg_csr *A, const sg_postings *B
             // and its host round trip (~1 ms): 4.0 vs 3.4 ms at 200 k rows, 17.7 vs 26.9 ms at 663 k
             // (profiles/r02_profile_k4p_v9b_sym.log)
             symmetric = prune && !(sy && sy[0] == '0') && A->n_rows == Bt->n_right && A->d_indptr == Bt->b_indptr &&
-                        A->d_indices == Bt->b_indices && A->d_data == Bt->b_data && a_max_nnz <= 64 &&
+                        A->d_indices == Bt->b_indices && A->d_data == Bt->b_data && a_max_nnz <= 128 &&
                         (A->n_rows >= (int64_t)env_int("SG_SYM_MIN_ROWS", 320000) || (sy && sy[0] == '1'));
         }
     }

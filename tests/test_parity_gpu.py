@@ -827,18 +827,44 @@ def test_pruned_multiply_is_exact_for_every_tuning(ctx, mats, env, monkeypatch):
     assert_csr_identical(out["1"][0], P.sp_matmul_topn_port(A, B.T, 10, 0.8, True, 8), str(env))
 
 
-def test_pruned_multiply_hands_long_rows_to_the_exact_kernel(ctx, monkeypatch):
-    """Rows with more than 64 distinct n-grams do not fit the pruned kernel's lanes."""
+def test_pruned_multiply_rows_beyond_64_terms(ctx, monkeypatch):
+    """Rows with 65 .. 128 distinct n-grams take the pruned kernel's second (wide) launch -- two staged terms per lane,
+    the row's sorted terms searched instead of hashed -- in both forms; rows beyond that, or with more than 64 prefix
+    terms, go to the exact kernel (and switch the self-join form off)."""
     rng = np.random.default_rng(5)
     letters = np.array(list("ABCDEFGHIJKLMNOPQRSTUVWXYZ "))
+    base = _names(6000, 9)
+    joined = [" ".join(base[3 * i:3 * i + 3]) for i in range(600)]               # ~75 characters: 65 .. 128 n-grams
+    medium = joined + [s[:-3] for s in joined[:200]] + [s + " LTD" for s in joined[200:300]]
+    names = list(base[:3000]) + medium
+    for dtype in (np.float32, np.float64):
+        A = _tfidf(names, dtype)
+        n_wide = int(((np.diff(A.indptr) > 64) & (np.diff(A.indptr) <= 128)).sum())
+        assert n_wide >= 500 and (np.diff(A.indptr) > 128).sum() == 0
+        dA = ctx.csr_from_scipy(A)
+        out = _multiply_both_ways(ctx, dA, dA, 5, 0.6, monkeypatch)
+        st = out["1"][1]
+        assert st["exact_rows"] < n_wide // 10 and st["prune_rows"] >= len(names) - 50, st      # the wide launch took them
+        C_ref = P.sp_matmul_topn_port(A, A.T, 5, 0.6, True, 8)
+        assert_csr_identical(out["1"][0], C_ref, "one-sided with wide rows")
+        assert_csr_identical(out["sym"][0], C_ref, "self-join form with wide rows")
+        assert out["sym"][1]["prune_symmetric"] == 1 or out["sym"][1]["exact_rows"] > 0
+        # without the wide launch the same rows go to the exact kernel: same bits
+        monkeypatch.setenv("SG_PRUNE_WIDE", "0")
+        out0 = _multiply_both_ways(ctx, dA, dA, 5, 0.6, monkeypatch)
+        monkeypatch.delenv("SG_PRUNE_WIDE")
+        assert out0["1"][1]["exact_rows"] >= n_wide
+        assert_csr_identical(out0["1"][0], C_ref, "wide launch off")
+    # rows beyond 128 terms (random letters: every n-gram distinct) are the exact kernel's
     long_names = ["".join(rng.choice(letters, 150)) for _ in range(40)]
-    names = list(_names(3000, 9)) + long_names + [s[:140] + "X" for s in long_names]
+    names = list(base[:3000]) + long_names + [s[:140] + "X" for s in long_names] + medium[:100]
     A = _tfidf(names, np.float32)
-    assert (np.diff(A.indptr) > 64).sum() >= 80
+    assert (np.diff(A.indptr) > 128).sum() >= 80
     dA = ctx.csr_from_scipy(A)
     out = _multiply_both_ways(ctx, dA, dA, 5, 0.6, monkeypatch)
     st = out["1"][1]
     assert st["exact_rows"] >= 80 and st["prune_rows"] > 0, st
+    assert out["sym"][1]["prune_symmetric"] == 0          # a row for the exact kernel: the self-join form stands down
     assert_csr_identical(out["1"][0], out["0"][0])
     assert_csr_identical(out["1"][0], P.sp_matmul_topn_port(A, A.T, 5, 0.6, True, 8))
 
