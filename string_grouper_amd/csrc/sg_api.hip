@@ -426,6 +426,7 @@ extern "C" int sg_csr_free(sg_csr *m) {
         m->ctx->release((void *)m->d_indptr);
         m->ctx->release((void *)m->d_indices);
         m->ctx->release((void *)m->d_data);
+        m->ctx->release(m->d_props_words);
     }
     delete m;
     return SG_OK;

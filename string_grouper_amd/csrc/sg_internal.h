@@ -117,6 +117,9 @@ struct sg_csr {
     mutable int props_state = 0;
     mutable float props_max_norm2 = 0.f;
     mutable uint32_t props_max_nnz = 0;  // longest row
+    // a matrix made by the vectoriser is cosine-like by construction; K2 leaves [0] violations (= 0), [1] max ||row||^2 as
+    // float bits, [2] longest row here and sg_csr_props reads them instead of scanning the matrix again (owned)
+    uint32_t *d_props_words = nullptr;
 };
 
 struct sg_postings {

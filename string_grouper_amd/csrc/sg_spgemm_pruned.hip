@@ -766,7 +766,9 @@ int sg_csr_props(sg_ctx *ctx, const sg_csr *m, bool *cosine_like, float *max_nor
         SG_TRY(sg_alloc(ctx, (size_t)4, &d));
         uint32_t h[4] = {0, 0, 0, 0};
         hipError_t e = hipMemsetAsync(d, 0, 16, ctx->stream);
-        if (e == hipSuccess && m->n_rows > 0) {
+        if (e == hipSuccess && m->d_props_words) {   // left by the vectoriser (K2): nothing to scan
+            e = hipMemcpyAsync(d, m->d_props_words, 12, hipMemcpyDeviceToDevice, ctx->stream);
+        } else if (e == hipSuccess && m->n_rows > 0) {
             const unsigned grid = (unsigned)((m->n_rows + 255) / 256);
             if (m->dtype == SG_F64)
                 hipLaunchKernelGGL(csr_props_kernel<double>, dim3(grid), dim3(256), 0, ctx->stream, m->d_indptr,

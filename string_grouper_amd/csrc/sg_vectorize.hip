@@ -441,26 +441,49 @@ __global__ void __launch_bounds__(256) weight_normalize_kernel(const int64_t *__
                                                                const int32_t *__restrict__ tf, Lookup lookup,
                                                                const T *__restrict__ idf, int64_t n,
                                                                const int64_t *__restrict__ indptr,
-                                                               int32_t *__restrict__ out_idx, T *__restrict__ out_val) {
+                                                               int32_t *__restrict__ out_idx, T *__restrict__ out_val,
+                                                               uint32_t *props /* [1] max ||row||^2 (float bits) [2] longest row */) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const int64_t b = ub_ptr[i];
-    const int c = cnt[i];
-    int64_t o = indptr[i];
-    const int64_t o0 = o;
-    double acc = 0.0;
-    for (int q = 0; q < c; ++q) {   // ascending key == ascending column
-        const int32_t col = lookup(keys[b + q]);
-        if (col < 0) continue;       // out-of-vocabulary n-gram of a string that was not part of fit()
-        const T w = tmul<T>((T)tf[b + q], idf[col]);
-        out_idx[o] = col;
-        out_val[o] = w;
-        acc = __dadd_rn(acc, (double)tmul<T>(w, w));
-        ++o;
+    float n2 = 0.f;
+    uint32_t len = 0;
+    if (i < n) {
+        const int64_t b = ub_ptr[i];
+        const int c = cnt[i];
+        int64_t o = indptr[i];
+        const int64_t o0 = o;
+        double acc = 0.0;
+        for (int q = 0; q < c; ++q) {   // ascending key == ascending column
+            const int32_t col = lookup(keys[b + q]);
+            if (col < 0) continue;       // out-of-vocabulary n-gram of a string that was not part of fit()
+            const T w = tmul<T>((T)tf[b + q], idf[col]);
+            out_idx[o] = col;
+            out_val[o] = w;
+            acc = __dadd_rn(acc, (double)tmul<T>(w, w));
+            ++o;
+        }
+        len = (uint32_t)(o - o0);
+        if (acc != 0.0) {
+            const double nrm = __dsqrt_rn(acc);
+            double s2 = 0.0;   // norm^2 of the row as stored (what sg_csr_props would compute by scanning the matrix)
+            for (int64_t q = o0; q < o; ++q) {
+                const T v = (T)__ddiv_rn((double)out_val[q], nrm);
+                out_val[q] = v;
+                s2 += (double)v * (double)v;
+            }
+            n2 = __double2float_ru(s2);
+        }
     }
-    if (acc == 0.0) return;
-    const double nrm = __dsqrt_rn(acc);
-    for (int64_t q = o0; q < o; ++q) out_val[q] = (T)__ddiv_rn((double)out_val[q], nrm);
+    // the multiply's pruning rules need the largest row norm and the longest row: reduce them here, where the rows are made
+    uint32_t nb = __float_as_uint(n2);   // non-negative floats order like unsigned integers
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) {
+        nb = max(nb, (uint32_t)__shfl_xor((int)nb, d, 64));
+        len = max(len, (uint32_t)__shfl_xor((int)len, d, 64));
+    }
+    if ((threadIdx.x & 63) == 0 && props) {
+        atomicMax(props + 1, nb);
+        atomicMax(props + 2, len);
+    }
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -929,10 +952,10 @@ extern "C" int sg_vocab_free(sg_vocab *v) {
 
 template <typename T, typename KeyT, typename Lookup>
 static void launch_weight(sg_ctx *ctx, const TokenCache *tc, Lookup lookup, const sg_vocab *v, int64_t n, const int64_t *indptr,
-                          int32_t *idx, void *val) {
+                          int32_t *idx, void *val, uint32_t *props) {
     hipLaunchKernelGGL((weight_normalize_kernel<T, KeyT, Lookup>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream,
                        (const int64_t *)tc->d_ub_ptr, (const int32_t *)tc->d_cnt, (const KeyT *)tc->d_keys,
-                       (const int32_t *)tc->d_tf, lookup, (const T *)v->d_idf, n, indptr, idx, (T *)val);
+                       (const int32_t *)tc->d_tf, lookup, (const T *)v->d_idf, n, indptr, idx, (T *)val, props);
 }
 
 extern "C" int sg_vec_transform(sg_ctx *ctx, const sg_vocab *v, const sg_strings *strings, sg_csr **out) {
@@ -999,13 +1022,16 @@ extern "C" int sg_vec_transform(sg_ctx *ctx, const sg_vocab *v, const sg_strings
         m->d_indices = idx;
         m->d_data = val;
         m->nnz = nnz;
+        if (st == SG_OK) st = sg_alloc(ctx, (size_t)4, &m->d_props_words);
+        if (st == SG_OK && hipMemsetAsync(m->d_props_words, 0, 16, ctx->stream) != hipSuccess) st = SG_ERR_HIP;
         if (st == SG_OK && n > 0) {
+            uint32_t *props = m->d_props_words;
             if (v->sorted_mode) {
-                if (m->dtype == SG_F64) launch_weight<double, uint64_t>(ctx, tc, sorted, v, n, indptr, idx, val);
-                else launch_weight<float, uint64_t>(ctx, tc, sorted, v, n, indptr, idx, val);
+                if (m->dtype == SG_F64) launch_weight<double, uint64_t>(ctx, tc, sorted, v, n, indptr, idx, val, props);
+                else launch_weight<float, uint64_t>(ctx, tc, sorted, v, n, indptr, idx, val, props);
             } else {
-                if (m->dtype == SG_F64) launch_weight<double, uint32_t>(ctx, tc, dense, v, n, indptr, idx, val);
-                else launch_weight<float, uint32_t>(ctx, tc, dense, v, n, indptr, idx, val);
+                if (m->dtype == SG_F64) launch_weight<double, uint32_t>(ctx, tc, dense, v, n, indptr, idx, val, props);
+                else launch_weight<float, uint32_t>(ctx, tc, dense, v, n, indptr, idx, val, props);
             }
             if (hipGetLastError() != hipSuccess) st = SG_ERR_HIP;
         }

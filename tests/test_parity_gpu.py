@@ -836,7 +836,7 @@ def test_pruned_multiply_rows_beyond_64_terms(ctx, monkeypatch):
     rng = np.random.default_rng(5)
     letters = np.array(list("ABCDEFGHIJKLMNOPQRSTUVWXYZ "))
     base = _names(6000, 9)
-    joined = [" ".join(base[3 * i:3 * i + 3]) for i in range(600)]               # ~75 characters: 65 .. 128 n-grams
+    joined = [" ".join(base[4 * i:4 * i + 4]) for i in range(600)]               # ~100 characters: mostly 65 .. 128 n-grams
     medium = joined + [s[:-3] for s in joined[:200]] + [s + " LTD" for s in joined[200:300]]
     names = list(base[:3000]) + medium
     for dtype in (np.float32, np.float64):
