@@ -861,11 +861,12 @@ def test_pruned_multiply_rows_beyond_64_terms(ctx, monkeypatch):
     long_names = ["".join(rng.choice(letters, 150)) for _ in range(40)]
     names = list(base[:3000]) + long_names + [s[:140] + "X" for s in long_names] + medium[:100]
     A = _tfidf(names, np.float32)
-    assert (np.diff(A.indptr) > 128).sum() >= 80
+    n_long = int((np.diff(A.indptr) > 128).sum())
+    assert n_long >= 70
     dA = ctx.csr_from_scipy(A)
     out = _multiply_both_ways(ctx, dA, dA, 5, 0.6, monkeypatch)
     st = out["1"][1]
-    assert st["exact_rows"] >= 80 and st["prune_rows"] > 0, st
+    assert st["exact_rows"] >= n_long and st["prune_rows"] > 0, st
     assert out["sym"][1]["prune_symmetric"] == 0          # a row for the exact kernel: the self-join form stands down
     assert_csr_identical(out["1"][0], out["0"][0])
     assert_csr_identical(out["1"][0], P.sp_matmul_topn_port(A, A.T, 5, 0.6, True, 8))
