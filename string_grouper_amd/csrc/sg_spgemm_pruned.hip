@@ -230,8 +230,7 @@ spgemm_topn_pruned_kernel(const int64_t *__restrict__ a_indptr, const int32_t *_
                           unsigned long long *stats /* [0] rows [1] postings streamed [2] survivors */,
                           uint32_t *pair_i, uint32_t *pair_j, T *pair_s, unsigned long long *pair_count,
                           unsigned long long pair_cap,
-                          const uint32_t *__restrict__ row_list /* WIDE: the rows to process */, const uint32_t *row_list_len,
-                          uint32_t flags /* bit 0: masked batch loads */) {
+                          const uint32_t *__restrict__ row_list /* WIDE: the rows to process */, const uint32_t *row_list_len) {
     constexpr int TILE = 1 << TILE_LOG2;
     constexpr int SLOTS = WIDE ? 2 : 1;   // row terms staged per lane
     constexpr int AB = TILE_LOG2 + 1;                          // address + half bits of a filter posting
@@ -495,17 +494,13 @@ spgemm_topn_pruned_kernel(const int64_t *__restrict__ a_indptr, const int32_t *_
         auto issue = [&](Batch &bt, uint32_t lo, uint32_t hi) {
             bt.base = lo + u4;
             bt.rem = (int32_t)(hi - bt.base);
-            if (flags & 1u) {   // only the lanes whose slot holds a posting load it (60 % of the slots are empty): fewer L1 requests
-                if (bt.rem > 0) bt.r0 = filt_at(bt.base);
-                if (bt.rem > (int32_t)G4) bt.r1 = filt_at(bt.base + G4);
-                if (bt.rem > (int32_t)G8) bt.r2 = filt_at(bt.base + G8);
-                if (bt.rem > (int32_t)G12) bt.r3 = filt_at(bt.base + G12);
-            } else {
-                bt.r0 = filt_at(bt.base);
-                bt.r1 = filt_at(bt.base + G4);
-                bt.r2 = filt_at(bt.base + G8);
-                bt.r3 = filt_at(bt.base + G12);
-            }
+            // unconditional on purpose: loading only the slots that hold a posting (60 % are empty) saves L1 requests, but
+            // the branches around the masked loads cost the compiler its exact count of loads in flight -- it then waits for
+            // (almost) all of them before a batch is used, i.e. the prefetch distance is gone: +9 % (profiles/r02_sessionI_*.log)
+            bt.r0 = filt_at(bt.base);
+            bt.r1 = filt_at(bt.base + G4);
+            bt.r2 = filt_at(bt.base + G8);
+            bt.r3 = filt_at(bt.base + G12);
         };
         // What one slot adds and what its accumulator must reach: side-effect free, computed for all lanes.
         struct Slot {
@@ -589,7 +584,7 @@ spgemm_topn_pruned_kernel(const int64_t *__restrict__ a_indptr, const int32_t *_
         uint4 E0 = ends_at(0);
         uint4 E1 = ends_at(min(1u, last_group));
         const uint32_t list_lo = g ? my_lo << 2 : 0u;
-        Batch b0 = {0, 0, 0, 0, 0, 0}, b1 = b0, b2 = b0, b3 = b0;
+        Batch b0, b1, b2, b3;
         issue(b0, list_lo, E0.x);
         issue(b1, E0.x, E0.y);
         issue(b2, E0.y, E0.z);
@@ -834,7 +829,7 @@ static int launch_pruned(sg_ctx *ctx, const sg_csr *A, const sg_postings *Bt, in
                        (const void *)Bt->d_fwd, keep, r->stride, thr, s_budget, Bt->norm_up, Bt->freq_min, r->d_cols,
                        (T *)r->d_vals,
                        r->d_counts, row_counter, flagged_count, flagged_rows, stats, pl.d_i, pl.d_j, (T *)pl.d_s, pl.d_count,
-                       pl.cap, row_list, row_list_len, (uint32_t)((getenv("SG_PRUNE_MASKED") && getenv("SG_PRUNE_MASKED")[0] == '1') ? 1 : 0));
+                       pl.cap, row_list, row_list_len);
     SG_HIP_TRY(hipGetLastError());
     return SG_OK;
 }
