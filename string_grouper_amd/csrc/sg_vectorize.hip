@@ -72,7 +72,8 @@ struct VocabImpl {
     std::vector<TokenCache> caches;
     uint16_t rank_of_byte[128];    // byte -> compact character code (SG_CHAR_ABSENT: did not occur at fit())
     uint8_t byte_of_rank[128];
-    int32_t *d_df_table = nullptr; // dense mode: key_space counters
+    int32_t *d_df_table = nullptr; // dense mode: key_space counters, or marks (df_marks)
+    bool df_marks = false;         // the table only marks the keys that occur; df is counted per column at fit_end
     bool local_alphabet = false;   // byte columns coded by rank among the bytes seen at fit() (7 * ngram_size > 24)
     bool symbols = false;          // the fit's columns are symbol columns (sg_strings_from_host_symbols)
     int32_t alphabet = 0;          // their alphabet size
@@ -137,6 +138,121 @@ __device__ __forceinline__ bool char_code(const void *chars, int64_t at, const T
 // string, which __syncthreads() implies); a compiler-level barrier keeps the LDS accesses in program order.
 __device__ __forceinline__ void wave_sync() { __builtin_amdgcn_wave_barrier(); }
 
+// Document frequencies.  Two forms:
+//  * counters (df_replicas >= 1): one device-scope atomic per (row, distinct n-gram) into a dense table over the key
+//    space -- the form whose table a multi-GPU caller sums across ranks (sg_vocab_df_table).  12.5 M atomics at 663 k
+//    names cost 0.85 ms, twice the rest of the tokeniser (profiles/r02_sessionK_k1_probe.log).
+//  * marks (df_replicas == 0; the single-GPU sg_vec_fit): the tokeniser only marks the keys that occur -- a load that
+//    hits in L1/L2 and, for the first rows that see a key, a plain store of 1 (racing stores all write the same value) --
+//    and the counts are made afterwards per COLUMN in LDS (df_count_lds_kernel), without any global atomic.
+__device__ __forceinline__ void count_document(int32_t *df_table, int32_t df_replicas, int64_t df_stride, int64_t row,
+                                               int64_t key) {
+    if (df_replicas == 0) {
+        if (df_table[key] == 0) df_table[key] = 1;
+    } else {
+        atomicAdd(&df_table[(int64_t)(row % df_replicas) * df_stride + key], 1);
+    }
+}
+
+// The common case -- a string of at most 64 characters -- one wave per string, four strings per workgroup, without the
+// LDS sorting network: every lane holds one n-gram key and finds its rank by comparing it with all the others, which
+// are broadcast from lane to lane through scalar registers (v_readlane: no memory, no dependent LDS round trips; an LDS
+// bitonic sort of 64 keys is 21 dependent read/compare/write stages).  Ties are broken by position so that the ranks
+// are a permutation; the keys are scattered to their ranks in LDS once, read back in order, and run-length encoded with
+// one ballot.  Longer strings are queued for tokenize_kernel.
+template <typename KeyT>
+__device__ __forceinline__ KeyT read_lane_key(KeyT v, int i);
+template <>
+__device__ __forceinline__ uint32_t read_lane_key<uint32_t>(uint32_t v, int i) {
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, i);
+}
+template <>
+__device__ __forceinline__ uint64_t read_lane_key<uint64_t>(uint64_t v, int i) {
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, i);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), i);
+    return ((uint64_t)hi << 32) | lo;
+}
+
+#define TOK_SHORT_WAVES 4
+template <typename KeyT, bool SYMBOLS>
+__global__ void __launch_bounds__(64 * TOK_SHORT_WAVES) tokenize_short_kernel(
+    const void *__restrict__ chars_in, const int64_t *__restrict__ offsets, int64_t n_rows, TokParams p,
+    const int64_t *__restrict__ ub_ptr, int32_t *__restrict__ out_cnt, KeyT *__restrict__ out_keys,
+    int32_t *__restrict__ out_tf, int32_t *df_table, int32_t df_replicas, int64_t df_stride, uint32_t *mid_count,
+    uint32_t *mid_rows) {
+    __shared__ KeyT skeys[TOK_SHORT_WAVES][64];
+    __shared__ uint16_t schars[TOK_SHORT_WAVES][64];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    KeyT *keys = skeys[wv];
+    uint16_t *chars = schars[wv];
+    const uint64_t lt_mask = ((uint64_t)1 << lane) - 1;
+    // keys that leave six spare bits are ranked with the lane number appended: one comparison per pair
+    const bool tagged = sizeof(KeyT) == 4 && p.bits * p.ngram <= 25;
+    const int64_t stride = (int64_t)gridDim.x * TOK_SHORT_WAVES;
+    for (int64_t row = (int64_t)blockIdx.x * TOK_SHORT_WAVES + wv; row < n_rows; row += stride) {
+        const int64_t b0 = offsets[row];
+        const int64_t len = offsets[row + 1] - b0;
+        if (len > 64) {
+            if (lane == 0) {
+                mid_rows[atomicAdd(mid_count, 1u)] = (uint32_t)row;
+                out_cnt[row] = 0;
+            }
+            continue;
+        }
+        uint32_t code = 0;
+        const bool keep = lane < len && char_code<SYMBOLS>(chars_in, b0 + lane, p, &code);
+        const uint64_t km = __ballot(keep);
+        const int g = __popcll(km) - p.ngram + 1;   // number of n-grams
+        if (g <= 0) {
+            if (lane == 0) out_cnt[row] = 0;
+            continue;
+        }
+        if (keep) chars[__popcll(km & lt_mask)] = (uint16_t)code;
+        wave_sync();
+        KeyT key = KeyTraits<KeyT>::PAD;
+        if (lane < g) {
+            key = 0;
+            bool absent = false;
+            for (int q = 0; q < p.ngram; ++q) {
+                const uint32_t ch = chars[lane + q];
+                absent |= ch == SG_CHAR_ABSENT;
+                key = (key << p.bits) | (KeyT)ch;
+            }
+            if (absent) key = KeyTraits<KeyT>::OOV;
+        }
+        uint32_t rank = 0;
+        if (tagged) {
+            const uint32_t body = key == KeyTraits<KeyT>::OOV ? 0x3FFFFFFu : (uint32_t)key;   // real keys are < 2^25
+            const uint32_t kt = lane < g ? (body << 6) | (uint32_t)lane : 0xFFFFFFFFu;
+            for (int i = 0; i < g; ++i) rank += (uint32_t)__builtin_amdgcn_readlane((int)kt, i) < kt;
+        } else {
+            for (int i = 0; i < g; ++i) {
+                const KeyT o = read_lane_key<KeyT>(key, i);
+                rank += (o < key) || (o == key && i < lane);
+            }
+        }
+        if (lane < g) keys[rank] = key;
+        wave_sync();
+        bool head = false;
+        KeyT mine = 0;
+        if (lane < g) {
+            mine = keys[lane];
+            head = lane == 0 || mine != keys[lane - 1];
+        }
+        const uint64_t hm = __ballot(head);
+        if (head) {
+            const uint64_t above = (hm >> lane) >> 1;   // the heads behind this one
+            const int next = above ? lane + 1 + __builtin_ctzll(above) : g;
+            const int64_t o = ub_ptr[row] + __popcll(hm & lt_mask);
+            out_keys[o] = mine;
+            out_tf[o] = next - lane;
+            if (df_table && mine != KeyTraits<KeyT>::OOV) count_document(df_table, df_replicas, df_stride, row, (int64_t)mine);
+        }
+        if (lane == 0) out_cnt[row] = __popcll(hm);
+        wave_sync();   // the next string overwrites chars / keys
+    }
+}
+
 template <typename KeyT, bool SYMBOLS>
 __global__ void __launch_bounds__(64) tokenize_kernel(const void *__restrict__ chars_in,
                                                       const int64_t *__restrict__ offsets, int64_t n_rows,
@@ -144,14 +260,18 @@ __global__ void __launch_bounds__(64) tokenize_kernel(const void *__restrict__ c
                                                       int32_t *__restrict__ out_cnt, KeyT *__restrict__ out_keys,
                                                       int32_t *__restrict__ out_tf, int32_t *df_table,
                                                       int32_t df_replicas, int64_t df_stride,
-                                                      uint32_t *long_count, uint32_t *long_rows) {
+                                                      uint32_t *long_count, uint32_t *long_rows,
+                                                      const uint32_t *__restrict__ row_list /* the rows to do, or null: all */,
+                                                      const uint32_t *__restrict__ row_list_len) {
     __shared__ KeyT keys[TOK_CAP];
     __shared__ uint16_t starts[TOK_CAP + 2];
     __shared__ uint16_t chars[TOK_CHARS];
     const int lane = threadIdx.x;
     const uint64_t lt_mask = ((uint64_t)1 << lane) - 1;
 
-    for (int64_t row = blockIdx.x; row < n_rows; row += gridDim.x) {
+    const int64_t n_todo = row_list ? (int64_t)*row_list_len : n_rows;
+    for (int64_t at = blockIdx.x; at < n_todo; at += gridDim.x) {
+        const int64_t row = row_list ? (int64_t)row_list[at] : at;
         const int64_t b0 = offsets[row];
         const int64_t len = offsets[row + 1] - b0;
         // ---- filter + compact into LDS
@@ -238,8 +358,7 @@ __global__ void __launch_bounds__(64) tokenize_kernel(const void *__restrict__ c
             out_tf[obase + u] = (int32_t)starts[u + 1] - s0;
             // the same few n-grams ('inc', ' co') occur in a fifth of all strings: spread their atomics over
             // several copies of the table (summed by df_reduce_kernel) instead of serialising on one address
-            if (df_table && key != KeyTraits<KeyT>::OOV)
-                atomicAdd(&df_table[(int64_t)(row % df_replicas) * df_stride + (int64_t)key], 1);
+            if (df_table && key != KeyTraits<KeyT>::OOV) count_document(df_table, df_replicas, df_stride, row, (int64_t)key);
         }
         if (lane == 0) out_cnt[row] = uniq;
         wave_sync();
@@ -337,8 +456,7 @@ __global__ void __launch_bounds__(256) tokenize_long_kernel(const void *__restri
             while (e < g && keys[e] == key) ++e;
             out_keys[obase + u] = key;
             out_tf[obase + u] = (int32_t)(e - idx);
-            if (df_table && key != KeyTraits<KeyT>::OOV)
-                atomicAdd(&df_table[(int64_t)(row % df_replicas) * df_stride + (int64_t)key], 1);
+            if (df_table && key != KeyTraits<KeyT>::OOV) count_document(df_table, df_replicas, df_stride, row, (int64_t)key);
         }
         __syncthreads();
         if (tid == 0) carry += wave_tot[0] + wave_tot[1] + wave_tot[2] + wave_tot[3];
@@ -381,6 +499,46 @@ __global__ void __launch_bounds__(256) vocab_finalize_kernel(const int32_t *__re
     } else {
         rank_io[i] = -1;
     }
+}
+
+
+// df of every column, marks form: a workgroup walks a block of rows (sixteen lanes per row: the token loads are
+// contiguous), counts the columns of its tokens in an LDS histogram over [col0, col0 + n_cols) and stores the histogram
+// as one row of `partial`; df_sum_kernel adds the rows up.
+__global__ void __launch_bounds__(1024) df_count_lds_kernel(const int64_t *__restrict__ ub_ptr, const int32_t *__restrict__ cnt,
+                                                            const uint32_t *__restrict__ keys,
+                                                            const int32_t *__restrict__ key_to_col, int64_t n_rows,
+                                                            int32_t col0, int32_t n_cols, int64_t n_terms,
+                                                            uint32_t *__restrict__ partial) {
+    extern __shared__ uint32_t df_hist[];
+    for (int k = threadIdx.x; k < n_cols; k += blockDim.x) df_hist[k] = 0;
+    __syncthreads();
+    const int64_t per_wg = (n_rows + gridDim.x - 1) / gridDim.x;
+    const int64_t r0 = (int64_t)blockIdx.x * per_wg;
+    int64_t r1 = r0 + per_wg;
+    if (r1 > n_rows) r1 = n_rows;
+    const int sub = threadIdx.x & 15;
+    for (int64_t row = r0 + (threadIdx.x >> 4); row < r1; row += blockDim.x >> 4) {
+        const int64_t b = ub_ptr[row];
+        const int c = cnt[row];
+        for (int q = sub; q < c; q += 16) {
+            const uint32_t key = keys[b + q];
+            if (key == SG_KEY_OOV32) continue;
+            const int32_t col = key_to_col[key] - col0;
+            if (col >= 0 && col < n_cols) atomicAdd(&df_hist[col], 1u);
+        }
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < n_cols; k += blockDim.x) partial[(int64_t)blockIdx.x * n_terms + col0 + k] = df_hist[k];
+}
+
+__global__ void __launch_bounds__(256) df_sum_kernel(const uint32_t *__restrict__ partial, int32_t n_partial, int64_t n_terms,
+                                                     int32_t *__restrict__ df) {
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n_terms) return;
+    uint32_t s = 0;
+    for (int r = 0; r < n_partial; ++r) s += partial[(int64_t)r * n_terms + k];
+    df[k] = (int32_t)s;
 }
 
 // column of a key: dense mode = table lookup, sorted mode = binary search in the ascending vocabulary
@@ -480,9 +638,110 @@ __global__ void __launch_bounds__(256) weight_normalize_kernel(const int64_t *__
         nb = max(nb, (uint32_t)__shfl_xor((int)nb, d, 64));
         len = max(len, (uint32_t)__shfl_xor((int)len, d, 64));
     }
+    // one counter takes ~12 ns per atomic whoever sends it: look first (a stale value is lower, never higher)
     if ((threadIdx.x & 63) == 0 && props) {
-        atomicMax(props + 1, nb);
-        atomicMax(props + 2, len);
+        const volatile uint32_t *seen = props;
+        if (nb > seen[1]) atomicMax(props + 1, nb);
+        if (len > seen[2]) atomicMax(props + 2, len);
+    }
+}
+
+// K2, the form that runs: sixteen lanes per row (four rows per wave), so that the token loads and the matrix stores of a
+// row are contiguous across lanes -- a thread per row (weight_normalize_kernel above, kept as the plain statement of the
+// arithmetic) walks 64 rows with a stride of one row per lane and misses in L1 on every step.
+// The sum of squares must be added in column order in double (sklearn's loop; the roundings of an f64 row depend on the
+// order): it runs down the sixteen lanes as a chain of row_shr:1 DPP moves -- after step k lane k holds the sum of the
+// tokens up to its own, lane 0 re-adds the carry of the previous sixteen tokens every step -- one add per token and no
+// memory.  The second pass recomputes the weights (the loads hit in L1) and writes col / w / ||row|| at the compacted
+// position.  Skipped (out-of-vocabulary) tokens add 0.0, which leaves the sum as it is.
+__device__ __forceinline__ double dpp_from_lower_lane(double v, double lane0_gets) {
+    const uint64_t b = (uint64_t)__double_as_longlong(v), o = (uint64_t)__double_as_longlong(lane0_gets);
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp((int)(uint32_t)o, (int)(uint32_t)b, 0x111 /* row_shr:1 */, 0xF, 0xF, false);
+    const uint32_t hi =
+        (uint32_t)__builtin_amdgcn_update_dpp((int)(uint32_t)(o >> 32), (int)(uint32_t)(b >> 32), 0x111, 0xF, 0xF, false);
+    return __longlong_as_double((long long)(((uint64_t)hi << 32) | lo));
+}
+__device__ __forceinline__ double shfl_double(double v, int src_lane) {
+    const uint64_t b = (uint64_t)__double_as_longlong(v);
+    const uint32_t lo = (uint32_t)__shfl((int)(uint32_t)b, src_lane, 64), hi = (uint32_t)__shfl((int)(uint32_t)(b >> 32), src_lane, 64);
+    return __longlong_as_double((long long)(((uint64_t)hi << 32) | lo));
+}
+
+template <typename T, typename KeyT, typename Lookup>
+__global__ void __launch_bounds__(256) weight_normalize_rows16_kernel(const int64_t *__restrict__ ub_ptr,
+                                                                      const int32_t *__restrict__ cnt,
+                                                                      const KeyT *__restrict__ keys,
+                                                                      const int32_t *__restrict__ tf, Lookup lookup,
+                                                                      const T *__restrict__ idf, int64_t n,
+                                                                      const int64_t *__restrict__ indptr,
+                                                                      int32_t *__restrict__ out_idx, T *__restrict__ out_val,
+                                                                      uint32_t *props) {
+    const int lane = threadIdx.x & 63, sub = lane & 15, grp_shift = lane & 48;
+    const int64_t row = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+    const bool valid = row < n;
+    const int64_t b = valid ? ub_ptr[row] : 0;
+    const int c = valid ? cnt[row] : 0;
+    const int64_t o0 = valid ? indptr[row] : 0;
+    int cmax = c;   // the wave walks its four rows together
+    cmax = max(cmax, __shfl_xor(cmax, 16, 64));
+    cmax = max(cmax, __shfl_xor(cmax, 32, 64));
+    double carry = 0.0;
+    for (int base = 0; base < cmax; base += 16) {
+        const int q = base + sub;
+        double w2 = 0.0;
+        if (q < c) {
+            const int32_t col = lookup(keys[b + q]);
+            if (col >= 0) {
+                const T w = tmul<T>((T)tf[b + q], idf[col]);
+                w2 = (double)tmul<T>(w, w);
+            }
+        }
+        double acc = w2;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) acc = __dadd_rn(dpp_from_lower_lane(acc, carry), w2);
+        carry = shfl_double(acc, lane | 15);
+    }
+    float n2 = 0.f;
+    uint32_t len = 0;
+    if (carry != 0.0) {
+        const double nrm = __dsqrt_rn(carry);
+        double s2 = 0.0;
+        int kept_before = 0;
+        for (int base = 0; base < cmax; base += 16) {
+            const int q = base + sub;
+            int32_t col = -1;
+            T w = 0;
+            if (q < c) {
+                col = lookup(keys[b + q]);
+                if (col >= 0) w = tmul<T>((T)tf[b + q], idf[col]);
+            }
+            const uint32_t km = (uint32_t)(__ballot(col >= 0) >> grp_shift) & 0xFFFFu;
+            if (col >= 0) {
+                const int64_t o = o0 + kept_before + __popc(km & ((1u << sub) - 1u));
+                const T v = (T)__ddiv_rn((double)w, nrm);
+                out_idx[o] = col;
+                out_val[o] = v;
+                s2 += (double)v * (double)v;
+            }
+            kept_before += __popc(km);
+        }
+        len = (uint32_t)kept_before;
+#pragma unroll
+        for (int d = 8; d > 0; d >>= 1) s2 += shfl_double(s2, lane ^ d);
+        // an upper bound of the norm^2 of the row as stored, whatever the order of the additions
+        n2 = __double2float_ru(s2 * (1.0 + 1e-12));
+    }
+    uint32_t nb = __float_as_uint(n2);   // non-negative floats order like unsigned integers
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) {
+        nb = max(nb, (uint32_t)__shfl_xor((int)nb, d, 64));
+        len = max(len, (uint32_t)__shfl_xor((int)len, d, 64));
+    }
+    // one counter takes ~12 ns per atomic whoever sends it: look first (a stale value is lower, never higher)
+    if (lane == 0 && props) {
+        const volatile uint32_t *seen = props;
+        if (nb > seen[1]) atomicMax(props + 1, nb);
+        if (len > seen[2]) atomicMax(props + 2, len);
     }
 }
 
@@ -517,10 +776,12 @@ static int tokenize_set_t(sg_ctx *ctx, const sg_strings *s, const TokParams &tp,
     c.n = s->n;
     int32_t *ub = nullptr;
     uint32_t *longs = nullptr;   // [0] count, then the rows
+    uint32_t *mids = nullptr;    // the same for the rows of more than 64 characters
     int st = sg_alloc(ctx, (size_t)s->n + 1, &ub);
     if (st == SG_OK) st = sg_alloc(ctx, (size_t)s->n + 1, &c.d_ub_ptr);
     if (st == SG_OK) st = sg_alloc(ctx, (size_t)s->n + 1, &c.d_cnt);
     if (st == SG_OK) st = sg_alloc(ctx, (size_t)s->n + 2, &longs);
+    if (st == SG_OK) st = sg_alloc(ctx, (size_t)s->n + 2, &mids);
     if (st == SG_OK && s->n > 0) {
         hipLaunchKernelGGL(ub_count_kernel, dim3((unsigned)((s->n + 255) / 256)), dim3(256), 0, ctx->stream,
                            s->d_offsets, s->n, tp.ngram, ub);
@@ -537,12 +798,21 @@ static int tokenize_set_t(sg_ctx *ctx, const sg_strings *s, const TokParams &tp,
     if (st == SG_OK) st = sg_alloc(ctx, (size_t)c.cap_total, &c.d_tf);
     uint32_t n_long = 0;
     if (st == SG_OK && s->n > 0) {
+        // strings of up to 64 characters: tokenize_short_kernel; what it queues (mids): tokenize_kernel, launched on the
+        // device-side count; what that one queues (longs, > TOK_CAP n-grams): tokenize_long_kernel after one host round trip
         hipError_t e = hipMemsetAsync(longs, 0, 4, ctx->stream);
-        unsigned grid = (unsigned)ctx->num_cu * 24u;
+        if (e == hipSuccess) e = hipMemsetAsync(mids, 0, 4, ctx->stream);
+        unsigned grid = (unsigned)ctx->num_cu * 8u;
+        const int64_t wgs = (s->n + TOK_SHORT_WAVES - 1) / TOK_SHORT_WAVES;
+        if ((int64_t)grid > wgs) grid = (unsigned)wgs;
+        hipLaunchKernelGGL((tokenize_short_kernel<KeyT, SYMBOLS>), dim3(grid), dim3(64 * TOK_SHORT_WAVES), 0, ctx->stream,
+                           (const void *)s->d_bytes, s->d_offsets, s->n, tp, (const int64_t *)c.d_ub_ptr, c.d_cnt, keys, c.d_tf,
+                           df_table, df_replicas, df_stride, mids, mids + 1);
+        grid = (unsigned)ctx->num_cu * 16u;
         if ((int64_t)grid > s->n) grid = (unsigned)s->n;
         hipLaunchKernelGGL((tokenize_kernel<KeyT, SYMBOLS>), dim3(grid), dim3(64), 0, ctx->stream, (const void *)s->d_bytes,
                            s->d_offsets, s->n, tp, (const int64_t *)c.d_ub_ptr, c.d_cnt, keys, c.d_tf, df_table, df_replicas,
-                           df_stride, longs, longs + 1);
+                           df_stride, longs, longs + 1, (const uint32_t *)(mids + 1), (const uint32_t *)mids);
         if (e == hipSuccess) e = hipGetLastError();
         if (e == hipSuccess) e = hipMemcpyAsync(&n_long, longs, 4, hipMemcpyDeviceToHost, ctx->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
@@ -601,6 +871,7 @@ static int tokenize_set_t(sg_ctx *ctx, const sg_strings *s, const TokParams &tp,
         }
     }
     ctx->release(longs);
+    ctx->release(mids);
     if (st != SG_OK) {
         free_cache(ctx, c);
         return st;
@@ -623,8 +894,8 @@ static int tokenize_set(sg_ctx *ctx, const sg_vocab *v, const sg_strings *s, int
 // fit = begin (tokenise, count document frequencies) + end (vocabulary).  The two halves are separate entry points so
 // that a multi-GPU caller can all-reduce the dense document-frequency table in between (one rank tokenises one block of
 // the strings; every rank then derives the SAME vocabulary and idf).
-extern "C" int sg_vec_fit_begin(sg_ctx *ctx, const sg_strings *const *sets, int32_t n_sets, const sg_vec_params *params,
-                                sg_vocab **out) {
+static int fit_begin(sg_ctx *ctx, const sg_strings *const *sets, int32_t n_sets, const sg_vec_params *params, bool df_marks,
+                     sg_vocab **out) {
     SG_REQUIRE(ctx && sets && params && out && n_sets >= 1, "null argument");
     SG_REQUIRE(params->ngram_size >= 1 && params->ngram_size <= 64, "ngram_size must be in [1, 64]");
     SG_REQUIRE(params->dtype == SG_F32 || params->dtype == SG_F64, "dtype must be SG_F32 or SG_F64");
@@ -725,10 +996,14 @@ extern "C" int sg_vec_fit_begin(sg_ctx *ctx, const sg_strings *const *sets, int3
             if (const char *e = getenv("SG_DF_REPLICAS")) replicas = atoi(e);
             while (replicas > 1 && df_stride * replicas > ((int64_t)1 << 25)) replicas >>= 1;   // <= 128 MiB of counters
             if (replicas < 1) replicas = 1;
-            st = sg_alloc(ctx, (size_t)(df_stride * replicas), &im->d_df_table);
+            if (const char *e = getenv("SG_DF_MARKS")) df_marks = df_marks && e[0] != '0';   // A/B hook
+            im->df_marks = df_marks;
+            const int64_t copies = df_marks ? 1 : replicas;
+            if (df_marks) replicas = 0;   // what the tokeniser kernels take as "mark, do not count"
+            st = sg_alloc(ctx, (size_t)(df_stride * copies), &im->d_df_table);
             if (st == SG_OK) st = sg_alloc(ctx, (size_t)v->key_space + 1, &v->d_key_to_col);
             if (st == SG_OK)
-                (void)hipMemsetAsync(im->d_df_table, 0, sizeof(int32_t) * (size_t)(df_stride * replicas), ctx->stream);
+                (void)hipMemsetAsync(im->d_df_table, 0, sizeof(int32_t) * (size_t)(df_stride * copies), ctx->stream);
         }
         for (int i = 0; i < n_sets && st == SG_OK; ++i) {
             TokenCache c;
@@ -753,9 +1028,15 @@ extern "C" int sg_vec_fit_begin(sg_ctx *ctx, const sg_strings *const *sets, int3
     return SG_OK;
 }
 
+extern "C" int sg_vec_fit_begin(sg_ctx *ctx, const sg_strings *const *sets, int32_t n_sets, const sg_vec_params *params,
+                                sg_vocab **out) {
+    return fit_begin(ctx, sets, n_sets, params, /*df_marks=*/false, out);   // the caller may want the counters (sg_vocab_df_table)
+}
+
 extern "C" int sg_vocab_df_table(sg_vocab *v, int32_t **d_table, int64_t *n_entries, int32_t *shareable) {
     SG_REQUIRE(v && v->impl && d_table && n_entries, "null argument");
     SG_REQUIRE(v->n_terms == 0, "the vocabulary is already finished");
+    SG_REQUIRE(!v->impl->df_marks, "this fit keeps marks, not counters");
     *d_table = v->impl->d_df_table;      // null in sorted mode
     *n_entries = v->key_space;
     // a table coded with the alphabet of the LOCAL strings (ngram_size > 3, symbol columns) means something else on
@@ -820,6 +1101,49 @@ static int finish_sorted_vocabulary(sg_ctx *ctx, sg_vocab *v) {
     return SG_OK;
 }
 
+// marks form of the fit: df[col] = number of rows of all fitted columns that hold the column's n-gram
+static int count_df_by_column(sg_ctx *ctx, sg_vocab *v) {
+    VocabImpl *im = v->impl;
+    const int32_t max_cols = 30 * 1024;   // 120 KiB of LDS counters per pass over the tokens
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void *)df_count_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, max_cols * 4);
+        attr_done = true;
+    }
+    std::vector<int32_t> wgs;
+    int32_t n_partial = 0;
+    for (const auto &c : im->caches) {
+        int64_t g = (c.n + 1023) / 1024;    // >= 1024 rows per workgroup, at most two workgroups per CU
+        if (g > (int64_t)ctx->num_cu * 2) g = (int64_t)ctx->num_cu * 2;
+        wgs.push_back((int32_t)g);
+        n_partial += (int32_t)g;
+    }
+    uint32_t *partial = nullptr;
+    int st = sg_alloc(ctx, (size_t)((int64_t)(n_partial > 0 ? n_partial : 1) * v->n_terms), &partial);
+    if (st != SG_OK) return st;
+    int32_t at = 0;
+    for (size_t i = 0; i < im->caches.size(); ++i) {
+        const TokenCache &c = im->caches[i];
+        if (wgs[i] == 0) continue;
+        for (int64_t col0 = 0; col0 < v->n_terms; col0 += max_cols) {
+            const int32_t n_cols = (int32_t)(v->n_terms - col0 < max_cols ? v->n_terms - col0 : max_cols);
+            hipLaunchKernelGGL(df_count_lds_kernel, dim3((unsigned)wgs[i]), dim3(1024), (size_t)n_cols * 4, ctx->stream,
+                               (const int64_t *)c.d_ub_ptr, (const int32_t *)c.d_cnt, (const uint32_t *)c.d_keys,
+                               (const int32_t *)v->d_key_to_col, c.n, (int32_t)col0, n_cols, v->n_terms,
+                               partial + (int64_t)at * v->n_terms);
+        }
+        at += wgs[i];
+    }
+    hipLaunchKernelGGL(df_sum_kernel, dim3((unsigned)((v->n_terms + 255) / 256)), dim3(256), 0, ctx->stream,
+                       (const uint32_t *)partial, n_partial, v->n_terms, v->d_df);
+    if (hipGetLastError() != hipSuccess) {
+        sg_set_error("df_count_lds_kernel: %s", hipGetErrorString(hipGetLastError()));
+        st = SG_ERR_HIP;
+    }
+    ctx->release(partial);
+    return st;
+}
+
 extern "C" int sg_vec_fit_end(sg_ctx *ctx, sg_vocab *v, int64_t n_docs_total) {
     SG_REQUIRE(ctx && v && v->impl, "null argument");
     SG_REQUIRE(v->n_terms == 0, "the vocabulary is already finished");
@@ -861,6 +1185,7 @@ extern "C" int sg_vec_fit_end(sg_ctx *ctx, sg_vocab *v, int64_t n_docs_total) {
                                            v->key_space, v->d_key_to_col, v->d_keys, v->d_df);
                         if (hipGetLastError() != hipSuccess) st = SG_ERR_HIP;
                     }
+                    if (st == SG_OK && im->df_marks) st = count_df_by_column(ctx, v);
                 }
             }
         }
@@ -876,7 +1201,7 @@ extern "C" int sg_vec_fit(sg_ctx *ctx, const sg_strings *const *sets, int32_t n_
                           sg_vocab **out) {
     SG_REQUIRE(out != nullptr, "null argument");
     sg_vocab *v = nullptr;
-    SG_TRY(sg_vec_fit_begin(ctx, sets, n_sets, params, &v));
+    SG_TRY(fit_begin(ctx, sets, n_sets, params, /*df_marks=*/true, &v));
     const int st = sg_vec_fit_end(ctx, v, 0);
     if (st != SG_OK) {
         sg_vocab_free(v);
@@ -953,9 +1278,15 @@ extern "C" int sg_vocab_free(sg_vocab *v) {
 template <typename T, typename KeyT, typename Lookup>
 static void launch_weight(sg_ctx *ctx, const TokenCache *tc, Lookup lookup, const sg_vocab *v, int64_t n, const int64_t *indptr,
                           int32_t *idx, void *val, uint32_t *props) {
-    hipLaunchKernelGGL((weight_normalize_kernel<T, KeyT, Lookup>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream,
-                       (const int64_t *)tc->d_ub_ptr, (const int32_t *)tc->d_cnt, (const KeyT *)tc->d_keys,
-                       (const int32_t *)tc->d_tf, lookup, (const T *)v->d_idf, n, indptr, idx, (T *)val, props);
+    static const bool plain = getenv("SG_K2_PLAIN") && getenv("SG_K2_PLAIN")[0] == '1';   // A/B hook
+    if (plain)
+        hipLaunchKernelGGL((weight_normalize_kernel<T, KeyT, Lookup>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream,
+                           (const int64_t *)tc->d_ub_ptr, (const int32_t *)tc->d_cnt, (const KeyT *)tc->d_keys,
+                           (const int32_t *)tc->d_tf, lookup, (const T *)v->d_idf, n, indptr, idx, (T *)val, props);
+    else
+        hipLaunchKernelGGL((weight_normalize_rows16_kernel<T, KeyT, Lookup>), dim3((unsigned)((n + 15) / 16)), dim3(256), 0,
+                           ctx->stream, (const int64_t *)tc->d_ub_ptr, (const int32_t *)tc->d_cnt, (const KeyT *)tc->d_keys,
+                           (const int32_t *)tc->d_tf, lookup, (const T *)v->d_idf, n, indptr, idx, (T *)val, props);
 }
 
 extern "C" int sg_vec_transform(sg_ctx *ctx, const sg_vocab *v, const sg_strings *strings, sg_csr **out) {
@@ -992,11 +1323,15 @@ extern "C" int sg_vec_transform(sg_ctx *ctx, const sg_vocab *v, const sg_strings
     const SortedLookup sorted{v->d_keys, v->n_terms};
     {
         SgTimer timer(ctx, SG_K_WEIGHT);
-        st = sg_alloc(ctx, (size_t)n + 1, &kept);
+        // the tokens of a column that was part of fit() are all in the vocabulary (min_df = 1): kept == distinct n-grams
+        const bool all_kept = tc != &local;
+        if (!all_kept) st = sg_alloc(ctx, (size_t)n + 1, &kept);
         if (st == SG_OK) st = sg_alloc(ctx, (size_t)n + 1, &indptr);
         if (st == SG_OK && n > 0) {
             const unsigned grid = (unsigned)((n + 255) / 256);
-            if (v->sorted_mode)
+            if (all_kept)
+                ;
+            else if (v->sorted_mode)
                 hipLaunchKernelGGL((kept_count_kernel<uint64_t, SortedLookup>), dim3(grid), dim3(256), 0, ctx->stream,
                                    (const int64_t *)tc->d_ub_ptr, (const int32_t *)tc->d_cnt, (const uint64_t *)tc->d_keys,
                                    sorted, n, kept);
@@ -1004,7 +1339,7 @@ extern "C" int sg_vec_transform(sg_ctx *ctx, const sg_vocab *v, const sg_strings
                 hipLaunchKernelGGL((kept_count_kernel<uint32_t, DenseLookup>), dim3(grid), dim3(256), 0, ctx->stream,
                                    (const int64_t *)tc->d_ub_ptr, (const int32_t *)tc->d_cnt, (const uint32_t *)tc->d_keys,
                                    dense, n, kept);
-            st = sg_exclusive_scan_i32_to_i64(ctx, kept, indptr, n);
+            st = sg_exclusive_scan_i32_to_i64(ctx, all_kept ? tc->d_cnt : kept, indptr, n);
         } else if (st == SG_OK) {
             (void)hipMemsetAsync(indptr, 0, sizeof(int64_t), ctx->stream);
         }
