@@ -4,14 +4,14 @@ mkdir -p gpurun_out
 export PYTHONPATH=$PWD
 LOG=gpurun_out/r02j.log
 : > $LOG
-timeout 1200 python -m pytest tests -x -q -m gpu -k "not 663k and not perf" > gpurun_out/r02j_pytest.log 2>&1
+timeout 1200 python -m pytest tests -x -q -m gpu -k "not perf" > gpurun_out/r02j_pytest.log 2>&1
 echo "pytest exit $?" >> $LOG
 tail -5 gpurun_out/r02j_pytest.log >> $LOG
 short() { python -c "
 import sys, json
 d = json.loads(sys.stdin.read())
 print(d['kernels_ms'], round(d['ms_per_step'], 3), d['parity_on_sample'] if 'parity_on_sample' in d else '')"; }
-for v in "SG_X=0" "SG_DF_MARKS=0" "SG_K2_PLAIN=1"; do
+for v in "SG_X=0" "SG_SYM=0" "SG_X=1"; do
   echo -n "$v : " >> $LOG
   env $v timeout 300 python bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-exact-kernel --no-end-to-end 2>/dev/null | short >> $LOG 2>&1
 done

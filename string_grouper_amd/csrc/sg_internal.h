@@ -135,6 +135,7 @@ struct sg_postings {
     const int32_t *b_indices = nullptr;
     const void *b_data = nullptr;
     uint32_t *d_seg = nullptr;           // n_terms * n_tiles + 1
+    uint32_t *d_term_len = nullptr;      // n_terms: entries of term k's list (= seg[(k+1) * n_tiles] - seg[k * n_tiles])
     int32_t *d_rows = nullptr;           // nnz   (row j of B)
     void *d_vals = nullptr;              // nnz   (value B[j, k])
     // rows of B packed for the pruned multiply's exact scoring (built only for cosine-like B):

@@ -115,69 +115,122 @@ __global__ void __launch_bounds__(256) postings_fill(const int64_t *__restrict__
     }
 }
 
-// The same two passes with the tile's counters in LDS: one workgroup per column tile (its rows are
-// consecutive), a histogram / cursor array over the vocabulary in LDS (4 bytes per term), LDS atomics
-// instead of 2 x nnz global ones.  Used when the vocabulary fits (n_terms * 4 <= 120 KiB).
-template <typename T>
+// The same two passes with the counters in LDS (4 bytes per term; used when the vocabulary fits: n_terms * 4 <= 120 KiB):
+// a workgroup owns a column tile -- or, with `split` > 1, one of `split` equal parts of it, so that 162 tiles still fill
+// 256 CUs; a segment (k, t) is then the parts' sub-segments back to back, which the multiply never notices since the
+// order inside a segment is free.  Sixteen lanes walk one row (the loads of a row are contiguous across lanes; a thread
+// per row steps 64 rows with one cache line each), LDS atomics take the place of 2 x nnz global ones.
+// Counter layout while building: bin (k, t, part) at (k * n_tiles + t) * split + part.
 __global__ void __launch_bounds__(1024) postings_count_lds(const int64_t *__restrict__ indptr,
                                                            const int32_t *__restrict__ indices, int64_t n_rows,
-                                                           int32_t tile_log2, int32_t n_tiles, int32_t n_terms,
+                                                           int32_t tile_log2, int32_t n_tiles, int32_t n_terms, int32_t split,
                                                            uint32_t *seg_counts) {
     extern __shared__ uint32_t hist[];
-    const int64_t t = blockIdx.x;
+    const int64_t t = blockIdx.x / split;
+    const int32_t part = blockIdx.x % split;
     for (int k = threadIdx.x; k < n_terms; k += blockDim.x) hist[k] = 0;
     __syncthreads();
-    const int64_t j0 = t << tile_log2;
-    int64_t j1 = j0 + ((int64_t)1 << tile_log2);
+    const int64_t part_rows = ((int64_t)1 << tile_log2) / split;
+    const int64_t j0 = (t << tile_log2) + part * part_rows;
+    int64_t j1 = j0 + part_rows;
     if (j1 > n_rows) j1 = n_rows;
-    for (int64_t j = j0 + threadIdx.x; j < j1; j += blockDim.x)
-        for (int64_t p = indptr[j]; p < indptr[j + 1]; ++p) atomicAdd(&hist[indices[p]], 1u);
+    const int sub = threadIdx.x & 15;
+    for (int64_t j = j0 + (threadIdx.x >> 4); j < j1; j += blockDim.x >> 4)
+        for (int64_t p = indptr[j] + sub; p < indptr[j + 1]; p += 16) atomicAdd(&hist[indices[p]], 1u);
     __syncthreads();
-    for (int k = threadIdx.x; k < n_terms; k += blockDim.x) seg_counts[(int64_t)k * n_tiles + t] = hist[k];
+    for (int k = threadIdx.x; k < n_terms; k += blockDim.x)
+        seg_counts[((int64_t)k * n_tiles + t) * split + part] = hist[k];
+}
+
+// is_frequent[k] = term k's list holds >= freq_min entries; seg[i] = start of bin i without the parts
+__global__ void __launch_bounds__(256) frequent_terms_kernel(const uint32_t *__restrict__ segp, int64_t n_terms, int64_t row_stride,
+                                                             uint32_t freq_min, uint8_t *__restrict__ is_frequent) {
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < n_terms) is_frequent[k] = segp[(k + 1) * row_stride] - segp[k * row_stride] >= freq_min ? 1 : 0;
+}
+__global__ void __launch_bounds__(256) term_len_kernel(const uint32_t *__restrict__ seg, int64_t n_terms, int32_t n_tiles,
+                                                       uint32_t *__restrict__ term_len) {
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < n_terms) term_len[k] = seg[(k + 1) * n_tiles] - seg[k * n_tiles];
+}
+__global__ void __launch_bounds__(256) unsplit_seg_kernel(const uint32_t *__restrict__ segp, int64_t n_bins, int32_t split,
+                                                          uint32_t *__restrict__ seg) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i <= n_bins) seg[i] = segp[i * split];
 }
 
 template <typename T>
 __global__ void __launch_bounds__(1024) postings_fill_lds(const int64_t *__restrict__ indptr,
                                                           const int32_t *__restrict__ indices,
                                                           const T *__restrict__ data, int64_t n_rows, int32_t tile_log2,
-                                                          int32_t n_tiles, int32_t n_terms, const uint32_t *__restrict__ seg,
-                                                          int32_t *out_rows, T *out_vals, uint32_t *out_filt,
-                                                          uint32_t freq_min, float inv_norm_up) {
-    extern __shared__ uint32_t cursor[];   // next free slot of (term k, this tile)
-    const int64_t t = blockIdx.x;
-    for (int k = threadIdx.x; k < n_terms; k += blockDim.x) cursor[k] = seg[(int64_t)k * n_tiles + t];
+                                                          int32_t n_tiles, int32_t n_terms, int32_t split,
+                                                          const uint32_t *__restrict__ segp,
+                                                          const uint8_t *__restrict__ is_frequent, int32_t *out_rows,
+                                                          T *out_vals, uint32_t *out_filt, float inv_norm_up) {
+    extern __shared__ uint32_t cursor[];   // next free slot of (term k, this tile, this part); then the frequent-term bits
+    uint32_t *freq_bits = cursor + n_terms;
+    const int64_t t = blockIdx.x / split;
+    const int32_t part = blockIdx.x % split;
+    for (int k = threadIdx.x; k < (n_terms + 31) / 32; k += blockDim.x) freq_bits[k] = 0;
+    for (int k = threadIdx.x; k < n_terms; k += blockDim.x) cursor[k] = segp[((int64_t)k * n_tiles + t) * split + part];
     __syncthreads();
-    const int64_t j0 = t << tile_log2;
-    int64_t j1 = j0 + ((int64_t)1 << tile_log2);
+    if (out_filt)
+        for (int k = threadIdx.x; k < n_terms; k += blockDim.x)
+            if (is_frequent[k]) atomicOr(&freq_bits[k >> 5], 1u << (k & 31));
+    __syncthreads();
+    const int64_t part_rows = ((int64_t)1 << tile_log2) / split;
+    const int64_t j0 = (t << tile_log2) + part * part_rows;
+    int64_t j1 = j0 + part_rows;
     if (j1 > n_rows) j1 = n_rows;
-    for (int64_t j = j0 + threadIdx.x; j < j1; j += blockDim.x) {
-        const int64_t lo = indptr[j], hi = indptr[j + 1];
-        const uint32_t col = (uint32_t)(j - j0);
-        const uint32_t fq = out_filt ? frequent_norm_q8<T>(indices, data, lo, hi, seg, n_tiles, freq_min, inv_norm_up) : 0u;
-        for (int64_t p = lo; p < hi; ++p) {
+    const int lane = threadIdx.x & 63, sub = lane & 15;
+    // every wave makes the same number of trips, so that the cross-lane sums below always run with all lanes
+    const int64_t trips = (j1 - j0 + (blockDim.x >> 4) - 1) / (blockDim.x >> 4);
+    for (int64_t it = 0; it < trips; ++it) {
+        const int64_t j = j0 + it * (blockDim.x >> 4) + (threadIdx.x >> 4);
+        const bool valid = j < j1;
+        const int64_t lo = valid ? indptr[j] : 0, hi = valid ? indptr[j + 1] : 0;
+        uint32_t fq = 0;
+        if (out_filt) {
+            // norm of the row's frequent part, quantised upwards to 8 bits relative to norm_up (the order of the additions
+            // is free: the result is rounded up with a margin far above the rounding of a double sum)
+            double f2 = 0.0;
+            for (int64_t p = lo + sub; p < hi; p += 16) {
+                const int32_t k = indices[p];
+                if ((freq_bits[k >> 5] >> (k & 31)) & 1u) f2 += (double)data[p] * (double)data[p];
+            }
+#pragma unroll
+            for (int d = 8; d > 0; d >>= 1) {
+                const uint64_t bits = (uint64_t)__double_as_longlong(f2);
+                const uint32_t l = (uint32_t)__shfl_xor((int)(uint32_t)bits, d, 64), h = (uint32_t)__shfl_xor((int)(uint32_t)(bits >> 32), d, 64);
+                f2 += __longlong_as_double((long long)(((uint64_t)h << 32) | l));
+            }
+            fq = (uint32_t)ceilf(__double2float_ru(sqrt(f2) * (1.0 + 1e-12)) * inv_norm_up * 255.0f * 1.000002f);
+            if (fq > 255u) fq = 255u;
+        }
+        const uint32_t col = (uint32_t)(j - (t << tile_log2));
+        for (int64_t p = lo + sub; p < hi; p += 16) {
             const uint32_t pos = atomicAdd(&cursor[indices[p]], 1u);
             emit_posting<T>(out_rows, out_vals, out_filt, pos, col, data[p], fq, tile_log2, inv_norm_up);
         }
     }
 }
 
-// Packed copy of B's rows for the pruned multiply (one 16-byte load = two f32 entries or one f64 entry).
+// Packed copy of B's rows for the pruned multiply (one 16-byte load = two f32 entries or one f64 entry): a thread per
+// entry, and a thread per row for the 32-bit row pointers.
 template <typename T>
 __global__ void __launch_bounds__(256) fwd_pack(const int64_t *__restrict__ indptr, const int32_t *__restrict__ indices,
-                                                const T *__restrict__ data, int64_t n_rows, uint32_t *__restrict__ fwd_ptr,
-                                                void *__restrict__ fwd) {
-    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (j > n_rows) return;
+                                                const T *__restrict__ data, int64_t n_rows, int64_t nnz,
+                                                uint32_t *__restrict__ fwd_ptr, void *__restrict__ fwd) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t base = indptr[0];
-    fwd_ptr[j] = (uint32_t)(indptr[j] - base);
-    if (j == n_rows) return;
-    for (int64_t p = indptr[j]; p < indptr[j + 1]; ++p) {
-        if (sizeof(T) == 4) {
-            reinterpret_cast<int2 *>(fwd)[p - base] = make_int2(indices[p], __float_as_int((float)data[p]));
-        } else {
-            const long long bits = __double_as_longlong((double)data[p]);
-            reinterpret_cast<int4 *>(fwd)[p - base] = make_int4(indices[p], 0, (int)(bits & 0xffffffffll), (int)(bits >> 32));
-        }
+    if (i <= n_rows) fwd_ptr[i] = (uint32_t)(indptr[i] - base);
+    if (i >= nnz) return;
+    const int64_t p = base + i;
+    if (sizeof(T) == 4) {
+        reinterpret_cast<int2 *>(fwd)[i] = make_int2(indices[p], __float_as_int((float)data[p]));
+    } else {
+        const long long bits = __double_as_longlong((double)data[p]);
+        reinterpret_cast<int4 *>(fwd)[i] = make_int4(indices[p], 0, (int)(bits & 0xffffffffll), (int)(bits >> 32));
     }
 }
 
@@ -249,11 +302,10 @@ extern "C" int sg_postings_build(sg_ctx *ctx, const sg_csr *B, int32_t tile_cols
     p->cosine_like = cosine_like;
     p->max_norm2 = max_norm2;
     const size_t vs = 8;   // f64 value, or packed {row, f32 value}
-    uint32_t *cursor = nullptr;
     int st = sg_alloc(ctx, (size_t)n_bins + 1, &p->d_seg);
+    if (st == SG_OK) st = sg_alloc(ctx, (size_t)B->n_cols + 1, &p->d_term_len);
     if (st == SG_OK && B->dtype == SG_F64) st = sg_alloc(ctx, (size_t)B->nnz + 64, &p->d_rows);
     if (st == SG_OK) st = ctx->alloc(((size_t)B->nnz + 64) * vs, &p->d_vals);
-    if (st == SG_OK) st = sg_alloc(ctx, (size_t)n_bins + 1, &cursor);
     if (st == SG_OK && want_pruned && sg_pruned_supports_tile(tile_log2) &&
         (B->n_cols + 1) * ((n_tiles64 + 3) & ~(int64_t)3) < ((int64_t)1 << 30)) {
         st = ctx->alloc(((size_t)B->nnz + 8) * (B->dtype == SG_F64 ? 16 : 8), &p->d_fwd);
@@ -277,63 +329,95 @@ extern "C" int sg_postings_build(sg_ctx *ctx, const sg_csr *B, int32_t tile_cols
     }
     {
         SgTimer timer(ctx, SG_K_POSTINGS);
-        SG_HIP_TRY(hipMemsetAsync(p->d_seg, 0, sizeof(uint32_t) * (size_t)(n_bins + 1), ctx->stream));
-        SG_HIP_TRY(hipMemsetAsync(cursor, 0, sizeof(uint32_t) * (size_t)(n_bins + 1), ctx->stream));
         // one thread per slot of the (tile x row-in-tile) grid: covers every row, see row_of_thread
         const unsigned grid = (unsigned)((((int64_t)p->n_tiles << tile_log2) + 255) / 256);
-        // the tile's counters fit in LDS: one workgroup per tile, LDS atomics (otherwise global ones)
-        const size_t lds = (size_t)B->n_cols * 4;
-        bool in_lds = B->n_rows > 0 && lds <= 120 * 1024 && lds > 0;
+        // the tile's counters fit in LDS: one workgroup per tile (part), LDS atomics (otherwise global ones)
+        const size_t lds = (size_t)B->n_cols * 4 + ((size_t)(B->n_cols + 31) / 32) * 4;
+        bool in_lds = B->n_rows > 0 && lds <= 124 * 1024 && B->n_cols > 0;
         if (const char *e = getenv("SG_POSTINGS_LDS")) in_lds = in_lds && e[0] != '0';
         const float inv_norm = p->d_filt ? 1.0f / p->norm_up : 0.f;
         if (in_lds) {
             static bool attr_done = false;
             if (!attr_done) {
-                (void)hipFuncSetAttribute((const void *)postings_count_lds<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024);
-                (void)hipFuncSetAttribute((const void *)postings_count_lds<double>, hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024);
-                (void)hipFuncSetAttribute((const void *)postings_fill_lds<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024);
-                (void)hipFuncSetAttribute((const void *)postings_fill_lds<double>, hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024);
+                (void)hipFuncSetAttribute((const void *)postings_count_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 124 * 1024);
+                (void)hipFuncSetAttribute((const void *)postings_fill_lds<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 124 * 1024);
+                (void)hipFuncSetAttribute((const void *)postings_fill_lds<double>, hipFuncAttributeMaxDynamicSharedMemorySize, 124 * 1024);
                 attr_done = true;
             }
-            if (B->dtype == SG_F64)
-                hipLaunchKernelGGL(postings_count_lds<double>, dim3((unsigned)p->n_tiles), dim3(1024), lds, ctx->stream, B->d_indptr,
-                                   B->d_indices, B->n_rows, tile_log2, p->n_tiles, (int32_t)B->n_cols, p->d_seg);
-            else
-                hipLaunchKernelGGL(postings_count_lds<float>, dim3((unsigned)p->n_tiles), dim3(1024), lds, ctx->stream, B->d_indptr,
-                                   B->d_indices, B->n_rows, tile_log2, p->n_tiles, (int32_t)B->n_cols, p->d_seg);
-            SG_HIP_TRY(hipGetLastError());
-        } else if (grid > 0) {
-            if (B->dtype == SG_F64)
-                hipLaunchKernelGGL(postings_count<double>, dim3(grid), dim3(256), 0, ctx->stream, B->d_indptr,
-                                   B->d_indices, B->n_rows, tile_log2, p->n_tiles, p->d_seg);
-            else
-                hipLaunchKernelGGL(postings_count<float>, dim3(grid), dim3(256), 0, ctx->stream, B->d_indptr,
-                                   B->d_indices, B->n_rows, tile_log2, p->n_tiles, p->d_seg);
-            SG_HIP_TRY(hipGetLastError());
+            // fewer tiles than CUs: split every tile between 2 or 4 workgroups (parts of >= 1024 rows)
+            int32_t split = 1;
+            while (split < 4 && (int64_t)p->n_tiles * split < ctx->num_cu && (tile_cols / (split * 2)) >= 1024 &&
+                   (n_bins * split * 2 + 1) < ((int64_t)1 << 31))
+                split *= 2;
+            if (const char *e = getenv("SG_POSTINGS_SPLIT")) {
+                const int o = atoi(e);
+                if ((o == 1 || o == 2 || o == 4) && tile_cols / o >= 64 && n_bins * o + 1 < ((int64_t)1 << 31)) split = o;
+            }
+            uint32_t *segp = p->d_seg;          // counters with the parts; the table itself when split == 1
+            uint8_t *is_frequent = nullptr;
+            if (split > 1) st = sg_alloc(ctx, (size_t)(n_bins * split) + 1, &segp);
+            if (st == SG_OK) st = sg_alloc(ctx, (size_t)B->n_cols + 1, &is_frequent);
+            if (st == SG_OK) {
+                const unsigned wgs = (unsigned)(p->n_tiles * split);
+                hipLaunchKernelGGL(postings_count_lds, dim3(wgs), dim3(1024), (size_t)B->n_cols * 4, ctx->stream, B->d_indptr,
+                                   B->d_indices, B->n_rows, tile_log2, p->n_tiles, (int32_t)B->n_cols, split, segp);
+                // counts -> offsets, in place; the last entry receives the total (= nnz)
+                st = sg_exclusive_scan_u32(ctx, segp, segp, n_bins * split, segp + n_bins * split);
+                if (st == SG_OK) {
+                    hipLaunchKernelGGL(frequent_terms_kernel, dim3((unsigned)((B->n_cols + 255) / 256)), dim3(256), 0, ctx->stream,
+                                       (const uint32_t *)segp, B->n_cols, (int64_t)p->n_tiles * split, p->freq_min, is_frequent);
+                    if (B->dtype == SG_F64)
+                        hipLaunchKernelGGL(postings_fill_lds<double>, dim3(wgs), dim3(1024), lds, ctx->stream, B->d_indptr,
+                                           B->d_indices, (const double *)B->d_data, B->n_rows, tile_log2, p->n_tiles,
+                                           (int32_t)B->n_cols, split, (const uint32_t *)segp, (const uint8_t *)is_frequent,
+                                           p->d_rows, (double *)p->d_vals, p->d_filt, inv_norm);
+                    else
+                        hipLaunchKernelGGL(postings_fill_lds<float>, dim3(wgs), dim3(1024), lds, ctx->stream, B->d_indptr,
+                                           B->d_indices, (const float *)B->d_data, B->n_rows, tile_log2, p->n_tiles,
+                                           (int32_t)B->n_cols, split, (const uint32_t *)segp, (const uint8_t *)is_frequent,
+                                           p->d_rows, (float *)p->d_vals, p->d_filt, inv_norm);
+                    if (split > 1)
+                        hipLaunchKernelGGL(unsplit_seg_kernel, dim3((unsigned)((n_bins + 256) / 256)), dim3(256), 0, ctx->stream,
+                                           (const uint32_t *)segp, n_bins, split, p->d_seg);
+                    if (hipGetLastError() != hipSuccess) st = SG_ERR_HIP;
+                }
+            }
+            if (split > 1) ctx->release(segp);
+            ctx->release(is_frequent);
+        } else {
+            uint32_t *cursor = nullptr;
+            st = sg_alloc(ctx, (size_t)n_bins + 1, &cursor);
+            if (st == SG_OK) {
+                SG_HIP_TRY(hipMemsetAsync(p->d_seg, 0, sizeof(uint32_t) * (size_t)(n_bins + 1), ctx->stream));
+                SG_HIP_TRY(hipMemsetAsync(cursor, 0, sizeof(uint32_t) * (size_t)(n_bins + 1), ctx->stream));
+            }
+            if (st == SG_OK && grid > 0) {
+                if (B->dtype == SG_F64)
+                    hipLaunchKernelGGL(postings_count<double>, dim3(grid), dim3(256), 0, ctx->stream, B->d_indptr,
+                                       B->d_indices, B->n_rows, tile_log2, p->n_tiles, p->d_seg);
+                else
+                    hipLaunchKernelGGL(postings_count<float>, dim3(grid), dim3(256), 0, ctx->stream, B->d_indptr,
+                                       B->d_indices, B->n_rows, tile_log2, p->n_tiles, p->d_seg);
+                SG_HIP_TRY(hipGetLastError());
+            }
+            // counts -> offsets, in place; seg[n_bins] receives the total (= nnz)
+            if (st == SG_OK) st = sg_exclusive_scan_u32(ctx, p->d_seg, p->d_seg, n_bins, p->d_seg + n_bins);
+            if (st == SG_OK && grid > 0) {
+                if (B->dtype == SG_F64)
+                    hipLaunchKernelGGL(postings_fill<double>, dim3(grid), dim3(256), 0, ctx->stream, B->d_indptr,
+                                       B->d_indices, (const double *)B->d_data, B->n_rows, tile_log2, p->n_tiles,
+                                       p->d_seg, cursor, p->d_rows, (double *)p->d_vals, p->d_filt, p->freq_min, inv_norm);
+                else
+                    hipLaunchKernelGGL(postings_fill<float>, dim3(grid), dim3(256), 0, ctx->stream, B->d_indptr,
+                                       B->d_indices, (const float *)B->d_data, B->n_rows, tile_log2, p->n_tiles,
+                                       p->d_seg, cursor, p->d_rows, (float *)p->d_vals, p->d_filt, p->freq_min, inv_norm);
+                if (hipGetLastError() != hipSuccess) st = SG_ERR_HIP;
+            }
+            ctx->release(cursor);
         }
-        // counts -> offsets, in place; seg[n_bins] receives the total (= nnz)
-        st = sg_exclusive_scan_u32(ctx, p->d_seg, p->d_seg, n_bins, p->d_seg + n_bins);
-        if (st == SG_OK && in_lds) {
-            if (B->dtype == SG_F64)
-                hipLaunchKernelGGL(postings_fill_lds<double>, dim3((unsigned)p->n_tiles), dim3(1024), lds, ctx->stream, B->d_indptr,
-                                   B->d_indices, (const double *)B->d_data, B->n_rows, tile_log2, p->n_tiles, (int32_t)B->n_cols,
-                                   p->d_seg, p->d_rows, (double *)p->d_vals, p->d_filt, p->freq_min, inv_norm);
-            else
-                hipLaunchKernelGGL(postings_fill_lds<float>, dim3((unsigned)p->n_tiles), dim3(1024), lds, ctx->stream, B->d_indptr,
-                                   B->d_indices, (const float *)B->d_data, B->n_rows, tile_log2, p->n_tiles, (int32_t)B->n_cols,
-                                   p->d_seg, p->d_rows, (float *)p->d_vals, p->d_filt, p->freq_min, inv_norm);
-            if (hipGetLastError() != hipSuccess) st = SG_ERR_HIP;
-        } else if (st == SG_OK && grid > 0) {
-            if (B->dtype == SG_F64)
-                hipLaunchKernelGGL(postings_fill<double>, dim3(grid), dim3(256), 0, ctx->stream, B->d_indptr,
-                                   B->d_indices, (const double *)B->d_data, B->n_rows, tile_log2, p->n_tiles,
-                                   p->d_seg, cursor, p->d_rows, (double *)p->d_vals, p->d_filt, p->freq_min, inv_norm);
-            else
-                hipLaunchKernelGGL(postings_fill<float>, dim3(grid), dim3(256), 0, ctx->stream, B->d_indptr,
-                                   B->d_indices, (const float *)B->d_data, B->n_rows, tile_log2, p->n_tiles,
-                                   p->d_seg, cursor, p->d_rows, (float *)p->d_vals, p->d_filt, p->freq_min, inv_norm);
-            if (hipGetLastError() != hipSuccess) st = SG_ERR_HIP;
-        }
+        if (st == SG_OK && B->n_cols > 0)
+            hipLaunchKernelGGL(term_len_kernel, dim3((unsigned)((B->n_cols + 255) / 256)), dim3(256), 0, ctx->stream,
+                               (const uint32_t *)p->d_seg, B->n_cols, p->n_tiles, p->d_term_len);
         if (st == SG_OK && p->d_ends && B->n_cols > 0) {
             const int64_t cells = (B->n_cols + 1) * (int64_t)p->nt_pad;
             hipLaunchKernelGGL(pack_ends_kernel, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, ctx->stream,
@@ -347,17 +431,17 @@ extern "C" int sg_postings_build(sg_ctx *ctx, const sg_csr *B, int32_t tile_cols
             if (hipMemsetAsync((char *)p->d_fwd + (size_t)B->nnz * es, 0, 8 * es, ctx->stream) != hipSuccess) st = SG_ERR_HIP;
         }
         if (st == SG_OK && p->d_fwd) {
-            const unsigned g2 = (unsigned)((B->n_rows + 1 + 255) / 256);
+            const int64_t work = B->nnz > B->n_rows + 1 ? B->nnz : B->n_rows + 1;
+            const unsigned g2 = (unsigned)((work + 255) / 256);
             if (B->dtype == SG_F64)
                 hipLaunchKernelGGL(fwd_pack<double>, dim3(g2), dim3(256), 0, ctx->stream, B->d_indptr, B->d_indices,
-                                   (const double *)B->d_data, B->n_rows, p->d_fwd_ptr, p->d_fwd);
+                                   (const double *)B->d_data, B->n_rows, B->nnz, p->d_fwd_ptr, p->d_fwd);
             else
                 hipLaunchKernelGGL(fwd_pack<float>, dim3(g2), dim3(256), 0, ctx->stream, B->d_indptr, B->d_indices,
-                                   (const float *)B->d_data, B->n_rows, p->d_fwd_ptr, p->d_fwd);
+                                   (const float *)B->d_data, B->n_rows, B->nnz, p->d_fwd_ptr, p->d_fwd);
             if (hipGetLastError() != hipSuccess) st = SG_ERR_HIP;
         }
     }
-    ctx->release(cursor);
     if (st != SG_OK) {
         sg_postings_free(p);
         return st;
@@ -369,6 +453,7 @@ extern "C" int sg_postings_build(sg_ctx *ctx, const sg_csr *B, int32_t tile_cols
 extern "C" int sg_postings_free(sg_postings *p) {
     if (!p) return SG_OK;
     p->ctx->release(p->d_seg);
+    p->ctx->release(p->d_term_len);
     p->ctx->release(p->d_rows);
     p->ctx->release(p->d_vals);
     p->ctx->release(p->d_fwd);

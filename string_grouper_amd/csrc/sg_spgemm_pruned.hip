@@ -181,14 +181,17 @@ __device__ __noinline__ TopList<T> drain_survivors(int nnz, const uint32_t *fwd_
     const T sum = exact_score<T, WIDE>(j, hk, ha, nnz, fwd_ptr, fwd);
     uint64_t hm = __ballot(j >= 0 && sum > thr);
     if (SYM) {
-        if (hm) {
-            const int n_hit = __popcll(hm);
+        // row i keeps its own matches j <= i in its top list like the one-sided form; what row j < i has to learn -- that
+        // i matches it -- goes to the pair list (pass 2 merges it into row j's list).  The diagonal is nobody's mirror.
+        const uint64_t mm = hm & __ballot((uint32_t)j != row);
+        if (mm) {
+            const int n_hit = __popcll(mm);
             unsigned long long base = 0;
             if (lane == 0) base = atomicAdd(pair_count, (unsigned long long)n_hit);
             base = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(base >> 32)) << 32) |
                    (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)base);
-            if ((hm >> lane) & 1ull) {
-                const unsigned long long at = base + (unsigned long long)__popcll(hm & ((1ull << lane) - 1ull));
+            if ((mm >> lane) & 1ull) {
+                const unsigned long long at = base + (unsigned long long)__popcll(mm & ((1ull << lane) - 1ull));
                 if (at < pair_cap) {   // past the capacity only the count grows: the caller sees it and falls back
                     pair_i[at] = row;
                     pair_j[at] = (uint32_t)j;
@@ -196,14 +199,13 @@ __device__ __noinline__ TopList<T> drain_survivors(int nnz, const uint32_t *fwd_
                 }
             }
         }
-    } else {
-        SG_WD_DECL(wd_h);
-        while (hm) {
-            SG_WD(wd_h, 70, 22)
-            const int src = __builtin_ctzll(hm);
-            hm &= hm - 1;
-            top.insert(wave_read<T>(sum, src), wave_read<int>(j, src), lane);
-        }
+    }
+    SG_WD_DECL(wd_h);
+    while (hm) {
+        SG_WD(wd_h, 70, 22)
+        const int src = __builtin_ctzll(hm);
+        hm &= hm - 1;
+        top.insert(wave_read<T>(sum, src), wave_read<int>(j, src), lane);
     }
     if (n_surv > 64) {   // < 64 left: move to the front
         const uint32_t rem = n_surv - 64;
@@ -622,7 +624,7 @@ spgemm_topn_pruned_kernel(const int64_t *__restrict__ a_indptr, const int32_t *_
                                                      n_surv);
             st_surv += n_surv;
         }
-        if (!SYM) {
+        {   // (symmetric mode: the row's matches j <= i; pass 2 merges the mirrored ones in)
             int cnt = __popcll(__ballot(top.c != INT32_MAX));
             if (cnt > keep) cnt = keep;
             const size_t obase = (size_t)row * (size_t)out_stride;
@@ -641,16 +643,14 @@ spgemm_topn_pruned_kernel(const int64_t *__restrict__ a_indptr, const int32_t *_
 }
 
 // ------------------------------------------------------------------------------------------------
-// Symmetric mode, second pass: the pair list -> per-row candidate lists (both directions) -> top-n.
-__global__ void __launch_bounds__(256) pairs_count_kernel(const uint32_t *__restrict__ pi, const uint32_t *__restrict__ pj,
+// Symmetric mode, second pass: the pair list (i, j < i, s) -> for every row j the list of the rows i > j that match it
+// -> merged with the row's own top list (its matches <= j, written by pass 1) -> top-n.
+__global__ void __launch_bounds__(256) pairs_count_kernel(const uint32_t *__restrict__ pj,
                                                           const unsigned long long *__restrict__ n_pairs, uint32_t *cnt) {
     const unsigned long long n = *n_pairs;
     for (unsigned long long p = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; p < n;
-         p += (unsigned long long)gridDim.x * blockDim.x) {
-        const uint32_t i = pi[p], j = pj[p];
-        atomicAdd(&cnt[i], 1u);
-        if (j != i) atomicAdd(&cnt[j], 1u);
-    }
+         p += (unsigned long long)gridDim.x * blockDim.x)
+        atomicAdd(&cnt[pj[p]], 1u);
 }
 
 template <typename T>
@@ -662,65 +662,79 @@ __global__ void __launch_bounds__(256) pairs_fill_kernel(const uint32_t *__restr
     const unsigned long long n = *n_pairs;
     for (unsigned long long p = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; p < n;
          p += (unsigned long long)gridDim.x * blockDim.x) {
-        const uint32_t i = pi[p], j = pj[p];
-        const T s = ps[p];
-        uint32_t at = ptr[i] + atomicAdd(&cursor[i], 1u);
-        lcol[at] = (int32_t)j;
-        lval[at] = s;
-        if (j != i) {
-            at = ptr[j] + atomicAdd(&cursor[j], 1u);
-            lcol[at] = (int32_t)i;
-            lval[at] = s;
-        }
+        const uint32_t j = pj[p];
+        const uint32_t at = ptr[j] + atomicAdd(&cursor[j], 1u);
+        lcol[at] = (int32_t)pi[p];
+        lval[at] = ps[p];
     }
 }
 
-// one wave per row: its candidates through the register top-n list (order of arrival is irrelevant)
+// A wave looks at 64 rows at a time and works on those that have mirrored matches: own list + mirrored list through the
+// rank sort (up to 64 candidates, the common case) or the register top-n list (order of arrival is irrelevant).
 template <typename T>
 __global__ void __launch_bounds__(64) pairs_select_kernel(const uint32_t *__restrict__ ptr, const int32_t *__restrict__ lcol,
                                                           const T *__restrict__ lval, uint32_t n_rows, int32_t keep,
                                                           int32_t out_stride, int32_t *__restrict__ out_cols,
                                                           T *__restrict__ out_vals, int32_t *__restrict__ out_cnt) {
     const int lane = threadIdx.x;
-    for (uint32_t row = blockIdx.x; row < n_rows; row += gridDim.x) {
-        const uint32_t lo = ptr[row], hi = ptr[row + 1];
-        TopList<T> top;
-        top.clear();
-        if (hi - lo <= 64u) {
-            // the common case: every lane holds one candidate and ranks it against the others
-            const bool have = lo + (uint32_t)lane < hi;
-            const T s = have ? lval[lo + lane] : (T)-INFINITY;
-            const int c = have ? lcol[lo + lane] : INT32_MAX;
-            int rank = 0;
-            const int m = (int)(hi - lo);
-            for (int q = 0; q < m; ++q) {
-                const T sq = wave_read<T>(s, q);
-                const int cq = wave_read<int>(c, q);
-                rank += (sq > s || (sq == s && cq < c)) ? 1 : 0;
-            }
+    for (uint32_t row0 = blockIdx.x * 64u; row0 < n_rows; row0 += gridDim.x * 64u) {
+        const uint32_t mine = row0 + (uint32_t)lane;
+        uint64_t todo = __ballot(mine < n_rows && ptr[mine + 1] != ptr[mine]);
+        while (todo) {
+            const uint32_t row = row0 + (uint32_t)__builtin_ctzll(todo);
+            todo &= todo - 1;
+            const uint32_t lo = ptr[row], hi = ptr[row + 1];
+            const int own = out_cnt[row];
             const size_t obase = (size_t)row * (size_t)out_stride;
-            if (have && rank < keep) {
-                out_vals[obase + rank] = s;
-                out_cols[obase + rank] = c;
+            const int m = own + (int)(hi - lo);
+            if (m <= 64) {
+                // every lane holds one candidate and ranks it against the others
+                const bool have = lane < m;
+                T s = (T)-INFINITY;
+                int c = INT32_MAX;
+                if (lane < own) {
+                    s = out_vals[obase + lane];
+                    c = out_cols[obase + lane];
+                } else if (have) {
+                    s = lval[lo + (uint32_t)(lane - own)];
+                    c = lcol[lo + (uint32_t)(lane - own)];
+                }
+                int rank = 0;
+                for (int q = 0; q < m; ++q) {
+                    const T sq = wave_read<T>(s, q);
+                    const int cq = wave_read<int>(c, q);
+                    rank += (sq > s || (sq == s && cq < c)) ? 1 : 0;
+                }
+                __builtin_amdgcn_wave_barrier();   // all of the own list is in registers before it is overwritten
+                if (have && rank < keep) {
+                    out_vals[obase + rank] = s;
+                    out_cols[obase + rank] = c;
+                }
+                if (lane == 0) out_cnt[row] = m < keep ? m : keep;
+                continue;
             }
-            if (lane == 0) out_cnt[row] = m < keep ? m : keep;
-            continue;
+            TopList<T> top;
+            top.clear();
+            {
+                const T s = lane < own ? out_vals[obase + lane] : (T)0;
+                const int c = lane < own ? out_cols[obase + lane] : 0;
+                for (int q = 0; q < own; ++q) top.insert(wave_read<T>(s, q), wave_read<int>(c, q), lane);
+            }
+            for (uint32_t base = lo; base < hi; base += 64) {
+                const bool have = base + (uint32_t)lane < hi;
+                const T s = have ? lval[base + lane] : (T)0;
+                const int c = have ? lcol[base + lane] : 0;
+                const int mm = (int)min(64u, hi - base);
+                for (int q = 0; q < mm; ++q) top.insert(wave_read<T>(s, q), wave_read<int>(c, q), lane);
+            }
+            int cnt = __popcll(__ballot(top.c != INT32_MAX));
+            if (cnt > keep) cnt = keep;
+            if (lane < cnt) {
+                out_vals[obase + lane] = top.s;
+                out_cols[obase + lane] = top.c;
+            }
+            if (lane == 0) out_cnt[row] = cnt;
         }
-        for (uint32_t base = lo; base < hi; base += 64) {
-            const bool have = base + (uint32_t)lane < hi;
-            const T s = have ? lval[base + lane] : (T)0;
-            const int c = have ? lcol[base + lane] : 0;
-            const int m = (int)min(64u, hi - base);
-            for (int q = 0; q < m; ++q) top.insert(wave_read<T>(s, q), wave_read<int>(c, q), lane);
-        }
-        int cnt = __popcll(__ballot(top.c != INT32_MAX));
-        if (cnt > keep) cnt = keep;
-        const size_t obase = (size_t)row * (size_t)out_stride;
-        if (lane < cnt) {
-            out_vals[obase + lane] = top.s;
-            out_cols[obase + lane] = top.c;
-        }
-        if (lane == 0) out_cnt[row] = cnt;
     }
 }
 
@@ -984,13 +998,13 @@ int sg_spgemm_pruned_symmetric(sg_ctx *ctx, const sg_csr *A, const sg_postings *
     }
     // ---- pass 2
     const unsigned pgrid = (unsigned)(n_pairs == 0 ? 1 : (n_pairs + 255) / 256 > 4096 ? 4096 : (n_pairs + 255) / 256);
-    hipLaunchKernelGGL(pairs_count_kernel, dim3(pgrid), dim3(256), 0, ctx->stream, pl.d_i, pl.d_j, pl.d_count, cnt);
+    hipLaunchKernelGGL(pairs_count_kernel, dim3(pgrid), dim3(256), 0, ctx->stream, pl.d_j, pl.d_count, cnt);
     st = sg_exclusive_scan_u32(ctx, cnt, cnt, n + 1, nullptr);   // cnt becomes ptr (n + 1 entries)
-    const size_t n_list = (size_t)(2 * n_pairs + 64);
+    const size_t n_list = (size_t)(n_pairs + 64);
     if (st == SG_OK) st = sg_alloc(ctx, n_list, &lcol);
     if (st == SG_OK) st = ctx->alloc(n_list * vs, &lval);
     if (st == SG_OK) {
-        unsigned sgrid = (unsigned)(n < 256 * 64 ? (n > 0 ? n : 1) : 256 * 64);
+        unsigned sgrid = (unsigned)((n + 63) / 64 < 256 * 16 ? ((n + 63) / 64 > 0 ? (n + 63) / 64 : 1) : 256 * 16);
         if (A->dtype == SG_F64) {
             hipLaunchKernelGGL(pairs_fill_kernel<double>, dim3(pgrid), dim3(256), 0, ctx->stream, pl.d_i, pl.d_j,
                                (const double *)pl.d_s, pl.d_count, cnt, cursor, lcol, (double *)lval);

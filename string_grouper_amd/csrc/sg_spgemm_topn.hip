@@ -318,33 +318,40 @@ spgemm_topn_kernel(const int64_t *__restrict__ a_indptr, const int32_t *__restri
     }
 }
 
+// One atomic per workgroup: a counter word takes ~12 ns per atomic whoever sends it, so a thousand waves adding to it
+// one by one cost more than the sum itself.
+__device__ __forceinline__ void block_add_u64(unsigned long long local, unsigned long long *out) {
+    __shared__ unsigned long long wave_sums[4];
+    for (int d = 32; d > 0; d >>= 1) local += __shfl_down(local, d, 64);
+    if ((threadIdx.x & 63) == 0) wave_sums[threadIdx.x >> 6] = local;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned long long s = wave_sums[0] + wave_sums[1] + wave_sums[2] + wave_sums[3];
+        if (s) atomicAdd(out, s);
+    }
+}
+
 // Sum over the non-zeros of A of the posting-list length of their term = number of intermediate
-// products; also sums the result counts.  Measurement only (bench.py roofline).
+// products.  Measurement only (bench.py roofline).
 __global__ void __launch_bounds__(256) count_macs_kernel(const int64_t *__restrict__ a_indptr,
                                                          const int32_t *__restrict__ a_indices, int64_t n_left,
-                                                         const uint32_t *__restrict__ seg, int32_t n_tiles,
+                                                         const uint32_t *__restrict__ term_len,
                                                          unsigned long long *out_macs) {
     const int64_t p0 = a_indptr[0], p1 = a_indptr[n_left];
     unsigned long long local = 0;
-    for (int64_t p = p0 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < p1; p += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t k = a_indices[p];
-        local += seg[(k + 1) * n_tiles] - seg[k * n_tiles];
-    }
-    for (int d = 32; d > 0; d >>= 1) local += __shfl_down(local, d, 64);
-    if ((threadIdx.x & 63) == 0 && local) atomicAdd(out_macs, local);
+    for (int64_t p = p0 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < p1; p += (int64_t)gridDim.x * blockDim.x)
+        local += term_len[a_indices[p]];
+    block_add_u64(local, out_macs);
 }
 
 __global__ void __launch_bounds__(256) row_cost_kernel(const int64_t *__restrict__ a_indptr,
                                                        const int32_t *__restrict__ a_indices, int64_t n_left,
-                                                       const uint32_t *__restrict__ seg, int32_t n_tiles,
+                                                       const uint32_t *__restrict__ term_len,
                                                        int64_t *__restrict__ out_cost) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_left) return;
     int64_t c = 0;
-    for (int64_t p = a_indptr[i]; p < a_indptr[i + 1]; ++p) {
-        const int64_t k = a_indices[p];
-        c += seg[(k + 1) * n_tiles] - seg[k * n_tiles];
-    }
+    for (int64_t p = a_indptr[i]; p < a_indptr[i + 1]; ++p) c += term_len[a_indices[p]];
     out_cost[i] = c;
 }
 
@@ -353,8 +360,7 @@ __global__ void __launch_bounds__(256) sum_counts_kernel(const int32_t *__restri
     unsigned long long local = 0;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
         local += (unsigned long long)cnt[i];
-    for (int d = 32; d > 0; d >>= 1) local += __shfl_down(local, d, 64);
-    if ((threadIdx.x & 63) == 0 && local) atomicAdd(out, local);
+    block_add_u64(local, out);
 }
 
 // Re-order every row of a fixed-stride result by ascending column (sort == 0).  One wave per row;
@@ -554,8 +560,8 @@ static int prune_pilot(sg_ctx *ctx, const sg_csr *A, const sg_postings *Bt, int3
             st = sg_spgemm_pruned_launch(ctx, &view, Bt, stride, scratch, threshold, delta, words, words + 1, words + 8, d_stats);
     }
     if (st == SG_OK && e == hipSuccess) {
-        hipLaunchKernelGGL(count_macs_kernel, dim3(1024), dim3(256), 0, ctx->stream, A->d_indptr, A->d_indices, A->n_rows,
-                           (const uint32_t *)Bt->d_seg, Bt->n_tiles, d_stats + 3);
+        hipLaunchKernelGGL(count_macs_kernel, dim3(512), dim3(256), 0, ctx->stream, A->d_indptr, A->d_indices, A->n_rows,
+                           (const uint32_t *)Bt->d_term_len, d_stats + 3);
         e = hipGetLastError();
     }
     unsigned long long h[4] = {0, 0, 0, 0};
@@ -745,11 +751,10 @@ extern "C" int sg_spgemm_topn(sg_ctx *ctx, const sg_csr *A, const sg_postings *B
     if (st == SG_OK) {
         (void)hipMemsetAsync(ctx->d_stat_words, 0, 2 * sizeof(int64_t), ctx->stream);
         if (A->nnz > 0)
-            hipLaunchKernelGGL(count_macs_kernel, dim3(1024), dim3(256), 0, ctx->stream, A->d_indptr, A->d_indices,
-                               A->n_rows, (const uint32_t *)Bt->d_seg, Bt->n_tiles,
-                               (unsigned long long *)ctx->d_stat_words);
+            hipLaunchKernelGGL(count_macs_kernel, dim3(512), dim3(256), 0, ctx->stream, A->d_indptr, A->d_indices,
+                               A->n_rows, (const uint32_t *)Bt->d_term_len, (unsigned long long *)ctx->d_stat_words);
         if (A->n_rows > 0)
-            hipLaunchKernelGGL(sum_counts_kernel, dim3(1024), dim3(256), 0, ctx->stream, r->d_counts, A->n_rows,
+            hipLaunchKernelGGL(sum_counts_kernel, dim3(256), dim3(256), 0, ctx->stream, r->d_counts, A->n_rows,
                                (unsigned long long *)(ctx->d_stat_words + 1));
         // algorithmic bytes (stream model): macs*(4+s) + nnz(A)*(4+s) + (nL+V+2)*4 + out*(4+s);
         // the MAC and output terms are added in sg_ctx_stats once the device counters are read
@@ -774,7 +779,7 @@ extern "C" int sg_row_costs(sg_ctx *ctx, const sg_csr *A, const sg_postings *Bt,
     int64_t *d = nullptr;
     SG_TRY(sg_alloc(ctx, (size_t)A->n_rows, &d));
     hipLaunchKernelGGL(row_cost_kernel, dim3((unsigned)((A->n_rows + 255) / 256)), dim3(256), 0, ctx->stream,
-                       A->d_indptr, A->d_indices, A->n_rows, (const uint32_t *)Bt->d_seg, Bt->n_tiles, d);
+                       A->d_indptr, A->d_indices, A->n_rows, (const uint32_t *)Bt->d_term_len, d);
     hipError_t e = hipMemcpyAsync(out_cost, d, sizeof(int64_t) * (size_t)A->n_rows, hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     ctx->release(d);

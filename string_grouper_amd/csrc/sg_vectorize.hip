@@ -533,12 +533,15 @@ __global__ void __launch_bounds__(1024) df_count_lds_kernel(const int64_t *__res
 }
 
 __global__ void __launch_bounds__(256) df_sum_kernel(const uint32_t *__restrict__ partial, int32_t n_partial, int64_t n_terms,
-                                                     int32_t *__restrict__ df) {
+                                                     int32_t *__restrict__ df /* zeroed */) {
+    // blockIdx.y picks 16 of the partial histograms: enough workgroups to fill the chip, distinct addresses per atomic
     const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n_terms) return;
+    const int r0 = blockIdx.y * 16;
+    const int r1 = r0 + 16 < n_partial ? r0 + 16 : n_partial;
     uint32_t s = 0;
-    for (int r = 0; r < n_partial; ++r) s += partial[(int64_t)r * n_terms + k];
-    df[k] = (int32_t)s;
+    for (int r = r0; r < r1; ++r) s += partial[(int64_t)r * n_terms + k];
+    if (s) atomicAdd(&df[k], (int32_t)s);
 }
 
 // column of a key: dense mode = table lookup, sorted mode = binary search in the ascending vocabulary
@@ -1113,8 +1116,8 @@ static int count_df_by_column(sg_ctx *ctx, sg_vocab *v) {
     std::vector<int32_t> wgs;
     int32_t n_partial = 0;
     for (const auto &c : im->caches) {
-        int64_t g = (c.n + 1023) / 1024;    // >= 1024 rows per workgroup, at most two workgroups per CU
-        if (g > (int64_t)ctx->num_cu * 2) g = (int64_t)ctx->num_cu * 2;
+        int64_t g = (c.n + 1023) / 1024;    // >= 1024 rows per workgroup, at most one workgroup per CU
+        if (g > (int64_t)ctx->num_cu) g = (int64_t)ctx->num_cu;
         wgs.push_back((int32_t)g);
         n_partial += (int32_t)g;
     }
@@ -1134,8 +1137,9 @@ static int count_df_by_column(sg_ctx *ctx, sg_vocab *v) {
         }
         at += wgs[i];
     }
-    hipLaunchKernelGGL(df_sum_kernel, dim3((unsigned)((v->n_terms + 255) / 256)), dim3(256), 0, ctx->stream,
-                       (const uint32_t *)partial, n_partial, v->n_terms, v->d_df);
+    (void)hipMemsetAsync(v->d_df, 0, sizeof(int32_t) * (size_t)v->n_terms, ctx->stream);
+    hipLaunchKernelGGL(df_sum_kernel, dim3((unsigned)((v->n_terms + 255) / 256), (unsigned)((n_partial + 15) / 16 > 0 ? (n_partial + 15) / 16 : 1)),
+                       dim3(256), 0, ctx->stream, (const uint32_t *)partial, n_partial, v->n_terms, v->d_df);
     if (hipGetLastError() != hipSuccess) {
         sg_set_error("df_count_lds_kernel: %s", hipGetErrorString(hipGetLastError()));
         st = SG_ERR_HIP;
