@@ -11,7 +11,7 @@ short() { python -c "
 import sys, json
 d = json.loads(sys.stdin.read())
 print(d['kernels_ms'], round(d['ms_per_step'], 3), d['parity_on_sample'] if 'parity_on_sample' in d else '')"; }
-for v in "SG_X=0" "SG_SYM=0" "SG_X=1"; do
+for v in "SG_X=0" "SG_PRUNE_BIG_TICKETS=0" "SG_SYM=0" "SG_SYM=0 SG_PRUNE_BIG_TICKETS=0"; do
   echo -n "$v : " >> $LOG
   env $v timeout 300 python bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-exact-kernel --no-end-to-end 2>/dev/null | short >> $LOG 2>&1
 done

@@ -61,6 +61,8 @@
 #define SG_WATCH_NAME sg_debug_watch_pruned
 #include "sg_k4_device.h"
 
+#define SG_PAIR_CHUNK 256u            // entries of a chunk of the symmetric mode's pair list
+#define SG_PAIR_NO_CHUNK 0xFFFFFFFFu
 #define SG_SURV_CAP 128   // survivors buffered per wave (scored 64 at a time as soon as 64 are there)
 
 // lane mask of a predicate as a wave-uniform scalar (s_and of the compare result, no VALU round trip)
@@ -168,9 +170,9 @@ __device__ __forceinline__ T exact_score(int j, const int *hk, const T *ha, int 
 // (LDS objects are addressed through the kernel's own shared array so that they stay ds_* accesses.)
 template <typename T, bool SYM, int TILE_LOG2, bool WIDE>
 __device__ __noinline__ TopList<T> drain_survivors(int nnz, const uint32_t *fwd_ptr, const void *fwd, T thr, uint32_t row,
-                                                   uint32_t *pair_i, uint32_t *pair_j, T *pair_s,
-                                                   unsigned long long *pair_count, unsigned long long pair_cap,
-                                                   TopList<T> top, uint32_t n_surv) {
+                                                   uint32_t *pair_i, uint32_t *pair_j, T *pair_s, uint32_t *pair_row_count,
+                                                   uint32_t *pair_chunk_count, uint32_t pair_chunks, uint32_t *pair_chunks_used,
+                                                   unsigned long long *pair_totals, TopList<T> top, uint32_t n_surv) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int TILE = 1 << TILE_LOG2;
     const int *hk = reinterpret_cast<const int *>(smem + TILE * 2);
@@ -185,19 +187,32 @@ __device__ __noinline__ TopList<T> drain_survivors(int nnz, const uint32_t *fwd_
         // i matches it -- goes to the pair list (pass 2 merges it into row j's list).  The diagonal is nobody's mirror.
         const uint64_t mm = hm & __ballot((uint32_t)j != row);
         if (mm) {
-            const int n_hit = __popcll(mm);
-            unsigned long long base = 0;
-            if (lane == 0) base = atomicAdd(pair_count, (unsigned long long)n_hit);
-            base = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(base >> 32)) << 32) |
-                   (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)base);
-            if ((mm >> lane) & 1ull) {
-                const unsigned long long at = base + (unsigned long long)__popcll(mm & ((1ull << lane) - 1ull));
-                if (at < pair_cap) {   // past the capacity only the count grows: the caller sees it and falls back
-                    pair_i[at] = row;
-                    pair_j[at] = (uint32_t)j;
-                    pair_s[at] = sum;
+            // Every wave appends to a chunk of the pair list that it owns (SG_PAIR_CHUNK entries, taken from a global counter:
+            // one returning atomic per chunk, not per row -- a returning atomic per row on one shared counter cost the
+            // kernel a fifth of its time).  Where it stands -- chunk << 9 | entries used -- lives in LDS, in the last word
+            // of the survivor buffer (which holds at most 127 columns).
+            uint32_t pos = (uint32_t)surv[SG_SURV_CAP - 1];
+            const uint32_t n_hit = (uint32_t)__popcll(mm);
+            if (pos == SG_PAIR_NO_CHUNK || (pos & 511u) + n_hit > SG_PAIR_CHUNK) {
+                uint32_t c = 0;
+                if (lane == 0) {
+                    if (pos != SG_PAIR_NO_CHUNK && (pos >> 9) < pair_chunks) {
+                        pair_chunk_count[pos >> 9] = pos & 511u;
+                        atomicAdd(pair_totals, (unsigned long long)(pos & 511u));
+                    }
+                    c = atomicAdd(pair_chunks_used, 1u);
                 }
+                pos = (uint32_t)__builtin_amdgcn_readfirstlane((int)c) << 9;
             }
+            if (((mm >> lane) & 1ull) && (pos >> 9) < pair_chunks) {   // past the capacity nothing is written: the caller falls back
+                const size_t o = (size_t)(pos >> 9) * SG_PAIR_CHUNK + (pos & 511u) + (uint32_t)__popcll(mm & ((1ull << lane) - 1ull));
+                pair_i[o] = row;
+                pair_j[o] = (uint32_t)j;
+                pair_s[o] = sum;
+                atomicAdd(&pair_row_count[j], 1u);   // how many mirrored matches row j will receive (pass 2 scans these)
+            }
+            __builtin_amdgcn_wave_barrier();
+            if (lane == 0) surv[SG_SURV_CAP - 1] = (int)(pos + n_hit);
         }
     }
     SG_WD_DECL(wd_h);
@@ -230,8 +245,10 @@ spgemm_topn_pruned_kernel(const int64_t *__restrict__ a_indptr, const int32_t *_
                           int32_t *__restrict__ out_cols, T *__restrict__ out_vals, int32_t *__restrict__ out_cnt,
                           uint32_t *row_counter, uint32_t *flagged_count, uint32_t *flagged_rows,
                           unsigned long long *stats /* [0] rows [1] postings streamed [2] survivors */,
-                          uint32_t *pair_i, uint32_t *pair_j, T *pair_s, unsigned long long *pair_count,
-                          unsigned long long pair_cap,
+                          uint32_t *pair_i, uint32_t *pair_j, T *pair_s, uint32_t *pair_row_count /* SYM: [n_left], zeroed */,
+                          uint32_t *pair_chunk_count /* SYM: entries used of every chunk of the pair list */,
+                          uint32_t pair_chunks /* chunks there are */, uint32_t *pair_chunks_used /* chunks handed out */,
+                          unsigned long long *pair_totals /* pairs in closed chunks */,
                           const uint32_t *__restrict__ row_list /* WIDE: the rows to process */, const uint32_t *row_list_len) {
     constexpr int TILE = 1 << TILE_LOG2;
     constexpr int SLOTS = WIDE ? 2 : 1;   // row terms staged per lane
@@ -247,6 +264,7 @@ spgemm_topn_pruned_kernel(const int64_t *__restrict__ a_indptr, const int32_t *_
     uint4 *tab_v = reinterpret_cast<uint4 *>(smem);
     const int lane = threadIdx.x;
     for (int x = lane; x < TILE * 2 / 16; x += 64) tab_v[x] = make_uint4(0, 0, 0, 0);
+    if (SYM && lane == 0) surv[SG_SURV_CAP - 1] = (int)SG_PAIR_NO_CHUNK;
     const uint64_t lanes_below = (1ull << lane) - 1ull;
     unsigned long long st_rows = 0, st_post = 0, st_surv = 0;
     // the accumulator tile is the kernel's first LDS object (address 0): a posting's address field IS the LDS address
@@ -258,10 +276,11 @@ spgemm_topn_pruned_kernel(const int64_t *__restrict__ a_indptr, const int32_t *_
         return *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(filt) + byte_off);
     };
 
-    // rows are handed out four at a time: one global atomic per row capped the kernel at ~88 rows/us.
-    // Symmetric mode walks the rows from the last to the first: a row's cost grows with its index there.
     SG_WD_DECL(wd_rows);
     const uint32_t n_here = WIDE ? (uint32_t)__builtin_amdgcn_readfirstlane((int)*row_list_len) : n_left;
+    // rows are handed out four at a time: one global atomic per row capped the kernel at ~88 rows/us (larger first
+    // helpings were tried -- sixteen rows for the first three quarters -- and changed nothing: profiles/r02_sessionJ6_*.log).
+    // Symmetric mode walks the rows from the last to the first: a row's cost grows with its index there.
     for (uint32_t row0 = next_row(row_counter, lane) * 4u; row0 < n_here; row0 = next_row(row_counter, lane) * 4u)
     for (uint32_t rr = row0; rr < min(row0 + 4u, n_here); ++rr) {
         SG_WD(wd_rows, n_left + 2, 11)
@@ -457,7 +476,7 @@ spgemm_topn_pruned_kernel(const int64_t *__restrict__ a_indptr, const int32_t *_
             if (cross) surv[n_surv + __popcll(cm & lanes_below)] = col;
             n_surv += __popcll(cm);
             if (n_surv >= 64) {
-                top = drain_survivors<T, SYM, TILE_LOG2, WIDE>(nnz, fwd_ptr, fwd, thr, row, pair_i, pair_j, pair_s, pair_count, pair_cap,
+                top = drain_survivors<T, SYM, TILE_LOG2, WIDE>(nnz, fwd_ptr, fwd, thr, row, pair_i, pair_j, pair_s, pair_row_count, pair_chunk_count, pair_chunks, pair_chunks_used, pair_totals,
                                                          top, n_surv);
                 st_surv += 64;
                 n_surv -= 64;
@@ -620,7 +639,7 @@ spgemm_topn_pruned_kernel(const int64_t *__restrict__ a_indptr, const int32_t *_
             st_post += (unsigned long long)wave_read<uint32_t>(mine, 0);
         }
         if (n_surv > 0) {   // fewer than 64 left
-            top = drain_survivors<T, SYM, TILE_LOG2, WIDE>(nnz, fwd_ptr, fwd, thr, row, pair_i, pair_j, pair_s, pair_count, pair_cap, top,
+            top = drain_survivors<T, SYM, TILE_LOG2, WIDE>(nnz, fwd_ptr, fwd, thr, row, pair_i, pair_j, pair_s, pair_row_count, pair_chunk_count, pair_chunks, pair_chunks_used, pair_totals, top,
                                                      n_surv);
             st_surv += n_surv;
         }
@@ -635,6 +654,13 @@ spgemm_topn_pruned_kernel(const int64_t *__restrict__ a_indptr, const int32_t *_
             if (lane == 0) out_cnt[row] = cnt;
         }
     }
+    if (SYM && lane == 0) {   // close the wave's last chunk
+        const uint32_t pos = (uint32_t)surv[SG_SURV_CAP - 1];
+        if (pos != SG_PAIR_NO_CHUNK && (pos >> 9) < pair_chunks) {
+            pair_chunk_count[pos >> 9] = pos & 511u;
+            atomicAdd(pair_totals, (unsigned long long)(pos & 511u));
+        }
+    }
     if (lane == 0) {
         if (st_rows) atomicAdd(stats + 0, st_rows);
         if (st_post) atomicAdd(stats + 1, st_post);
@@ -645,28 +671,18 @@ spgemm_topn_pruned_kernel(const int64_t *__restrict__ a_indptr, const int32_t *_
 // ------------------------------------------------------------------------------------------------
 // Symmetric mode, second pass: the pair list (i, j < i, s) -> for every row j the list of the rows i > j that match it
 // -> merged with the row's own top list (its matches <= j, written by pass 1) -> top-n.
-__global__ void __launch_bounds__(256) pairs_count_kernel(const uint32_t *__restrict__ pj,
-                                                          const unsigned long long *__restrict__ n_pairs, uint32_t *cnt) {
-    const unsigned long long n = *n_pairs;
-    for (unsigned long long p = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; p < n;
-         p += (unsigned long long)gridDim.x * blockDim.x)
-        atomicAdd(&cnt[pj[p]], 1u);
-}
-
+// (one workgroup per chunk of the pair list, one thread per entry)
 template <typename T>
-__global__ void __launch_bounds__(256) pairs_fill_kernel(const uint32_t *__restrict__ pi, const uint32_t *__restrict__ pj,
-                                                         const T *__restrict__ ps,
-                                                         const unsigned long long *__restrict__ n_pairs,
-                                                         const uint32_t *__restrict__ ptr, uint32_t *cursor,
-                                                         int32_t *__restrict__ lcol, T *__restrict__ lval) {
-    const unsigned long long n = *n_pairs;
-    for (unsigned long long p = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; p < n;
-         p += (unsigned long long)gridDim.x * blockDim.x) {
-        const uint32_t j = pj[p];
-        const uint32_t at = ptr[j] + atomicAdd(&cursor[j], 1u);
-        lcol[at] = (int32_t)pi[p];
-        lval[at] = ps[p];
-    }
+__global__ void __launch_bounds__(SG_PAIR_CHUNK) pairs_fill_kernel(const uint32_t *__restrict__ pi, const uint32_t *__restrict__ pj,
+                                                                   const T *__restrict__ ps, const uint32_t *__restrict__ chunk_count,
+                                                                   const uint32_t *__restrict__ ptr, uint32_t *cursor,
+                                                                   int32_t *__restrict__ lcol, T *__restrict__ lval) {
+    if (threadIdx.x >= chunk_count[blockIdx.x]) return;
+    const size_t p = (size_t)blockIdx.x * SG_PAIR_CHUNK + threadIdx.x;
+    const uint32_t j = pj[p];
+    const uint32_t at = ptr[j] + atomicAdd(&cursor[j], 1u);
+    lcol[at] = (int32_t)pi[p];
+    lval[at] = ps[p];
 }
 
 // A wave looks at 64 rows at a time and works on those that have mirrored matches: own list + mirrored list through the
@@ -815,26 +831,36 @@ int sg_csr_props(sg_ctx *ctx, const sg_csr *m, bool *cosine_like, float *max_nor
 }
 
 // ------------------------------------------------------------------------------------------------
-struct PairList {   // symmetric mode: every pair (i, j <= i) above the threshold, in order of discovery
+struct PairList {   // symmetric mode: the mirrored pairs (i, j < i) above the threshold, in chunks of SG_PAIR_CHUNK entries
     uint32_t *d_i = nullptr;
     uint32_t *d_j = nullptr;
     void *d_s = nullptr;
-    unsigned long long *d_count = nullptr;
-    unsigned long long cap = 0;
+    uint32_t *d_row_count = nullptr;           // mirrored matches per row (counted by pass 1)
+    uint32_t *d_chunk_count = nullptr;         // entries used of every chunk
+    uint32_t *d_chunks_used = nullptr;         // chunks handed out
+    unsigned long long *d_totals = nullptr;    // pairs
+    uint32_t chunks = 0;
 };
 
-template <typename T, int TILE_LOG2, bool SYM, bool WIDE>
-static int launch_pruned(sg_ctx *ctx, const sg_csr *A, const sg_postings *Bt, int32_t keep, sg_topn *r, T thr,
-                         float s_budget, uint32_t *row_counter, uint32_t *flagged_count, uint32_t *flagged_rows,
-                         unsigned long long *stats, const PairList &pl, const uint32_t *row_list, const uint32_t *row_list_len) {
-    const size_t lds = ((size_t)2 << TILE_LOG2) + 512 + 1024 + (size_t)SG_SURV_CAP * 4;
+// single-wave workgroups of the pruned kernel: as many as the LDS of the chip holds
+static unsigned pruned_grid(const sg_ctx *ctx, int32_t tile_log2, int64_t n_rows) {
+    const size_t lds = ((size_t)2 << tile_log2) + 512 + 1024 + (size_t)SG_SURV_CAP * 4;
     int waves_per_cu = (int)(ctx->lds_per_cu / lds);
     if (waves_per_cu > 32) waves_per_cu = 32;
     if (waves_per_cu < 1) waves_per_cu = 1;
     if (const char *v = getenv("SG_PRUNE_WAVES_PER_CU"))
         if (atoi(v) > 0) waves_per_cu = atoi(v);
     unsigned grid = (unsigned)ctx->num_cu * (unsigned)waves_per_cu;
-    if ((int64_t)grid > A->n_rows) grid = (unsigned)(A->n_rows > 0 ? A->n_rows : 1);
+    if ((int64_t)grid > n_rows) grid = (unsigned)(n_rows > 0 ? n_rows : 1);
+    return grid;
+}
+
+template <typename T, int TILE_LOG2, bool SYM, bool WIDE>
+static int launch_pruned(sg_ctx *ctx, const sg_csr *A, const sg_postings *Bt, int32_t keep, sg_topn *r, T thr,
+                         float s_budget, uint32_t *row_counter, uint32_t *flagged_count, uint32_t *flagged_rows,
+                         unsigned long long *stats, const PairList &pl, const uint32_t *row_list, const uint32_t *row_list_len) {
+    const size_t lds = ((size_t)2 << TILE_LOG2) + 512 + 1024 + (size_t)SG_SURV_CAP * 4;
+    unsigned grid = pruned_grid(ctx, TILE_LOG2, A->n_rows);
     if (WIDE && grid > (unsigned)ctx->num_cu * 4u) grid = (unsigned)ctx->num_cu * 4u;   // few rows, if any: idle waves leave at once
     hipLaunchKernelGGL((spgemm_topn_pruned_kernel<T, TILE_LOG2, SYM, WIDE>), dim3(grid), dim3(64), lds, ctx->stream, A->d_indptr,
                        A->d_indices, (const T *)A->d_data, (uint32_t)A->n_rows, (const uint32_t *)Bt->d_seg,
@@ -842,8 +868,8 @@ static int launch_pruned(sg_ctx *ctx, const sg_csr *A, const sg_postings *Bt, in
                        (const uint32_t *)Bt->d_filt, Bt->n_tiles, (const uint32_t *)Bt->d_fwd_ptr,
                        (const void *)Bt->d_fwd, keep, r->stride, thr, s_budget, Bt->norm_up, Bt->freq_min, r->d_cols,
                        (T *)r->d_vals,
-                       r->d_counts, row_counter, flagged_count, flagged_rows, stats, pl.d_i, pl.d_j, (T *)pl.d_s, pl.d_count,
-                       pl.cap, row_list, row_list_len);
+                       r->d_counts, row_counter, flagged_count, flagged_rows, stats, pl.d_i, pl.d_j, (T *)pl.d_s, pl.d_row_count, pl.d_chunk_count,
+                       pl.chunks, pl.d_chunks_used, pl.d_totals, row_list, row_list_len);
     SG_HIP_TRY(hipGetLastError());
     return SG_OK;
 }
@@ -922,16 +948,24 @@ int sg_spgemm_pruned_symmetric(sg_ctx *ctx, const sg_csr *A, const sg_postings *
     PairList pl;
     // a name list has a few matches per row; hubs of identical names can have far more -> fall back then
     int64_t cap = 8 * n + ((int64_t)1 << 20);
-    if (const char *v = getenv("SG_SYM_PAIR_CAP"))
-        if (atoll(v) > 0) cap = atoll(v);
-    if (2 * cap >= ((int64_t)1 << 32)) cap = ((int64_t)1 << 31) - 1;   // list offsets are 32-bit
-    pl.cap = (unsigned long long)cap;
-    uint32_t *words = nullptr;   // [0] row counter [1] flagged count [2..3] pair count (64-bit)
+    bool cap_forced = false;
+    if (const char *v = getenv("SG_SYM_PAIR_CAP"))   // test hook: a list that is too small
+        if (atoll(v) > 0) {
+            cap = atoll(v);
+            cap_forced = true;
+        }
+    if (cap >= ((int64_t)1 << 31)) cap = ((int64_t)1 << 31) - 1;   // list offsets are 32-bit
+    // every wave of the kernel holds one open chunk: count those in
+    pl.chunks = (uint32_t)(cap / SG_PAIR_CHUNK);
+    if (!cap_forced) pl.chunks += pruned_grid(ctx, Bt->tile_log2, n) + (uint32_t)ctx->num_cu * 4u;
+    if (pl.chunks < 1) pl.chunks = 1;
+    cap = (int64_t)pl.chunks * SG_PAIR_CHUNK;
+    uint32_t *words = nullptr;   // [0] row counter [1] flagged count [2..3] pairs [4] chunks handed out; [8 ..) entries per chunk
     uint32_t *cnt = nullptr, *cursor = nullptr;
     int32_t *lcol = nullptr;
     void *lval = nullptr;
     uint32_t *flagged_rows = nullptr;
-    int st = sg_alloc(ctx, (size_t)8, &words);
+    int st = sg_alloc(ctx, (size_t)8 + pl.chunks, &words);
     if (st == SG_OK) st = sg_alloc(ctx, (size_t)cap, &pl.d_i);
     if (st == SG_OK) st = sg_alloc(ctx, (size_t)cap, &pl.d_j);
     if (st == SG_OK) st = ctx->alloc((size_t)cap * vs, &pl.d_s);
@@ -954,12 +988,15 @@ int sg_spgemm_pruned_symmetric(sg_ctx *ctx, const sg_csr *A, const sg_postings *
         cleanup();
         return st;
     }
-    pl.d_count = (unsigned long long *)(words + 2);
+    pl.d_totals = (unsigned long long *)(words + 2);
+    pl.d_chunks_used = words + 4;
+    pl.d_row_count = cnt;
+    pl.d_chunk_count = words + 8;
     unsigned long long *d_stats3 = nullptr;   // this pass's own statistics: they only count when the pass does
     st = sg_alloc(ctx, (size_t)4, &d_stats3);
     hipError_t e = hipSuccess;
     if (st == SG_OK) {
-        e = hipMemsetAsync(words, 0, 8 * sizeof(uint32_t), ctx->stream);
+        e = hipMemsetAsync(words, 0, (8 + (size_t)pl.chunks) * sizeof(uint32_t), ctx->stream);
         if (e == hipSuccess) e = hipMemsetAsync(d_stats3, 0, 4 * sizeof(unsigned long long), ctx->stream);
         if (e == hipSuccess) e = hipMemsetAsync(cnt, 0, sizeof(uint32_t) * (size_t)(n + 2), ctx->stream);
         if (e == hipSuccess) e = hipMemsetAsync(cursor, 0, sizeof(uint32_t) * (size_t)(n + 2), ctx->stream);
@@ -976,8 +1013,8 @@ int sg_spgemm_pruned_symmetric(sg_ctx *ctx, const sg_csr *A, const sg_postings *
                                               d_stats3, pl);
     }
     if (st == SG_OK) {
-        // h[0] = {row counter, flagged}, h[1] = pair count
-        e = hipMemcpyAsync(h, words, 16, hipMemcpyDeviceToHost, ctx->stream);
+        // h[0] = {row counter, flagged}, h[1] = pairs, h[2] = chunks handed out
+        e = hipMemcpyAsync(h, words, 24, hipMemcpyDeviceToHost, ctx->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
         if (e != hipSuccess) {
             sg_set_error("symmetric multiply: %s", hipGetErrorString(e));
@@ -991,28 +1028,28 @@ int sg_spgemm_pruned_symmetric(sg_ctx *ctx, const sg_csr *A, const sg_postings *
     }
     const uint32_t flagged = (uint32_t)(h[0] >> 32);
     const unsigned long long n_pairs = h[1];
-    if (flagged != 0 || n_pairs > pl.cap) {
+    const uint32_t chunks_used = (uint32_t)h[2];
+    if (flagged != 0 || chunks_used > pl.chunks) {
         ctx->release(d_stats3);
         cleanup();
         return SG_OK;   // *done stays false
     }
     // ---- pass 2
-    const unsigned pgrid = (unsigned)(n_pairs == 0 ? 1 : (n_pairs + 255) / 256 > 4096 ? 4096 : (n_pairs + 255) / 256);
-    hipLaunchKernelGGL(pairs_count_kernel, dim3(pgrid), dim3(256), 0, ctx->stream, pl.d_j, pl.d_count, cnt);
+    const dim3 pgrid(chunks_used > 0 ? chunks_used : 1);
     st = sg_exclusive_scan_u32(ctx, cnt, cnt, n + 1, nullptr);   // cnt becomes ptr (n + 1 entries)
     const size_t n_list = (size_t)(n_pairs + 64);
     if (st == SG_OK) st = sg_alloc(ctx, n_list, &lcol);
     if (st == SG_OK) st = ctx->alloc(n_list * vs, &lval);
     if (st == SG_OK) {
-        unsigned sgrid = (unsigned)((n + 63) / 64 < 256 * 16 ? ((n + 63) / 64 > 0 ? (n + 63) / 64 : 1) : 256 * 16);
+        unsigned sgrid = (unsigned)((n + 63) / 64 > 0 ? (n + 63) / 64 : 1);
         if (A->dtype == SG_F64) {
-            hipLaunchKernelGGL(pairs_fill_kernel<double>, dim3(pgrid), dim3(256), 0, ctx->stream, pl.d_i, pl.d_j,
-                               (const double *)pl.d_s, pl.d_count, cnt, cursor, lcol, (double *)lval);
+            hipLaunchKernelGGL(pairs_fill_kernel<double>, pgrid, dim3(SG_PAIR_CHUNK), 0, ctx->stream, pl.d_i, pl.d_j,
+                               (const double *)pl.d_s, pl.d_chunk_count, cnt, cursor, lcol, (double *)lval);
             hipLaunchKernelGGL(pairs_select_kernel<double>, dim3(sgrid), dim3(64), 0, ctx->stream, cnt, lcol, (const double *)lval,
                                (uint32_t)n, keep, r->stride, r->d_cols, (double *)r->d_vals, r->d_counts);
         } else {
-            hipLaunchKernelGGL(pairs_fill_kernel<float>, dim3(pgrid), dim3(256), 0, ctx->stream, pl.d_i, pl.d_j,
-                               (const float *)pl.d_s, pl.d_count, cnt, cursor, lcol, (float *)lval);
+            hipLaunchKernelGGL(pairs_fill_kernel<float>, pgrid, dim3(SG_PAIR_CHUNK), 0, ctx->stream, pl.d_i, pl.d_j,
+                               (const float *)pl.d_s, pl.d_chunk_count, cnt, cursor, lcol, (float *)lval);
             hipLaunchKernelGGL(pairs_select_kernel<float>, dim3(sgrid), dim3(64), 0, ctx->stream, cnt, lcol, (const float *)lval,
                                (uint32_t)n, keep, r->stride, r->d_cols, (float *)r->d_vals, r->d_counts);
         }

@@ -584,7 +584,7 @@ static int prune_pilot(sg_ctx *ctx, const sg_csr *A, const sg_postings *Bt, int3
     // plus its own per-visit cost
     const double row_len = Bt->n_right > 0 ? (double)Bt->nnz / (double)Bt->n_right : 0.0;
     double ms_pruned = rows * (double)Bt->n_tiles * 2.0e-7 + candidates * 2.9e-9 * row_len;
-    if (symmetric) ms_pruned = 0.62 * ms_pruned + 0.9;
+    if (symmetric) ms_pruned = 0.55 * ms_pruned + 0.3;   // profiles/r02_sessionM_sym_sweep.log
     const double ms_exact = (double)h[3] * (4.0 + s) * 0.6 / 3.7e9 + rows * (double)Bt->n_tiles * 8.0e-7;
     *keep_pruned = ms_pruned <= ms_exact;
     ctx->pilot_ms_pruned = ms_pruned;
@@ -662,11 +662,11 @@ extern "C" int sg_spgemm_topn(sg_ctx *ctx, const sg_csr *A, const sg_postings *B
             // score every pair once, from the row with the larger index (sg_spgemm_pruned.hip, symmetric mode)
             const char *sy = getenv("SG_SYM");
             // ... from the size at which halving the (row, tile) visits outweighs the second pass over the pair list
-            // and its host round trip (~1 ms): 4.0 vs 3.4 ms at 200 k rows, 17.7 vs 26.9 ms at 663 k
-            // (profiles/r02_profile_k4p_v9b_sym.log)
+            // and its host round trip: 0.58 vs 0.57 ms at 50 k rows, 0.95 vs 1.20 at 100 k, 14.0 vs 26.8 at 663 k
+            // (profiles/r02_sessionM_sym_sweep.log)
             symmetric = prune && !(sy && sy[0] == '0') && A->n_rows == Bt->n_right && A->d_indptr == Bt->b_indptr &&
                         A->d_indices == Bt->b_indices && A->d_data == Bt->b_data && a_max_nnz <= 128 &&
-                        (A->n_rows >= (int64_t)env_int("SG_SYM_MIN_ROWS", 320000) || (sy && sy[0] == '1'));
+                        (A->n_rows >= (int64_t)env_int("SG_SYM_MIN_ROWS", 65536) || (sy && sy[0] == '1'));
         }
     }
     // ---- pruned or exact?  On a vocabulary that is small next to the rows (2-grams: a row holds 2 % of all terms) the

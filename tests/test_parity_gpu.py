@@ -702,7 +702,7 @@ def test_oversized_right_hand_side_is_split_and_zipped(ctx, mats, monkeypatch):
 # ------------------------------------------------------------------------------------------------
 # The pruned multiply (K4p, sg_spgemm_pruned.hip) must be indistinguishable from the exact kernel (K4)
 # and from the oracle: same entries, same bits, same order.
-def _multiply_both_ways(ctx, dA, dB, top_n, thr, monkeypatch, **env):
+def _multiply_both_ways(ctx, dA, dB, top_n, thr, monkeypatch, expect_sym=True, **env):
     """pruned ("1"), exact ("0") and -- self-joins -- the pruned kernel's self-join form forced at any size ("sym":
     by default it only runs from SG_SYM_MIN_ROWS rows on)."""
     out = {}
@@ -720,7 +720,7 @@ def _multiply_both_ways(ctx, dA, dB, top_n, thr, monkeypatch, **env):
     monkeypatch.delenv("SG_SYM")
     if "sym" in out:
         assert_csr_identical(out["sym"][0], out["0"][0], "self-join form vs exact")
-        if out["1"][1]["prune_rows"] > 0 and out["1"][1]["exact_rows"] == 0:
+        if expect_sym and out["1"][1]["prune_rows"] > 0 and out["1"][1]["exact_rows"] == 0:
             assert out["sym"][1]["prune_symmetric"] == 1
     return out
 
@@ -870,6 +870,23 @@ def test_pruned_multiply_rows_beyond_64_terms(ctx, monkeypatch):
     assert out["sym"][1]["prune_symmetric"] == 0          # a row for the exact kernel: the self-join form stands down
     assert_csr_identical(out["1"][0], out["0"][0])
     assert_csr_identical(out["1"][0], P.sp_matmul_topn_port(A, A.T, 5, 0.6, True, 8))
+
+
+def test_selfjoin_form_with_a_pair_list_that_is_too_small_falls_back(ctx, monkeypatch):
+    """The self-join form collects the mirrored pairs in a list of bounded size (chunks handed to the waves); hubs of
+    duplicates can outgrow it.  Then nothing of that pass may survive: the one-sided form runs and the result is the
+    same, bit for bit."""
+    base = list(_names(6000, 5))
+    names = base + [base[3]] * 400 + [base[9] + " LLC"] * 300
+    A = _tfidf(names, np.float32)
+    dA = ctx.csr_from_scipy(A)
+    ref = _multiply_both_ways(ctx, dA, dA, 10, 0.8, monkeypatch)
+    assert ref["sym"][1]["prune_symmetric"] == 1
+    small = _multiply_both_ways(ctx, dA, dA, 10, 0.8, monkeypatch, expect_sym=False, SG_SYM_PAIR_CAP=512)     # two chunks
+    monkeypatch.delenv("SG_SYM_PAIR_CAP")
+    assert small["sym"][1]["prune_symmetric"] == 0 and small["sym"][1]["prune_rows"] > 0
+    assert_csr_identical(small["sym"][0], ref["0"][0], "fallback after a full pair list")
+    assert_csr_identical(ref["sym"][0], P.sp_matmul_topn_port(A, A.T, 10, 0.8, True, 8))
 
 
 def test_pruned_multiply_with_hubs_of_duplicates(ctx, monkeypatch):
