@@ -544,15 +544,15 @@ spgemm_topn_pruned_kernel(const int64_t *__restrict__ a_indptr, const int32_t *_
         // profiles/r02_sessionA_*.log).  Everything but the LDS operations runs for all lanes.
         auto apply = [&](const Batch &bt, uint32_t t) {
             const bool v0 = bt.rem > 0, v1 = bt.rem > (int32_t)G4, v2 = bt.rem > (int32_t)G8, v3 = bt.rem > (int32_t)G12;
-            const uint64_t m0 = ballot64(v0);
-            if (m0 == 0) return;
+            const uint64_t m0 = ballot64(v0), m1 = ballot64(v1), m2 = ballot64(v2), m3 = ballot64(v3);   // (next to the compares:
+            if (m0 == 0) return;                                                  //  taken across a branch, a mask is rebuilt through a VGPR)
             if (ballot64(bt.rem > (int32_t)G16)) {
                 // a segment longer than four entries per lane (rare): slot by slot, then a full clear
                 uint32_t zz = 0;
                 round(bt.r0, v0, m0, t, zz);
-                round(bt.r1, v1, ballot64(v1), t, zz);
-                round(bt.r2, v2, ballot64(v2), t, zz);
-                round(bt.r3, v3, ballot64(v3), t, zz);
+                round(bt.r1, v1, m1, t, zz);
+                round(bt.r2, v2, m2, t, zz);
+                round(bt.r3, v3, m3, t, zz);
                 int32_t left = bt.rem - (int32_t)G16;
                 uint32_t at = bt.base + G16;
                 SG_WD_DECL(wd_b);
@@ -567,23 +567,23 @@ spgemm_topn_pruned_kernel(const int64_t *__restrict__ a_indptr, const int32_t *_
                 for (int x = lane; x < TILE * 2 / 16; x += 64) tab_v[x] = make_uint4(0, 0, 0, 0);
                 return;
             }
-            const uint64_t m1 = ballot64(v1), m2 = ballot64(v2), m3 = ballot64(v3);
             const Slot s0 = prep(bt.r0), s1 = prep(bt.r1), s2 = prep(bt.r2), s3 = prep(bt.r3);
-            uint32_t o0, o1, o2, o3;
-            asm("" : "=v"(o0));   // lanes without a posting: whatever the register holds, masked below
-            asm("" : "=v"(o1));
-            asm("" : "=v"(o2));
-            asm("" : "=v"(o3));
-            if (v0) o0 = __hip_atomic_fetch_add(tab_at(s0.z), s0.xs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            if (v1) o1 = __hip_atomic_fetch_add(tab_at(s1.z), s1.xs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            if (v2) o2 = __hip_atomic_fetch_add(tab_at(s2.z), s2.xs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            if (v3) o3 = __hip_atomic_fetch_add(tab_at(s3.z), s3.xs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            // No lane mask on the eight LDS operations: a slot without a posting holds whatever lies behind the segment, i.e.
+            // SOME accumulator address of this tile; it adds 0 there, and its re-zeroing store is harmless because this batch
+            // is the row's whole visit of the tile -- every accumulator it touches ends at zero anyway and DS operations
+            // execute in order, after all four adds.  (Under masks every operation cost a saveexec, two taken branches and a
+            // restore: 16 branches per tile.)
+            const uint32_t a0 = v0 ? s0.xs : 0u, a1 = v1 ? s1.xs : 0u, a2 = v2 ? s2.xs : 0u, a3 = v3 ? s3.xs : 0u;
+            uint32_t o0 = __hip_atomic_fetch_add(tab_at(s0.z), a0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            uint32_t o1 = __hip_atomic_fetch_add(tab_at(s1.z), a1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            uint32_t o2 = __hip_atomic_fetch_add(tab_at(s2.z), a2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            uint32_t o3 = __hip_atomic_fetch_add(tab_at(s3.z), a3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             // re-zero only what was touched (a few dozen of the tile's accumulators): sweeping the tile for every
             // row costs rows * columns * 2 B of LDS writes, 11 ms at 663 k
-            if (v0) *tab_at(s0.z) = 0u;
-            if (v1) *tab_at(s1.z) = 0u;
-            if (v2) *tab_at(s2.z) = 0u;
-            if (v3) *tab_at(s3.z) = 0u;
+            *tab_at(s0.z) = 0u;
+            *tab_at(s1.z) = 0u;
+            *tab_at(s2.z) = 0u;
+            *tab_at(s3.z) = 0u;
             asm volatile("" : "+v"(o0), "+v"(o1), "+v"(o2), "+v"(o3));   // the one wait; the tests below stay outside the masks
             // oh < tq && oh + x >= tq  (unsigned wrap when oh >= tq); the mask of a compare ANDed with a scalar mask
             // stays scalar (the mask of a combined predicate would be rebuilt through a VALU select)
