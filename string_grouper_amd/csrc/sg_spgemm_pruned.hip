@@ -428,7 +428,12 @@ spgemm_topn_pruned_kernel(const int64_t *__restrict__ a_indptr, const int32_t *_
         const uint32_t CA = (uint32_t)(c_a * (float)(1u << (32 - AB))) + 1u;   // < 2^24
         // lane (term, u of G): byte offset of its first entry inside a segment, stride; idle lanes read the
         // all-zero row K3 appends to the table of segment ends (empty segments, rem == 0) and entry 0
-        const uint32_t u4 = u << 2, G4 = g << 2, G8 = g << 3, G12 = 3u * G4, G16 = g << 4;
+        // Lane u of the g lanes of a term owns entries 4u .. 4u + 3 of the term's segment in every tile: one 16-byte load.
+        // (Four dword loads at stride g were the first layout: the same bytes, four times the work for the address unit,
+        // which was the busiest block of the kernel -- profiles/r02_sessionB_*.log, TCP_GATE_EN ~ 100 %.)  What a segment
+        // holds beyond 4g entries goes slot by slot (round), lane u taking entries 4g + u, 4g + u + g, ...
+        const uint32_t u4 = u << 2, u16 = u << 4, G4 = g << 2, G16 = g << 4;
+        const int32_t over16 = (int32_t)(G16 - u16);   // rem > over16: the segment holds more than 4g entries
         const uint32_t erow = (g ? (uint32_t)my_k : n_terms) * (uint32_t)nt_pad;
         auto ends_at = [&](uint32_t group) {
             return *reinterpret_cast<const uint4 *>(reinterpret_cast<const char *>(ends) + ((erow + (group << 2)) << 2));
@@ -513,15 +518,19 @@ spgemm_topn_pruned_kernel(const int64_t *__restrict__ a_indptr, const int32_t *_
             uint32_t base;
         };
         auto issue = [&](Batch &bt, uint32_t lo, uint32_t hi) {
-            bt.base = lo + u4;
+            bt.base = lo + u16;
             bt.rem = (int32_t)(hi - bt.base);
-            // unconditional on purpose: loading only the slots that hold a posting (60 % are empty) saves L1 requests, but
-            // the branches around the masked loads cost the compiler its exact count of loads in flight -- it then waits for
-            // (almost) all of them before a batch is used, i.e. the prefetch distance is gone: +9 % (profiles/r02_sessionI_*.log)
-            bt.r0 = filt_at(bt.base);
-            bt.r1 = filt_at(bt.base + G4);
-            bt.r2 = filt_at(bt.base + G8);
-            bt.r3 = filt_at(bt.base + G12);
+            // unconditional on purpose: loading only for the lanes whose slots hold postings (60 % are empty) would put the
+            // loads under branches, and the compiler then loses its exact count of loads in flight -- it waits for (almost)
+            // all of them before a batch is used, i.e. the prefetch distance is gone: +9 % (profiles/r02_sessionI_*.log)
+            struct __attribute__((packed, aligned(4))) Quad {
+                uint32_t x, y, z, w;
+            };
+            const Quad q = *reinterpret_cast<const Quad *>(reinterpret_cast<const char *>(filt) + bt.base);
+            bt.r0 = q.x;
+            bt.r1 = q.y;
+            bt.r2 = q.z;
+            bt.r3 = q.w;
         };
         // What one slot adds and what its accumulator must reach: side-effect free, computed for all lanes.
         struct Slot {
@@ -543,18 +552,18 @@ spgemm_topn_pruned_kernel(const int64_t *__restrict__ a_indptr, const int32_t *_
         // (round 2's first version waited per slot: 2.5 LDS round trips per tile made the loop latency-bound,
         // profiles/r02_sessionA_*.log).  Everything but the LDS operations runs for all lanes.
         auto apply = [&](const Batch &bt, uint32_t t) {
-            const bool v0 = bt.rem > 0, v1 = bt.rem > (int32_t)G4, v2 = bt.rem > (int32_t)G8, v3 = bt.rem > (int32_t)G12;
+            const bool v0 = bt.rem > 0, v1 = bt.rem > 4, v2 = bt.rem > 8, v3 = bt.rem > 12;
             const uint64_t m0 = ballot64(v0), m1 = ballot64(v1), m2 = ballot64(v2), m3 = ballot64(v3);   // (next to the compares:
             if (m0 == 0) return;                                                  //  taken across a branch, a mask is rebuilt through a VGPR)
-            if (ballot64(bt.rem > (int32_t)G16)) {
+            if (ballot64(bt.rem > over16)) {
                 // a segment longer than four entries per lane (rare): slot by slot, then a full clear
                 uint32_t zz = 0;
                 round(bt.r0, v0, m0, t, zz);
                 round(bt.r1, v1, m1, t, zz);
                 round(bt.r2, v2, m2, t, zz);
                 round(bt.r3, v3, m3, t, zz);
-                int32_t left = bt.rem - (int32_t)G16;
-                uint32_t at = bt.base + G16;
+                int32_t left = bt.rem - over16 - (int32_t)u4;
+                uint32_t at = bt.base + (uint32_t)over16 + u4;
                 SG_WD_DECL(wd_b);
                 uint64_t ml;
                 while ((ml = ballot64(left > 0)) != 0) {
