@@ -1,0 +1,18 @@
+#!/bin/bash
+mkdir -p gpurun_out
+export PYTHONPATH=$PWD
+LOG=gpurun_out/r02r.log
+: > $LOG
+short() { python -c "
+import sys, json
+d = json.loads(sys.stdin.read())
+print(d['kernels_ms']['spgemm_topn'], round(d['ms_per_step'], 3), d['roofline']['avg_ms'], d.get('parity_on_sample'))"; }
+for rep in 1 2; do
+for lib in libsg_hip.so libsg_hip_probeE.so; do
+for v in "SG_SYM=1" "SG_SYM=0"; do
+  echo -n "$lib $v : " >> $LOG
+  env $v SG_HIP_LIB=$PWD/string_grouper_amd/$lib timeout 300 python bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-exact-kernel --no-end-to-end 2>/dev/null | short >> $LOG 2>&1
+done
+done
+done
+cat $LOG

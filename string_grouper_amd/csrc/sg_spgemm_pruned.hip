@@ -468,6 +468,9 @@ spgemm_topn_pruned_kernel(const int64_t *__restrict__ a_indptr, const int32_t *_
         TopList<T> top;
         top.clear();
         uint32_t n_surv = 0;
+#ifdef SG_K4P_PROBE_NO_COLLECT
+        uint64_t probe_sink = 0;
+#endif
 
         // The survivors of one slot of a tile (rare: a few per row): append the crossing lanes' columns, score a
         // full wave of them at once.
@@ -526,11 +529,21 @@ spgemm_topn_pruned_kernel(const int64_t *__restrict__ a_indptr, const int32_t *_
             struct __attribute__((packed, aligned(4))) Quad {
                 uint32_t x, y, z, w;
             };
+#ifdef SG_K4P_PROBE_NO_LOADS   // timing probes (wrong results): scripts/gpu_r02_q.sh
+            Quad q;
+            q.x = q.y = q.z = q.w = bt.base & 0x1ffcu;
+#else
+            // (pointing the lanes without a posting at one common line instead made the kernel 2.5 x slower:
+            // profiles/r02_sessionR_idle_lanes_one_line.log)
             const Quad q = *reinterpret_cast<const Quad *>(reinterpret_cast<const char *>(filt) + bt.base);
+#endif
             bt.r0 = q.x;
             bt.r1 = q.y;
             bt.r2 = q.z;
             bt.r3 = q.w;
+#ifdef SG_K4P_PROBE_NO_PREFETCH   // latency probe: every batch load is waited for where it is issued
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
         };
         // What one slot adds and what its accumulator must reach: side-effect free, computed for all lanes.
         struct Slot {
@@ -582,6 +595,9 @@ spgemm_topn_pruned_kernel(const int64_t *__restrict__ a_indptr, const int32_t *_
             // is the row's whole visit of the tile -- every accumulator it touches ends at zero anyway and DS operations
             // execute in order, after all four adds.  (Under masks every operation cost a saveexec, two taken branches and a
             // restore: 16 branches per tile.)
+#ifdef SG_K4P_PROBE_NO_LDS
+            uint32_t o0 = s0.z + (v0 ? s0.xs : 0u), o1 = s1.z + (v1 ? s1.xs : 0u), o2 = s2.z + (v2 ? s2.xs : 0u), o3 = s3.z + (v3 ? s3.xs : 0u);
+#else
             const uint32_t a0 = v0 ? s0.xs : 0u, a1 = v1 ? s1.xs : 0u, a2 = v2 ? s2.xs : 0u, a3 = v3 ? s3.xs : 0u;
             uint32_t o0 = __hip_atomic_fetch_add(tab_at(s0.z), a0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             uint32_t o1 = __hip_atomic_fetch_add(tab_at(s1.z), a1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -593,6 +609,7 @@ spgemm_topn_pruned_kernel(const int64_t *__restrict__ a_indptr, const int32_t *_
             *tab_at(s1.z) = 0u;
             *tab_at(s2.z) = 0u;
             *tab_at(s3.z) = 0u;
+#endif
             asm volatile("" : "+v"(o0), "+v"(o1), "+v"(o2), "+v"(o3));   // the one wait; the tests below stay outside the masks
             // oh < tq && oh + x >= tq  (unsigned wrap when oh >= tq); the mask of a compare ANDed with a scalar mask
             // stays scalar (the mask of a combined predicate would be rebuilt through a VALU select)
@@ -600,12 +617,16 @@ spgemm_topn_pruned_kernel(const int64_t *__restrict__ a_indptr, const int32_t *_
             const uint64_t c1m = ballot64(s1.tq1 - __builtin_amdgcn_ubfe(o1, s1.sh, 16u) < s1.x) & m1;
             const uint64_t c2 = ballot64(s2.tq1 - __builtin_amdgcn_ubfe(o2, s2.sh, 16u) < s2.x) & m2;
             const uint64_t c3 = ballot64(s3.tq1 - __builtin_amdgcn_ubfe(o3, s3.sh, 16u) < s3.x) & m3;
+#ifdef SG_K4P_PROBE_NO_COLLECT
+            probe_sink ^= c0 + c1m + c2 + c3;
+#else
             if (c0 | c1m | c2 | c3) {
                 if (c0) collect(c0, bt.r0, t);
                 if (c1m) collect(c1m, bt.r1, t);
                 if (c2) collect(c2, bt.r2, t);
                 if (c3) collect(c3, bt.r3, t);
             }
+#endif
         };
 
         // Software pipeline, four tiles per trip: E = segment ends of tiles 4m .. 4m + 3 (byte offsets),
@@ -647,6 +668,9 @@ spgemm_topn_pruned_kernel(const int64_t *__restrict__ a_indptr, const int32_t *_
             for (int d = 32; d > 0; d >>= 1) mine += __shfl_xor(mine, d, 64);
             st_post += (unsigned long long)wave_read<uint32_t>(mine, 0);
         }
+#ifdef SG_K4P_PROBE_NO_COLLECT
+        if (probe_sink == 0x1234567887654321ull) n_surv = 1;   // keeps the tests alive
+#endif
         if (n_surv > 0) {   // fewer than 64 left
             top = drain_survivors<T, SYM, TILE_LOG2, WIDE>(nnz, fwd_ptr, fwd, thr, row, pair_i, pair_j, pair_s, pair_row_count, pair_chunk_count, pair_chunks, pair_chunks_used, pair_totals, top,
                                                      n_surv);
