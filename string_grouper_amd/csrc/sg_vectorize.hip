@@ -1282,7 +1282,8 @@ extern "C" int sg_vocab_free(sg_vocab *v) {
 template <typename T, typename KeyT, typename Lookup>
 static void launch_weight(sg_ctx *ctx, const TokenCache *tc, Lookup lookup, const sg_vocab *v, int64_t n, const int64_t *indptr,
                           int32_t *idx, void *val, uint32_t *props) {
-    static const bool plain = getenv("SG_K2_PLAIN") && getenv("SG_K2_PLAIN")[0] == '1';   // A/B hook
+    const char *pe = getenv("SG_K2_PLAIN");   // A/B and test hook: the thread-per-row statement of the arithmetic
+    const bool plain = pe && pe[0] == '1';
     if (plain)
         hipLaunchKernelGGL((weight_normalize_kernel<T, KeyT, Lookup>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream,
                            (const int64_t *)tc->d_ub_ptr, (const int32_t *)tc->d_cnt, (const KeyT *)tc->d_keys,

@@ -138,6 +138,36 @@ def test_vectoriser_matches_sklearn_bitexact(ctx, dtype):
     assert_csr_identical(m_dev, sp.csr_matrix(m_ref))
 
 
+@pytest.mark.parametrize("env", [{"SG_DF_MARKS": "0"}, {"SG_K2_PLAIN": "1"}, {"SG_POSTINGS_SPLIT": "1"},
+                                 {"SG_POSTINGS_SPLIT": "4"}, {"SG_POSTINGS_LDS": "0"}])
+def test_alternative_forms_of_k1_k2_k3_give_the_same_bits(ctx, env, monkeypatch):
+    """Every kernel that got a faster form in round 2 keeps its first form behind a switch (document frequencies by
+    global atomics -- the form the multi-GPU fit uses --, K2 with a thread per row, K3 without the tile split / without
+    LDS counters): each must still reproduce sklearn and the port bit for bit."""
+    from string_grouper_amd.vectorizer import HipTfidfVectorizer
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    names = _names(20000, seed=17)
+    names[5] = ""
+    names[6] = "x" * 300
+    names[7] = "".join(chr(97 + (i * 11) % 26) for i in range(400))
+    for dtype in (np.float32, np.float64):
+        (m_ref,), vocab, idf = O.tfidf_sklearn(names, [names], dtype=dtype)
+        vec = HipTfidfVectorizer(dtype=dtype, ctx=ctx)
+        p = vec.prepare(names)
+        dA = vec.fit_prepared([p]).transform_prepared(p)
+        assert vec.vocabulary_ == vocab
+        np.testing.assert_array_equal(vec.idf_, idf)
+        A = dA.to_scipy()
+        assert_csr_identical(A, sp.csr_matrix(m_ref))
+        post = ctx.postings_build(dA)
+        res = ctx.spgemm_topn(dA, post, 10, 0.8, True)
+        assert_csr_identical(res.to_scipy(), P.sp_matmul_topn_port(A, A.T, 10, 0.8, True, 8))
+        res.free()
+        post.free()
+        dA.free()
+
+
 def test_vectoriser_master_and_duplicates(ctx):
     """fit on master + duplicates, transform each (string_grouper.py:689-706); out-of-vocabulary
     n-grams of a third series are dropped like sklearn does."""
