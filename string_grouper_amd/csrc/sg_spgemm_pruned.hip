@@ -534,7 +534,8 @@ spgemm_topn_pruned_kernel(const int64_t *__restrict__ a_indptr, const int32_t *_
             q.x = q.y = q.z = q.w = bt.base & 0x1ffcu;
 #else
             // (pointing the lanes without a posting at one common line instead made the kernel 2.5 x slower:
-            // profiles/r02_sessionR_idle_lanes_one_line.log)
+            // profiles/r02_sessionR_idle_lanes_one_line.log; loads under an exec mask written in inline assembly, with
+            // hand-counted waits, changed nothing: profiles/r02_sessionT_masked_asm_loads.log)
             const Quad q = *reinterpret_cast<const Quad *>(reinterpret_cast<const char *>(filt) + bt.base);
 #endif
             bt.r0 = q.x;
