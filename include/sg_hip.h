@@ -210,6 +210,26 @@ int sg_matchlist_group_reps(sg_ctx *ctx, const sg_matchlist *ml, int32_t centroi
  * (The reference has no analogue: its n_blocks[0] split is by row count, string_grouper.py:714-722.) */
 int sg_row_costs(sg_ctx *ctx, const sg_csr *A, const sg_postings *Bt, int64_t *out_cost);
 
+/* Self-join across GPUs.  One GPU scores every pair (i, j) of a self-join once, from the row
+ * with the larger index (half the work of the one-sided multiply the reference's n_blocks[0] split implies,
+ * string_grouper.py:714-752).  Across ranks that form splits by LEFT-ROW RANGES of the same, replicated matrix:
+ *
+ * sg_selfjoin_range: the rows [row_lo, row_hi) of A against the columns j <= i.  A must be the matrix Bt was built
+ *   from.  *out: a result object over ALL rows of A in which the rows of the range hold their matches j <= i (the
+ *   other rows are empty); *d_pairs: the mirrored pairs -- that row i of the range matches row j < i, which may belong
+ *   to another rank -- as *n_pairs records of *pair_words int32 words: {i, j, score bits} (f32) or {i, j, lo, hi} (f64);
+ *   device memory owned by the library (sg_device_free).  *applicable == 0: the form cannot take this input (not
+ *   cosine-like, top_n > 64, threshold too low, a row for the exact kernel, pair list full): nothing is returned and
+ *   the caller uses sg_spgemm_topn on its rows.  All ranks must take the same branch.
+ * sg_selfjoin_merge: the pairs of ALL ranks, concatenated in any order, merged into the rows [row_lo, row_hi) of
+ *   `res`: afterwards these rows equal the rows sg_spgemm_topn(A, Bt) would give, bit for bit. */
+int sg_selfjoin_range(sg_ctx *ctx, const sg_csr *A, const sg_postings *Bt, int32_t top_n, double threshold,
+                      int64_t row_lo, int64_t row_hi, sg_topn **out, int32_t **d_pairs, int64_t *n_pairs,
+                      int32_t *pair_words, int32_t *applicable);
+int sg_selfjoin_merge(sg_ctx *ctx, sg_topn *res, const int32_t *d_pairs, int64_t n_pairs, int32_t pair_words,
+                      int64_t row_lo, int64_t row_hi);
+int sg_device_free(sg_ctx *ctx, void *d_ptr);
+
 /* ------------------------------------------------------------------ measurement */
 enum { SG_K_TOKENIZE = 0, SG_K_WEIGHT = 1, SG_K_POSTINGS = 2, SG_K_SPGEMM = 3 /* the multiply's whole launch group */,
        SG_K_ZIP = 4, SG_K_VOCAB = 5, SG_K_SPGEMM_KERNEL = 6 /* its dominant kernel alone (pruned: the pruned kernel without

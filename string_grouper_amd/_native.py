@@ -89,6 +89,9 @@ ABI = {
     "sg_matchlist_best_master": (C.c_int, [_P, _P, _P]),
     "sg_matchlist_group_reps": (C.c_int, [_P, _P, C.c_int32, _P]),
     "sg_row_costs": (C.c_int, [_P, _P, _P, _P]),
+    "sg_selfjoin_range": (C.c_int, [_P, _P, _P, C.c_int32, C.c_double, C.c_int64, C.c_int64, _P, _P, _P, _P, _P]),
+    "sg_selfjoin_merge": (C.c_int, [_P, _P, _P, C.c_int64, C.c_int32, C.c_int64, C.c_int64]),
+    "sg_device_free": (C.c_int, [_P, _P]),
     "sg_csr_rowwise_dot": (C.c_int, [_P, _P, _P, _P]),
     "sg_ctx_stats": (C.c_int, [_P, C.POINTER(SgStats)]),
 }
@@ -462,6 +465,26 @@ class Context:
         out = np.zeros(max(r, 1), code_np_dtype(d))
         check(lib().sg_csr_rowwise_dot(self.h, A.h, B.h, _ptr(out)))
         return out[:r]
+
+    def selfjoin_range(self, A: Csr, Bt: Postings, top_n: int, threshold: float, row_lo: int, row_hi: int):
+        """The rows [row_lo, row_hi) of the self-join form (include/sg_hip.h: sg_selfjoin_range).  Returns
+        (TopN over all rows, device pointer of the mirrored pairs, number of pairs, int32 words per pair), or None when
+        the form does not apply to this input."""
+        out, pairs = C.c_void_p(), C.c_void_p()
+        n_pairs, words, ok = C.c_int64(), C.c_int32(), C.c_int32()
+        check(lib().sg_selfjoin_range(self.h, A.h, Bt.h, int(top_n), float(threshold), int(row_lo), int(row_hi),
+                                      C.byref(out), C.byref(pairs), C.byref(n_pairs), C.byref(words), C.byref(ok)))
+        if not ok.value:
+            return None
+        return TopN(self, out), pairs.value, n_pairs.value, words.value
+
+    def selfjoin_merge(self, res: TopN, d_pairs: int, n_pairs: int, pair_words: int, row_lo: int, row_hi: int) -> None:
+        check(lib().sg_selfjoin_merge(self.h, res.h, C.c_void_p(d_pairs), int(n_pairs), int(pair_words), int(row_lo),
+                                      int(row_hi)))
+
+    def device_free(self, d_ptr: int) -> None:
+        if d_ptr:
+            check(lib().sg_device_free(self.h, C.c_void_p(d_ptr)))
 
     def row_costs(self, A: Csr, Bt: Postings) -> np.ndarray:
         out = np.zeros(max(A.dims()[0], 1), np.int64)

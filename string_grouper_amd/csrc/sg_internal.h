@@ -196,7 +196,10 @@ int sg_spgemm_pruned_launch(sg_ctx *ctx, const sg_csr *A, const sg_postings *Bt,
                             uint32_t *flagged_count, uint32_t *flagged_rows, unsigned long long *stats);
 
 int sg_spgemm_pruned_symmetric(sg_ctx *ctx, const sg_csr *A, const sg_postings *Bt, int32_t keep, sg_topn *r,
-                               double threshold, double delta, unsigned long long *stats, bool *done);
+                               double threshold, double delta, unsigned long long *stats, bool *done, int64_t row_lo = 0,
+                               int64_t row_hi = -1 /* the whole matrix */, int32_t **export_pairs = nullptr,
+                               int64_t *export_n = nullptr);
+int sg_selfjoin_merge_pairs(sg_ctx *ctx, sg_topn *r, const int32_t *d_pairs, int64_t n_pairs, int64_t row_lo, int64_t row_hi);
 
 // sg_sortvocab.hip: ascending distinct values of d_keys[0 .. n) and how often each occurs (d_keys is overwritten)
 int sg_sort_unique_u64(sg_ctx *ctx, uint64_t *d_keys, int64_t n, uint64_t *d_unique, int32_t *d_counts, int64_t *n_unique);

@@ -249,6 +249,7 @@ spgemm_topn_pruned_kernel(const int64_t *__restrict__ a_indptr, const int32_t *_
                           uint32_t *pair_chunk_count /* SYM: entries used of every chunk of the pair list */,
                           uint32_t pair_chunks /* chunks there are */, uint32_t *pair_chunks_used /* chunks handed out */,
                           unsigned long long *pair_totals /* pairs in closed chunks */,
+                          uint32_t sym_lo, uint32_t sym_hi /* SYM: the left rows this launch scores (multi-GPU: a rank's range) */,
                           const uint32_t *__restrict__ row_list /* WIDE: the rows to process */, const uint32_t *row_list_len) {
     constexpr int TILE = 1 << TILE_LOG2;
     constexpr int SLOTS = WIDE ? 2 : 1;   // row terms staged per lane
@@ -277,14 +278,14 @@ spgemm_topn_pruned_kernel(const int64_t *__restrict__ a_indptr, const int32_t *_
     };
 
     SG_WD_DECL(wd_rows);
-    const uint32_t n_here = WIDE ? (uint32_t)__builtin_amdgcn_readfirstlane((int)*row_list_len) : n_left;
+    const uint32_t n_here = WIDE ? (uint32_t)__builtin_amdgcn_readfirstlane((int)*row_list_len) : (SYM ? sym_hi - sym_lo : n_left);
     // rows are handed out four at a time: one global atomic per row capped the kernel at ~88 rows/us (larger first
     // helpings were tried -- sixteen rows for the first three quarters -- and changed nothing: profiles/r02_sessionJ6_*.log).
     // Symmetric mode walks the rows from the last to the first: a row's cost grows with its index there.
     for (uint32_t row0 = next_row(row_counter, lane) * 4u; row0 < n_here; row0 = next_row(row_counter, lane) * 4u)
     for (uint32_t rr = row0; rr < min(row0 + 4u, n_here); ++rr) {
         SG_WD(wd_rows, n_left + 2, 11)
-        const uint32_t row = WIDE ? (uint32_t)__builtin_amdgcn_readfirstlane((int)row_list[rr]) : (SYM ? n_left - 1u - rr : rr);
+        const uint32_t row = WIDE ? (uint32_t)__builtin_amdgcn_readfirstlane((int)row_list[rr]) : (SYM ? sym_hi - 1u - rr : rr);
         const int64_t rlo = a_indptr[row];
         const int nnz = __builtin_amdgcn_readfirstlane((int)(a_indptr[row + 1] - rlo));
         if (nnz > 64 * SLOTS) {   // more non-zeros than this launch stages: the wide launch, or the exact kernel
@@ -719,6 +720,55 @@ __global__ void __launch_bounds__(SG_PAIR_CHUNK) pairs_fill_kernel(const uint32_
     lval[at] = ps[p];
 }
 
+// ---- multi-GPU form of the second pass: the pair list leaves the GPU as one array of {i, j, score bits} records
+// (W = 3 words for f32, 4 for f64), the lists of all ranks come back concatenated, and every rank merges the pairs
+// whose row j lies in its range.
+template <typename T>
+__global__ void __launch_bounds__(SG_PAIR_CHUNK) pairs_export_kernel(const uint32_t *__restrict__ pi, const uint32_t *__restrict__ pj,
+                                                                     const T *__restrict__ ps, const uint32_t *__restrict__ chunk_count,
+                                                                     const uint32_t *__restrict__ chunk_start, int32_t *__restrict__ out) {
+    constexpr int W = sizeof(T) == 8 ? 4 : 3;
+    if (threadIdx.x >= chunk_count[blockIdx.x]) return;
+    const size_t p = (size_t)blockIdx.x * SG_PAIR_CHUNK + threadIdx.x;
+    int32_t *o = out + ((size_t)chunk_start[blockIdx.x] + threadIdx.x) * W;
+    o[0] = (int32_t)pi[p];
+    o[1] = (int32_t)pj[p];
+    if (sizeof(T) == 8) {
+        const long long b = __double_as_longlong((double)ps[p]);
+        o[2] = (int32_t)(b & 0xffffffffll);
+        o[3] = (int32_t)(b >> 32);
+    } else {
+        o[2] = __float_as_int((float)ps[p]);
+    }
+}
+
+template <int W>
+__global__ void __launch_bounds__(256) pairs_flat_count_kernel(const int32_t *__restrict__ pairs, int64_t n_pairs, uint32_t lo,
+                                                               uint32_t hi, uint32_t *cnt) {
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n_pairs) return;
+    const uint32_t j = (uint32_t)pairs[p * W + 1];
+    if (j >= lo && j < hi) atomicAdd(&cnt[j], 1u);
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) pairs_flat_fill_kernel(const int32_t *__restrict__ pairs, int64_t n_pairs, uint32_t lo,
+                                                              uint32_t hi, const uint32_t *__restrict__ ptr, uint32_t *cursor,
+                                                              int32_t *__restrict__ lcol, T *__restrict__ lval) {
+    constexpr int W = sizeof(T) == 8 ? 4 : 3;
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n_pairs) return;
+    const int32_t *rec = pairs + p * W;
+    const uint32_t j = (uint32_t)rec[1];
+    if (j < lo || j >= hi) return;
+    const uint32_t at = ptr[j] + atomicAdd(&cursor[j], 1u);
+    lcol[at] = rec[0];
+    if (sizeof(T) == 8)
+        lval[at] = (T)__longlong_as_double(((long long)rec[3] << 32) | (long long)(uint32_t)rec[2]);
+    else
+        lval[at] = (T)__int_as_float(rec[2]);
+}
+
 // A wave looks at 64 rows at a time and works on those that have mirrored matches: own list + mirrored list through the
 // rank sort (up to 64 candidates, the common case) or the register top-n list (order of arrival is irrelevant).
 template <typename T>
@@ -874,6 +924,7 @@ struct PairList {   // symmetric mode: the mirrored pairs (i, j < i) above the t
     uint32_t *d_chunks_used = nullptr;         // chunks handed out
     unsigned long long *d_totals = nullptr;    // pairs
     uint32_t chunks = 0;
+    uint32_t row_lo = 0, row_hi = 0;           // the left rows to score (the whole matrix on one GPU)
 };
 
 // single-wave workgroups of the pruned kernel: as many as the LDS of the chip holds
@@ -894,7 +945,7 @@ static int launch_pruned(sg_ctx *ctx, const sg_csr *A, const sg_postings *Bt, in
                          float s_budget, uint32_t *row_counter, uint32_t *flagged_count, uint32_t *flagged_rows,
                          unsigned long long *stats, const PairList &pl, const uint32_t *row_list, const uint32_t *row_list_len) {
     const size_t lds = ((size_t)2 << TILE_LOG2) + 512 + 1024 + (size_t)SG_SURV_CAP * 4;
-    unsigned grid = pruned_grid(ctx, TILE_LOG2, A->n_rows);
+    unsigned grid = pruned_grid(ctx, TILE_LOG2, SYM ? (int64_t)(pl.row_hi - pl.row_lo) : A->n_rows);
     if (WIDE && grid > (unsigned)ctx->num_cu * 4u) grid = (unsigned)ctx->num_cu * 4u;   // few rows, if any: idle waves leave at once
     hipLaunchKernelGGL((spgemm_topn_pruned_kernel<T, TILE_LOG2, SYM, WIDE>), dim3(grid), dim3(64), lds, ctx->stream, A->d_indptr,
                        A->d_indices, (const T *)A->d_data, (uint32_t)A->n_rows, (const uint32_t *)Bt->d_seg,
@@ -903,7 +954,7 @@ static int launch_pruned(sg_ctx *ctx, const sg_csr *A, const sg_postings *Bt, in
                        (const void *)Bt->d_fwd, keep, r->stride, thr, s_budget, Bt->norm_up, Bt->freq_min, r->d_cols,
                        (T *)r->d_vals,
                        r->d_counts, row_counter, flagged_count, flagged_rows, stats, pl.d_i, pl.d_j, (T *)pl.d_s, pl.d_row_count, pl.d_chunk_count,
-                       pl.chunks, pl.d_chunks_used, pl.d_totals, row_list, row_list_len);
+                       pl.chunks, pl.d_chunks_used, pl.d_totals, pl.row_lo, pl.row_hi, row_list, row_list_len);
     SG_HIP_TRY(hipGetLastError());
     return SG_OK;
 }
@@ -975,11 +1026,15 @@ int sg_spgemm_pruned_launch(sg_ctx *ctx, const sg_csr *A, const sg_postings *Bt,
 // *done == false: nothing usable was produced (too many pairs for the list, or rows for the exact kernel) and
 // the caller runs the one-sided form; the result object and the statistics words are untouched then.
 int sg_spgemm_pruned_symmetric(sg_ctx *ctx, const sg_csr *A, const sg_postings *Bt, int32_t keep, sg_topn *r,
-                               double threshold, double delta, unsigned long long *stats, bool *done) {
+                               double threshold, double delta, unsigned long long *stats, bool *done, int64_t row_lo,
+                               int64_t row_hi, int32_t **export_pairs, int64_t *export_n) {
     *done = false;
     const size_t vs = A->dtype == SG_F64 ? 8 : 4;
     const int64_t n = A->n_rows;
+    if (row_hi < 0) row_hi = n;   // the whole matrix
     PairList pl;
+    pl.row_lo = (uint32_t)row_lo;
+    pl.row_hi = (uint32_t)row_hi;
     // a name list has a few matches per row; hubs of identical names can have far more -> fall back then
     int64_t cap = 8 * n + ((int64_t)1 << 20);
     bool cap_forced = false;
@@ -1068,8 +1123,41 @@ int sg_spgemm_pruned_symmetric(sg_ctx *ctx, const sg_csr *A, const sg_postings *
         cleanup();
         return SG_OK;   // *done stays false
     }
-    // ---- pass 2
     const dim3 pgrid(chunks_used > 0 ? chunks_used : 1);
+    if (export_pairs) {
+        // ---- multi-GPU: hand the pair list out (the caller gathers the lists of all ranks, then sg_selfjoin_merge)
+        const int W = A->dtype == SG_F64 ? 4 : 3;
+        uint32_t *chunk_start = nullptr;
+        int32_t *flat = nullptr;
+        st = sg_alloc(ctx, (size_t)chunks_used + 2, &chunk_start);
+        if (st == SG_OK && chunks_used > 0)
+            st = sg_exclusive_scan_u32(ctx, pl.d_chunk_count, chunk_start, chunks_used, nullptr);
+        if (st == SG_OK) st = sg_alloc(ctx, (size_t)(n_pairs + 1) * W, &flat);
+        if (st == SG_OK && chunks_used > 0) {
+            if (A->dtype == SG_F64)
+                hipLaunchKernelGGL(pairs_export_kernel<double>, pgrid, dim3(SG_PAIR_CHUNK), 0, ctx->stream, pl.d_i, pl.d_j,
+                                   (const double *)pl.d_s, pl.d_chunk_count, chunk_start, flat);
+            else
+                hipLaunchKernelGGL(pairs_export_kernel<float>, pgrid, dim3(SG_PAIR_CHUNK), 0, ctx->stream, pl.d_i, pl.d_j,
+                                   (const float *)pl.d_s, pl.d_chunk_count, chunk_start, flat);
+            if (hipGetLastError() != hipSuccess) st = SG_ERR_HIP;
+        }
+        if (st == SG_OK && hipMemcpyAsync(stats, d_stats3, 3 * sizeof(unsigned long long), hipMemcpyDeviceToDevice,
+                                          ctx->stream) != hipSuccess)
+            st = SG_ERR_HIP;
+        ctx->release(chunk_start);
+        ctx->release(d_stats3);
+        cleanup();
+        if (st != SG_OK) {
+            ctx->release(flat);
+            return st;
+        }
+        *export_pairs = flat;
+        *export_n = (int64_t)n_pairs;
+        *done = true;
+        return SG_OK;
+    }
+    // ---- pass 2
     st = sg_exclusive_scan_u32(ctx, cnt, cnt, n + 1, nullptr);   // cnt becomes ptr (n + 1 entries)
     const size_t n_list = (size_t)(n_pairs + 64);
     if (st == SG_OK) st = sg_alloc(ctx, n_list, &lcol);
@@ -1096,5 +1184,58 @@ int sg_spgemm_pruned_symmetric(sg_ctx *ctx, const sg_csr *A, const sg_postings *
     ctx->release(d_stats3);
     cleanup();
     if (st == SG_OK) *done = true;
+    return st;
+}
+
+
+// Second pass of the multi-GPU self-join: merge the mirrored pairs (of all ranks) whose row lies in [row_lo, row_hi)
+// into those rows of `r` (which hold their own matches from sg_spgemm_pruned_symmetric over the same range).
+int sg_selfjoin_merge_pairs(sg_ctx *ctx, sg_topn *r, const int32_t *d_pairs, int64_t n_pairs, int64_t row_lo, int64_t row_hi) {
+    const int64_t n = r->n_rows;
+    if (n_pairs <= 0 || row_hi <= row_lo) return SG_OK;
+    const size_t vs = r->dtype == SG_F64 ? 8 : 4;
+    uint32_t *cnt = nullptr, *cursor = nullptr;
+    int32_t *lcol = nullptr;
+    void *lval = nullptr;
+    int st = sg_alloc(ctx, (size_t)n + 2, &cnt);
+    if (st == SG_OK) st = sg_alloc(ctx, (size_t)n + 2, &cursor);
+    if (st == SG_OK) st = sg_alloc(ctx, (size_t)n_pairs + 64, &lcol);
+    if (st == SG_OK) st = ctx->alloc(((size_t)n_pairs + 64) * vs, &lval);
+    if (st == SG_OK) {
+        if (hipMemsetAsync(cnt, 0, sizeof(uint32_t) * (size_t)(n + 2), ctx->stream) != hipSuccess ||
+            hipMemsetAsync(cursor, 0, sizeof(uint32_t) * (size_t)(n + 2), ctx->stream) != hipSuccess)
+            st = SG_ERR_HIP;
+    }
+    if (st == SG_OK) {
+        const unsigned pg = (unsigned)((n_pairs + 255) / 256);
+        if (r->dtype == SG_F64)
+            hipLaunchKernelGGL(pairs_flat_count_kernel<4>, dim3(pg), dim3(256), 0, ctx->stream, d_pairs, n_pairs, (uint32_t)row_lo,
+                               (uint32_t)row_hi, cnt);
+        else
+            hipLaunchKernelGGL(pairs_flat_count_kernel<3>, dim3(pg), dim3(256), 0, ctx->stream, d_pairs, n_pairs, (uint32_t)row_lo,
+                               (uint32_t)row_hi, cnt);
+        st = sg_exclusive_scan_u32(ctx, cnt, cnt, n + 1, nullptr);
+        if (st == SG_OK) {
+            const unsigned sgrid = (unsigned)((n + 63) / 64 > 0 ? (n + 63) / 64 : 1);
+            if (r->dtype == SG_F64) {
+                hipLaunchKernelGGL(pairs_flat_fill_kernel<double>, dim3(pg), dim3(256), 0, ctx->stream, d_pairs, n_pairs,
+                                   (uint32_t)row_lo, (uint32_t)row_hi, cnt, cursor, lcol, (double *)lval);
+                hipLaunchKernelGGL(pairs_select_kernel<double>, dim3(sgrid), dim3(64), 0, ctx->stream, cnt, lcol,
+                                   (const double *)lval, (uint32_t)n, r->stride, r->stride, r->d_cols, (double *)r->d_vals,
+                                   r->d_counts);
+            } else {
+                hipLaunchKernelGGL(pairs_flat_fill_kernel<float>, dim3(pg), dim3(256), 0, ctx->stream, d_pairs, n_pairs,
+                                   (uint32_t)row_lo, (uint32_t)row_hi, cnt, cursor, lcol, (float *)lval);
+                hipLaunchKernelGGL(pairs_select_kernel<float>, dim3(sgrid), dim3(64), 0, ctx->stream, cnt, lcol,
+                                   (const float *)lval, (uint32_t)n, r->stride, r->stride, r->d_cols, (float *)r->d_vals,
+                                   r->d_counts);
+            }
+            if (hipGetLastError() != hipSuccess) st = SG_ERR_HIP;
+        }
+    }
+    ctx->release(cnt);
+    ctx->release(cursor);
+    ctx->release(lcol);
+    ctx->release(lval);
     return st;
 }

@@ -592,6 +592,37 @@ static int prune_pilot(sg_ctx *ctx, const sg_csr *A, const sg_postings *Bt, int3
     return SG_OK;
 }
 
+// Can the pruned multiply (sg_spgemm_pruned.hip) take this product -- both sides cosine-like, one register list holds a
+// row's result, room below the threshold for its survivor bound -- and can it take its self-join form?
+static bool pruned_applicable(sg_ctx *ctx, const sg_csr *A, const sg_postings *Bt, int32_t stride, double threshold, double *delta,
+                              bool *symmetric, int *status, bool any_size = false) {
+    *symmetric = false;
+    *status = SG_OK;
+    const char *pr = getenv("SG_PRUNE");
+    if ((pr && pr[0] == '0') || !Bt->cosine_like || !Bt->d_filt || stride > SG_TOPN_LANES || A->n_rows <= 0 || Bt->nnz <= 0 ||
+        !sg_pruned_supports_tile(Bt->tile_log2) ||
+        !(threshold >= env_double("SG_PRUNE_MIN_THRESHOLD", 0.45)))   // below ~0.4 the filter passes too much (profiles/r01_prune_tuning.log)
+        return false;
+    *delta = env_double("SG_PRUNE_DELTA", 0.05);   // tuned at 663 k: profiles/r01_prune_tuning.log
+    if (*delta > 0.5 * threshold) *delta = 0.5 * threshold;
+    if (*delta < 0.02) *delta = 0.02;
+    bool a_ok = false;
+    float a_n2 = 0.f;
+    uint32_t a_max_nnz = 0;
+    *status = sg_csr_props(ctx, A, &a_ok, &a_n2, &a_max_nnz);
+    if (*status != SG_OK || !a_ok) return false;
+    // self-join (A is the matrix the postings were built from) whose rows all fit the pruned kernel:
+    // score every pair once, from the row with the larger index (sg_spgemm_pruned.hip, symmetric mode)
+    const char *sy = getenv("SG_SYM");
+    // ... from the size at which halving the (row, tile) visits outweighs the second pass over the pair list
+    // and its host round trip: 0.58 vs 0.57 ms at 50 k rows, 0.95 vs 1.20 at 100 k, 14.0 vs 26.8 at 663 k
+    // (profiles/r02_sessionM_sym_sweep.log)
+    *symmetric = !(sy && sy[0] == '0') && A->n_rows == Bt->n_right && A->d_indptr == Bt->b_indptr &&
+                 A->d_indices == Bt->b_indices && A->d_data == Bt->b_data && a_max_nnz <= 128 &&
+                 (any_size || A->n_rows >= (int64_t)env_int("SG_SYM_MIN_ROWS", 65536) || (sy && sy[0] == '1'));
+    return true;
+}
+
 extern "C" int sg_spgemm_topn(sg_ctx *ctx, const sg_csr *A, const sg_postings *Bt, int32_t top_n, double threshold,
                               int32_t sort, sg_topn **out) {
     SG_REQUIRE(ctx && A && Bt && out, "null argument");
@@ -643,30 +674,11 @@ extern "C" int sg_spgemm_topn(sg_ctx *ctx, const sg_csr *A, const sg_postings *B
     bool prune = false, symmetric = false;
     double delta = 0.0;
     {
-        const char *pr = getenv("SG_PRUNE");
-        if (!(pr && pr[0] == '0') && Bt->cosine_like && Bt->d_filt && stride <= SG_TOPN_LANES && A->n_rows > 0 && Bt->nnz > 0 &&
-            sg_pruned_supports_tile(Bt->tile_log2) && threshold >= env_double("SG_PRUNE_MIN_THRESHOLD", 0.45)) {   // below ~0.4 the filter passes too much (profiles/r01_prune_tuning.log)
-            delta = env_double("SG_PRUNE_DELTA", 0.05);   // tuned at 663 k: profiles/r01_prune_tuning.log
-            if (delta > 0.5 * threshold) delta = 0.5 * threshold;
-            if (delta < 0.02) delta = 0.02;
-            bool a_ok = false;
-            float a_n2 = 0.f;
-            uint32_t a_max_nnz = 0;
-            const int pst = sg_csr_props(ctx, A, &a_ok, &a_n2, &a_max_nnz);
-            if (pst != SG_OK) {
-                sg_topn_free(r);
-                return pst;
-            }
-            prune = a_ok;
-            // self-join (A is the matrix the postings were built from) whose rows all fit the pruned kernel:
-            // score every pair once, from the row with the larger index (sg_spgemm_pruned.hip, symmetric mode)
-            const char *sy = getenv("SG_SYM");
-            // ... from the size at which halving the (row, tile) visits outweighs the second pass over the pair list
-            // and its host round trip: 0.58 vs 0.57 ms at 50 k rows, 0.95 vs 1.20 at 100 k, 14.0 vs 26.8 at 663 k
-            // (profiles/r02_sessionM_sym_sweep.log)
-            symmetric = prune && !(sy && sy[0] == '0') && A->n_rows == Bt->n_right && A->d_indptr == Bt->b_indptr &&
-                        A->d_indices == Bt->b_indices && A->d_data == Bt->b_data && a_max_nnz <= 128 &&
-                        (A->n_rows >= (int64_t)env_int("SG_SYM_MIN_ROWS", 65536) || (sy && sy[0] == '1'));
+        int pst = SG_OK;
+        prune = pruned_applicable(ctx, A, Bt, stride, threshold, &delta, &symmetric, &pst);
+        if (pst != SG_OK) {
+            sg_topn_free(r);
+            return pst;
         }
     }
     // ---- pruned or exact?  On a vocabulary that is small next to the rows (2-grams: a row holds 2 % of all terms) the
@@ -769,6 +781,73 @@ extern "C" int sg_spgemm_topn(sg_ctx *ctx, const sg_csr *A, const sg_postings *B
         return st;
     }
     *out = r;
+    return SG_OK;
+}
+
+// ---- multi-GPU self-join: the self-join form split over ranks by left-row ranges
+extern "C" int sg_selfjoin_range(sg_ctx *ctx, const sg_csr *A, const sg_postings *Bt, int32_t top_n, double threshold,
+                                 int64_t row_lo, int64_t row_hi, sg_topn **out, int32_t **d_pairs, int64_t *n_pairs,
+                                 int32_t *pair_words, int32_t *applicable) {
+    SG_REQUIRE(ctx && A && Bt && out && d_pairs && n_pairs && pair_words && applicable, "null argument");
+    SG_REQUIRE(A->n_cols == Bt->n_terms && A->dtype == Bt->dtype, "A and B differ in columns or value type");
+    SG_REQUIRE(top_n >= 1, "top_n must be >= 1");
+    SG_REQUIRE(row_lo >= 0 && row_lo <= row_hi && row_hi <= A->n_rows, "row range outside the matrix");
+    *out = nullptr;
+    *d_pairs = nullptr;
+    *n_pairs = 0;
+    *pair_words = A->dtype == SG_F64 ? 4 : 3;
+    *applicable = 0;
+    if (!(threshold > 0.0)) threshold = 0.0;
+    int64_t stride64 = top_n;
+    if (stride64 > Bt->n_right) stride64 = Bt->n_right > 0 ? Bt->n_right : 1;
+    if ((double)A->n_rows * (double)stride64 > 2.0e9) return SG_OK;   // not applicable: the caller's other path reports it
+    const int32_t stride = (int32_t)stride64;
+    double delta = 0.0;
+    bool symmetric = false;
+    int pst = SG_OK;
+    const bool prune = pruned_applicable(ctx, A, Bt, stride, threshold, &delta, &symmetric, &pst, /*any_size=*/true);
+    if (pst != SG_OK) return pst;
+    if (!prune || !symmetric) return SG_OK;
+    sg_topn *r = nullptr;
+    SG_TRY(topn_alloc(ctx, A->n_rows, Bt->n_right, stride, A->dtype, &r));
+    int st = SG_OK;
+    bool done = false;
+    {
+        SgTimer timer(ctx, SG_K_SPGEMM);
+        if (hipMemsetAsync(r->d_counts, 0, sizeof(int32_t) * (size_t)A->n_rows, ctx->stream) != hipSuccess ||
+            hipMemsetAsync(ctx->d_stat_words, 0, 8 * sizeof(int64_t), ctx->stream) != hipSuccess)
+            st = SG_ERR_HIP;
+        if (st == SG_OK)
+            st = sg_spgemm_pruned_symmetric(ctx, A, Bt, stride, r, threshold, delta, (unsigned long long *)(ctx->d_stat_words + 2),
+                                            &done, row_lo, row_hi, d_pairs, n_pairs);
+    }
+    const size_t s = A->dtype == SG_F64 ? 8 : 4;
+    ctx->spgemm_entry_bytes = (int64_t)(4 + s);
+    ctx->spgemm_fixed_bytes = A->nnz * (int64_t)(4 + s) + (A->n_rows + Bt->n_terms + 2) * 4;
+    ctx->prune_row_bytes = 8.0 + (Bt->n_right > 0 ? (double)Bt->nnz / (double)Bt->n_right : 0.0) * (s == 8 ? 16.0 : 8.0);
+    ctx->prune_symmetric = done;
+    if (st != SG_OK || !done) {   // a row for the exact kernel, or the pair list was full: the one-sided form is the caller's
+        sg_topn_free(r);
+        return st;
+    }
+    *out = r;
+    *applicable = 1;
+    return SG_OK;
+}
+
+extern "C" int sg_selfjoin_merge(sg_ctx *ctx, sg_topn *res, const int32_t *d_pairs, int64_t n_pairs, int32_t pair_words,
+                                 int64_t row_lo, int64_t row_hi) {
+    SG_REQUIRE(ctx && res, "null argument");
+    SG_REQUIRE(n_pairs == 0 || d_pairs != nullptr, "pairs are null");
+    SG_REQUIRE(pair_words == (res->dtype == SG_F64 ? 4 : 3), "pair records do not match the result's value type");
+    SG_REQUIRE(row_lo >= 0 && row_lo <= row_hi && row_hi <= res->n_rows, "row range outside the result");
+    SgTimer timer(ctx, SG_K_ZIP);
+    return sg_selfjoin_merge_pairs(ctx, res, d_pairs, n_pairs, row_lo, row_hi);
+}
+
+extern "C" int sg_device_free(sg_ctx *ctx, void *d_ptr) {
+    SG_REQUIRE(ctx != nullptr, "null argument");
+    ctx->release(d_ptr);
     return SG_OK;
 }
 

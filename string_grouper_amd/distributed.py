@@ -151,12 +151,63 @@ def replicate_csr(ops, local_csr, group=None):
     return ops.csr_from_tensors(*all_gather_csr(ip, ix, d, n_cols, group))
 
 
-def sharded_topn(ops, left_local, right_full, top_n: int, threshold: float, tile_cols: int = 0):
-    """Step 4b: inverted index of the whole right-hand side, multiply of the local left rows."""
+def sharded_topn(ops, left_local, right_full, top_n: int, threshold: float, tile_cols: int = 0, self_join: bool = False,
+                 group=None):
+    """Step 4b: inverted index of the whole right-hand side, multiply of the local left rows -- or, for a self-join
+    that is large enough, the self-join form over row ranges (``sharded_selfjoin_topn``; the rank's block of the result
+    is then the rows of its RANGE, which ``gather_topn`` concatenates just the same)."""
     post = ops.postings(right_full, tile_cols)
+    if self_join and dist.is_initialized() and selfjoin_form_wanted(ops.csr_shape(right_full)[0], dist.get_world_size(group)):
+        res = sharded_selfjoin_topn(ops, right_full, post, top_n, threshold, group)
+        if res is not None:
+            ops.keep_alive(res, post, left_local, right_full)
+            return res
     res = ops.multiply(left_local, post, top_n, threshold)
     ops.keep_alive(res, post, left_local, right_full)
     return res
+
+
+def selfjoin_row_ranges(n_rows: int, world: int) -> np.ndarray:
+    """Left-row ranges of the self-join form across ranks: rank r scores the rows [b[r], b[r + 1]) against the columns
+    j <= i, so a row's cost grows with its index (the tiles up to its own + a constant ~3 % of the last row's cost,
+    profiles/r02_sessionM_sym_sweep.log): cumulative cost ~ x^2 / 2 + c x, cut into equal shares."""
+    c = 0.03
+    share = np.arange(world + 1, dtype=np.float64) / world
+    x = -c + np.sqrt(c * c + 2.0 * share * (0.5 + c))
+    b = np.minimum(np.round(x * n_rows).astype(np.int64), n_rows)
+    b[0], b[-1] = 0, n_rows
+    return np.maximum.accumulate(b)
+
+
+def selfjoin_form_wanted(n_rows: int, world: int) -> bool:
+    """From this size on the self-join form (every pair scored once, mirrored pairs exchanged by one all-gather) beats
+    the one-sided multiply of row blocks; ``SG_DIST_SYM=0|1`` forces it off / on."""
+    import os
+    flag = os.environ.get("SG_DIST_SYM", "")
+    if flag in ("0", "1"):
+        return flag == "1"                     # (forced on even on one rank: the plumbing test)
+    return world > 1 and n_rows >= int(os.environ.get("SG_DIST_SYM_MIN_ROWS", "131072"))
+
+
+def sharded_selfjoin_topn(ops, A_full, post, top_n: int, threshold: float, group=None):
+    """The self-join form across ranks (include/sg_hip.h: sg_selfjoin_range / sg_selfjoin_merge).  Every rank scores
+    the pairs (i, j <= i) of ITS row range on the replicated matrix, keeps its rows' own matches, and publishes the
+    mirrored pairs; ONE all-gather later every rank merges the pairs that point into its range.  Returns the rank's
+    block of the result (rows of its range, in rank order = row order), or None when the form does not apply to the
+    input on some rank (then nothing has been changed and the caller multiplies row blocks)."""
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    n = ops.csr_shape(A_full)[0]
+    bounds = selfjoin_row_ranges(n, world)
+    lo, hi = int(bounds[rank]), int(bounds[rank + 1])
+    part = ops.selfjoin_range(A_full, post, top_n, threshold, lo, hi)
+    ok = torch.tensor([1 if part is not None else 0], dtype=torch.int32, device=ops.device)
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
+    if int(ok.item()) == 0:
+        if part is not None:
+            ops.selfjoin_discard(part)
+        return None
+    pairs_all = torch.cat(all_gather_ragged(ops.selfjoin_pairs(part), group))
+    return ops.selfjoin_merge(part, pairs_all, lo, hi)
 
 
 def gather_topn(ops, res, group=None):
@@ -180,7 +231,7 @@ def distributed_self_join(ops, local_block, top_n: int, threshold: float, group=
     Returns (TopN of the local rows -- columns index the WHOLE column --, fit state)."""
     state, (A_local,) = sharded_tfidf(ops, [local_block], group)
     A_full = replicate_csr(ops, A_local, group)
-    return sharded_topn(ops, A_local, A_full, top_n, threshold, tile_cols), state
+    return sharded_topn(ops, A_local, A_full, top_n, threshold, tile_cols, self_join=True, group=group), state
 
 
 def distributed_match(ops, master_block, duplicates_block, top_n: int, threshold: float, group=None,
@@ -222,6 +273,33 @@ def csr_from_torch(ctx, indptr, indices, data, shape):
     indptr, indices, data = indptr.contiguous(), indices.contiguous(), data.contiguous()
     return ctx.csr_from_device(shape[0], shape[1], nnz, indptr.data_ptr(), indices.data_ptr() if nnz else 0,
                                data.data_ptr() if nnz else 0, dtype, keepalive=(indptr, indices, data))
+
+
+class TopNRows:
+    """The rows [lo, hi) of a device result (a rank's block of the self-join form over row ranges)."""
+
+    def __init__(self, res, lo: int, hi: int):
+        self.res, self.lo, self.hi = res, lo, hi
+        self._keep = None
+
+    def free(self):
+        self.res.free()
+
+    def dims(self):
+        r, s, d, c = self.res.dims()
+        return self.hi - self.lo, s, d, c
+
+    def to_host(self):
+        cols, vals, cnt = self.res.to_host()
+        return cols[self.lo:self.hi], vals[self.lo:self.hi], cnt[self.lo:self.hi]
+
+    def to_scipy(self):
+        import scipy.sparse as sp
+        cols, vals, cnt = self.to_host()
+        indptr = np.zeros(len(cnt) + 1, np.int64)
+        np.cumsum(cnt, out=indptr[1:])
+        mask = np.arange(cols.shape[1], dtype=np.int32)[None, :] < cnt[:, None]
+        return sp.csr_matrix((vals[mask], cols[mask], indptr), shape=(len(cnt), self.res.dims()[3]))
 
 
 class HipOps:
@@ -281,9 +359,40 @@ class HipOps:
     def keep_alive(self, res, *objs):
         res._keep = objs
 
+    # ---- the self-join form over row ranges (sharded_selfjoin_topn)
+    def selfjoin_range(self, A_full, post, top_n, threshold, lo, hi):
+        got = self.ctx.selfjoin_range(A_full, post, top_n, threshold, lo, hi)
+        if got is None:
+            return None
+        res, ptr, n_pairs, words = got
+        return {"res": res, "ptr": ptr, "n": n_pairs, "words": words}
+
+    def selfjoin_pairs(self, part):
+        self._sync()
+        n = part["n"] * part["words"]
+        if n == 0:
+            return torch.zeros(0, dtype=torch.int32, device=self.device)
+        return torch.as_tensor(DeviceTensorView(part["ptr"], n, "<i4"), device=self.device)[:n]
+
+    def selfjoin_discard(self, part):
+        self.ctx.device_free(part["ptr"])
+        part["res"].free()
+
+    def selfjoin_merge(self, part, pairs_all, lo, hi):
+        self._sync()                                  # the gathered list is torch's: ordered before the library reads it
+        words = part["words"]
+        pairs_all = pairs_all.contiguous()
+        self.ctx.selfjoin_merge(part["res"], pairs_all.data_ptr(), pairs_all.numel() // words, words, lo, hi)
+        self.ctx.sync()                               # ... and the library is done with it before torch frees it
+        self.ctx.device_free(part["ptr"])
+        return TopNRows(part["res"], lo, hi)
+
     def topn_tensors(self, res):
         import ctypes as C
         from . import _native as N
+        if isinstance(res, TopNRows):
+            cols, vals, counts = self.topn_tensors(res.res)
+            return cols[res.lo:res.hi], vals[res.lo:res.hi], counts[res.lo:res.hi]
         r, s, d, _ = res.dims()
         pc, pv, pn = C.c_void_p(), C.c_void_p(), C.c_void_p()
         N.check(N.lib().sg_topn_device_ptrs(res.h, C.byref(pc), C.byref(pv), C.byref(pn)))

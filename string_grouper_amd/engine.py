@@ -289,7 +289,7 @@ class DistributedHipEngine(HipEngine):
             return super()._topn_device(A, B, top_n, threshold)      # replicated inputs: every rank does it all
         from . import distributed as D
         right = B.full() if isinstance(B, ShardedMatrix) else B.csr
-        res_local = D.sharded_topn(A._ops, A.csr, right, top_n, threshold)
+        res_local = D.sharded_topn(A._ops, A.csr, right, top_n, threshold, self_join=B is A, group=self.group)
         cols, vals, counts = D.gather_topn(A._ops, res_local, self.group)
         res_local.free()
         return self.ctx.topn_from_host(cols, vals, counts, B.shape[0])

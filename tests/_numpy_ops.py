@@ -108,5 +108,56 @@ class NumpyOps:
     def keep_alive(self, res, *objs):
         pass
 
+    # ---- the self-join form over row ranges: the contract of sg_selfjoin_range / sg_selfjoin_merge restated with the
+    #      oracle's multiply (rows of the range keep their matches j <= i; mirrored pairs (i, j < i, score) go out)
+    def selfjoin_range(self, A_full, post, top_n, threshold, lo, hi):
+        n = A_full.shape[0]
+        C = P.sp_matmul_topn_port(A_full[lo:hi], A_full.T, n, threshold, True, 2)      # every match of the rows
+        stride = max(1, min(top_n, n))
+        cols = np.zeros((n, stride), np.int32)
+        vals = np.zeros((n, stride), self.dtype)
+        cnt = np.zeros(n, np.int32)
+        pairs = []
+        for r in range(hi - lo):
+            i = lo + r
+            a, b = C.indptr[r], C.indptr[r + 1]
+            j, sc = C.indices[a:b], C.data[a:b]
+            own = j <= i                                    # port order: score descending, column ascending
+            k = min(int(own.sum()), stride)
+            cols[i, :k] = j[own][:k]
+            vals[i, :k] = sc[own][:k]
+            cnt[i] = k
+            for jj, ss in zip(j[j < i], sc[j < i]):
+                pairs.append((i, int(jj), ss))
+        words = 4 if np.dtype(self.dtype) == np.float64 else 3
+        flat = np.zeros((len(pairs), words), np.int32)
+        for p, (i, jj, ss) in enumerate(pairs):
+            flat[p, 0], flat[p, 1] = i, jj
+            flat[p, 2:] = np.frombuffer(np.asarray([ss], self.dtype).tobytes(), np.int32)
+        return {"res": (cols, vals, cnt), "pairs": torch.from_numpy(flat.reshape(-1)), "words": words, "top_n": stride}
+
+    def selfjoin_pairs(self, part):
+        return part["pairs"]
+
+    def selfjoin_discard(self, part):
+        pass
+
+    def selfjoin_merge(self, part, pairs_all, lo, hi):
+        cols, vals, cnt = part["res"]
+        words, stride = part["words"], part["top_n"]
+        rec = pairs_all.numpy().reshape(-1, words)
+        scores = np.frombuffer(np.ascontiguousarray(rec[:, 2:]).tobytes(), self.dtype)
+        for row in range(lo, hi):
+            mine = np.flatnonzero(rec[:, 1] == row)
+            if len(mine) == 0:
+                continue
+            c = np.concatenate([cols[row, :cnt[row]], rec[mine, 0]])
+            v = np.concatenate([vals[row, :cnt[row]], scores[mine]])
+            order = np.lexsort((c, -v))[:stride]
+            cnt[row] = len(order)
+            cols[row, :len(order)] = c[order]
+            vals[row, :len(order)] = v[order]
+        return cols[lo:hi], vals[lo:hi], cnt[lo:hi]
+
     def topn_tensors(self, res):
         return torch.from_numpy(res[0]), torch.from_numpy(res[1]), torch.from_numpy(res[2])

@@ -122,6 +122,23 @@ def _sharded_worker(rank, world, port, ret):
         full = D.replicate_csr(ops, ops.transform(state, names[lo:hi]))
         ok["replicated_matrix"] = (np.array_equal(full.indptr, A.indptr) and np.array_equal(full.indices, A.indices)
                                    and np.array_equal(full.data, A.data))
+        # ---- the same self-join in its form over row ranges: every rank scores the pairs (i, j <= i) of its range, the
+        #      mirrored pairs are all-gathered, every rank merges those that point into its range (SG_DIST_SYM=1 forces
+        #      the form at this size); hubs of duplicates make rows whose top-n is cut inside the merge
+        os.environ["SG_DIST_SYM"] = "1"
+        hubs = names + [names[5]] * 40 + [names[9] + " INC"] * 25
+        lo2, hi2 = D.row_block(rank, world, len(hubs))
+        res, _ = D.distributed_self_join(ops, hubs[lo2:hi2], 10, 0.8)
+        os.environ["SG_DIST_SYM"] = "0"
+        bounds = D.selfjoin_row_ranges(len(hubs), world)
+        ok["ranges_cover"] = bounds[0] == 0 and bounds[-1] == len(hubs) and bool(np.all(np.diff(bounds) > 0))
+        ok["range_block_is_mine"] = len(res[2]) == int(bounds[rank + 1] - bounds[rank])
+        cols, vals, counts = D.gather_topn(ops, res)
+        _, _, C = _expected(hubs, None, 10, 0.8, np.float32)
+        got = _csr_of(cols, vals, counts, len(hubs))
+        ok["ranges_counts"] = np.array_equal(np.diff(got.indptr), np.diff(C.indptr))
+        ok["ranges_indices"] = np.array_equal(got.indices, C.indices)
+        ok["ranges_scores"] = np.array_equal(got.data, C.data)
         # ---- master x duplicates (configs[4]): both columns sharded, vocabulary from both, duplicates replicated
         master = synth_names(1800, 7)
         dups = synth_names(901, 8, perturb_of=master, perturb_frac=0.5)

@@ -514,6 +514,17 @@ def test_device_resident_inputs_and_rccl_plumbing(ctx):
         np.testing.assert_array_equal(vec3.idf_, O.tfidf_sklearn(names, [names], dtype=np.float32)[2])
         cols, vals, counts = D.gather_topn(ops, res3)
         assert counts.tolist() == np.diff(C_ref.indptr).tolist()
+        # the self-join form over row ranges, forced on the one rank: range = everything, the pair list goes through the
+        # (1-rank) all-gather and comes back for the merge
+        os.environ["SG_DIST_SYM"] = "1"
+        try:
+            res5, _ = D.distributed_self_join(ops, block, 10, 0.8)
+            assert isinstance(res5, D.TopNRows) and ctx.stats()["prune_symmetric"] == 1
+            assert_csr_identical(res5.to_scipy(), C_ref)
+            c5, v5, n5 = D.gather_topn(ops, res5)
+            assert n5.tolist() == np.diff(C_ref.indptr).tolist()
+        finally:
+            os.environ["SG_DIST_SYM"] = "0"
         ipg, ixg, dg, shp = D.all_gather_csr(*D.csr_as_torch(A), A.dims()[1])     # the collective form, explicitly
         A3 = ops.csr_from_tensors(ipg, ixg, dg, shp)
         assert_csr_identical(A3.to_scipy(), sp.csr_matrix(A_ref))
@@ -900,6 +911,48 @@ def test_pruned_multiply_rows_beyond_64_terms(ctx, monkeypatch):
     assert out["sym"][1]["prune_symmetric"] == 0          # a row for the exact kernel: the self-join form stands down
     assert_csr_identical(out["1"][0], out["0"][0])
     assert_csr_identical(out["1"][0], P.sp_matmul_topn_port(A, A.T, 5, 0.6, True, 8))
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_selfjoin_form_over_row_ranges_equals_the_whole(ctx, dtype):
+    """The multi-GPU form of the self-join (sg_selfjoin_range / sg_selfjoin_merge) with the ranks played one after the
+    other on this GPU: every range scores its pairs (i, j <= i), the pair lists are concatenated, every range merges
+    the pairs that point into it -- the rows put together must equal the one-GPU result and the port, bit for bit, for
+    one, two, three and five ranges (hubs of duplicates: rows whose top-n is cut inside the merge; rows of 65 .. 128
+    terms: the wide launch inside a range)."""
+    import torch
+    from string_grouper_amd import distributed as D
+    from string_grouper_amd.vectorizer import HipTfidfVectorizer
+    base = list(_names(9000, 21))
+    rng = np.random.default_rng(4)
+    wide = [" ".join(rng.choice(base, 5)) for _ in range(60)]
+    names = base + [base[3]] * 150 + wide + [base[11] + " CO"] * 90 + [w + " X" for w in wide[:20]]
+    A = _tfidf(names, dtype)
+    assert int((np.diff(A.indptr) > 64).sum()) > 20
+    dA = ctx.csr_from_scipy(A)
+    post = ctx.postings_build(dA)
+    want = P.sp_matmul_topn_port(A, A.T, 10, 0.75, True, 8)
+    ops = D.HipOps(ctx, lambda: HipTfidfVectorizer(dtype=dtype, ctx=ctx))
+    n = len(names)
+    for world in (1, 2, 3, 5):
+        bounds = D.selfjoin_row_ranges(n, world)
+        assert bounds[0] == 0 and bounds[-1] == n
+        parts = [ops.selfjoin_range(dA, post, 10, 0.75, int(bounds[r]), int(bounds[r + 1])) for r in range(world)]
+        assert all(p is not None for p in parts)
+        pairs_all = torch.cat([ops.selfjoin_pairs(p).clone() for p in parts])
+        assert pairs_all.numel() % parts[0]["words"] == 0 and pairs_all.numel() > 0
+        rows = []
+        for r in range(world):
+            blk = ops.selfjoin_merge(parts[r], pairs_all, int(bounds[r]), int(bounds[r + 1]))
+            rows.append(blk.to_scipy())
+            blk.free()
+        assert_csr_identical(sp.vstack(rows).tocsr(), want, f"{world} ranges")
+    # a range the form cannot take (a row for the exact kernel) says so and changes nothing
+    long_names = names + ["".join(rng.choice(list("ABCDEFGHIJKLMNOPQRSTUVWXYZ"), 180)) for _ in range(3)]
+    dL = ctx.csr_from_scipy(_tfidf(long_names, dtype))
+    postL = ctx.postings_build(dL)
+    assert ops.selfjoin_range(dL, postL, 10, 0.75, 0, len(long_names)) is None
+    postL.free(); dL.free(); post.free(); dA.free()
 
 
 def test_selfjoin_form_with_a_pair_list_that_is_too_small_falls_back(ctx, monkeypatch):
