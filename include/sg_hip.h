@@ -219,8 +219,9 @@ int sg_row_costs(sg_ctx *ctx, const sg_csr *A, const sg_postings *Bt, int64_t *o
  *   other rows are empty); *d_pairs: the mirrored pairs -- that row i of the range matches row j < i, which may belong
  *   to another rank -- as *n_pairs records of *pair_words int32 words: {i, j, score bits} (f32) or {i, j, lo, hi} (f64);
  *   device memory owned by the library (sg_device_free).  *applicable == 0: the form cannot take this input (not
- *   cosine-like, top_n > 64, threshold too low, a row for the exact kernel, pair list full): nothing is returned and
- *   the caller uses sg_spgemm_topn on its rows.  All ranks must take the same branch.
+ *   cosine-like, top_n > 64, threshold too low, pair list full): nothing is returned and the caller uses
+ *   sg_spgemm_topn on its rows.  All ranks must take the same branch.  (Rows the pruned kernel cannot take -- more
+ *   than 128 non-zeros -- are scored by the exact kernel inside the same pass; they do not switch the form off.)
  * sg_selfjoin_merge: the pairs of ALL ranks, concatenated in any order, merged into the rows [row_lo, row_hi) of
  *   `res`: afterwards these rows equal the rows sg_spgemm_topn(A, Bt) would give, bit for bit. */
 int sg_selfjoin_range(sg_ctx *ctx, const sg_csr *A, const sg_postings *Bt, int32_t top_n, double threshold,

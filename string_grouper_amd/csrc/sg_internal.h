@@ -201,6 +201,28 @@ int sg_spgemm_pruned_symmetric(sg_ctx *ctx, const sg_csr *A, const sg_postings *
                                int64_t *export_n = nullptr);
 int sg_selfjoin_merge_pairs(sg_ctx *ctx, sg_topn *r, const int32_t *d_pairs, int64_t n_pairs, int64_t row_lo, int64_t row_hi);
 
+// The pair list of the self-join form: the MIRRORED pairs (i, j < i, score) above the threshold, in chunks of
+// SG_PAIR_CHUNK entries that a wave owns while it fills them (one returning atomic per chunk).  Written by the pruned
+// kernel and -- for the rows that kernel cannot take -- by the exact kernel's self-join launch (sg_spgemm_topn.hip).
+#define SG_PAIR_CHUNK 256u
+#define SG_PAIR_NO_CHUNK 0xFFFFFFFFu
+struct SgPairSink {
+    uint32_t *d_i = nullptr;
+    uint32_t *d_j = nullptr;
+    void *d_s = nullptr;
+    uint32_t *d_row_count = nullptr;           // mirrored matches per row (counted as the pairs are written)
+    uint32_t *d_chunk_count = nullptr;         // entries used of every chunk
+    uint32_t *d_chunks_used = nullptr;         // chunks handed out
+    unsigned long long *d_totals = nullptr;    // pairs in closed chunks
+    uint32_t chunks = 0;
+};
+// sg_spgemm_topn.hip: the rows of `row_list` (device-side length) through the exact kernel in its self-join form --
+// a row keeps its matches j <= i and appends the mirrored pairs to the sink, exactly as the pruned kernel's rows do.
+unsigned sg_spgemm_exact_selfjoin_grid(const sg_ctx *ctx);
+int sg_spgemm_exact_selfjoin_rows(sg_ctx *ctx, const sg_csr *A, const sg_postings *Bt, int32_t keep, sg_topn *r,
+                                  double threshold, uint32_t *row_counter, const uint32_t *row_list,
+                                  const uint32_t *row_list_len, const SgPairSink &sink);
+
 // sg_sortvocab.hip: ascending distinct values of d_keys[0 .. n) and how often each occurs (d_keys is overwritten)
 int sg_sort_unique_u64(sg_ctx *ctx, uint64_t *d_keys, int64_t n, uint64_t *d_unique, int32_t *d_counts, int64_t *n_unique);
 

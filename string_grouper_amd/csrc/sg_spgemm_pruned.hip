@@ -57,12 +57,11 @@
 // value hash (for the exact scoring) and the survivor buffer: 10 KiB -> 16 waves per CU.
 // Rows with 65 .. 128 non-zeros are appended to a list and taken by a second launch of the same kernel that stages two
 // terms per lane (WIDE); what that one cannot take either (more than 128 non-zeros, more than 64 prefix terms) goes to
-// K4 (in symmetric mode the presence of such a row makes the caller fall back to the one-sided form).
+// K4 (in symmetric mode: to K4's self-join launch, spgemm_topn_selfjoin_rows_kernel, inside the same pass).
 #define SG_WATCH_NAME sg_debug_watch_pruned
 #include "sg_k4_device.h"
 
-#define SG_PAIR_CHUNK 256u            // entries of a chunk of the symmetric mode's pair list
-#define SG_PAIR_NO_CHUNK 0xFFFFFFFFu
+// (SG_PAIR_CHUNK, the entries of a chunk of the symmetric mode's pair list: sg_internal.h)
 #define SG_SURV_CAP 128   // survivors buffered per wave (scored 64 at a time as soon as 64 are there)
 
 // lane mask of a predicate as a wave-uniform scalar (s_and of the compare result, no VALU round trip)
@@ -1021,10 +1020,11 @@ int sg_spgemm_pruned_launch(sg_ctx *ctx, const sg_csr *A, const sg_postings *Bt,
                                          flagged_rows, stats, none);
 }
 
-// Self-join form: pass 1 (the pruned kernel over the pairs j <= i) + the decision whether its pair list is
-// complete (one host round trip: pair count, rows the kernel could not handle) + pass 2 (lists, top-n).
-// *done == false: nothing usable was produced (too many pairs for the list, or rows for the exact kernel) and
-// the caller runs the one-sided form; the result object and the statistics words are untouched then.
+// Self-join form: pass 1 (the pruned kernel over the pairs j <= i, then the exact kernel's self-join launch over the
+// rows the pruned kernel passed on) + the decision whether the pair list is complete (one host round trip: pair
+// count, chunks handed out) + pass 2 (lists, top-n).
+// *done == false: nothing usable was produced (too many pairs for the list) and the caller runs the one-sided
+// form; the statistics words are untouched then (the result rows are overwritten by that form).
 int sg_spgemm_pruned_symmetric(sg_ctx *ctx, const sg_csr *A, const sg_postings *Bt, int32_t keep, sg_topn *r,
                                double threshold, double delta, unsigned long long *stats, bool *done, int64_t row_lo,
                                int64_t row_hi, int32_t **export_pairs, int64_t *export_n) {
@@ -1046,10 +1046,12 @@ int sg_spgemm_pruned_symmetric(sg_ctx *ctx, const sg_csr *A, const sg_postings *
     if (cap >= ((int64_t)1 << 31)) cap = ((int64_t)1 << 31) - 1;   // list offsets are 32-bit
     // every wave of the kernel holds one open chunk: count those in
     pl.chunks = (uint32_t)(cap / SG_PAIR_CHUNK);
-    if (!cap_forced) pl.chunks += pruned_grid(ctx, Bt->tile_log2, n) + (uint32_t)ctx->num_cu * 4u;
+    if (!cap_forced) pl.chunks += pruned_grid(ctx, Bt->tile_log2, n) + (uint32_t)ctx->num_cu * 4u + sg_spgemm_exact_selfjoin_grid(ctx);
     if (pl.chunks < 1) pl.chunks = 1;
     cap = (int64_t)pl.chunks * SG_PAIR_CHUNK;
-    uint32_t *words = nullptr;   // [0] row counter [1] flagged count [2..3] pairs [4] chunks handed out; [8 ..) entries per chunk
+    // [0] row counter [1] flagged count [2..3] pairs [4] chunks handed out [5] row counter of the exact kernel's launch;
+    // [8 ..) entries per chunk
+    uint32_t *words = nullptr;
     uint32_t *cnt = nullptr, *cursor = nullptr;
     int32_t *lcol = nullptr;
     void *lval = nullptr;
@@ -1100,6 +1102,21 @@ int sg_spgemm_pruned_symmetric(sg_ctx *ctx, const sg_csr *A, const sg_postings *
         else
             st = dispatch_pruned<float, true>(ctx, A, Bt, keep, r, (float)threshold, s_budget, words, words + 1, flagged_rows,
                                               d_stats3, pl);
+        // the rows neither launch of the pruned kernel could take (more than 128 non-zeros, more than 64 prefix terms, no
+        // room for the fixed-point filter): through the exact kernel, in the same form -- pairs (i, j <= i), mirrored ones
+        // into the pair list.  Launched on the device-side count: without such rows its waves leave at once.
+        if (st == SG_OK) {
+            SgPairSink sink;
+            sink.d_i = pl.d_i;
+            sink.d_j = pl.d_j;
+            sink.d_s = pl.d_s;
+            sink.d_row_count = pl.d_row_count;
+            sink.d_chunk_count = pl.d_chunk_count;
+            sink.d_chunks_used = pl.d_chunks_used;
+            sink.d_totals = pl.d_totals;
+            sink.chunks = pl.chunks;
+            st = sg_spgemm_exact_selfjoin_rows(ctx, A, Bt, keep, r, threshold, words + 5, flagged_rows, words + 1, sink);
+        }
     }
     if (st == SG_OK) {
         // h[0] = {row counter, flagged}, h[1] = pairs, h[2] = chunks handed out
@@ -1115,10 +1132,9 @@ int sg_spgemm_pruned_symmetric(sg_ctx *ctx, const sg_csr *A, const sg_postings *
         cleanup();
         return st;
     }
-    const uint32_t flagged = (uint32_t)(h[0] >> 32);
     const unsigned long long n_pairs = h[1];
     const uint32_t chunks_used = (uint32_t)h[2];
-    if (flagged != 0 || chunks_used > pl.chunks) {
+    if (chunks_used > pl.chunks) {   // more pairs than the list holds (hubs of thousands of identical names)
         ctx->release(d_stats3);
         cleanup();
         return SG_OK;   // *done stays false
@@ -1142,8 +1158,9 @@ int sg_spgemm_pruned_symmetric(sg_ctx *ctx, const sg_csr *A, const sg_postings *
                                    (const float *)pl.d_s, pl.d_chunk_count, chunk_start, flat);
             if (hipGetLastError() != hipSuccess) st = SG_ERR_HIP;
         }
-        if (st == SG_OK && hipMemcpyAsync(stats, d_stats3, 3 * sizeof(unsigned long long), hipMemcpyDeviceToDevice,
-                                          ctx->stream) != hipSuccess)
+        if (st == SG_OK && (hipMemcpyAsync(stats, d_stats3, 3 * sizeof(unsigned long long), hipMemcpyDeviceToDevice,
+                                           ctx->stream) != hipSuccess ||
+                            hipMemcpyAsync(stats + 3, words + 1, 4, hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess))
             st = SG_ERR_HIP;
         ctx->release(chunk_start);
         ctx->release(d_stats3);
@@ -1176,9 +1193,10 @@ int sg_spgemm_pruned_symmetric(sg_ctx *ctx, const sg_csr *A, const sg_postings *
                                (uint32_t)n, keep, r->stride, r->d_cols, (float *)r->d_vals, r->d_counts);
         }
         if (hipGetLastError() != hipSuccess) st = SG_ERR_HIP;
-        // the statistics of the pass that counted
-        if (st == SG_OK && hipMemcpyAsync(stats, d_stats3, 3 * sizeof(unsigned long long), hipMemcpyDeviceToDevice,
-                                          ctx->stream) != hipSuccess)
+        // the statistics of the pass that counted ([3]: rows that went through the exact kernel)
+        if (st == SG_OK && (hipMemcpyAsync(stats, d_stats3, 3 * sizeof(unsigned long long), hipMemcpyDeviceToDevice,
+                                           ctx->stream) != hipSuccess ||
+                            hipMemcpyAsync(stats + 3, words + 1, 4, hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess))
             st = SG_ERR_HIP;
     }
     ctx->release(d_stats3);

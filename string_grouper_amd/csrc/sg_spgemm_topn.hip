@@ -152,15 +152,45 @@ __device__ __forceinline__ void segment_batch(T *acc, const char *vals, const ch
     }
 }
 
-template <typename T, int TILE_LOG2, int NB>
+// Self-join launch (SELF): one mirrored pair (row, j < row, s) into the wave's chunk of the pair list -- the protocol of
+// the pruned kernel's drain_survivors (sg_spgemm_pruned.hip); all arguments are wave-uniform, `pos` = chunk << 9 |
+// entries used is the wave's state.
+template <typename T>
+__device__ __forceinline__ void emit_mirrored_pair(const SgPairSink &sk, uint32_t &pos, uint32_t row, uint32_t j, T s, int lane) {
+    if (pos == SG_PAIR_NO_CHUNK || (pos & 511u) >= SG_PAIR_CHUNK) {
+        uint32_t c = 0;
+        if (lane == 0) {
+            if (pos != SG_PAIR_NO_CHUNK && (pos >> 9) < sk.chunks) {
+                sk.d_chunk_count[pos >> 9] = pos & 511u;
+                atomicAdd(sk.d_totals, (unsigned long long)(pos & 511u));
+            }
+            c = atomicAdd(sk.d_chunks_used, 1u);
+        }
+        pos = (uint32_t)__builtin_amdgcn_readfirstlane((int)c) << 9;
+    }
+    if (lane == 0 && (pos >> 9) < sk.chunks) {   // past the capacity nothing is written: the caller falls back
+        const size_t o = (size_t)(pos >> 9) * SG_PAIR_CHUNK + (pos & 511u);
+        sk.d_i[o] = row;
+        sk.d_j[o] = j;
+        reinterpret_cast<T *>(sk.d_s)[o] = s;
+        atomicAdd(&sk.d_row_count[j], 1u);
+    }
+    pos += 1u;
+}
+
+// SELF: the row scores the columns j <= row only (the tiles up to its own), keeps those matches and hands the
+// mirrored pairs to `sink` -- the exact kernel standing in for the pruned one inside the self-join form.
+template <typename T, int TILE_LOG2, int NB, bool SELF = false>
 __device__ __forceinline__ void process_row(T *acc, uint32_t row, const int64_t *__restrict__ a_indptr,
                                             const int32_t *__restrict__ a_indices, const T *__restrict__ a_data,
                                             const uint32_t *__restrict__ seg, const int32_t *__restrict__ post_rows,
                                             const T *__restrict__ post_vals, int32_t n_tiles, int32_t tile_begin,
                                             int32_t tile_end, int32_t keep, int32_t pass_off, int32_t out_stride, T thr,
                                             int32_t *__restrict__ out_cols, T *__restrict__ out_vals,
-                                            int32_t *__restrict__ out_cnt, int lane) {
+                                            int32_t *__restrict__ out_cnt, int lane, const SgPairSink *sink = nullptr,
+                                            uint32_t *pair_pos = nullptr) {
     constexpr int TILE = 1 << TILE_LOG2;
+    if (SELF) tile_end = min(tile_end, (int32_t)(row >> TILE_LOG2) + 1);
     constexpr int VEC = 16 / sizeof(T);   // values per 16-byte LDS access
     typedef T vec_t __attribute__((ext_vector_type(VEC)));
     vec_t *acc_v = reinterpret_cast<vec_t *>(acc);
@@ -268,6 +298,10 @@ __device__ __forceinline__ void process_row(T *acc, uint32_t row, const int64_t 
                                     hm &= hm - 1;
                                     const T ns = wave_read<T>(v[e], src);
                                     const int nc = col_base + (x0 + src) * VEC + e;
+                                    if (SELF) {
+                                        if ((uint32_t)nc > row) continue;   // the pair (i, j > i) is row j's to score
+                                        if ((uint32_t)nc < row) emit_mirrored_pair<T>(*sink, *pair_pos, row, (uint32_t)nc, ns, lane);
+                                    }
                                     if (ns < floor_s || (ns == floor_s && nc > floor_c)) top.insert(ns, nc, lane);
                                 }
                             }
@@ -315,6 +349,44 @@ spgemm_topn_kernel(const int64_t *__restrict__ a_indptr, const int32_t *__restri
         process_row<T, TILE_LOG2, NB>(acc, row, a_indptr, a_indices, a_data, seg, post_rows, post_vals, n_tiles,
                                       tile_begin, tile_end, keep, pass_off, out_stride, thr, out_cols, out_vals,
                                       out_cnt, lane);
+    }
+}
+
+// The exact kernel inside the self-join form (sg_spgemm_pruned.hip, symmetric mode): the rows the pruned kernel
+// cannot take -- more than 128 non-zeros, more than 64 prefix terms, no room for the fixed-point filter -- arrive as a
+// list; each scores its pairs (i, j <= i) exactly over the tiles up to its own and appends the mirrored ones to the
+// pair list like every other row of the pass.  (Before this launch existed one such row sent the whole multiply back
+// to the one-sided form: twice the time at 663 k rows.)
+template <typename T, int TILE_LOG2, int NB>
+__global__ void __launch_bounds__(64)
+spgemm_topn_selfjoin_rows_kernel(const int64_t *__restrict__ a_indptr, const int32_t *__restrict__ a_indices,
+                                 const T *__restrict__ a_data, const uint32_t *__restrict__ seg,
+                                 const int32_t *__restrict__ post_rows, const T *__restrict__ post_vals, int32_t n_tiles,
+                                 int32_t keep, int32_t out_stride, T thr, int32_t *__restrict__ out_cols,
+                                 T *__restrict__ out_vals, int32_t *__restrict__ out_cnt, uint32_t *row_counter,
+                                 const uint32_t *__restrict__ row_list, const uint32_t *__restrict__ row_list_len,
+                                 SgPairSink sink) {
+    constexpr int TILE = 1 << TILE_LOG2;
+    constexpr int VEC = 16 / sizeof(T);
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    T *acc = reinterpret_cast<T *>(smem);
+    const int lane = threadIdx.x;
+    typedef T vec_t __attribute__((ext_vector_type(VEC)));
+    vec_t *acc_v = reinterpret_cast<vec_t *>(acc);
+    const uint32_t n_rows = (uint32_t)__builtin_amdgcn_readfirstlane((int)row_list_len[0]);
+    if (blockIdx.x >= n_rows) return;   // (usually there is no such row at all)
+    for (int x = lane; x < TILE / VEC; x += 64) acc_v[x] = (vec_t)(T)0;
+    uint32_t pos = SG_PAIR_NO_CHUNK;
+    SG_WD_DECL(wd_rows);
+    for (uint32_t idx = next_row(row_counter, lane); idx < n_rows; idx = next_row(row_counter, lane)) {
+        SG_WD(wd_rows, n_rows + 2, 1)
+        const uint32_t row = (uint32_t)__builtin_amdgcn_readfirstlane((int)row_list[idx]);
+        process_row<T, TILE_LOG2, NB, true>(acc, row, a_indptr, a_indices, a_data, seg, post_rows, post_vals, n_tiles, 0,
+                                            n_tiles, keep, 0, out_stride, thr, out_cols, out_vals, out_cnt, lane, &sink, &pos);
+    }
+    if (lane == 0 && pos != SG_PAIR_NO_CHUNK && (pos >> 9) < sink.chunks) {   // close the wave's last chunk
+        sink.d_chunk_count[pos >> 9] = pos & 511u;
+        atomicAdd(sink.d_totals, (unsigned long long)(pos & 511u));
     }
 }
 
@@ -514,6 +586,52 @@ static int dispatch_spgemm(sg_ctx *ctx, const sg_csr *A, const sg_postings *Bt, 
     }
 }
 
+// ---- the exact kernel's self-join launch over a device-side row list (see spgemm_topn_selfjoin_rows_kernel)
+unsigned sg_spgemm_exact_selfjoin_grid(const sg_ctx *ctx) { return (unsigned)ctx->num_cu * 2u; }
+
+template <typename T, int TILE_LOG2>
+static int launch_selfjoin_rows(sg_ctx *ctx, const sg_csr *A, const sg_postings *Bt, int32_t keep, sg_topn *r, T thr,
+                                uint32_t *row_counter, const uint32_t *row_list, const uint32_t *row_list_len,
+                                const SgPairSink &sink) {
+    const size_t lds = sizeof(T) << TILE_LOG2;
+    auto kern = spgemm_topn_selfjoin_rows_kernel<T, TILE_LOG2, 8>;
+    if (lds > 48 * 1024) {
+        static bool done = false;   // per instantiation
+        if (!done) {
+            SG_HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            done = true;
+        }
+    }
+    hipLaunchKernelGGL(kern, dim3(sg_spgemm_exact_selfjoin_grid(ctx)), dim3(64), lds, ctx->stream, A->d_indptr, A->d_indices,
+                       (const T *)A->d_data, (const uint32_t *)Bt->d_seg, (const int32_t *)Bt->d_rows, (const T *)Bt->d_vals,
+                       Bt->n_tiles, keep, r->stride, thr, r->d_cols, (T *)r->d_vals, r->d_counts, row_counter, row_list,
+                       row_list_len, sink);
+    SG_HIP_TRY(hipGetLastError());
+    return SG_OK;
+}
+
+template <typename T>
+static int dispatch_selfjoin_rows(sg_ctx *ctx, const sg_csr *A, const sg_postings *Bt, int32_t keep, sg_topn *r, T thr,
+                                  uint32_t *row_counter, const uint32_t *row_list, const uint32_t *row_list_len,
+                                  const SgPairSink &sink) {
+    switch (Bt->tile_log2) {
+        case 11: return launch_selfjoin_rows<T, 11>(ctx, A, Bt, keep, r, thr, row_counter, row_list, row_list_len, sink);
+        case 12: return launch_selfjoin_rows<T, 12>(ctx, A, Bt, keep, r, thr, row_counter, row_list, row_list_len, sink);
+        case 13: return launch_selfjoin_rows<T, 13>(ctx, A, Bt, keep, r, thr, row_counter, row_list, row_list_len, sink);
+        default:
+            sg_set_error("postings tile of 2^%d columns is not supported by the self-join form (2^11..2^13)", Bt->tile_log2);
+            return SG_ERR_UNSUPPORTED;
+    }
+}
+
+int sg_spgemm_exact_selfjoin_rows(sg_ctx *ctx, const sg_csr *A, const sg_postings *Bt, int32_t keep, sg_topn *r,
+                                  double threshold, uint32_t *row_counter, const uint32_t *row_list,
+                                  const uint32_t *row_list_len, const SgPairSink &sink) {
+    if (A->dtype == SG_F64)
+        return dispatch_selfjoin_rows<double>(ctx, A, Bt, keep, r, (double)threshold, row_counter, row_list, row_list_len, sink);
+    return dispatch_selfjoin_rows<float>(ctx, A, Bt, keep, r, (float)threshold, row_counter, row_list, row_list_len, sink);
+}
+
 static int topn_alloc(sg_ctx *ctx, int64_t n_rows, int64_t n_cols, int32_t stride, int32_t dtype, sg_topn **out) {
     sg_topn *r = new (std::nothrow) sg_topn();
     if (!r) return SG_ERR_OOM;
@@ -611,14 +729,15 @@ static bool pruned_applicable(sg_ctx *ctx, const sg_csr *A, const sg_postings *B
     uint32_t a_max_nnz = 0;
     *status = sg_csr_props(ctx, A, &a_ok, &a_n2, &a_max_nnz);
     if (*status != SG_OK || !a_ok) return false;
-    // self-join (A is the matrix the postings were built from) whose rows all fit the pruned kernel:
-    // score every pair once, from the row with the larger index (sg_spgemm_pruned.hip, symmetric mode)
+    // self-join (A is the matrix the postings were built from): score every pair once, from the row with the larger
+    // index (sg_spgemm_pruned.hip, symmetric mode; rows the pruned kernel cannot take go through the exact kernel's
+    // self-join launch inside the same pass)
     const char *sy = getenv("SG_SYM");
     // ... from the size at which halving the (row, tile) visits outweighs the second pass over the pair list
     // and its host round trip: 0.58 vs 0.57 ms at 50 k rows, 0.95 vs 1.20 at 100 k, 14.0 vs 26.8 at 663 k
     // (profiles/r02_sessionM_sym_sweep.log)
     *symmetric = !(sy && sy[0] == '0') && A->n_rows == Bt->n_right && A->d_indptr == Bt->b_indptr &&
-                 A->d_indices == Bt->b_indices && A->d_data == Bt->b_data && a_max_nnz <= 128 &&
+                 A->d_indices == Bt->b_indices && A->d_data == Bt->b_data &&
                  (any_size || A->n_rows >= (int64_t)env_int("SG_SYM_MIN_ROWS", 65536) || (sy && sy[0] == '1'));
     return true;
 }
@@ -742,7 +861,7 @@ extern "C" int sg_spgemm_topn(sg_ctx *ctx, const sg_csr *A, const sg_postings *B
             }
         }
         delete exact_timer;   // stop event of the exact kernel's launches
-        if (prune && st == SG_OK &&
+        if (prune && !sym_done && st == SG_OK &&   // (the self-join form has left its own count there)
             hipMemcpyAsync(ctx->d_stat_words + 5, handed_count, 4, hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess)
             st = SG_ERR_HIP;
     }

@@ -891,26 +891,36 @@ def test_pruned_multiply_rows_beyond_64_terms(ctx, monkeypatch):
         C_ref = P.sp_matmul_topn_port(A, A.T, 5, 0.6, True, 8)
         assert_csr_identical(out["1"][0], C_ref, "one-sided with wide rows")
         assert_csr_identical(out["sym"][0], C_ref, "self-join form with wide rows")
-        assert out["sym"][1]["prune_symmetric"] == 1 or out["sym"][1]["exact_rows"] > 0
+        assert out["sym"][1]["prune_symmetric"] == 1
         # without the wide launch the same rows go to the exact kernel: same bits
         monkeypatch.setenv("SG_PRUNE_WIDE", "0")
         out0 = _multiply_both_ways(ctx, dA, dA, 5, 0.6, monkeypatch)
         monkeypatch.delenv("SG_PRUNE_WIDE")
         assert out0["1"][1]["exact_rows"] >= n_wide
         assert_csr_identical(out0["1"][0], C_ref, "wide launch off")
-    # rows beyond 128 terms (random letters: every n-gram distinct) are the exact kernel's
+    # rows beyond 128 terms (random letters: every n-gram distinct) are the exact kernel's -- in the self-join form
+    # through its self-join launch INSIDE the pass (pairs j <= i, mirrored ones into the pair list): such rows match
+    # rows of every kind here, before and behind them (shorter cuts of themselves that the wide launch takes, other
+    # long rows, a hub of copies whose top-n is cut in the merge)
     long_names = ["".join(rng.choice(letters, 150)) for _ in range(40)]
-    names = list(base[:3000]) + long_names + [s[:140] + "X" for s in long_names] + medium[:100]
-    A = _tfidf(names, np.float32)
-    n_long = int((np.diff(A.indptr) > 128).sum())
-    assert n_long >= 70
-    dA = ctx.csr_from_scipy(A)
-    out = _multiply_both_ways(ctx, dA, dA, 5, 0.6, monkeypatch)
-    st = out["1"][1]
-    assert st["exact_rows"] >= n_long and st["prune_rows"] > 0, st
-    assert out["sym"][1]["prune_symmetric"] == 0          # a row for the exact kernel: the self-join form stands down
-    assert_csr_identical(out["1"][0], out["0"][0])
-    assert_csr_identical(out["1"][0], P.sp_matmul_topn_port(A, A.T, 5, 0.6, True, 8))
+    names = (list(base[:1500]) + [s[:125] for s in long_names[:20]] + long_names + [s[:140] + "X" for s in long_names]
+             + [s[:126] for s in long_names[10:30]] + [long_names[5]] * 9 + list(base[1500:3000]) + medium[:100]
+             + [long_names[7][:148]] * 3)
+    for dtype in (np.float32, np.float64):
+        A = _tfidf(names, dtype)
+        n_long = int((np.diff(A.indptr) > 128).sum())
+        assert n_long >= 90
+        dA = ctx.csr_from_scipy(A)
+        for top_n, thr in ((5, 0.6), (10, 0.8)):
+            out = _multiply_both_ways(ctx, dA, dA, top_n, thr, monkeypatch)
+            st = out["1"][1]
+            assert st["exact_rows"] >= n_long and st["prune_rows"] > 0, st
+            sym = out["sym"][1]
+            assert sym["prune_symmetric"] == 1 and sym["exact_rows"] >= n_long, sym   # the form no longer stands down
+            C_ref = P.sp_matmul_topn_port(A, A.T, top_n, thr, True, 8)
+            assert (np.diff(C_ref.indptr)[np.diff(A.indptr) > 128] > 1).sum() >= 80   # the long rows do have matches
+            assert_csr_identical(out["1"][0], C_ref, "one-sided with long rows")
+            assert_csr_identical(out["sym"][0], C_ref, "self-join form with long rows")
 
 
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
@@ -947,11 +957,25 @@ def test_selfjoin_form_over_row_ranges_equals_the_whole(ctx, dtype):
             rows.append(blk.to_scipy())
             blk.free()
         assert_csr_identical(sp.vstack(rows).tocsr(), want, f"{world} ranges")
-    # a range the form cannot take (a row for the exact kernel) says so and changes nothing
-    long_names = names + ["".join(rng.choice(list("ABCDEFGHIJKLMNOPQRSTUVWXYZ"), 180)) for _ in range(3)]
-    dL = ctx.csr_from_scipy(_tfidf(long_names, dtype))
+    # rows for the exact kernel (more than 128 terms) are scored inside the range's pass by that kernel's self-join launch
+    extra = ["".join(rng.choice(list("ABCDEFGHIJKLMNOPQRSTUVWXYZ"), 180)) for _ in range(3)]
+    long_names = names[:4000] + extra + names[4000:] + [extra[1][:170], extra[2]]
+    AL = _tfidf(long_names, dtype)
+    dL = ctx.csr_from_scipy(AL)
     postL = ctx.postings_build(dL)
-    assert ops.selfjoin_range(dL, postL, 10, 0.75, 0, len(long_names)) is None
+    wantL = P.sp_matmul_topn_port(AL, AL.T, 10, 0.75, True, 8)
+    nL = len(long_names)
+    for world in (1, 3):
+        bounds = D.selfjoin_row_ranges(nL, world)
+        parts = [ops.selfjoin_range(dL, postL, 10, 0.75, int(bounds[r]), int(bounds[r + 1])) for r in range(world)]
+        assert all(p is not None for p in parts)
+        pairs_all = torch.cat([ops.selfjoin_pairs(p).clone() for p in parts])
+        rows = []
+        for r in range(world):
+            blk = ops.selfjoin_merge(parts[r], pairs_all, int(bounds[r]), int(bounds[r + 1]))
+            rows.append(blk.to_scipy())
+            blk.free()
+        assert_csr_identical(sp.vstack(rows).tocsr(), wantL, f"{world} ranges with rows for the exact kernel")
     postL.free(); dL.free(); post.free(); dA.free()
 
 
