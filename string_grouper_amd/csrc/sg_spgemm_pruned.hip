@@ -232,9 +232,7 @@ __device__ __noinline__ TopList<T> drain_survivors(int nnz, const uint32_t *fwd_
 
 // WIDE: the second launch, over the rows the first one could not take because they have 65 .. 128 non-zeros: every lane
 // stages two of the row's terms; still one posting list per lane, so the row's prefix P must fit 64 lanes.
-// HEAVY: the third launch, over the rows of up to 64 non-zeros whose prefix keeps a term too long for its lanes (see the
-// classifier below and the heavy tile loop): rounds of four slots per tile instead of one.
-template <typename T, int TILE_LOG2, bool SYM, bool WIDE, bool HEAVY = false>
+template <typename T, int TILE_LOG2, bool SYM, bool WIDE>
 __global__ void __launch_bounds__(64, 4)   // 16 single-wave workgroups per CU (the LDS limit) = 4 waves per SIMD: <= 128 VGPRs
 spgemm_topn_pruned_kernel(const int64_t *__restrict__ a_indptr, const int32_t *__restrict__ a_indices,
                           const T *__restrict__ a_data, uint32_t n_left, const uint32_t *__restrict__ seg,
@@ -251,12 +249,7 @@ spgemm_topn_pruned_kernel(const int64_t *__restrict__ a_indptr, const int32_t *_
                           uint32_t pair_chunks /* chunks there are */, uint32_t *pair_chunks_used /* chunks handed out */,
                           unsigned long long *pair_totals /* pairs in closed chunks */,
                           uint32_t sym_lo, uint32_t sym_hi /* SYM: the left rows this launch scores (multi-GPU: a rank's range) */,
-                          const uint32_t *__restrict__ row_list /* WIDE, HEAVY: the rows to process */, const uint32_t *row_list_len,
-                          float heavy_load /* first launch: a row whose fullest term expects more than this share of its
-                                              lanes' four slots per tile goes to the HEAVY launch; <= 0: every row, huge: none */,
-                          uint32_t *heavy_count, uint32_t *heavy_rows) {
-    static_assert(!(WIDE && HEAVY), "the heavy launch takes rows of up to 64 non-zeros");
-    constexpr bool LISTED = WIDE || HEAVY;
+                          const uint32_t *__restrict__ row_list /* WIDE: the rows to process */, const uint32_t *row_list_len) {
     constexpr int TILE = 1 << TILE_LOG2;
     constexpr int SLOTS = WIDE ? 2 : 1;   // row terms staged per lane
     constexpr int AB = TILE_LOG2 + 1;                          // address + half bits of a filter posting
@@ -284,14 +277,14 @@ spgemm_topn_pruned_kernel(const int64_t *__restrict__ a_indptr, const int32_t *_
     };
 
     SG_WD_DECL(wd_rows);
-    const uint32_t n_here = LISTED ? (uint32_t)__builtin_amdgcn_readfirstlane((int)*row_list_len) : (SYM ? sym_hi - sym_lo : n_left);
+    const uint32_t n_here = WIDE ? (uint32_t)__builtin_amdgcn_readfirstlane((int)*row_list_len) : (SYM ? sym_hi - sym_lo : n_left);
     // rows are handed out four at a time: one global atomic per row capped the kernel at ~88 rows/us (larger first
     // helpings were tried -- sixteen rows for the first three quarters -- and changed nothing: profiles/r02_sessionJ6_*.log).
     // Symmetric mode walks the rows from the last to the first: a row's cost grows with its index there.
     for (uint32_t row0 = next_row(row_counter, lane) * 4u; row0 < n_here; row0 = next_row(row_counter, lane) * 4u)
     for (uint32_t rr = row0; rr < min(row0 + 4u, n_here); ++rr) {
         SG_WD(wd_rows, n_left + 2, 11)
-        const uint32_t row = LISTED ? (uint32_t)__builtin_amdgcn_readfirstlane((int)row_list[rr]) : (SYM ? sym_hi - 1u - rr : rr);
+        const uint32_t row = WIDE ? (uint32_t)__builtin_amdgcn_readfirstlane((int)row_list[rr]) : (SYM ? sym_hi - 1u - rr : rr);
         const int64_t rlo = a_indptr[row];
         const int nnz = __builtin_amdgcn_readfirstlane((int)(a_indptr[row + 1] - rlo));
         if (nnz > 64 * SLOTS) {   // more non-zeros than this launch stages: the wide launch, or the exact kernel
@@ -395,19 +388,6 @@ spgemm_topn_pruned_kernel(const int64_t *__restrict__ a_indptr, const int32_t *_
             }
             start[sl] = before_slot + inc - G[sl];
             before_slot += wave_read<uint32_t>(inc, 63);
-        }
-        if (!LISTED && heavy_rows) {
-            // Heavy rows.  The lanes' four slots per tile hold 4 G entries of a term; a term that expects more than that per
-            // tile (its list spread evenly over the column tiles) overflows them in most visits, and every such visit
-            // costs several dependent round trips.  At 663 k names 14 % of the rows are like that -- their prefix keeps a
-            // frequent term the suffix budget had no room for -- and hold four fifths of the overflowing visits
-            // (scripts/k4p_model_stats.py): they are passed on to the HEAVY launch, whose tile loop runs rounds.
-            const bool full = in_p[0] && (float)df[0] > heavy_load * 4.f * (float)G[0] * (float)n_tiles;
-            if (__ballot(full) != 0) {
-                if (lane == 0) heavy_rows[atomicAdd(heavy_count, 1u)] = row;
-                --st_rows;
-                continue;
-            }
         }
         int src = 0, src_slot = 0;
         uint32_t u = 0, g = 0;
@@ -650,108 +630,34 @@ spgemm_topn_pruned_kernel(const int64_t *__restrict__ a_indptr, const int32_t *_
 #endif
         };
 
-        if constexpr (HEAVY) {
-            // The heavy tile loop: a tile takes as many ROUNDS of four slots as its longest segment needs -- in round r lane
-            // u of a term's g lanes owns entries 4g r + 4u .. + 3, one 16-byte load -- and the load of the next step (the
-            // tile's next round, or the next tile's first) is in flight while this one is applied.  A column can receive
-            // postings in several rounds, so a tile is re-zeroed when it ends: the four slots of its only round, or the
-            // whole tile after several.  Everything else -- filter arithmetic, survivor handling -- is the other loop's.
-            const uint32_t *erp = ends + (size_t)erow;
-            const uint32_t last_t = (uint32_t)nt_pad - 1u;
-            const uint32_t list_lo = g ? my_lo << 2 : 0u;
-            uint32_t e0 = erp[0], e1 = erp[min(1u, last_t)], e2 = erp[min(2u, last_t)];   // ends of tiles t, t + 1, t + 2 (bytes)
-            struct __attribute__((packed, aligned(4))) Quad {
-                uint32_t x, y, z, w;
-            };
-            auto fetch = [&](uint32_t at, bool have) {   // a lane without a posting in that step re-reads the start of its list:
-                return *reinterpret_cast<const Quad *>(reinterpret_cast<const char *>(filt) + (have ? at : list_lo));   // `at` may lie past the array
-            };
-            uint32_t t = 0, rounds = 0;
-            uint32_t base = list_lo + u16;
-            int32_t rem = (int32_t)(e0 - base);
-            Quad cur = fetch(base, rem > 0);
-            SG_WD_DECL(wd_t);
-            for (;;) {
-                SG_WD(wd_t, 1 << 24, 13)
-                const int32_t rem_r = rem - (int32_t)G16;
-                const bool more = ballot64(rem_r > 0) != 0;          // another round of this tile
-                const bool last = !more && t + 1u >= t_end;
-                const uint32_t nbase = more ? base + G16 : e0 + u16;
-                const int32_t nrem = more ? rem_r : (int32_t)(e1 - nbase);
-                // both loads of a step are unconditional (after the last step: the start of the list once more, the table's
-                // last entry): under branches the compiler would lose its count of the loads in flight and wait for the
-                // prefetch where it only needs `cur`
-                const Quad nxt = fetch(nbase, nrem > 0 && !last);
-                const uint32_t t_next = more ? t : t + 1u;
-                const uint32_t en = erp[min(t_next + 2u, last_t)];   // the end of tile t_next + 2: needed two tiles from now
-                const bool v0 = rem > 0, v1 = rem > 4, v2 = rem > 8, v3 = rem > 12;
-                const uint64_t m0 = ballot64(v0), m1 = ballot64(v1), m2 = ballot64(v2), m3 = ballot64(v3);
-                if (m0) {
-                    const Slot s0 = prep(cur.x), s1 = prep(cur.y), s2 = prep(cur.z), s3 = prep(cur.w);
-                    const uint32_t a0 = v0 ? s0.xs : 0u, a1 = v1 ? s1.xs : 0u, a2 = v2 ? s2.xs : 0u, a3 = v3 ? s3.xs : 0u;
-                    uint32_t o0 = __hip_atomic_fetch_add(tab_at(s0.z), a0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    uint32_t o1 = __hip_atomic_fetch_add(tab_at(s1.z), a1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    uint32_t o2 = __hip_atomic_fetch_add(tab_at(s2.z), a2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    uint32_t o3 = __hip_atomic_fetch_add(tab_at(s3.z), a3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    if (!more && rounds == 0) {   // the tile's only round: re-zero what it touched (DS operations execute in order)
-                        *tab_at(s0.z) = 0u;
-                        *tab_at(s1.z) = 0u;
-                        *tab_at(s2.z) = 0u;
-                        *tab_at(s3.z) = 0u;
-                    }
-                    asm volatile("" : "+v"(o0), "+v"(o1), "+v"(o2), "+v"(o3));
-                    const uint64_t c0 = ballot64(s0.tq1 - __builtin_amdgcn_ubfe(o0, s0.sh, 16u) < s0.x) & m0;
-                    const uint64_t c1m = ballot64(s1.tq1 - __builtin_amdgcn_ubfe(o1, s1.sh, 16u) < s1.x) & m1;
-                    const uint64_t c2 = ballot64(s2.tq1 - __builtin_amdgcn_ubfe(o2, s2.sh, 16u) < s2.x) & m2;
-                    const uint64_t c3 = ballot64(s3.tq1 - __builtin_amdgcn_ubfe(o3, s3.sh, 16u) < s3.x) & m3;
-                    if (c0) collect(c0, cur.x, t);
-                    if (c1m) collect(c1m, cur.y, t);
-                    if (c2) collect(c2, cur.z, t);
-                    if (c3) collect(c3, cur.w, t);
-                }
-                if (!more && rounds) {
-                    for (int x = lane; x < TILE * 2 / 16; x += 64) tab_v[x] = make_uint4(0, 0, 0, 0);
-                }
-                if (last) break;
-                rounds = more ? rounds + 1u : 0u;
-                e0 = more ? e0 : e1;
-                e1 = more ? e1 : e2;
-                e2 = en;
-                t = t_next;
-                base = nbase;
-                rem = nrem;
-                cur = nxt;
-            }
-        } else {
-            // Software pipeline, four tiles per trip: E = segment ends of tiles 4m .. 4m + 3 (byte offsets),
-            // prev = end of tile 4m - 1 (= start of tile 4m); batch j of a trip belongs to tile 4m + j and is
-            // re-issued for tile 4m + j + 4 ... no: the batch of tile t + 3 is issued while tile t is applied.
-            uint4 E0 = ends_at(0);
-            uint4 E1 = ends_at(min(1u, last_group));
-            const uint32_t list_lo = g ? my_lo << 2 : 0u;
-            Batch b0, b1, b2, b3;
-            issue(b0, list_lo, E0.x);
-            issue(b1, E0.x, E0.y);
-            issue(b2, E0.y, E0.z);
-            SG_WD_DECL(wd_t);
-            for (uint32_t t = 0; t < t_end; t += 4) {
-                SG_WD(wd_t, n_tiles + 2, 13)
-                // tiles t .. t + 3 use E0; E1 = the next four; E2 is fetched for the trip after
-                const uint4 E2 = ends_at(min((t >> 2) + 2u, last_group));
-                issue(b3, E0.z, E0.w);
-                apply(b0, t);
-                if (t + 1 >= t_end) break;
-                issue(b0, E0.w, E1.x);
-                apply(b1, t + 1);
-                if (t + 2 >= t_end) break;
-                issue(b1, E1.x, E1.y);
-                apply(b2, t + 2);
-                if (t + 3 >= t_end) break;
-                issue(b2, E1.y, E1.z);
-                apply(b3, t + 3);
-                E0 = E1;
-                E1 = E2;
-            }
+        // Software pipeline, four tiles per trip: E = segment ends of tiles 4m .. 4m + 3 (byte offsets),
+        // prev = end of tile 4m - 1 (= start of tile 4m); batch j of a trip belongs to tile 4m + j and is
+        // re-issued for tile 4m + j + 4 ... no: the batch of tile t + 3 is issued while tile t is applied.
+        uint4 E0 = ends_at(0);
+        uint4 E1 = ends_at(min(1u, last_group));
+        const uint32_t list_lo = g ? my_lo << 2 : 0u;
+        Batch b0, b1, b2, b3;
+        issue(b0, list_lo, E0.x);
+        issue(b1, E0.x, E0.y);
+        issue(b2, E0.y, E0.z);
+        SG_WD_DECL(wd_t);
+        for (uint32_t t = 0; t < t_end; t += 4) {
+            SG_WD(wd_t, n_tiles + 2, 13)
+            // tiles t .. t + 3 use E0; E1 = the next four; E2 is fetched for the trip after
+            const uint4 E2 = ends_at(min((t >> 2) + 2u, last_group));
+            issue(b3, E0.z, E0.w);
+            apply(b0, t);
+            if (t + 1 >= t_end) break;
+            issue(b0, E0.w, E1.x);
+            apply(b1, t + 1);
+            if (t + 2 >= t_end) break;
+            issue(b1, E1.x, E1.y);
+            apply(b2, t + 2);
+            if (t + 3 >= t_end) break;
+            issue(b2, E1.y, E1.z);
+            apply(b3, t + 3);
+            E0 = E1;
+            E1 = E2;
         }
         {   // postings streamed = entries of P's lists in the tiles visited
             uint32_t mine = 0;
@@ -1033,53 +939,38 @@ static unsigned pruned_grid(const sg_ctx *ctx, int32_t tile_log2, int64_t n_rows
     return grid;
 }
 
-template <typename T, int TILE_LOG2, bool SYM, bool WIDE, bool HEAVY = false>
+template <typename T, int TILE_LOG2, bool SYM, bool WIDE>
 static int launch_pruned(sg_ctx *ctx, const sg_csr *A, const sg_postings *Bt, int32_t keep, sg_topn *r, T thr,
                          float s_budget, uint32_t *row_counter, uint32_t *flagged_count, uint32_t *flagged_rows,
-                         unsigned long long *stats, const PairList &pl, const uint32_t *row_list, const uint32_t *row_list_len,
-                         float heavy_load = 0.f, uint32_t *heavy_count = nullptr, uint32_t *heavy_rows = nullptr) {
+                         unsigned long long *stats, const PairList &pl, const uint32_t *row_list, const uint32_t *row_list_len) {
     const size_t lds = ((size_t)2 << TILE_LOG2) + 512 + 1024 + (size_t)SG_SURV_CAP * 4;
     unsigned grid = pruned_grid(ctx, TILE_LOG2, SYM ? (int64_t)(pl.row_hi - pl.row_lo) : A->n_rows);
     if (WIDE && grid > (unsigned)ctx->num_cu * 4u) grid = (unsigned)ctx->num_cu * 4u;   // few rows, if any: idle waves leave at once
-    hipLaunchKernelGGL((spgemm_topn_pruned_kernel<T, TILE_LOG2, SYM, WIDE, HEAVY>), dim3(grid), dim3(64), lds, ctx->stream, A->d_indptr,
+    hipLaunchKernelGGL((spgemm_topn_pruned_kernel<T, TILE_LOG2, SYM, WIDE>), dim3(grid), dim3(64), lds, ctx->stream, A->d_indptr,
                        A->d_indices, (const T *)A->d_data, (uint32_t)A->n_rows, (const uint32_t *)Bt->d_seg,
                        (const uint32_t *)Bt->d_ends, Bt->nt_pad, (uint32_t)Bt->n_terms,
                        (const uint32_t *)Bt->d_filt, Bt->n_tiles, (const uint32_t *)Bt->d_fwd_ptr,
                        (const void *)Bt->d_fwd, keep, r->stride, thr, s_budget, Bt->norm_up, Bt->freq_min, r->d_cols,
                        (T *)r->d_vals,
                        r->d_counts, row_counter, flagged_count, flagged_rows, stats, pl.d_i, pl.d_j, (T *)pl.d_s, pl.d_row_count, pl.d_chunk_count,
-                       pl.chunks, pl.d_chunks_used, pl.d_totals, pl.row_lo, pl.row_hi, row_list, row_list_len, heavy_load, heavy_count,
-                       heavy_rows);
+                       pl.chunks, pl.d_chunks_used, pl.d_totals, pl.row_lo, pl.row_hi, row_list, row_list_len);
     SG_HIP_TRY(hipGetLastError());
     return SG_OK;
 }
 
-// The launches of one multiply: every row through the 64-term kernel; the rows it passes on -- 65 .. 128 non-zeros --
-// through the wide one, its heavy rows (a prefix term too long for its lanes' four slots per tile) through the heavy
-// one; what the first two cannot take at all (more than 128 non-zeros, more than 64 prefix terms, delta too small for
+// Both launches of one multiply: every row through the 64-term kernel; the rows it passes on (65 .. 128 non-zeros)
+// through the wide one; what THAT passes on (more than 128 non-zeros, more than 64 prefix terms, delta too small for
 // the fixed point) lands in (flagged_count, flagged_rows) for the exact kernel.
 template <typename T, int TILE_LOG2, bool SYM>
 static int launch_both(sg_ctx *ctx, const sg_csr *A, const sg_postings *Bt, int32_t keep, sg_topn *r, T thr,
                        float s_budget, uint32_t *row_counter, uint32_t *flagged_count, uint32_t *flagged_rows,
                        unsigned long long *stats, const PairList &pl) {
-    // SG_PRUNE_HEAVY: the load (expected entries per tile of a row's fullest prefix term / its lanes' four slots) from which
-    // a row takes the heavy launch; 0 = every row (tests), "off" = no heavy launch.  0.75: scripts/k4p_model_stats.py --
-    // 14 % of the rows at 663 k, four fifths of the visits that overflow their slots.
-    float heavy_load = 0.75f;
-    bool heavy = true;
-    if (const char *v = getenv("SG_PRUNE_HEAVY")) {
-        if (v[0] == 'o' || v[0] == 'O') heavy = false;
-        else heavy_load = (float)atof(v);
-    }
-    uint32_t *l1 = nullptr, *l2 = nullptr;   // [0] rows listed [1] row counter of the launch over them; [4 ..) the rows
+    uint32_t *l1 = nullptr;
     SG_TRY(sg_alloc(ctx, (size_t)A->n_rows + 8, &l1));
-    int st = heavy ? sg_alloc(ctx, (size_t)A->n_rows + 8, &l2) : SG_OK;
-    if (st == SG_OK && (hipMemsetAsync(l1, 0, 4 * sizeof(uint32_t), ctx->stream) != hipSuccess ||
-                        (l2 && hipMemsetAsync(l2, 0, 4 * sizeof(uint32_t), ctx->stream) != hipSuccess)))
-        st = SG_ERR_HIP;
+    int st = hipMemsetAsync(l1, 0, 4 * sizeof(uint32_t), ctx->stream) == hipSuccess ? SG_OK : SG_ERR_HIP;
     if (st == SG_OK)
         st = launch_pruned<T, TILE_LOG2, SYM, false>(ctx, A, Bt, keep, r, thr, s_budget, row_counter, l1, l1 + 4, stats, pl,
-                                                     nullptr, nullptr, heavy_load, l2, l2 ? l2 + 4 : nullptr);
+                                                     nullptr, nullptr);
     if (st == SG_OK && !(getenv("SG_PRUNE_WIDE") && getenv("SG_PRUNE_WIDE")[0] == '0'))
         st = launch_pruned<T, TILE_LOG2, SYM, true>(ctx, A, Bt, keep, r, thr, s_budget, l1 + 1, flagged_count, flagged_rows, stats,
                                                     pl, l1 + 4, l1);
@@ -1089,11 +980,7 @@ static int launch_both(sg_ctx *ctx, const sg_csr *A, const sg_postings *Bt, int3
                 hipSuccess)
             st = SG_ERR_HIP;
     }
-    if (st == SG_OK && l2)   // (after the wide launch or the copy: all three append to the same final list)
-        st = launch_pruned<T, TILE_LOG2, SYM, false, true>(ctx, A, Bt, keep, r, thr, s_budget, l2 + 1, flagged_count, flagged_rows,
-                                                           stats, pl, l2 + 4, l2);
     ctx->release(l1);   // stream-ordered: the pool hands it out again only to work queued behind these launches
-    ctx->release(l2);
     return st;
 }
 
@@ -1159,8 +1046,7 @@ int sg_spgemm_pruned_symmetric(sg_ctx *ctx, const sg_csr *A, const sg_postings *
     if (cap >= ((int64_t)1 << 31)) cap = ((int64_t)1 << 31) - 1;   // list offsets are 32-bit
     // every wave of the kernel holds one open chunk: count those in
     pl.chunks = (uint32_t)(cap / SG_PAIR_CHUNK);
-    // (the first and the heavy launch: a full grid each; the wide launch: four waves per CU; the exact kernel's launch)
-    if (!cap_forced) pl.chunks += 2u * pruned_grid(ctx, Bt->tile_log2, n) + (uint32_t)ctx->num_cu * 4u + sg_spgemm_exact_selfjoin_grid(ctx);
+    if (!cap_forced) pl.chunks += pruned_grid(ctx, Bt->tile_log2, n) + (uint32_t)ctx->num_cu * 4u + sg_spgemm_exact_selfjoin_grid(ctx);
     if (pl.chunks < 1) pl.chunks = 1;
     cap = (int64_t)pl.chunks * SG_PAIR_CHUNK;
     // [0] row counter [1] flagged count [2..3] pairs [4] chunks handed out [5] row counter of the exact kernel's launch;

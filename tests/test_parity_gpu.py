@@ -858,7 +858,7 @@ def test_low_thresholds_can_be_forced_through_the_pruned_kernel(ctx, mats, monke
 
 @pytest.mark.parametrize("env", [{"SG_PRUNE_DELTA": 0.02}, {"SG_PRUNE_DELTA": 0.35}, {"SG_PRUNE_FREQ": 0.0},
                                  {"SG_PRUNE_FREQ": 0.05}, {"SG_PRUNE_FREQ": 2.0}, {"SG_PRUNE_TILE": 11},
-                                 {"SG_PRUNE_TILE": 13}, {"SG_PRUNE_HEAVY": 0}, {"SG_PRUNE_HEAVY": "off"}])
+                                 {"SG_PRUNE_TILE": 13}])
 def test_pruned_multiply_is_exact_for_every_tuning(ctx, mats, env, monkeypatch):
     """delta / the frequent-term share / the tile only move work between the filter and the exact scoring."""
     A = mats[np.float32][:8000]
@@ -868,36 +868,6 @@ def test_pruned_multiply_is_exact_for_every_tuning(ctx, mats, env, monkeypatch):
     assert out["1"][1]["prune_rows"] > 0
     assert_csr_identical(out["1"][0], out["0"][0], str(env))
     assert_csr_identical(out["1"][0], P.sp_matmul_topn_port(A, B.T, 10, 0.8, True, 8), str(env))
-
-
-@pytest.mark.parametrize("dtype", [np.float32, np.float64])
-@pytest.mark.parametrize("heavy", ["0", "0.3", "0.75", "off"])
-def test_pruned_multiply_heavy_rows_take_the_rounds_loop(ctx, dtype, heavy, monkeypatch):
-    """Rows whose prefix keeps a term too long for its lanes' four slots per tile are passed on to the pruned kernel's
-    HEAVY launch (a tile takes as many rounds of four slots as its longest segment needs).  SG_PRUNE_HEAVY moves the
-    line: 0 sends EVERY row through that loop, "off" none (they overflow inside the first launch, slot by slot); same
-    bits in both forms -- with hubs of duplicates (the survivor buffer drains inside a round; tiles of many rounds), rows
-    of 65 .. 128 terms beside them (the wide launch) and a right-hand side of several tiles."""
-    base = list(_names(14000, 17))
-    rng = np.random.default_rng(2)
-    wide = [" ".join(rng.choice(base, 5)) for _ in range(40)]
-    names = base + [base[5]] * 700 + [base[8] + " INC"] * 260 + wide + [base[5][:-1]] * 90 + [w + " CO" for w in wide[:10]]
-    A = _tfidf(names, dtype)
-    dA = ctx.csr_from_scipy(A)
-    monkeypatch.setenv("SG_PRUNE_TILE", "11")          # 2048 columns: eight tiles, rows walk several
-    for top_n, thr in ((10, 0.8), (64, 0.55)):
-        out = _multiply_both_ways(ctx, dA, dA, top_n, thr, monkeypatch, SG_PRUNE_HEAVY=heavy)
-        assert out["1"][1]["prune_rows"] >= 0.95 * len(names) and out["sym"][1]["prune_symmetric"] == 1
-        C_ref = P.sp_matmul_topn_port(A, A.T, top_n, thr, True, 8)
-        assert_csr_identical(out["1"][0], C_ref, f"one-sided, heavy from {heavy}")
-        assert_csr_identical(out["sym"][0], C_ref, f"self-join form, heavy from {heavy}")
-    monkeypatch.delenv("SG_PRUNE_HEAVY")
-    # master x duplicates: other left rows than columns
-    (Am, Bm), _, _ = O.tfidf_sklearn(names, [names[:6000], names[3000:9000] + names[14000:14800]], dtype=dtype)
-    dAm, dBm = ctx.csr_from_scipy(Am), ctx.csr_from_scipy(Bm)
-    out = _multiply_both_ways(ctx, dAm, dBm, 10, 0.8, monkeypatch, SG_PRUNE_HEAVY=heavy)
-    assert_csr_identical(out["1"][0], P.sp_matmul_topn_port(Am, Bm.T, 10, 0.8, True, 8), f"master x duplicates, heavy from {heavy}")
-    monkeypatch.delenv("SG_PRUNE_HEAVY")
 
 
 def test_pruned_multiply_rows_beyond_64_terms(ctx, monkeypatch):
