@@ -43,6 +43,8 @@ def main():
     tot = dict(rows=0, visits=0, empty=0, post=0, post_rare=0, post_freq=0, np_=0, nS=0, overflow=0, nnz=0, slots_used=0,
                visits_le64=0, visits_le128=0, post_all=0)
     per_visit = []
+    TAUS = (0.4, 0.5, 0.6, 0.75, 0.9, 1.1)
+    cls = {tau: [0, 0, 0] for tau in TAUS}
     np_hist = np.zeros(65, np.int64)
     for i in rows:
         lo, hi = m.indptr[i], m.indptr[i + 1]
@@ -97,6 +99,13 @@ def main():
         tot["slow_rounds16"] = tot.get("slow_rounds16", 0) + int(np.ceil(over / (4 * G[:, None])).max(axis=0).sum())
         tot["post_in_slow"] = tot.get("post_in_slow", 0) + int(per_tile[ov_visit].sum())
         tot["slots_used"] += int(np.minimum(counts, 4 * G[:, None]).sum())
+        # row classifier: expected entries per tile of the fullest term against its lanes' four slots
+        load = float(((dfp / (n / tile)) / (4.0 * G)).max())
+        for tau in TAUS:
+            if load > tau:
+                cls[tau][0] += 1
+                cls[tau][1] += t_end
+                cls[tau][2] += int(ov_visit.sum())
         per_visit.append(per_tile)
     pv = np.concatenate(per_visit)
     r = tot["rows"]
@@ -108,6 +117,10 @@ def main():
     print(f"overflow visits: {tot['slow_rounds'] / max(1, tot['overflow']):.1f} slot-by-slot rounds each on average "
           f"({tot['slow_rounds'] / tot['visits']:.2f} per visit over all visits; with 16-byte rounds: "
           f"{tot['slow_rounds16'] / tot['visits']:.2f}); they hold {100 * tot['post_in_slow'] / tot['post']:.1f} % of the postings")
+    for tau in TAUS:
+        c = cls[tau]
+        print(f"rows with fullest-term load > {tau}: {100 * c[0] / r:.1f} % of rows, {100 * c[1] / tot['visits']:.1f} % of visits, "
+              f"hold {100 * c[2] / max(1, tot['overflow']):.1f} % of the overflow visits; overflow share inside: {100 * c[2] / max(1, c[1]):.1f} %")
     print("postings per visit, percentiles 10/25/50/75/90/99:", np.percentile(pv, [10, 25, 50, 75, 90, 99]).round(0).tolist())
     print("prefix-term count histogram (np: rows):", {int(x): int(c) for x, c in enumerate(np_hist) if c})
     est_total = tot["post"] / r * n
