@@ -281,7 +281,7 @@ spgemm_topn_pruned_kernel(const int64_t *__restrict__ a_indptr, const int32_t *_
     // rows are handed out four at a time: one global atomic per row capped the kernel at ~88 rows/us (larger first
     // helpings were tried -- sixteen rows for the first three quarters -- and changed nothing: profiles/r02_sessionJ6_*.log).
     // Symmetric mode walks the rows from the last to the first: a row's cost grows with its index there.
-    for (uint32_t row0 = next_row(row_counter, lane) * 4u; row0 < n_here; row0 = next_row(row_counter, lane) * 4u)
+    for (uint32_t row0 = next_row(row_counter, lane) * 4u; row0 < n_here; row0 = next_row(row_counter, lane) * 4u) {
     for (uint32_t rr = row0; rr < min(row0 + 4u, n_here); ++rr) {
         SG_WD(wd_rows, n_left + 2, 11)
         const uint32_t row = WIDE ? (uint32_t)__builtin_amdgcn_readfirstlane((int)row_list[rr]) : (SYM ? sym_hi - 1u - rr : rr);
@@ -687,6 +687,15 @@ spgemm_topn_pruned_kernel(const int64_t *__restrict__ a_indptr, const int32_t *_
             }
             if (lane == 0) out_cnt[row] = cnt;
         }
+        if (SYM) {
+            // The pair list is full (this wave was handed a chunk past its end): whatever the pass still does is thrown away,
+            // the caller runs the one-sided form.  Push the row counter past the last row so that every wave leaves at its
+            // next helping.  (Looking at the shared chunk counter instead -- one load per helping -- cost 3.3 ms at 663 k:
+            // accesses to one word are serialised at ~12 ns each, profiles/r02_sessionZ_*.log.)
+            const uint32_t pos = (uint32_t)__builtin_amdgcn_readfirstlane(surv[SG_SURV_CAP - 1]);
+            if (pos != SG_PAIR_NO_CHUNK && (pos >> 9) >= pair_chunks && lane == 0) atomicMax(row_counter, 0x20000000u);
+        }
+    }
     }
     if (SYM && lane == 0) {   // close the wave's last chunk
         const uint32_t pos = (uint32_t)surv[SG_SURV_CAP - 1];
@@ -1035,8 +1044,19 @@ int sg_spgemm_pruned_symmetric(sg_ctx *ctx, const sg_csr *A, const sg_postings *
     PairList pl;
     pl.row_lo = (uint32_t)row_lo;
     pl.row_hi = (uint32_t)row_hi;
-    // a name list has a few matches per row; hubs of identical names can have far more -> fall back then
-    int64_t cap = 8 * n + ((int64_t)1 << 20);
+    // A name list has a few matches per row, but hubs of identical names have h^2 / 2 pairs each, and the largest hubs
+    // grow with the list (5 M synthetic names: 53 M pairs above 0.8 for 18 M matches kept -- with room for 8 n pairs the
+    // pass was thrown away after 630 ms and the one-sided form took another 1300; scripts/full_configs.py).  The list
+    // costs nothing until it is written: room for 64 n pairs, at most a sixteenth of the device memory.
+    int64_t cap = 64 * n + ((int64_t)1 << 20);
+    {
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && total_b > 0) {
+            const int64_t by_memory = (int64_t)(total_b / 16 / (8 + vs));
+            if (cap > by_memory) cap = by_memory;
+        }
+        if (cap < 8 * n + ((int64_t)1 << 20)) cap = 8 * n + ((int64_t)1 << 20);
+    }
     bool cap_forced = false;
     if (const char *v = getenv("SG_SYM_PAIR_CAP"))   // test hook: a list that is too small
         if (atoll(v) > 0) {
