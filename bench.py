@@ -205,8 +205,10 @@ def main():
                    "ngram_size": 3, "max_n_matches": args.top_n, "min_similarity": args.min_similarity,
                    "parallelism": "single GPU" if world == 1 else
                    f"{world} GPUs, one process each: rows of the string column in {world} contiguous blocks; tokenise local "
-                   f"block -> all-reduce df table -> weight local block -> all-gather CSR -> inverted index + multiply of "
-                   f"the local rows; no collective in the multiply ({dist_mode})"},
+                   f"block -> all-reduce df table -> weight local block -> all-gather CSR -> inverted index -> multiply: "
+                   + ("self-join form over left-row ranges (pairs j <= i, one all-gather of the mirrored pairs, merge)"
+                      if (distributed and dist_mode == "sharded" and D.selfjoin_form_wanted(args.rows, world))
+                      else "the local rows against all columns, no collective in the multiply") + f" ({dist_mode})"},
         # launch groups of one step (HIP events on the library's stream); spgemm_topn = the multiply's whole group (pruned
         # kernel + pair-list pass in the self-join form), of which the dominant kernel alone is roofline.avg_ms
         "kernels_ms": {k[3:]: round(v, 4) for k, v in stats.items() if k.startswith("ms_") and k != "ms_spgemm_kernel"},
