@@ -154,14 +154,20 @@ def main():
     t0 = time.perf_counter()
     k4_ms = []
     stats = None
+    last = None
     for _ in range(args.steps):
-        r = step()
+        if last is not None:
+            last.free()
+        last = step()
         stats = ctx.stats()
         k4_ms.append(stats["ms_spgemm_kernel"] or stats["ms_spgemm_topn"])      # the dominant kernel alone
         out_nnz = stats["out_nnz"]
-        r.free()
     barrier()
     elapsed = time.perf_counter() - t0
+    if distributed and dist_mode == "sharded":
+        # (the multi-GPU self-join form merges the mirrored pairs after the multiply's own count: count the rank's rows)
+        out_nnz = int(ops.topn_tensors(last)[2].sum().item())
+    last.free()
     if distributed:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

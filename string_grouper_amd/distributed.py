@@ -58,24 +58,36 @@ def weighted_row_blocks(row_cost: np.ndarray, world: int) -> np.ndarray:
 
 
 # ---------------------------------------------------------------------------------------------- collectives
-def _all_sizes(n: int, device, group=None) -> List[int]:
+def all_headers(values: Sequence[int], device, group=None) -> List[List[int]]:
+    """Every rank's small vector of integers (sizes, flags), as a list in rank order: ONE collective and ONE
+    device-to-host copy -- the only synchronisation a group of ragged gathers needs."""
     world = dist.get_world_size(group)
-    mine = torch.tensor([int(n)], dtype=torch.int64, device=device)
-    sizes = [torch.zeros_like(mine) for _ in range(world)]
-    dist.all_gather(sizes, mine, group=group)
-    return [int(s.item()) for s in sizes]
+    mine = torch.tensor([int(v) for v in values], dtype=torch.int64, device=device)
+    out = torch.empty(world * mine.numel(), dtype=torch.int64, device=device)
+    dist.all_gather_into_tensor(out, mine, group=group)
+    return out.reshape(world, mine.numel()).tolist()
 
 
-def all_gather_ragged(t, group=None) -> list:
-    """All ranks' 1-d tensors (different lengths, same dtype) as a list in rank order: one exchange of the
-    lengths, one padded all-gather of the payload."""
-    sizes = _all_sizes(t.numel(), t.device, group)
+def _all_sizes(n: int, device, group=None) -> List[int]:
+    return [h[0] for h in all_headers([n], device, group)]
+
+
+def all_gather_ragged(t, group=None, sizes: Optional[Sequence[int]] = None) -> list:
+    """All ranks' 1-d tensors (different lengths, same dtype) as a list in rank order: one padded all-gather into one
+    buffer.  ``sizes``: the ranks' lengths when the caller has exchanged them already (``all_headers``: several
+    gathers share one exchange); otherwise they are exchanged here."""
+    if sizes is None:
+        sizes = _all_sizes(t.numel(), t.device, group)
+    sizes = [int(n) for n in sizes]
     longest = max(max(sizes), 1)
-    padded = torch.zeros(longest, dtype=t.dtype, device=t.device)
-    padded[: t.numel()] = t
-    out = [torch.empty_like(padded) for _ in sizes]
-    dist.all_gather(out, padded, group=group)
-    return [o[:n] for o, n in zip(out, sizes)]
+    if t.numel() == longest:
+        padded = t.contiguous()
+    else:
+        padded = torch.empty(longest, dtype=t.dtype, device=t.device)
+        padded[: t.numel()] = t
+    out = torch.empty(len(sizes) * longest, dtype=t.dtype, device=t.device)
+    dist.all_gather_into_tensor(out, padded, group=group)
+    return [out[r * longest: r * longest + n] for r, n in enumerate(sizes)]
 
 
 def gather_counts(local_counts, n_total: int, group=None):
@@ -114,9 +126,11 @@ def broadcast_csr(indptr, indices, data, shape, src: int = 0, device=None, group
 def all_gather_csr(indptr, indices, data, n_cols: int, group=None):
     """Concatenate the ranks' CSR row blocks (rank order = row order): returns (indptr, indices, data, shape) of
     the whole matrix on every rank.  Row pointers are exchanged as row lengths and rebuilt by a prefix sum."""
-    lens = all_gather_ragged((indptr[1:] - indptr[:-1]).to(torch.int64), group)
-    idx = all_gather_ragged(indices, group)
-    val = all_gather_ragged(data, group)
+    head = all_headers([indptr.numel() - 1, indices.numel()], indptr.device, group)   # rows, non-zeros of every block
+    rows, nnz = [h[0] for h in head], [h[1] for h in head]
+    lens = all_gather_ragged((indptr[1:] - indptr[:-1]).to(torch.int32), group, rows)     # (a row holds < 2^31 entries)
+    idx = all_gather_ragged(indices, group, nnz)
+    val = all_gather_ragged(data, group, nnz)
     row_len = torch.cat(lens)
     full_ptr = torch.zeros(row_len.numel() + 1, dtype=torch.int64, device=indptr.device)
     torch.cumsum(row_len, 0, out=full_ptr[1:])
@@ -200,13 +214,14 @@ def sharded_selfjoin_topn(ops, A_full, post, top_n: int, threshold: float, group
     bounds = selfjoin_row_ranges(n, world)
     lo, hi = int(bounds[rank]), int(bounds[rank + 1])
     part = ops.selfjoin_range(A_full, post, top_n, threshold, lo, hi)
-    ok = torch.tensor([1 if part is not None else 0], dtype=torch.int32, device=ops.device)
-    dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
-    if int(ok.item()) == 0:
+    pairs = ops.selfjoin_pairs(part) if part is not None else None
+    # one exchange tells every rank the lengths of all pair lists AND whether every range was applicable (-1: not)
+    sizes = [h[0] for h in all_headers([pairs.numel() if pairs is not None else -1], ops.device, group)]
+    if min(sizes) < 0:
         if part is not None:
             ops.selfjoin_discard(part)
         return None
-    pairs_all = torch.cat(all_gather_ragged(ops.selfjoin_pairs(part), group))
+    pairs_all = torch.cat(all_gather_ragged(pairs, group, sizes))
     return ops.selfjoin_merge(part, pairs_all, lo, hi)
 
 
@@ -217,12 +232,14 @@ def gather_topn(ops, res, group=None):
     cols, vals, counts = ops.topn_tensors(res)
     stride = cols.shape[1] if cols.dim() == 2 else 1
     if dist.get_world_size(group) > 1:
-        strides = _all_sizes(stride, counts.device, group)
+        head = all_headers([stride, counts.numel()], counts.device, group)
+        strides, rows = [h[0] for h in head], [h[1] for h in head]
         if len(set(strides)) != 1:
             raise RuntimeError(f"ranks disagree on the result stride: {strides}")
-        cols = torch.cat(all_gather_ragged(cols.reshape(-1), group)).reshape(-1, stride)
-        vals = torch.cat(all_gather_ragged(vals.reshape(-1), group)).reshape(-1, stride)
-        counts = torch.cat(all_gather_ragged(counts, group))
+        cells = [r * stride for r in rows]
+        cols = torch.cat(all_gather_ragged(cols.reshape(-1), group, cells)).reshape(-1, stride)
+        vals = torch.cat(all_gather_ragged(vals.reshape(-1), group, cells)).reshape(-1, stride)
+        counts = torch.cat(all_gather_ragged(counts, group, rows))
     return cols.cpu().numpy(), vals.cpu().numpy(), counts.cpu().numpy()
 
 
