@@ -151,6 +151,13 @@ int sg_csr_rowwise_dot(sg_ctx *ctx, const sg_csr *A, const sg_csr *B, void *out_
  * The postings keep a reference to B's arrays (the multiply re-scores candidates against B's rows):
  * B must stay alive until the postings are freed. */
 int sg_postings_build(sg_ctx *ctx, const sg_csr *B, int32_t tile_cols, sg_postings **out);
+/* The same with options.  SG_POSTINGS_NO_PERMUTATION: by default the index is built over a fixed permutation of B's rows
+ * (a sorted name list has its similar names side by side, which piles a row's candidates into a few column tiles: the
+ * pruned multiply ran 2.6 x slower on 663 k sorted names than on the same names shuffled); results never show it --
+ * rows, columns and the order of equal scores are B's own.  The multi-GPU self-join form (sg_selfjoin_range) hands row
+ * RANGES around and needs the index in row order. */
+enum { SG_POSTINGS_NO_PERMUTATION = 1 };
+int sg_postings_build_flags(sg_ctx *ctx, const sg_csr *B, int32_t tile_cols, int32_t flags, sg_postings **out);
 int sg_postings_free(sg_postings *p);
 
 /* C = topn_rowwise(A . B^T restricted to > threshold).  A: n_left x V, postings of B: n_right x V.

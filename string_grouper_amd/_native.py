@@ -70,6 +70,7 @@ ABI = {
     "sg_csr_row_block": (C.c_int, [_P, _P, C.c_int64, C.c_int64, _PP]),
     "sg_csr_free": (C.c_int, [_P]),
     "sg_postings_build": (C.c_int, [_P, _P, C.c_int32, _PP]),
+    "sg_postings_build_flags": (C.c_int, [_P, _P, C.c_int32, C.c_int32, _PP]),
     "sg_postings_free": (C.c_int, [_P]),
     "sg_spgemm_topn": (C.c_int, [_P, _P, _P, C.c_int32, C.c_double, C.c_int32, _PP]),
     "sg_topn_dims": (C.c_int, [_P, C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.POINTER(C.c_int32),
@@ -443,9 +444,10 @@ class Context:
         return m
 
     # ---- multiply
-    def postings_build(self, B: Csr, tile_cols: int = 0) -> Postings:
+    def postings_build(self, B: Csr, tile_cols: int = 0, permute: bool = True) -> Postings:
+        """``permute=False``: the index in row order (SG_POSTINGS_NO_PERMUTATION; the multi-GPU self-join form needs it)."""
         out = C.c_void_p()
-        check(lib().sg_postings_build(self.h, B.h, int(tile_cols), C.byref(out)))
+        check(lib().sg_postings_build_flags(self.h, B.h, int(tile_cols), 0 if permute else 1, C.byref(out)))
         return Postings(self, out)
 
     def spgemm_topn(self, A: Csr, Bt: Postings, top_n: int, threshold: float, sort: bool = True) -> TopN:

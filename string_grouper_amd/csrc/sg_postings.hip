@@ -249,8 +249,118 @@ __global__ void __launch_bounds__(256) pack_ends_kernel(const uint32_t *__restri
     ends[i] = seg[k * n_tiles + t + 1] << 2;
 }
 
+// ---- position space: a fixed permutation of the right-hand rows (see sg_postings in sg_internal.h)
+// pos_of[j] = j * M mod n with gcd(M, n) = 1, M ~ 0.618 n: neighbours land 0.618 n apart and any run of rows spreads
+// evenly over the positions (a low-discrepancy sequence) -- what a sorted list needs, and harmless on any other.
+__global__ void __launch_bounds__(256) permutation_kernel(uint32_t n, uint64_t mult, uint32_t *__restrict__ pos_of,
+                                                          uint32_t *__restrict__ orig_of, const int64_t *__restrict__ indptr,
+                                                          uint32_t *__restrict__ len_by_pos) {
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    const uint32_t p = (uint32_t)(((uint64_t)j * mult) % (uint64_t)n);
+    pos_of[j] = p;
+    orig_of[p] = j;
+    len_by_pos[p] = (uint32_t)(indptr[j + 1] - indptr[j]);
+}
+
+// rows of B copied into position order: sixteen lanes per row
+template <typename T>
+__global__ void __launch_bounds__(256) permute_rows_kernel(const int64_t *__restrict__ indptr, const int32_t *__restrict__ indices,
+                                                           const T *__restrict__ data, int64_t n_rows,
+                                                           const uint32_t *__restrict__ orig_of, const int64_t *__restrict__ out_ptr,
+                                                           int32_t *__restrict__ out_indices, T *__restrict__ out_data) {
+    const int64_t p = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+    const int sub = threadIdx.x & 15;
+    if (p >= n_rows) return;
+    const int64_t j = orig_of[p];
+    const int64_t src = indptr[j], n = indptr[j + 1] - src, dst = out_ptr[p];
+    for (int64_t e = sub; e < n; e += 16) {
+        out_indices[dst + e] = indices[src + e];
+        out_data[dst + e] = data[src + e];
+    }
+}
+
+static uint64_t gcd_u64(uint64_t a, uint64_t b) {
+    while (b) {
+        const uint64_t t = a % b;
+        a = b;
+        b = t;
+    }
+    return a;
+}
+
+// B with its rows in position order + the two tables; *out_perm stays null when the permutation is off or pointless
+static int build_permuted(sg_ctx *ctx, const sg_csr *B, int64_t tile_cols, sg_csr **out_perm, uint32_t **out_orig_of,
+                          uint32_t **out_pos_of) {
+    *out_perm = nullptr;
+    *out_orig_of = *out_pos_of = nullptr;
+    const char *e = getenv("SG_PERMUTE");
+    if ((e && e[0] == '0') || B->n_rows <= 2 * tile_cols || B->n_rows >= ((int64_t)1 << 31) || B->nnz <= 0) return SG_OK;
+    const uint64_t n = (uint64_t)B->n_rows;
+    uint64_t mult = (uint64_t)(0.6180339887498949 * (double)n) | 1ull;
+    while (gcd_u64(mult, n) != 1) mult += 2;
+    uint32_t *orig_of = nullptr, *pos_of = nullptr, *len_by_pos = nullptr;
+    int64_t *ptr = nullptr;
+    int32_t *idx = nullptr;
+    void *val = nullptr;
+    const size_t vs = B->dtype == SG_F64 ? 8 : 4;
+    int st = sg_alloc(ctx, (size_t)n + 1, &orig_of);
+    if (st == SG_OK) st = sg_alloc(ctx, (size_t)n + 1, &pos_of);
+    if (st == SG_OK) st = sg_alloc(ctx, (size_t)n + 1, &len_by_pos);
+    if (st == SG_OK) st = sg_alloc(ctx, (size_t)n + 2, &ptr);
+    if (st == SG_OK) st = sg_alloc(ctx, (size_t)B->nnz + 64, &idx);
+    if (st == SG_OK) st = ctx->alloc(((size_t)B->nnz + 64) * vs, &val);
+    if (st == SG_OK) {
+        hipLaunchKernelGGL(permutation_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, (uint32_t)n, mult, pos_of,
+                           orig_of, B->d_indptr, len_by_pos);
+        st = sg_exclusive_scan_i32_to_i64(ctx, (const int32_t *)len_by_pos, ptr, (int64_t)n);
+    }
+    if (st == SG_OK) {
+        const unsigned grid = (unsigned)((n * 16 + 255) / 256);
+        if (B->dtype == SG_F64)
+            hipLaunchKernelGGL(permute_rows_kernel<double>, dim3(grid), dim3(256), 0, ctx->stream, B->d_indptr, B->d_indices,
+                               (const double *)B->d_data, B->n_rows, (const uint32_t *)orig_of, (const int64_t *)ptr, idx, (double *)val);
+        else
+            hipLaunchKernelGGL(permute_rows_kernel<float>, dim3(grid), dim3(256), 0, ctx->stream, B->d_indptr, B->d_indices,
+                               (const float *)B->d_data, B->n_rows, (const uint32_t *)orig_of, (const int64_t *)ptr, idx, (float *)val);
+        if (hipGetLastError() != hipSuccess) st = SG_ERR_HIP;
+    }
+    ctx->release(len_by_pos);
+    sg_csr *m = st == SG_OK ? new (std::nothrow) sg_csr() : nullptr;
+    if (st == SG_OK && !m) st = SG_ERR_OOM;
+    if (st != SG_OK) {
+        ctx->release(orig_of);
+        ctx->release(pos_of);
+        ctx->release(ptr);
+        ctx->release(idx);
+        ctx->release(val);
+        return st;
+    }
+    m->ctx = ctx;
+    m->n_rows = B->n_rows;
+    m->n_cols = B->n_cols;
+    m->nnz = B->nnz;
+    m->dtype = B->dtype;
+    m->d_indptr = ptr;
+    m->d_indices = idx;
+    m->d_data = val;
+    m->owned = true;
+    m->props_state = B->props_state;         // same rows: same properties
+    m->props_max_norm2 = B->props_max_norm2;
+    m->props_max_nnz = B->props_max_nnz;
+    *out_perm = m;
+    *out_orig_of = orig_of;
+    *out_pos_of = pos_of;
+    return SG_OK;
+}
+
 extern "C" int sg_postings_build(sg_ctx *ctx, const sg_csr *B, int32_t tile_cols, sg_postings **out) {
-    SG_REQUIRE(ctx && B && out, "null argument");
+    return sg_postings_build_flags(ctx, B, tile_cols, 0, out);
+}
+
+extern "C" int sg_postings_build_flags(sg_ctx *ctx, const sg_csr *B_in, int32_t tile_cols, int32_t flags, sg_postings **out) {
+    SG_REQUIRE(ctx && B_in && out, "null argument");
+    const sg_csr *B = B_in;
     // cosine-like right-hand sides (non-negative, sorted rows, norms <= 1: TF-IDF) take the pruned multiply,
     // whose 16-bit accumulators make a 4096-column tile 8 KiB; everything else the exact kernel with 8 KiB
     // of float / double accumulators per wave
@@ -287,8 +397,21 @@ extern "C" int sg_postings_build(sg_ctx *ctx, const sg_csr *B, int32_t tile_cols
                      (long long)B->n_cols, (long long)n_tiles64);
         return SG_ERR_OVERFLOW;
     }
+    sg_csr *permuted = nullptr;
+    uint32_t *orig_of = nullptr, *pos_of = nullptr;
+    SgTimer timer(ctx, SG_K_POSTINGS);   // the whole build, the permuted copy included
+    if (!(flags & SG_POSTINGS_NO_PERMUTATION)) SG_TRY(build_permuted(ctx, B_in, tile_cols, &permuted, &orig_of, &pos_of));
+    if (permuted) B = permuted;   // everything below indexes right-hand rows by POSITION
     sg_postings *p = new (std::nothrow) sg_postings();
-    if (!p) return SG_ERR_OOM;
+    if (!p) {
+        sg_csr_free(permuted);
+        ctx->release(orig_of);
+        ctx->release(pos_of);
+        return SG_ERR_OOM;
+    }
+    p->permuted = permuted;
+    p->d_orig_of = orig_of;
+    p->d_pos_of = pos_of;
     p->ctx = ctx;
     p->n_right = B->n_rows;
     p->n_terms = B->n_cols;
@@ -296,9 +419,9 @@ extern "C" int sg_postings_build(sg_ctx *ctx, const sg_csr *B, int32_t tile_cols
     p->dtype = B->dtype;
     p->tile_log2 = tile_log2;
     p->n_tiles = (int32_t)n_tiles64;
-    p->b_indptr = B->d_indptr;
-    p->b_indices = B->d_indices;
-    p->b_data = B->d_data;
+    p->b_indptr = B_in->d_indptr;      // the caller's matrix: what "A is the matrix the postings were built from" compares
+    p->b_indices = B_in->d_indices;
+    p->b_data = B_in->d_data;
     p->cosine_like = cosine_like;
     p->max_norm2 = max_norm2;
     const size_t vs = 8;   // f64 value, or packed {row, f32 value}
@@ -328,7 +451,6 @@ extern "C" int sg_postings_build(sg_ctx *ctx, const sg_csr *B, int32_t tile_cols
         return st;
     }
     {
-        SgTimer timer(ctx, SG_K_POSTINGS);
         // one thread per slot of the (tile x row-in-tile) grid: covers every row, see row_of_thread
         const unsigned grid = (unsigned)((((int64_t)p->n_tiles << tile_log2) + 255) / 256);
         // the tile's counters fit in LDS: one workgroup per tile (part), LDS atomics (otherwise global ones)
@@ -460,6 +582,9 @@ extern "C" int sg_postings_free(sg_postings *p) {
     p->ctx->release(p->d_fwd_ptr);
     p->ctx->release(p->d_filt);
     p->ctx->release(p->d_ends);
+    p->ctx->release(p->d_orig_of);
+    p->ctx->release(p->d_pos_of);
+    sg_csr_free(p->permuted);
     delete p;
     return SG_OK;
 }

@@ -171,16 +171,20 @@ template <typename T, bool SYM, int TILE_LOG2, bool WIDE>
 __device__ __noinline__ TopList<T> drain_survivors(int nnz, const uint32_t *fwd_ptr, const void *fwd, T thr, uint32_t row,
                                                    uint32_t *pair_i, uint32_t *pair_j, T *pair_s, uint32_t *pair_row_count,
                                                    uint32_t *pair_chunk_count, uint32_t pair_chunks, uint32_t *pair_chunks_used,
-                                                   unsigned long long *pair_totals, TopList<T> top, uint32_t n_surv) {
+                                                   unsigned long long *pair_totals, TopList<T> top, uint32_t n_surv,
+                                                   const uint32_t *__restrict__ orig_of /* position -> right-hand row; null: identity */,
+                                                   uint32_t row_out /* the left row's index in the result */) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int TILE = 1 << TILE_LOG2;
     const int *hk = reinterpret_cast<const int *>(smem + TILE * 2);
     const T *ha = reinterpret_cast<const T *>(smem + TILE * 2 + 512);
     int *surv = reinterpret_cast<int *>(smem + TILE * 2 + 512 + 1024);
     const int lane = threadIdx.x;
-    const int j = (uint32_t)lane < n_surv ? surv[lane] : -1;
+    const int j = (uint32_t)lane < n_surv ? surv[lane] : -1;   // a POSITION: the index is built over a permutation of B's rows
     const T sum = exact_score<T, WIDE>(j, hk, ha, nnz, fwd_ptr, fwd);
     uint64_t hm = __ballot(j >= 0 && sum > thr);
+    // what leaves the kernel is the row itself: the top list orders equal scores by the ORIGINAL column, the pairs name rows
+    const int jo = (orig_of && j >= 0) ? (int)orig_of[j] : j;
     if (SYM) {
         // row i keeps its own matches j <= i in its top list like the one-sided form; what row j < i has to learn -- that
         // i matches it -- goes to the pair list (pass 2 merges it into row j's list).  The diagonal is nobody's mirror.
@@ -205,10 +209,10 @@ __device__ __noinline__ TopList<T> drain_survivors(int nnz, const uint32_t *fwd_
             }
             if (((mm >> lane) & 1ull) && (pos >> 9) < pair_chunks) {   // past the capacity nothing is written: the caller falls back
                 const size_t o = (size_t)(pos >> 9) * SG_PAIR_CHUNK + (pos & 511u) + (uint32_t)__popcll(mm & ((1ull << lane) - 1ull));
-                pair_i[o] = row;
-                pair_j[o] = (uint32_t)j;
+                pair_i[o] = row_out;
+                pair_j[o] = (uint32_t)jo;
                 pair_s[o] = sum;
-                atomicAdd(&pair_row_count[j], 1u);   // how many mirrored matches row j will receive (pass 2 scans these)
+                atomicAdd(&pair_row_count[jo], 1u);   // how many mirrored matches row j will receive (pass 2 scans these)
             }
             __builtin_amdgcn_wave_barrier();
             if (lane == 0) surv[SG_SURV_CAP - 1] = (int)(pos + n_hit);
@@ -219,7 +223,7 @@ __device__ __noinline__ TopList<T> drain_survivors(int nnz, const uint32_t *fwd_
         SG_WD(wd_h, 70, 22)
         const int src = __builtin_ctzll(hm);
         hm &= hm - 1;
-        top.insert(wave_read<T>(sum, src), wave_read<int>(j, src), lane);
+        top.insert(wave_read<T>(sum, src), wave_read<int>(jo, src), lane);
     }
     if (n_surv > 64) {   // < 64 left: move to the front
         const uint32_t rem = n_surv - 64;
@@ -249,7 +253,8 @@ spgemm_topn_pruned_kernel(const int64_t *__restrict__ a_indptr, const int32_t *_
                           uint32_t pair_chunks /* chunks there are */, uint32_t *pair_chunks_used /* chunks handed out */,
                           unsigned long long *pair_totals /* pairs in closed chunks */,
                           uint32_t sym_lo, uint32_t sym_hi /* SYM: the left rows this launch scores (multi-GPU: a rank's range) */,
-                          const uint32_t *__restrict__ row_list /* WIDE: the rows to process */, const uint32_t *row_list_len) {
+                          const uint32_t *__restrict__ row_list /* WIDE: the rows to process */, const uint32_t *row_list_len,
+                          const uint32_t *__restrict__ orig_of /* position -> right-hand row (sg_postings.hip); null: identity */) {
     constexpr int TILE = 1 << TILE_LOG2;
     constexpr int SLOTS = WIDE ? 2 : 1;   // row terms staged per lane
     constexpr int AB = TILE_LOG2 + 1;                          // address + half bits of a filter posting
@@ -285,6 +290,9 @@ spgemm_topn_pruned_kernel(const int64_t *__restrict__ a_indptr, const int32_t *_
     for (uint32_t rr = row0; rr < min(row0 + 4u, n_here); ++rr) {
         SG_WD(wd_rows, n_left + 2, 11)
         const uint32_t row = WIDE ? (uint32_t)__builtin_amdgcn_readfirstlane((int)row_list[rr]) : (SYM ? sym_hi - 1u - rr : rr);
+        // self-join form: the left matrix IS the permuted one, `row` a position; its result row and its name in the pairs
+        // are the original row's.  (One-sided form: the left rows are the caller's, only the columns are positions.)
+        const uint32_t row_out = (SYM && orig_of) ? (uint32_t)__builtin_amdgcn_readfirstlane((int)orig_of[row]) : row;
         const int64_t rlo = a_indptr[row];
         const int nnz = __builtin_amdgcn_readfirstlane((int)(a_indptr[row + 1] - rlo));
         if (nnz > 64 * SLOTS) {   // more non-zeros than this launch stages: the wide launch, or the exact kernel
@@ -485,7 +493,7 @@ spgemm_topn_pruned_kernel(const int64_t *__restrict__ a_indptr, const int32_t *_
             n_surv += __popcll(cm);
             if (n_surv >= 64) {
                 top = drain_survivors<T, SYM, TILE_LOG2, WIDE>(nnz, fwd_ptr, fwd, thr, row, pair_i, pair_j, pair_s, pair_row_count, pair_chunk_count, pair_chunks, pair_chunks_used, pair_totals,
-                                                         top, n_surv);
+                                                         top, n_surv, orig_of, row_out);
                 st_surv += 64;
                 n_surv -= 64;
             }
@@ -674,18 +682,18 @@ spgemm_topn_pruned_kernel(const int64_t *__restrict__ a_indptr, const int32_t *_
 #endif
         if (n_surv > 0) {   // fewer than 64 left
             top = drain_survivors<T, SYM, TILE_LOG2, WIDE>(nnz, fwd_ptr, fwd, thr, row, pair_i, pair_j, pair_s, pair_row_count, pair_chunk_count, pair_chunks, pair_chunks_used, pair_totals, top,
-                                                     n_surv);
+                                                     n_surv, orig_of, row_out);
             st_surv += n_surv;
         }
         {   // (symmetric mode: the row's matches j <= i; pass 2 merges the mirrored ones in)
             int cnt = __popcll(__ballot(top.c != INT32_MAX));
             if (cnt > keep) cnt = keep;
-            const size_t obase = (size_t)row * (size_t)out_stride;
+            const size_t obase = (size_t)row_out * (size_t)out_stride;
             if (lane < cnt) {
                 out_vals[obase + lane] = top.s;
                 out_cols[obase + lane] = top.c;
             }
-            if (lane == 0) out_cnt[row] = cnt;
+            if (lane == 0) out_cnt[row_out] = cnt;
         }
         if (SYM) {
             // The pair list is full (this wave was handed a chunk past its end): whatever the pass still does is thrown away,
@@ -785,11 +793,15 @@ __global__ void __launch_bounds__(64) pairs_select_kernel(const uint32_t *__rest
                                                           int32_t out_stride, int32_t *__restrict__ out_cols,
                                                           T *__restrict__ out_vals, int32_t *__restrict__ out_cnt) {
     const int lane = threadIdx.x;
-    for (uint32_t row0 = blockIdx.x * 64u; row0 < n_rows; row0 += gridDim.x * 64u) {
-        const uint32_t mine = row0 + (uint32_t)lane;
+    // The 64 rows a wave looks at are n_groups apart, not neighbours: on a sorted list the rows with long mirrored lists
+    // (hubs of near-identical names) ARE neighbours, and a wave that owned 64 of them in a row worked through them one
+    // after the other while the others idled (4.9 ms instead of 0.25 at 663 k sorted names).
+    const uint32_t n_groups = (n_rows + 63u) / 64u;
+    for (uint32_t g = blockIdx.x; g < n_groups; g += gridDim.x) {
+        const uint32_t mine = g + (uint32_t)lane * n_groups;
         uint64_t todo = __ballot(mine < n_rows && ptr[mine + 1] != ptr[mine]);
         while (todo) {
-            const uint32_t row = row0 + (uint32_t)__builtin_ctzll(todo);
+            const uint32_t row = g + (uint32_t)__builtin_ctzll(todo) * n_groups;
             todo &= todo - 1;
             const uint32_t lo = ptr[row], hi = ptr[row + 1];
             const int own = out_cnt[row];
@@ -962,7 +974,8 @@ static int launch_pruned(sg_ctx *ctx, const sg_csr *A, const sg_postings *Bt, in
                        (const void *)Bt->d_fwd, keep, r->stride, thr, s_budget, Bt->norm_up, Bt->freq_min, r->d_cols,
                        (T *)r->d_vals,
                        r->d_counts, row_counter, flagged_count, flagged_rows, stats, pl.d_i, pl.d_j, (T *)pl.d_s, pl.d_row_count, pl.d_chunk_count,
-                       pl.chunks, pl.d_chunks_used, pl.d_totals, pl.row_lo, pl.row_hi, row_list, row_list_len);
+                       pl.chunks, pl.d_chunks_used, pl.d_totals, pl.row_lo, pl.row_hi, row_list, row_list_len,
+                       (const uint32_t *)Bt->d_orig_of);
     SG_HIP_TRY(hipGetLastError());
     return SG_OK;
 }
@@ -1038,6 +1051,8 @@ int sg_spgemm_pruned_symmetric(sg_ctx *ctx, const sg_csr *A, const sg_postings *
                                double threshold, double delta, unsigned long long *stats, bool *done, int64_t row_lo,
                                int64_t row_hi, int32_t **export_pairs, int64_t *export_n) {
     *done = false;
+    // the self-join runs in position space: its left matrix is the one the index was built over (sg_postings.hip)
+    if (Bt->permuted) A = Bt->permuted;
     const size_t vs = A->dtype == SG_F64 ? 8 : 4;
     const int64_t n = A->n_rows;
     if (row_hi < 0) row_hi = n;   // the whole matrix

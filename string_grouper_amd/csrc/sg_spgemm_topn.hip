@@ -188,9 +188,13 @@ __device__ __forceinline__ void process_row(T *acc, uint32_t row, const int64_t 
                                             int32_t tile_end, int32_t keep, int32_t pass_off, int32_t out_stride, T thr,
                                             int32_t *__restrict__ out_cols, T *__restrict__ out_vals,
                                             int32_t *__restrict__ out_cnt, int lane, const SgPairSink *sink = nullptr,
-                                            uint32_t *pair_pos = nullptr) {
+                                            uint32_t *pair_pos = nullptr,
+                                            const uint32_t *__restrict__ orig_of = nullptr /* position -> right-hand row; null: identity */) {
     constexpr int TILE = 1 << TILE_LOG2;
     if (SELF) tile_end = min(tile_end, (int32_t)(row >> TILE_LOG2) + 1);
+    // columns are POSITIONS of right-hand rows (the index is built over a permutation, sg_postings.hip); SELF: so is `row`,
+    // and the left matrix is the permuted one.  The result names rows: row_out, and the columns as they are inserted.
+    const uint32_t row_out = (SELF && orig_of) ? orig_of[row] : row;
     constexpr int VEC = 16 / sizeof(T);   // values per 16-byte LDS access
     typedef T vec_t __attribute__((ext_vector_type(VEC)));
     vec_t *acc_v = reinterpret_cast<vec_t *>(acc);
@@ -199,7 +203,7 @@ __device__ __forceinline__ void process_row(T *acc, uint32_t row, const int64_t 
 
     const int64_t rlo = a_indptr[row];
     const int nnz = (int)(a_indptr[row + 1] - rlo);
-    const size_t obase = (size_t)row * (size_t)out_stride + (size_t)pass_off;
+    const size_t obase = (size_t)row_out * (size_t)out_stride + (size_t)pass_off;
 
     // ---- restore the row's running state (written by the previous tile group / pass)
     TopList<T> top;
@@ -207,7 +211,7 @@ __device__ __forceinline__ void process_row(T *acc, uint32_t row, const int64_t 
     T floor_s = INFINITY;
     int floor_c = -1;
     int prev_cnt = 0;
-    if (tile_begin > 0 || pass_off > 0) prev_cnt = __builtin_amdgcn_readfirstlane(out_cnt[row]);
+    if (tile_begin > 0 || pass_off > 0) prev_cnt = __builtin_amdgcn_readfirstlane(out_cnt[row_out]);
     if (pass_off > 0) {
         if (prev_cnt < pass_off) return;                // earlier passes did not fill up: row is complete
         floor_s = out_vals[obase - 1];
@@ -297,10 +301,11 @@ __device__ __forceinline__ void process_row(T *acc, uint32_t row, const int64_t 
                                     const int src = __builtin_ctzll(hm);
                                     hm &= hm - 1;
                                     const T ns = wave_read<T>(v[e], src);
-                                    const int nc = col_base + (x0 + src) * VEC + e;
+                                    const int np = col_base + (x0 + src) * VEC + e;   // position
+                                    const int nc = orig_of ? (int)orig_of[np] : np;   // the row: equal scores are ordered by IT
                                     if (SELF) {
-                                        if ((uint32_t)nc > row) continue;   // the pair (i, j > i) is row j's to score
-                                        if ((uint32_t)nc < row) emit_mirrored_pair<T>(*sink, *pair_pos, row, (uint32_t)nc, ns, lane);
+                                        if ((uint32_t)np > row) continue;   // the pair (i, j > i) is row j's to score
+                                        if ((uint32_t)np < row) emit_mirrored_pair<T>(*sink, *pair_pos, row_out, (uint32_t)nc, ns, lane);
                                     }
                                     if (ns < floor_s || (ns == floor_s && nc > floor_c)) top.insert(ns, nc, lane);
                                 }
@@ -319,7 +324,7 @@ __device__ __forceinline__ void process_row(T *acc, uint32_t row, const int64_t 
         out_vals[obase + lane] = top.s;
         out_cols[obase + lane] = top.c;
     }
-    if (lane == 0) out_cnt[row] = pass_off + cnt;
+    if (lane == 0) out_cnt[row_out] = pass_off + cnt;
 }
 
 template <typename T, int TILE_LOG2, int NB>
@@ -331,7 +336,7 @@ spgemm_topn_kernel(const int64_t *__restrict__ a_indptr, const int32_t *__restri
                    int32_t pass_off /* 64 * pass */, int32_t out_stride, T thr, int32_t *__restrict__ out_cols,
                    T *__restrict__ out_vals, int32_t *__restrict__ out_cnt, uint32_t *row_counter,
                    const uint32_t *__restrict__ row_list /* null: all rows */,
-                   const uint32_t *__restrict__ row_list_len) {
+                   const uint32_t *__restrict__ row_list_len, const uint32_t *__restrict__ orig_of) {
     constexpr int TILE = 1 << TILE_LOG2;
     constexpr int VEC = 16 / sizeof(T);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -348,7 +353,7 @@ spgemm_topn_kernel(const int64_t *__restrict__ a_indptr, const int32_t *__restri
         const uint32_t row = row_list ? row_list[idx] : idx;
         process_row<T, TILE_LOG2, NB>(acc, row, a_indptr, a_indices, a_data, seg, post_rows, post_vals, n_tiles,
                                       tile_begin, tile_end, keep, pass_off, out_stride, thr, out_cols, out_vals,
-                                      out_cnt, lane);
+                                      out_cnt, lane, nullptr, nullptr, orig_of);
     }
 }
 
@@ -365,7 +370,7 @@ spgemm_topn_selfjoin_rows_kernel(const int64_t *__restrict__ a_indptr, const int
                                  int32_t keep, int32_t out_stride, T thr, int32_t *__restrict__ out_cols,
                                  T *__restrict__ out_vals, int32_t *__restrict__ out_cnt, uint32_t *row_counter,
                                  const uint32_t *__restrict__ row_list, const uint32_t *__restrict__ row_list_len,
-                                 SgPairSink sink) {
+                                 SgPairSink sink, const uint32_t *__restrict__ orig_of) {
     constexpr int TILE = 1 << TILE_LOG2;
     constexpr int VEC = 16 / sizeof(T);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -382,7 +387,7 @@ spgemm_topn_selfjoin_rows_kernel(const int64_t *__restrict__ a_indptr, const int
         SG_WD(wd_rows, n_rows + 2, 1)
         const uint32_t row = (uint32_t)__builtin_amdgcn_readfirstlane((int)row_list[idx]);
         process_row<T, TILE_LOG2, NB, true>(acc, row, a_indptr, a_indices, a_data, seg, post_rows, post_vals, n_tiles, 0,
-                                            n_tiles, keep, 0, out_stride, thr, out_cols, out_vals, out_cnt, lane, &sink, &pos);
+                                            n_tiles, keep, 0, out_stride, thr, out_cols, out_vals, out_cnt, lane, &sink, &pos, orig_of);
     }
     if (lane == 0 && pos != SG_PAIR_NO_CHUNK && (pos >> 9) < sink.chunks) {   // close the wave's last chunk
         sink.d_chunk_count[pos >> 9] = pos & 511u;
@@ -554,7 +559,7 @@ static int launch_spgemm(sg_ctx *ctx, const sg_csr *A, const sg_postings *Bt, in
     hipLaunchKernelGGL(kern, dim3(grid), dim3(64), lds, ctx->stream, A->d_indptr, A->d_indices, (const T *)A->d_data,
                        (uint32_t)A->n_rows, (const uint32_t *)Bt->d_seg, (const int32_t *)Bt->d_rows,
                        (const T *)Bt->d_vals, Bt->n_tiles, tile_begin, tile_end, keep, pass_off, r->stride, thr,
-                       r->d_cols, (T *)r->d_vals, r->d_counts, counter, row_list, row_list_len);
+                       r->d_cols, (T *)r->d_vals, r->d_counts, counter, row_list, row_list_len, (const uint32_t *)Bt->d_orig_of);
     SG_HIP_TRY(hipGetLastError());
     return SG_OK;
 }
@@ -605,7 +610,7 @@ static int launch_selfjoin_rows(sg_ctx *ctx, const sg_csr *A, const sg_postings 
     hipLaunchKernelGGL(kern, dim3(sg_spgemm_exact_selfjoin_grid(ctx)), dim3(64), lds, ctx->stream, A->d_indptr, A->d_indices,
                        (const T *)A->d_data, (const uint32_t *)Bt->d_seg, (const int32_t *)Bt->d_rows, (const T *)Bt->d_vals,
                        Bt->n_tiles, keep, r->stride, thr, r->d_cols, (T *)r->d_vals, r->d_counts, row_counter, row_list,
-                       row_list_len, sink);
+                       row_list_len, sink, (const uint32_t *)Bt->d_orig_of);
     SG_HIP_TRY(hipGetLastError());
     return SG_OK;
 }
@@ -927,6 +932,9 @@ extern "C" int sg_selfjoin_range(sg_ctx *ctx, const sg_csr *A, const sg_postings
     const bool prune = pruned_applicable(ctx, A, Bt, stride, threshold, &delta, &symmetric, &pst, /*any_size=*/true);
     if (pst != SG_OK) return pst;
     if (!prune || !symmetric) return SG_OK;
+    // a range of the self-join form is a range of POSITIONS; the ranks' driver hands rows around in row order, so it
+    // builds its index without the permutation (sg_postings_build_flags, SG_POSTINGS_NO_PERMUTATION)
+    if (Bt->permuted) return SG_OK;
     sg_topn *r = nullptr;
     SG_TRY(topn_alloc(ctx, A->n_rows, Bt->n_right, stride, A->dtype, &r));
     int st = SG_OK;

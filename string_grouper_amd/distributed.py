@@ -170,8 +170,11 @@ def sharded_topn(ops, left_local, right_full, top_n: int, threshold: float, tile
     """Step 4b: inverted index of the whole right-hand side, multiply of the local left rows -- or, for a self-join
     that is large enough, the self-join form over row ranges (``sharded_selfjoin_topn``; the rank's block of the result
     is then the rows of its RANGE, which ``gather_topn`` concatenates just the same)."""
-    post = ops.postings(right_full, tile_cols)
-    if self_join and dist.is_initialized() and selfjoin_form_wanted(ops.csr_shape(right_full)[0], dist.get_world_size(group)):
+    want_ranges = bool(self_join and dist.is_initialized() and
+                       selfjoin_form_wanted(ops.csr_shape(right_full)[0], dist.get_world_size(group)))
+    # (row ranges are handed around in row order: that form's index is built without the library's row permutation)
+    post = ops.postings(right_full, tile_cols, permute=not want_ranges)
+    if want_ranges:
         res = sharded_selfjoin_topn(ops, right_full, post, top_n, threshold, group)
         if res is not None:
             ops.keep_alive(res, post, left_local, right_full)
@@ -367,8 +370,8 @@ class HipOps:
         self._sync()
         return csr_from_torch(self.ctx, indptr, indices, data, shape)
 
-    def postings(self, csr, tile_cols: int = 0):
-        return self.ctx.postings_build(csr, tile_cols)
+    def postings(self, csr, tile_cols: int = 0, permute: bool = True):
+        return self.ctx.postings_build(csr, tile_cols, permute)
 
     def multiply(self, left, post, top_n, threshold):
         return self.ctx.spgemm_topn(left, post, top_n, threshold, True)

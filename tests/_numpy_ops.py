@@ -89,7 +89,7 @@ class NumpyOps:
     def csr_from_tensors(self, indptr, indices, data, shape):
         return sp.csr_matrix((data.numpy(), indices.numpy(), indptr.numpy()), shape=shape)
 
-    def postings(self, m, tile_cols=0):
+    def postings(self, m, tile_cols=0, permute=True):
         return m
 
     def multiply(self, left, right, top_n, threshold):
