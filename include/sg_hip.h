@@ -154,8 +154,8 @@ int sg_postings_build(sg_ctx *ctx, const sg_csr *B, int32_t tile_cols, sg_postin
 /* The same with options.  SG_POSTINGS_NO_PERMUTATION: by default the index is built over a fixed permutation of B's rows
  * (a sorted name list has its similar names side by side, which piles a row's candidates into a few column tiles: the
  * pruned multiply ran 2.6 x slower on 663 k sorted names than on the same names shuffled); results never show it --
- * rows, columns and the order of equal scores are B's own.  The multi-GPU self-join form (sg_selfjoin_range) hands row
- * RANGES around and needs the index in row order. */
+ * rows, columns and the order of equal scores are B's own.  (The ranges of the multi-GPU self-join form,
+ * sg_selfjoin_range, are ranges of positions then: sg_postings_permutation.) */
 enum { SG_POSTINGS_NO_PERMUTATION = 1 };
 int sg_postings_build_flags(sg_ctx *ctx, const sg_csr *B, int32_t tile_cols, int32_t flags, sg_postings **out);
 int sg_postings_free(sg_postings *p);
@@ -229,13 +229,18 @@ int sg_row_costs(sg_ctx *ctx, const sg_csr *A, const sg_postings *Bt, int64_t *o
  *   cosine-like, top_n > 64, threshold too low, pair list full): nothing is returned and the caller uses
  *   sg_spgemm_topn on its rows.  All ranks must take the same branch.  (Rows the pruned kernel cannot take -- more
  *   than 128 non-zeros -- are scored by the exact kernel inside the same pass; they do not switch the form off.)
- * sg_selfjoin_merge: the pairs of ALL ranks, concatenated in any order, merged into the rows [row_lo, row_hi) of
- *   `res`: afterwards these rows equal the rows sg_spgemm_topn(A, Bt) would give, bit for bit. */
+ * sg_selfjoin_merge: the pairs of ALL ranks, concatenated in any order, merged into the rows of the range of `res`:
+ *   afterwards these rows equal the rows sg_spgemm_topn(A, Bt) would give, bit for bit.
+ * When the index is built over the row permutation (the default, sg_postings_build_flags) a range is a range of
+ *   POSITIONS: the rows it covers are orig_of[row_lo .. row_hi) (sg_postings_permutation; null tables = row order).
+ *   Pass the same Bt to sg_selfjoin_merge. */
 int sg_selfjoin_range(sg_ctx *ctx, const sg_csr *A, const sg_postings *Bt, int32_t top_n, double threshold,
                       int64_t row_lo, int64_t row_hi, sg_topn **out, int32_t **d_pairs, int64_t *n_pairs,
                       int32_t *pair_words, int32_t *applicable);
-int sg_selfjoin_merge(sg_ctx *ctx, sg_topn *res, const int32_t *d_pairs, int64_t n_pairs, int32_t pair_words,
-                      int64_t row_lo, int64_t row_hi);
+int sg_selfjoin_merge(sg_ctx *ctx, sg_topn *res, const sg_postings *Bt, const int32_t *d_pairs, int64_t n_pairs,
+                      int32_t pair_words, int64_t row_lo, int64_t row_hi);
+/* device tables of Bt's row permutation, n_right entries each: position -> row, row -> position (both null: none) */
+int sg_postings_permutation(const sg_postings *Bt, const uint32_t **d_orig_of, const uint32_t **d_pos_of);
 int sg_device_free(sg_ctx *ctx, void *d_ptr);
 
 /* ------------------------------------------------------------------ measurement */

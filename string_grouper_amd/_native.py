@@ -91,7 +91,8 @@ ABI = {
     "sg_matchlist_group_reps": (C.c_int, [_P, _P, C.c_int32, _P]),
     "sg_row_costs": (C.c_int, [_P, _P, _P, _P]),
     "sg_selfjoin_range": (C.c_int, [_P, _P, _P, C.c_int32, C.c_double, C.c_int64, C.c_int64, _P, _P, _P, _P, _P]),
-    "sg_selfjoin_merge": (C.c_int, [_P, _P, _P, C.c_int64, C.c_int32, C.c_int64, C.c_int64]),
+    "sg_selfjoin_merge": (C.c_int, [_P, _P, _P, _P, C.c_int64, C.c_int32, C.c_int64, C.c_int64]),
+    "sg_postings_permutation": (C.c_int, [_P, _PP, _PP]),
     "sg_device_free": (C.c_int, [_P, _P]),
     "sg_csr_rowwise_dot": (C.c_int, [_P, _P, _P, _P]),
     "sg_ctx_stats": (C.c_int, [_P, C.POINTER(SgStats)]),
@@ -480,9 +481,16 @@ class Context:
             return None
         return TopN(self, out), pairs.value, n_pairs.value, words.value
 
-    def selfjoin_merge(self, res: TopN, d_pairs: int, n_pairs: int, pair_words: int, row_lo: int, row_hi: int) -> None:
-        check(lib().sg_selfjoin_merge(self.h, res.h, C.c_void_p(d_pairs), int(n_pairs), int(pair_words), int(row_lo),
-                                      int(row_hi)))
+    def selfjoin_merge(self, res: TopN, Bt: Optional[Postings], d_pairs: int, n_pairs: int, pair_words: int, row_lo: int,
+                       row_hi: int) -> None:
+        check(lib().sg_selfjoin_merge(self.h, res.h, Bt.h if Bt is not None else None, C.c_void_p(d_pairs), int(n_pairs),
+                                      int(pair_words), int(row_lo), int(row_hi)))
+
+    def postings_permutation(self, Bt: Postings):
+        """(device pointer of orig_of, of pos_of), or (0, 0) when the index is in row order."""
+        a, b = C.c_void_p(), C.c_void_p()
+        check(lib().sg_postings_permutation(Bt.h, C.byref(a), C.byref(b)))
+        return a.value or 0, b.value or 0
 
     def device_free(self, d_ptr: int) -> None:
         if d_ptr:

@@ -760,23 +760,26 @@ __global__ void __launch_bounds__(SG_PAIR_CHUNK) pairs_export_kernel(const uint3
 
 template <int W>
 __global__ void __launch_bounds__(256) pairs_flat_count_kernel(const int32_t *__restrict__ pairs, int64_t n_pairs, uint32_t lo,
-                                                               uint32_t hi, uint32_t *cnt) {
+                                                               uint32_t hi, const uint32_t *__restrict__ pos_of, uint32_t *cnt) {
     const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n_pairs) return;
     const uint32_t j = (uint32_t)pairs[p * W + 1];
-    if (j >= lo && j < hi) atomicAdd(&cnt[j], 1u);
+    const uint32_t at = pos_of ? pos_of[j] : j;   // a rank's range is a range of POSITIONS when the index is permuted
+    if (at >= lo && at < hi) atomicAdd(&cnt[j], 1u);
 }
 
 template <typename T>
 __global__ void __launch_bounds__(256) pairs_flat_fill_kernel(const int32_t *__restrict__ pairs, int64_t n_pairs, uint32_t lo,
-                                                              uint32_t hi, const uint32_t *__restrict__ ptr, uint32_t *cursor,
+                                                              uint32_t hi, const uint32_t *__restrict__ pos_of,
+                                                              const uint32_t *__restrict__ ptr, uint32_t *cursor,
                                                               int32_t *__restrict__ lcol, T *__restrict__ lval) {
     constexpr int W = sizeof(T) == 8 ? 4 : 3;
     const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n_pairs) return;
     const int32_t *rec = pairs + p * W;
     const uint32_t j = (uint32_t)rec[1];
-    if (j < lo || j >= hi) return;
+    const uint32_t pj = pos_of ? pos_of[j] : j;
+    if (pj < lo || pj >= hi) return;
     const uint32_t at = ptr[j] + atomicAdd(&cursor[j], 1u);
     lcol[at] = rec[0];
     if (sizeof(T) == 8)
@@ -1243,7 +1246,8 @@ int sg_spgemm_pruned_symmetric(sg_ctx *ctx, const sg_csr *A, const sg_postings *
 
 // Second pass of the multi-GPU self-join: merge the mirrored pairs (of all ranks) whose row lies in [row_lo, row_hi)
 // into those rows of `r` (which hold their own matches from sg_spgemm_pruned_symmetric over the same range).
-int sg_selfjoin_merge_pairs(sg_ctx *ctx, sg_topn *r, const int32_t *d_pairs, int64_t n_pairs, int64_t row_lo, int64_t row_hi) {
+int sg_selfjoin_merge_pairs(sg_ctx *ctx, sg_topn *r, const int32_t *d_pairs, int64_t n_pairs, int64_t row_lo, int64_t row_hi,
+                            const uint32_t *pos_of) {
     const int64_t n = r->n_rows;
     if (n_pairs <= 0 || row_hi <= row_lo) return SG_OK;
     const size_t vs = r->dtype == SG_F64 ? 8 : 4;
@@ -1263,22 +1267,22 @@ int sg_selfjoin_merge_pairs(sg_ctx *ctx, sg_topn *r, const int32_t *d_pairs, int
         const unsigned pg = (unsigned)((n_pairs + 255) / 256);
         if (r->dtype == SG_F64)
             hipLaunchKernelGGL(pairs_flat_count_kernel<4>, dim3(pg), dim3(256), 0, ctx->stream, d_pairs, n_pairs, (uint32_t)row_lo,
-                               (uint32_t)row_hi, cnt);
+                               (uint32_t)row_hi, pos_of, cnt);
         else
             hipLaunchKernelGGL(pairs_flat_count_kernel<3>, dim3(pg), dim3(256), 0, ctx->stream, d_pairs, n_pairs, (uint32_t)row_lo,
-                               (uint32_t)row_hi, cnt);
+                               (uint32_t)row_hi, pos_of, cnt);
         st = sg_exclusive_scan_u32(ctx, cnt, cnt, n + 1, nullptr);
         if (st == SG_OK) {
             const unsigned sgrid = (unsigned)((n + 63) / 64 > 0 ? (n + 63) / 64 : 1);
             if (r->dtype == SG_F64) {
                 hipLaunchKernelGGL(pairs_flat_fill_kernel<double>, dim3(pg), dim3(256), 0, ctx->stream, d_pairs, n_pairs,
-                                   (uint32_t)row_lo, (uint32_t)row_hi, cnt, cursor, lcol, (double *)lval);
+                                   (uint32_t)row_lo, (uint32_t)row_hi, pos_of, cnt, cursor, lcol, (double *)lval);
                 hipLaunchKernelGGL(pairs_select_kernel<double>, dim3(sgrid), dim3(64), 0, ctx->stream, cnt, lcol,
                                    (const double *)lval, (uint32_t)n, r->stride, r->stride, r->d_cols, (double *)r->d_vals,
                                    r->d_counts);
             } else {
                 hipLaunchKernelGGL(pairs_flat_fill_kernel<float>, dim3(pg), dim3(256), 0, ctx->stream, d_pairs, n_pairs,
-                                   (uint32_t)row_lo, (uint32_t)row_hi, cnt, cursor, lcol, (float *)lval);
+                                   (uint32_t)row_lo, (uint32_t)row_hi, pos_of, cnt, cursor, lcol, (float *)lval);
                 hipLaunchKernelGGL(pairs_select_kernel<float>, dim3(sgrid), dim3(64), 0, ctx->stream, cnt, lcol,
                                    (const float *)lval, (uint32_t)n, r->stride, r->stride, r->d_cols, (float *)r->d_vals,
                                    r->d_counts);

@@ -932,9 +932,6 @@ extern "C" int sg_selfjoin_range(sg_ctx *ctx, const sg_csr *A, const sg_postings
     const bool prune = pruned_applicable(ctx, A, Bt, stride, threshold, &delta, &symmetric, &pst, /*any_size=*/true);
     if (pst != SG_OK) return pst;
     if (!prune || !symmetric) return SG_OK;
-    // a range of the self-join form is a range of POSITIONS; the ranks' driver hands rows around in row order, so it
-    // builds its index without the permutation (sg_postings_build_flags, SG_POSTINGS_NO_PERMUTATION)
-    if (Bt->permuted) return SG_OK;
     sg_topn *r = nullptr;
     SG_TRY(topn_alloc(ctx, A->n_rows, Bt->n_right, stride, A->dtype, &r));
     int st = SG_OK;
@@ -962,14 +959,21 @@ extern "C" int sg_selfjoin_range(sg_ctx *ctx, const sg_csr *A, const sg_postings
     return SG_OK;
 }
 
-extern "C" int sg_selfjoin_merge(sg_ctx *ctx, sg_topn *res, const int32_t *d_pairs, int64_t n_pairs, int32_t pair_words,
-                                 int64_t row_lo, int64_t row_hi) {
+extern "C" int sg_selfjoin_merge(sg_ctx *ctx, sg_topn *res, const sg_postings *Bt, const int32_t *d_pairs, int64_t n_pairs,
+                                 int32_t pair_words, int64_t row_lo, int64_t row_hi) {
     SG_REQUIRE(ctx && res, "null argument");
     SG_REQUIRE(n_pairs == 0 || d_pairs != nullptr, "pairs are null");
     SG_REQUIRE(pair_words == (res->dtype == SG_F64 ? 4 : 3), "pair records do not match the result's value type");
     SG_REQUIRE(row_lo >= 0 && row_lo <= row_hi && row_hi <= res->n_rows, "row range outside the result");
     SgTimer timer(ctx, SG_K_ZIP);
-    return sg_selfjoin_merge_pairs(ctx, res, d_pairs, n_pairs, row_lo, row_hi);
+    return sg_selfjoin_merge_pairs(ctx, res, d_pairs, n_pairs, row_lo, row_hi, Bt ? (const uint32_t *)Bt->d_pos_of : nullptr);
+}
+
+extern "C" int sg_postings_permutation(const sg_postings *Bt, const uint32_t **d_orig_of, const uint32_t **d_pos_of) {
+    SG_REQUIRE(Bt != nullptr, "postings are null");
+    if (d_orig_of) *d_orig_of = Bt->d_orig_of;
+    if (d_pos_of) *d_pos_of = Bt->d_pos_of;
+    return SG_OK;
 }
 
 extern "C" int sg_device_free(sg_ctx *ctx, void *d_ptr) {

@@ -170,11 +170,8 @@ def sharded_topn(ops, left_local, right_full, top_n: int, threshold: float, tile
     """Step 4b: inverted index of the whole right-hand side, multiply of the local left rows -- or, for a self-join
     that is large enough, the self-join form over row ranges (``sharded_selfjoin_topn``; the rank's block of the result
     is then the rows of its RANGE, which ``gather_topn`` concatenates just the same)."""
-    want_ranges = bool(self_join and dist.is_initialized() and
-                       selfjoin_form_wanted(ops.csr_shape(right_full)[0], dist.get_world_size(group)))
-    # (row ranges are handed around in row order: that form's index is built without the library's row permutation)
-    post = ops.postings(right_full, tile_cols, permute=not want_ranges)
-    if want_ranges:
+    post = ops.postings(right_full, tile_cols)
+    if self_join and dist.is_initialized() and selfjoin_form_wanted(ops.csr_shape(right_full)[0], dist.get_world_size(group)):
         res = sharded_selfjoin_topn(ops, right_full, post, top_n, threshold, group)
         if res is not None:
             ops.keep_alive(res, post, left_local, right_full)
@@ -243,6 +240,15 @@ def gather_topn(ops, res, group=None):
         cols = torch.cat(all_gather_ragged(cols.reshape(-1), group, cells)).reshape(-1, stride)
         vals = torch.cat(all_gather_ragged(vals.reshape(-1), group, cells)).reshape(-1, stride)
         counts = torch.cat(all_gather_ragged(counts, group, rows))
+    orig_of = getattr(res, "orig_of", None)
+    if orig_of is not None:
+        # the ranks' ranges were ranges of positions of the library's row permutation: block p of the concatenation is
+        # row orig_of[p]
+        if counts.numel() != orig_of.numel():
+            raise RuntimeError(f"the ranks' ranges hold {counts.numel()} rows, the permutation {orig_of.numel()}")
+        cols = torch.empty_like(cols).index_copy_(0, orig_of, cols)
+        vals = torch.empty_like(vals).index_copy_(0, orig_of, vals)
+        counts = torch.empty_like(counts).index_copy_(0, orig_of, counts)
     return cols.cpu().numpy(), vals.cpu().numpy(), counts.cpu().numpy()
 
 
@@ -296,10 +302,12 @@ def csr_from_torch(ctx, indptr, indices, data, shape):
 
 
 class TopNRows:
-    """The rows [lo, hi) of a device result (a rank's block of the self-join form over row ranges)."""
+    """The rows [lo, hi) of a device result (a rank's block of the self-join form over row ranges).  ``orig_of`` given:
+    the range is one of POSITIONS of the library's row permutation (int64 tensor, position -> row): the block's rows are
+    orig_of[lo:hi], in that order; the blocks of all ranks concatenated are the result in position order."""
 
-    def __init__(self, res, lo: int, hi: int):
-        self.res, self.lo, self.hi = res, lo, hi
+    def __init__(self, res, lo: int, hi: int, orig_of=None):
+        self.res, self.lo, self.hi, self.orig_of = res, lo, hi, orig_of
         self._keep = None
 
     def free(self):
@@ -311,6 +319,9 @@ class TopNRows:
 
     def to_host(self):
         cols, vals, cnt = self.res.to_host()
+        if self.orig_of is not None:
+            ids = self.orig_of[self.lo:self.hi].cpu().numpy()
+            return cols[ids], vals[ids], cnt[ids]
         return cols[self.lo:self.hi], vals[self.lo:self.hi], cnt[self.lo:self.hi]
 
     def to_scipy(self):
@@ -385,7 +396,7 @@ class HipOps:
         if got is None:
             return None
         res, ptr, n_pairs, words = got
-        return {"res": res, "ptr": ptr, "n": n_pairs, "words": words}
+        return {"res": res, "ptr": ptr, "n": n_pairs, "words": words, "post": post}
 
     def selfjoin_pairs(self, part):
         self._sync()
@@ -402,16 +413,27 @@ class HipOps:
         self._sync()                                  # the gathered list is torch's: ordered before the library reads it
         words = part["words"]
         pairs_all = pairs_all.contiguous()
-        self.ctx.selfjoin_merge(part["res"], pairs_all.data_ptr(), pairs_all.numel() // words, words, lo, hi)
+        post = part.get("post")
+        self.ctx.selfjoin_merge(part["res"], post, pairs_all.data_ptr(), pairs_all.numel() // words, words, lo, hi)
         self.ctx.sync()                               # ... and the library is done with it before torch frees it
         self.ctx.device_free(part["ptr"])
-        return TopNRows(part["res"], lo, hi)
+        # the index is built over a permutation of the rows: the range [lo, hi) is one of POSITIONS, its rows are orig_of[lo:hi]
+        orig_of = None
+        if post is not None:
+            p_orig, _ = self.ctx.postings_permutation(post)
+            if p_orig:
+                n = part["res"].dims()[0]
+                orig_of = torch.as_tensor(DeviceTensorView(p_orig, n, "<i4"), device=self.device)[:n].to(torch.int64)
+        return TopNRows(part["res"], lo, hi, orig_of)
 
     def topn_tensors(self, res):
         import ctypes as C
         from . import _native as N
         if isinstance(res, TopNRows):
             cols, vals, counts = self.topn_tensors(res.res)
+            if res.orig_of is not None:               # rows of the range in POSITION order
+                ids = res.orig_of[res.lo:res.hi]
+                return cols.index_select(0, ids), vals.index_select(0, ids), counts.index_select(0, ids)
             return cols[res.lo:res.hi], vals[res.lo:res.hi], counts[res.lo:res.hi]
         r, s, d, _ = res.dims()
         pc, pv, pn = C.c_void_p(), C.c_void_p(), C.c_void_p()

@@ -520,7 +520,10 @@ def test_device_resident_inputs_and_rccl_plumbing(ctx):
         try:
             res5, _ = D.distributed_self_join(ops, block, 10, 0.8)
             assert isinstance(res5, D.TopNRows) and ctx.stats()["prune_symmetric"] == 1
-            assert_csr_identical(res5.to_scipy(), C_ref)
+            C5 = res5.to_scipy()              # the rank's block: rows in POSITION order when the index is permuted
+            if res5.orig_of is not None:
+                C5 = C5[np.argsort(res5.orig_of.cpu().numpy(), kind="stable")]
+            assert_csr_identical(C5, C_ref)
             c5, v5, n5 = D.gather_topn(ops, res5)
             assert n5.tolist() == np.diff(C_ref.indptr).tolist()
         finally:
@@ -977,29 +980,43 @@ def test_selfjoin_form_over_row_ranges_equals_the_whole(ctx, dtype):
     A = _tfidf(names, dtype)
     assert int((np.diff(A.indptr) > 64).sum()) > 20
     dA = ctx.csr_from_scipy(A)
-    post = ctx.postings_build(dA, permute=False)       # ranges are ranges of rows: the index in row order
     want = P.sp_matmul_topn_port(A, A.T, 10, 0.75, True, 8)
     ops = D.HipOps(ctx, lambda: HipTfidfVectorizer(dtype=dtype, ctx=ctx))
     n = len(names)
-    for world in (1, 2, 3, 5):
-        bounds = D.selfjoin_row_ranges(n, world)
-        assert bounds[0] == 0 and bounds[-1] == n
-        parts = [ops.selfjoin_range(dA, post, 10, 0.75, int(bounds[r]), int(bounds[r + 1])) for r in range(world)]
-        assert all(p is not None for p in parts)
-        pairs_all = torch.cat([ops.selfjoin_pairs(p).clone() for p in parts])
-        assert pairs_all.numel() % parts[0]["words"] == 0 and pairs_all.numel() > 0
-        rows = []
-        for r in range(world):
-            blk = ops.selfjoin_merge(parts[r], pairs_all, int(bounds[r]), int(bounds[r + 1]))
-            rows.append(blk.to_scipy())
-            blk.free()
-        assert_csr_identical(sp.vstack(rows).tocsr(), want, f"{world} ranges")
+
+    def stacked(rows, blk_orig_of):
+        """the ranks' blocks put together; with the index over the library's row permutation the ranges are ranges of
+        POSITIONS and block row p is row orig_of[p]"""
+        C = sp.vstack(rows).tocsr()
+        if blk_orig_of is None:
+            return C
+        inverse = np.argsort(blk_orig_of.cpu().numpy(), kind="stable")
+        return C[inverse]
+
+    for permute in (False, True):
+        post = ctx.postings_build(dA, permute=permute)
+        for world in (1, 2, 3, 5):
+            bounds = D.selfjoin_row_ranges(n, world)
+            assert bounds[0] == 0 and bounds[-1] == n
+            parts = [ops.selfjoin_range(dA, post, 10, 0.75, int(bounds[r]), int(bounds[r + 1])) for r in range(world)]
+            assert all(p is not None for p in parts)
+            pairs_all = torch.cat([ops.selfjoin_pairs(p).clone() for p in parts])
+            assert pairs_all.numel() % parts[0]["words"] == 0 and pairs_all.numel() > 0
+            rows, orig_of = [], None
+            for r in range(world):
+                blk = ops.selfjoin_merge(parts[r], pairs_all, int(bounds[r]), int(bounds[r + 1]))
+                assert (blk.orig_of is not None) == permute
+                orig_of = blk.orig_of
+                rows.append(blk.to_scipy())
+                blk.free()
+            assert_csr_identical(stacked(rows, orig_of), want, f"{world} ranges, permutation {permute}")
+        post.free()
     # rows for the exact kernel (more than 128 terms) are scored inside the range's pass by that kernel's self-join launch
     extra = ["".join(rng.choice(list("ABCDEFGHIJKLMNOPQRSTUVWXYZ"), 180)) for _ in range(3)]
     long_names = names[:4000] + extra + names[4000:] + [extra[1][:170], extra[2]]
     AL = _tfidf(long_names, dtype)
     dL = ctx.csr_from_scipy(AL)
-    postL = ctx.postings_build(dL, permute=False)
+    postL = ctx.postings_build(dL)                     # (over the row permutation: ranges of positions)
     wantL = P.sp_matmul_topn_port(AL, AL.T, 10, 0.75, True, 8)
     nL = len(long_names)
     for world in (1, 3):
@@ -1007,13 +1024,15 @@ def test_selfjoin_form_over_row_ranges_equals_the_whole(ctx, dtype):
         parts = [ops.selfjoin_range(dL, postL, 10, 0.75, int(bounds[r]), int(bounds[r + 1])) for r in range(world)]
         assert all(p is not None for p in parts)
         pairs_all = torch.cat([ops.selfjoin_pairs(p).clone() for p in parts])
-        rows = []
+        rows, orig_of = [], None
         for r in range(world):
             blk = ops.selfjoin_merge(parts[r], pairs_all, int(bounds[r]), int(bounds[r + 1]))
+            orig_of = blk.orig_of
             rows.append(blk.to_scipy())
             blk.free()
-        assert_csr_identical(sp.vstack(rows).tocsr(), wantL, f"{world} ranges with rows for the exact kernel")
-    postL.free(); dL.free(); post.free(); dA.free()
+        assert orig_of is not None
+        assert_csr_identical(stacked(rows, orig_of), wantL, f"{world} ranges with rows for the exact kernel")
+    postL.free(); dL.free(); dA.free()
 
 
 def test_selfjoin_form_with_a_pair_list_that_is_too_small_falls_back(ctx, monkeypatch):
