@@ -114,6 +114,7 @@ extern "C" int sg_ctx_create(int device, void *hip_stream, sg_ctx **out) {
     if (!ctx) return SG_ERR_OOM;
     ctx->device = device;
     ctx->num_cu = prop.multiProcessorCount;
+    ctx->total_mem = prop.totalGlobalMem;
     if (hip_stream) {
         ctx->stream = (hipStream_t)hip_stream;
     } else {

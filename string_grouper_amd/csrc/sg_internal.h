@@ -51,6 +51,7 @@ struct sg_ctx {
     bool own_stream = false;
     int num_cu = 256;
     size_t lds_per_cu = 160 * 1024;
+    size_t total_mem = 0;                // device memory, bytes (hipDeviceProp_t::totalGlobalMem)
 
     std::mutex mu;
     std::multimap<size_t, void *> free_blocks;   // size -> ptr

@@ -1067,14 +1067,11 @@ int sg_spgemm_pruned_symmetric(sg_ctx *ctx, const sg_csr *A, const sg_postings *
     // pass was thrown away after 630 ms and the one-sided form took another 1300; scripts/full_configs.py).  The list
     // costs nothing until it is written: room for 64 n pairs, at most a sixteenth of the device memory.
     int64_t cap = 64 * n + ((int64_t)1 << 20);
-    {
-        size_t free_b = 0, total_b = 0;
-        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && total_b > 0) {
-            const int64_t by_memory = (int64_t)(total_b / 16 / (8 + vs));
-            if (cap > by_memory) cap = by_memory;
-        }
-        if (cap < 8 * n + ((int64_t)1 << 20)) cap = 8 * n + ((int64_t)1 << 20);
+    if (ctx->total_mem > 0) {
+        const int64_t by_memory = (int64_t)(ctx->total_mem / 16 / (8 + vs));
+        if (cap > by_memory) cap = by_memory;
     }
+    if (cap < 8 * n + ((int64_t)1 << 20)) cap = 8 * n + ((int64_t)1 << 20);
     bool cap_forced = false;
     if (const char *v = getenv("SG_SYM_PAIR_CAP"))   // test hook: a list that is too small
         if (atoll(v) > 0) {
