@@ -169,9 +169,9 @@ __device__ __forceinline__ T exact_score(int j, const int *hk, const T *ha, int 
 // (LDS objects are addressed through the kernel's own shared array so that they stay ds_* accesses.)
 template <typename T, bool SYM, int TILE_LOG2, bool WIDE>
 __device__ __noinline__ TopList<T> drain_survivors(int nnz, const uint32_t *fwd_ptr, const void *fwd, T thr, uint32_t row,
-                                                   uint32_t *pair_i, uint32_t *pair_j, T *pair_s, uint32_t *pair_row_count,
-                                                   uint32_t *pair_chunk_count, uint32_t pair_chunks, uint32_t *pair_chunks_used,
-                                                   unsigned long long *pair_totals, TopList<T> top, uint32_t n_surv,
+                                                   const SgPairSink *__restrict__ pairs /* SYM: the pair list, a struct in device memory
+                                                      (one pointer instead of eight arguments at every call site) */,
+                                                   TopList<T> top, uint32_t n_surv,
                                                    const uint32_t *__restrict__ orig_of /* position -> right-hand row; null: identity */,
                                                    uint32_t row_out /* the left row's index in the result */) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -196,14 +196,17 @@ __device__ __noinline__ TopList<T> drain_survivors(int nnz, const uint32_t *fwd_
             // of the survivor buffer (which holds at most 127 columns).
             uint32_t pos = (uint32_t)surv[SG_SURV_CAP - 1];
             const uint32_t n_hit = (uint32_t)__popcll(mm);
+            uint32_t *const pair_i = pairs->d_i, *const pair_j = pairs->d_j, *const pair_row_count = pairs->d_row_count;
+            T *const pair_s = reinterpret_cast<T *>(pairs->d_s);
+            const uint32_t pair_chunks = pairs->chunks;
             if (pos == SG_PAIR_NO_CHUNK || (pos & 511u) + n_hit > SG_PAIR_CHUNK) {
                 uint32_t c = 0;
                 if (lane == 0) {
                     if (pos != SG_PAIR_NO_CHUNK && (pos >> 9) < pair_chunks) {
-                        pair_chunk_count[pos >> 9] = pos & 511u;
-                        atomicAdd(pair_totals, (unsigned long long)(pos & 511u));
+                        pairs->d_chunk_count[pos >> 9] = pos & 511u;
+                        atomicAdd(pairs->d_totals, (unsigned long long)(pos & 511u));
                     }
-                    c = atomicAdd(pair_chunks_used, 1u);
+                    c = atomicAdd(pairs->d_chunks_used, 1u);
                 }
                 pos = (uint32_t)__builtin_amdgcn_readfirstlane((int)c) << 9;
             }
@@ -248,10 +251,8 @@ spgemm_topn_pruned_kernel(const int64_t *__restrict__ a_indptr, const int32_t *_
                           int32_t *__restrict__ out_cols, T *__restrict__ out_vals, int32_t *__restrict__ out_cnt,
                           uint32_t *row_counter, uint32_t *flagged_count, uint32_t *flagged_rows,
                           unsigned long long *stats /* [0] rows [1] postings streamed [2] survivors */,
-                          uint32_t *pair_i, uint32_t *pair_j, T *pair_s, uint32_t *pair_row_count /* SYM: [n_left], zeroed */,
-                          uint32_t *pair_chunk_count /* SYM: entries used of every chunk of the pair list */,
-                          uint32_t pair_chunks /* chunks there are */, uint32_t *pair_chunks_used /* chunks handed out */,
-                          unsigned long long *pair_totals /* pairs in closed chunks */,
+                          const SgPairSink *__restrict__ pairs /* SYM: the pair list (sg_internal.h), in device memory */,
+                          uint32_t pair_chunks /* chunks there are */,
                           uint32_t sym_lo, uint32_t sym_hi /* SYM: the left rows this launch scores (multi-GPU: a rank's range) */,
                           const uint32_t *__restrict__ row_list /* WIDE: the rows to process */, const uint32_t *row_list_len,
                           const uint32_t *__restrict__ orig_of /* position -> right-hand row (sg_postings.hip); null: identity */) {
@@ -492,8 +493,7 @@ spgemm_topn_pruned_kernel(const int64_t *__restrict__ a_indptr, const int32_t *_
             if (cross) surv[n_surv + __popcll(cm & lanes_below)] = col;
             n_surv += __popcll(cm);
             if (n_surv >= 64) {
-                top = drain_survivors<T, SYM, TILE_LOG2, WIDE>(nnz, fwd_ptr, fwd, thr, row, pair_i, pair_j, pair_s, pair_row_count, pair_chunk_count, pair_chunks, pair_chunks_used, pair_totals,
-                                                         top, n_surv, orig_of, row_out);
+                top = drain_survivors<T, SYM, TILE_LOG2, WIDE>(nnz, fwd_ptr, fwd, thr, row, pairs, top, n_surv, orig_of, row_out);
                 st_surv += 64;
                 n_surv -= 64;
             }
@@ -681,8 +681,7 @@ spgemm_topn_pruned_kernel(const int64_t *__restrict__ a_indptr, const int32_t *_
         if (probe_sink == 0x1234567887654321ull) n_surv = 1;   // keeps the tests alive
 #endif
         if (n_surv > 0) {   // fewer than 64 left
-            top = drain_survivors<T, SYM, TILE_LOG2, WIDE>(nnz, fwd_ptr, fwd, thr, row, pair_i, pair_j, pair_s, pair_row_count, pair_chunk_count, pair_chunks, pair_chunks_used, pair_totals, top,
-                                                     n_surv, orig_of, row_out);
+            top = drain_survivors<T, SYM, TILE_LOG2, WIDE>(nnz, fwd_ptr, fwd, thr, row, pairs, top, n_surv, orig_of, row_out);
             st_surv += n_surv;
         }
         {   // (symmetric mode: the row's matches j <= i; pass 2 merges the mirrored ones in)
@@ -708,8 +707,8 @@ spgemm_topn_pruned_kernel(const int64_t *__restrict__ a_indptr, const int32_t *_
     if (SYM && lane == 0) {   // close the wave's last chunk
         const uint32_t pos = (uint32_t)surv[SG_SURV_CAP - 1];
         if (pos != SG_PAIR_NO_CHUNK && (pos >> 9) < pair_chunks) {
-            pair_chunk_count[pos >> 9] = pos & 511u;
-            atomicAdd(pair_totals, (unsigned long long)(pos & 511u));
+            pairs->d_chunk_count[pos >> 9] = pos & 511u;
+            atomicAdd(pairs->d_totals, (unsigned long long)(pos & 511u));
         }
     }
     if (lane == 0) {
@@ -948,7 +947,10 @@ struct PairList {   // symmetric mode: the mirrored pairs (i, j < i) above the t
     unsigned long long *d_totals = nullptr;    // pairs
     uint32_t chunks = 0;
     uint32_t row_lo = 0, row_hi = 0;           // the left rows to score (the whole matrix on one GPU)
+    const SgPairSink *d_sink = nullptr;        // the same pointers as a struct in device memory: what the kernel is handed
 };
+
+__global__ void pair_sink_kernel(SgPairSink v, SgPairSink *out) { *out = v; }
 
 // single-wave workgroups of the pruned kernel: as many as the LDS of the chip holds
 static unsigned pruned_grid(const sg_ctx *ctx, int32_t tile_log2, int64_t n_rows) {
@@ -976,8 +978,8 @@ static int launch_pruned(sg_ctx *ctx, const sg_csr *A, const sg_postings *Bt, in
                        (const uint32_t *)Bt->d_filt, Bt->n_tiles, (const uint32_t *)Bt->d_fwd_ptr,
                        (const void *)Bt->d_fwd, keep, r->stride, thr, s_budget, Bt->norm_up, Bt->freq_min, r->d_cols,
                        (T *)r->d_vals,
-                       r->d_counts, row_counter, flagged_count, flagged_rows, stats, pl.d_i, pl.d_j, (T *)pl.d_s, pl.d_row_count, pl.d_chunk_count,
-                       pl.chunks, pl.d_chunks_used, pl.d_totals, pl.row_lo, pl.row_hi, row_list, row_list_len,
+                       r->d_counts, row_counter, flagged_count, flagged_rows, stats, pl.d_sink, pl.chunks, pl.row_lo, pl.row_hi, row_list,
+                       row_list_len,
                        (const uint32_t *)Bt->d_orig_of);
     SG_HIP_TRY(hipGetLastError());
     return SG_OK;
@@ -1085,13 +1087,13 @@ int sg_spgemm_pruned_symmetric(sg_ctx *ctx, const sg_csr *A, const sg_postings *
     if (pl.chunks < 1) pl.chunks = 1;
     cap = (int64_t)pl.chunks * SG_PAIR_CHUNK;
     // [0] row counter [1] flagged count [2..3] pairs [4] chunks handed out [5] row counter of the exact kernel's launch;
-    // [8 ..) entries per chunk
+    // [64, 80) the pair list as a struct; [128 ..) entries per chunk
     uint32_t *words = nullptr;
     uint32_t *cnt = nullptr, *cursor = nullptr;
     int32_t *lcol = nullptr;
     void *lval = nullptr;
     uint32_t *flagged_rows = nullptr;
-    int st = sg_alloc(ctx, (size_t)8 + pl.chunks, &words);
+    int st = sg_alloc(ctx, (size_t)128 + pl.chunks, &words);   // ([64, 80): the SgPairSink handed to the kernels)
     if (st == SG_OK) st = sg_alloc(ctx, (size_t)cap, &pl.d_i);
     if (st == SG_OK) st = sg_alloc(ctx, (size_t)cap, &pl.d_j);
     if (st == SG_OK) st = ctx->alloc((size_t)cap * vs, &pl.d_s);
@@ -1117,18 +1119,35 @@ int sg_spgemm_pruned_symmetric(sg_ctx *ctx, const sg_csr *A, const sg_postings *
     pl.d_totals = (unsigned long long *)(words + 2);
     pl.d_chunks_used = words + 4;
     pl.d_row_count = cnt;
-    pl.d_chunk_count = words + 8;
+    pl.d_chunk_count = words + 128;
+    // (a cache line of its own, 256 bytes from the counters: every access to the line of the row counter and the chunk
+    //  counter queues behind their atomics -- with the struct next to them the kernel took twice its time)
+    pl.d_sink = reinterpret_cast<const SgPairSink *>(words + 64);
+    static_assert(sizeof(SgPairSink) <= 64, "the pair list's struct must fit the sixteen words reserved for it");
     unsigned long long *d_stats3 = nullptr;   // this pass's own statistics: they only count when the pass does
     st = sg_alloc(ctx, (size_t)4, &d_stats3);
     hipError_t e = hipSuccess;
     if (st == SG_OK) {
-        e = hipMemsetAsync(words, 0, (8 + (size_t)pl.chunks) * sizeof(uint32_t), ctx->stream);
+        e = hipMemsetAsync(words, 0, (128 + (size_t)pl.chunks) * sizeof(uint32_t), ctx->stream);
         if (e == hipSuccess) e = hipMemsetAsync(d_stats3, 0, 4 * sizeof(unsigned long long), ctx->stream);
         if (e == hipSuccess) e = hipMemsetAsync(cnt, 0, sizeof(uint32_t) * (size_t)(n + 2), ctx->stream);
         if (e == hipSuccess) e = hipMemsetAsync(cursor, 0, sizeof(uint32_t) * (size_t)(n + 2), ctx->stream);
         if (e != hipSuccess) st = SG_ERR_HIP;
     }
     const float s_budget = prune_budget(Bt, threshold, delta);
+    SgPairSink sink;
+    sink.d_i = pl.d_i;
+    sink.d_j = pl.d_j;
+    sink.d_s = pl.d_s;
+    sink.d_row_count = pl.d_row_count;
+    sink.d_chunk_count = pl.d_chunk_count;
+    sink.d_chunks_used = pl.d_chunks_used;
+    sink.d_totals = pl.d_totals;
+    sink.chunks = pl.chunks;
+    if (st == SG_OK) {
+        hipLaunchKernelGGL(pair_sink_kernel, dim3(1), dim3(1), 0, ctx->stream, sink, (SgPairSink *)(words + 64));
+        if (hipGetLastError() != hipSuccess) st = SG_ERR_HIP;
+    }
     if (st == SG_OK) {
         SgTimer kt(ctx, SG_K_SPGEMM_KERNEL);   // the kernel alone (the launch group's timer also covers the second pass)
         if (A->dtype == SG_F64)
@@ -1141,15 +1160,6 @@ int sg_spgemm_pruned_symmetric(sg_ctx *ctx, const sg_csr *A, const sg_postings *
         // room for the fixed-point filter): through the exact kernel, in the same form -- pairs (i, j <= i), mirrored ones
         // into the pair list.  Launched on the device-side count: without such rows its waves leave at once.
         if (st == SG_OK) {
-            SgPairSink sink;
-            sink.d_i = pl.d_i;
-            sink.d_j = pl.d_j;
-            sink.d_s = pl.d_s;
-            sink.d_row_count = pl.d_row_count;
-            sink.d_chunk_count = pl.d_chunk_count;
-            sink.d_chunks_used = pl.d_chunks_used;
-            sink.d_totals = pl.d_totals;
-            sink.chunks = pl.chunks;
             st = sg_spgemm_exact_selfjoin_rows(ctx, A, Bt, keep, r, threshold, words + 5, flagged_rows, words + 1, sink);
         }
     }
