@@ -123,6 +123,12 @@ struct sg_csr {
     uint32_t *d_props_words = nullptr;
 };
 
+struct SgScoreCtx {
+    const uint32_t *fwd_ptr = nullptr;   // packed rows of B: row at position q = entries [fwd_ptr[q], fwd_ptr[q + 1])
+    const void *fwd = nullptr;
+    const uint32_t *orig_of = nullptr;   // position -> row; null: identity
+};
+
 struct sg_postings {
     sg_ctx *ctx = nullptr;
     int64_t n_right = 0, n_terms = 0, nnz = 0;
@@ -158,6 +164,9 @@ struct sg_postings {
     // the pairs they exchange.  All null: positions are rows.
     sg_csr *permuted = nullptr;
     uint32_t *d_orig_of = nullptr, *d_pos_of = nullptr;
+    // what the pruned multiply's survivor routine needs of the index, as ONE struct in device memory: that routine is a
+    // real call inside the tile loop, and every argument it takes is a register the loop cannot use at the call sites
+    struct SgScoreCtx *d_score_ctx = nullptr;
     // per term a 16-byte aligned row of nt_pad entries: d_ends[k * nt_pad + t] = BYTE offset into d_filt of the end
     // of segment (k, t) (entries past the last tile repeat the end of the list): one 16-byte load = four tiles
     uint32_t *d_ends = nullptr;

@@ -280,6 +280,8 @@ __global__ void __launch_bounds__(256) permute_rows_kernel(const int64_t *__rest
     }
 }
 
+__global__ void score_ctx_kernel(SgScoreCtx v, SgScoreCtx *out) { *out = v; }
+
 static uint64_t gcd_u64(uint64_t a, uint64_t b) {
     while (b) {
         const uint64_t t = a % b;
@@ -564,6 +566,17 @@ extern "C" int sg_postings_build_flags(sg_ctx *ctx, const sg_csr *B_in, int32_t 
             if (hipGetLastError() != hipSuccess) st = SG_ERR_HIP;
         }
     }
+    if (st == SG_OK && p->d_fwd) {
+        st = ctx->alloc(256, (void **)&p->d_score_ctx);
+        if (st == SG_OK) {
+            SgScoreCtx sc;
+            sc.fwd_ptr = p->d_fwd_ptr;
+            sc.fwd = p->d_fwd;
+            sc.orig_of = p->d_orig_of;
+            hipLaunchKernelGGL(score_ctx_kernel, dim3(1), dim3(1), 0, ctx->stream, sc, p->d_score_ctx);
+            if (hipGetLastError() != hipSuccess) st = SG_ERR_HIP;
+        }
+    }
     if (st != SG_OK) {
         sg_postings_free(p);
         return st;
@@ -582,6 +595,7 @@ extern "C" int sg_postings_free(sg_postings *p) {
     p->ctx->release(p->d_fwd_ptr);
     p->ctx->release(p->d_filt);
     p->ctx->release(p->d_ends);
+    p->ctx->release(p->d_score_ctx);
     p->ctx->release(p->d_orig_of);
     p->ctx->release(p->d_pos_of);
     sg_csr_free(p->permuted);

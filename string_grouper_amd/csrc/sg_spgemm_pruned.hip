@@ -168,12 +168,10 @@ __device__ __forceinline__ T exact_score(int j, const int *hk, const T *ha, int 
 // not inlined: the tile loop has sixteen unrolled rounds and must not carry sixteen copies of this.
 // (LDS objects are addressed through the kernel's own shared array so that they stay ds_* accesses.)
 template <typename T, bool SYM, int TILE_LOG2, bool WIDE>
-__device__ __noinline__ TopList<T> drain_survivors(int nnz, const uint32_t *fwd_ptr, const void *fwd, T thr, uint32_t row,
-                                                   const SgPairSink *__restrict__ pairs /* SYM: the pair list, a struct in device memory
-                                                      (one pointer instead of eight arguments at every call site) */,
-                                                   TopList<T> top, uint32_t n_surv,
-                                                   const uint32_t *__restrict__ orig_of /* position -> right-hand row; null: identity */,
-                                                   uint32_t row_out /* the left row's index in the result */) {
+__device__ __noinline__ TopList<T> drain_survivors(int nnz, T thr, uint32_t row,
+                                                   const SgScoreCtx *__restrict__ sc /* packed rows of B, position -> row */,
+                                                   const SgPairSink *__restrict__ pairs /* SYM: the pair list */,
+                                                   TopList<T> top, uint32_t n_surv) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int TILE = 1 << TILE_LOG2;
     const int *hk = reinterpret_cast<const int *>(smem + TILE * 2);
@@ -181,7 +179,8 @@ __device__ __noinline__ TopList<T> drain_survivors(int nnz, const uint32_t *fwd_
     int *surv = reinterpret_cast<int *>(smem + TILE * 2 + 512 + 1024);
     const int lane = threadIdx.x;
     const int j = (uint32_t)lane < n_surv ? surv[lane] : -1;   // a POSITION: the index is built over a permutation of B's rows
-    const T sum = exact_score<T, WIDE>(j, hk, ha, nnz, fwd_ptr, fwd);
+    const uint32_t *const orig_of = sc->orig_of;
+    const T sum = exact_score<T, WIDE>(j, hk, ha, nnz, sc->fwd_ptr, sc->fwd);
     uint64_t hm = __ballot(j >= 0 && sum > thr);
     // what leaves the kernel is the row itself: the top list orders equal scores by the ORIGINAL column, the pairs name rows
     const int jo = (orig_of && j >= 0) ? (int)orig_of[j] : j;
@@ -212,7 +211,7 @@ __device__ __noinline__ TopList<T> drain_survivors(int nnz, const uint32_t *fwd_
             }
             if (((mm >> lane) & 1ull) && (pos >> 9) < pair_chunks) {   // past the capacity nothing is written: the caller falls back
                 const size_t o = (size_t)(pos >> 9) * SG_PAIR_CHUNK + (pos & 511u) + (uint32_t)__popcll(mm & ((1ull << lane) - 1ull));
-                pair_i[o] = row_out;
+                pair_i[o] = orig_of ? orig_of[row] : row;   // the left row's own name
                 pair_j[o] = (uint32_t)jo;
                 pair_s[o] = sum;
                 atomicAdd(&pair_row_count[jo], 1u);   // how many mirrored matches row j will receive (pass 2 scans these)
@@ -244,8 +243,9 @@ __global__ void __launch_bounds__(64, 4)   // 16 single-wave workgroups per CU (
 spgemm_topn_pruned_kernel(const int64_t *__restrict__ a_indptr, const int32_t *__restrict__ a_indices,
                           const T *__restrict__ a_data, uint32_t n_left, const uint32_t *__restrict__ seg,
                           const uint32_t *__restrict__ ends, int32_t nt_pad, uint32_t n_terms,
-                          const uint32_t *__restrict__ filt, int32_t n_tiles, const uint32_t *__restrict__ fwd_ptr,
-                          const void *__restrict__ fwd, int32_t keep, int32_t out_stride, T thr,
+                          const uint32_t *__restrict__ filt, int32_t n_tiles,
+                          const SgScoreCtx *__restrict__ sc /* packed rows of B and the position -> row table (sg_internal.h) */,
+                          int32_t keep, int32_t out_stride, T thr,
                           float s_budget /* (beta / max ||b_j||)^2, rounded down */, float norm_b /* max ||b_j||, rounded up */,
                           uint32_t freq_min /* list length from which a term may join the suffix */,
                           int32_t *__restrict__ out_cols, T *__restrict__ out_vals, int32_t *__restrict__ out_cnt,
@@ -254,8 +254,7 @@ spgemm_topn_pruned_kernel(const int64_t *__restrict__ a_indptr, const int32_t *_
                           const SgPairSink *__restrict__ pairs /* SYM: the pair list (sg_internal.h), in device memory */,
                           uint32_t pair_chunks /* chunks there are */,
                           uint32_t sym_lo, uint32_t sym_hi /* SYM: the left rows this launch scores (multi-GPU: a rank's range) */,
-                          const uint32_t *__restrict__ row_list /* WIDE: the rows to process */, const uint32_t *row_list_len,
-                          const uint32_t *__restrict__ orig_of /* position -> right-hand row (sg_postings.hip); null: identity */) {
+                          const uint32_t *__restrict__ row_list /* WIDE: the rows to process */, const uint32_t *row_list_len) {
     constexpr int TILE = 1 << TILE_LOG2;
     constexpr int SLOTS = WIDE ? 2 : 1;   // row terms staged per lane
     constexpr int AB = TILE_LOG2 + 1;                          // address + half bits of a filter posting
@@ -293,7 +292,11 @@ spgemm_topn_pruned_kernel(const int64_t *__restrict__ a_indptr, const int32_t *_
         const uint32_t row = WIDE ? (uint32_t)__builtin_amdgcn_readfirstlane((int)row_list[rr]) : (SYM ? sym_hi - 1u - rr : rr);
         // self-join form: the left matrix IS the permuted one, `row` a position; its result row and its name in the pairs
         // are the original row's.  (One-sided form: the left rows are the caller's, only the columns are positions.)
-        const uint32_t row_out = (SYM && orig_of) ? (uint32_t)__builtin_amdgcn_readfirstlane((int)orig_of[row]) : row;
+        uint32_t row_out = row;
+        if (SYM) {
+            const uint32_t *orig_of = sc->orig_of;   // position -> row (sg_postings.hip); null: identity
+            if (orig_of) row_out = (uint32_t)__builtin_amdgcn_readfirstlane((int)orig_of[row]);
+        }
         const int64_t rlo = a_indptr[row];
         const int nnz = __builtin_amdgcn_readfirstlane((int)(a_indptr[row + 1] - rlo));
         if (nnz > 64 * SLOTS) {   // more non-zeros than this launch stages: the wide launch, or the exact kernel
@@ -493,7 +496,7 @@ spgemm_topn_pruned_kernel(const int64_t *__restrict__ a_indptr, const int32_t *_
             if (cross) surv[n_surv + __popcll(cm & lanes_below)] = col;
             n_surv += __popcll(cm);
             if (n_surv >= 64) {
-                top = drain_survivors<T, SYM, TILE_LOG2, WIDE>(nnz, fwd_ptr, fwd, thr, row, pairs, top, n_surv, orig_of, row_out);
+                top = drain_survivors<T, SYM, TILE_LOG2, WIDE>(nnz, thr, row, sc, pairs, top, n_surv);
                 st_surv += 64;
                 n_surv -= 64;
             }
@@ -681,7 +684,7 @@ spgemm_topn_pruned_kernel(const int64_t *__restrict__ a_indptr, const int32_t *_
         if (probe_sink == 0x1234567887654321ull) n_surv = 1;   // keeps the tests alive
 #endif
         if (n_surv > 0) {   // fewer than 64 left
-            top = drain_survivors<T, SYM, TILE_LOG2, WIDE>(nnz, fwd_ptr, fwd, thr, row, pairs, top, n_surv, orig_of, row_out);
+            top = drain_survivors<T, SYM, TILE_LOG2, WIDE>(nnz, thr, row, sc, pairs, top, n_surv);
             st_surv += n_surv;
         }
         {   // (symmetric mode: the row's matches j <= i; pass 2 merges the mirrored ones in)
@@ -975,12 +978,11 @@ static int launch_pruned(sg_ctx *ctx, const sg_csr *A, const sg_postings *Bt, in
     hipLaunchKernelGGL((spgemm_topn_pruned_kernel<T, TILE_LOG2, SYM, WIDE>), dim3(grid), dim3(64), lds, ctx->stream, A->d_indptr,
                        A->d_indices, (const T *)A->d_data, (uint32_t)A->n_rows, (const uint32_t *)Bt->d_seg,
                        (const uint32_t *)Bt->d_ends, Bt->nt_pad, (uint32_t)Bt->n_terms,
-                       (const uint32_t *)Bt->d_filt, Bt->n_tiles, (const uint32_t *)Bt->d_fwd_ptr,
-                       (const void *)Bt->d_fwd, keep, r->stride, thr, s_budget, Bt->norm_up, Bt->freq_min, r->d_cols,
+                       (const uint32_t *)Bt->d_filt, Bt->n_tiles, (const SgScoreCtx *)Bt->d_score_ctx, keep, r->stride, thr, s_budget,
+                       Bt->norm_up, Bt->freq_min, r->d_cols,
                        (T *)r->d_vals,
                        r->d_counts, row_counter, flagged_count, flagged_rows, stats, pl.d_sink, pl.chunks, pl.row_lo, pl.row_hi, row_list,
-                       row_list_len,
-                       (const uint32_t *)Bt->d_orig_of);
+                       row_list_len);
     SG_HIP_TRY(hipGetLastError());
     return SG_OK;
 }
