@@ -89,6 +89,22 @@ class NumpyOps:
     def csr_from_tensors(self, indptr, indices, data, shape):
         return sp.csr_matrix((data.numpy(), indices.numpy(), indptr.numpy()), shape=shape)
 
+    # The library builds its index over a fixed permutation of the rows (sg_postings.hip): position p holds row
+    # orig_of[p]; the ranges of the self-join form are then ranges of POSITIONS.  ``permuted = True`` restates that
+    # contract here (same formula), so that the driver's handling of it runs on two real ranks.
+    permuted = False
+
+    @staticmethod
+    def permutation(n):
+        import math
+        mult = int(0.6180339887498949 * n) | 1
+        while math.gcd(mult, n) != 1:
+            mult += 2
+        pos_of = (np.arange(n, dtype=np.int64) * mult) % n
+        orig_of = np.empty(n, np.int64)
+        orig_of[pos_of] = np.arange(n)
+        return orig_of, pos_of
+
     def postings(self, m, tile_cols=0, permute=True):
         return m
 
@@ -112,22 +128,24 @@ class NumpyOps:
     #      oracle's multiply (rows of the range keep their matches j <= i; mirrored pairs (i, j < i, score) go out)
     def selfjoin_range(self, A_full, post, top_n, threshold, lo, hi):
         n = A_full.shape[0]
-        C = P.sp_matmul_topn_port(A_full[lo:hi], A_full.T, n, threshold, True, 2)      # every match of the rows
+        orig_of, pos_of = self.permutation(n) if self.permuted else (np.arange(n), np.arange(n))
+        rows = orig_of[lo:hi]                               # the rows of the range (of positions)
+        C = P.sp_matmul_topn_port(A_full[rows], A_full.T, n, threshold, True, 2)      # every match of the rows
         stride = max(1, min(top_n, n))
         cols = np.zeros((n, stride), np.int32)
         vals = np.zeros((n, stride), self.dtype)
         cnt = np.zeros(n, np.int32)
         pairs = []
         for r in range(hi - lo):
-            i = lo + r
+            i = int(rows[r])
             a, b = C.indptr[r], C.indptr[r + 1]
             j, sc = C.indices[a:b], C.data[a:b]
-            own = j <= i                                    # port order: score descending, column ascending
+            own = pos_of[j] <= pos_of[i]                    # port order: score descending, column ascending
             k = min(int(own.sum()), stride)
             cols[i, :k] = j[own][:k]
             vals[i, :k] = sc[own][:k]
             cnt[i] = k
-            for jj, ss in zip(j[j < i], sc[j < i]):
+            for jj, ss in zip(j[pos_of[j] < pos_of[i]], sc[pos_of[j] < pos_of[i]]):
                 pairs.append((i, int(jj), ss))
         words = 4 if np.dtype(self.dtype) == np.float64 else 3
         flat = np.zeros((len(pairs), words), np.int32)
@@ -147,7 +165,9 @@ class NumpyOps:
         words, stride = part["words"], part["top_n"]
         rec = pairs_all.numpy().reshape(-1, words)
         scores = np.frombuffer(np.ascontiguousarray(rec[:, 2:]).tobytes(), self.dtype)
-        for row in range(lo, hi):
+        n = cols.shape[0]
+        orig_of = self.permutation(n)[0] if self.permuted else np.arange(n)
+        for row in orig_of[lo:hi]:
             mine = np.flatnonzero(rec[:, 1] == row)
             if len(mine) == 0:
                 continue
@@ -157,7 +177,23 @@ class NumpyOps:
             cnt[row] = len(order)
             cols[row, :len(order)] = c[order]
             vals[row, :len(order)] = v[order]
+        if self.permuted:
+            ids = orig_of[lo:hi]
+            return PermutedBlock((cols[ids], vals[ids], cnt[ids]), torch.from_numpy(orig_of))
         return cols[lo:hi], vals[lo:hi], cnt[lo:hi]
 
     def topn_tensors(self, res):
+        if isinstance(res, PermutedBlock):
+            res = res.arrays
         return torch.from_numpy(res[0]), torch.from_numpy(res[1]), torch.from_numpy(res[2])
+
+
+class PermutedBlock:
+    """A rank's block of the self-join form when the ranges are ranges of positions: rows orig_of[lo:hi] in that order
+    (what distributed.TopNRows is for the device library)."""
+
+    def __init__(self, arrays, orig_of):
+        self.arrays, self.orig_of = arrays, orig_of
+
+    def __getitem__(self, k):
+        return self.arrays[k]

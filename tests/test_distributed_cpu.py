@@ -139,6 +139,19 @@ def _sharded_worker(rank, world, port, ret):
         ok["ranges_counts"] = np.array_equal(np.diff(got.indptr), np.diff(C.indptr))
         ok["ranges_indices"] = np.array_equal(got.indices, C.indices)
         ok["ranges_scores"] = np.array_equal(got.data, C.data)
+        # ---- ... and with the index over the library's row permutation: the ranges are ranges of POSITIONS, a rank's block
+        #      holds the rows orig_of[lo:hi], gather_topn puts the gathered blocks back into row order
+        ops.permuted = True
+        os.environ["SG_DIST_SYM"] = "1"
+        res, _ = D.distributed_self_join(ops, hubs[lo2:hi2], 10, 0.8)
+        os.environ["SG_DIST_SYM"] = "0"
+        ops.permuted = False
+        ok["position_block_is_mine"] = len(res[2]) == int(bounds[rank + 1] - bounds[rank]) and res.orig_of is not None
+        cols, vals, counts = D.gather_topn(ops, res)
+        got = _csr_of(cols, vals, counts, len(hubs))
+        ok["positions_counts"] = np.array_equal(np.diff(got.indptr), np.diff(C.indptr))
+        ok["positions_indices"] = np.array_equal(got.indices, C.indices)
+        ok["positions_scores"] = np.array_equal(got.data, C.data)
         # ---- master x duplicates (configs[4]): both columns sharded, vocabulary from both, duplicates replicated
         master = synth_names(1800, 7)
         dups = synth_names(901, 8, perturb_of=master, perturb_frac=0.5)
