@@ -124,7 +124,8 @@ struct sg_csr {
 };
 
 struct SgScoreCtx {
-    const uint32_t *fwd_ptr = nullptr;   // packed rows of B: row at position q = entries [fwd_ptr[q], fwd_ptr[q + 1])
+    const uint32_t *fwd_ptr = nullptr;   // packed rows of B, a uint2 per position q: {first entry, the row's own index};
+                                         // row at q = entries [fwd_ptr[2 q], fwd_ptr[2 q + 2])
     const void *fwd = nullptr;
     const uint32_t *orig_of = nullptr;   // position -> row; null: identity
 };
@@ -149,7 +150,7 @@ struct sg_postings {
     // f32: {int32 term, float value} (8 B), f64: {int32 term, pad, double value} (16 B); row j = entries
     // [d_fwd_ptr[j], d_fwd_ptr[j+1])
     void *d_fwd = nullptr;
-    uint32_t *d_fwd_ptr = nullptr;       // n_right + 1
+    uint32_t *d_fwd_ptr = nullptr;       // (n_right + 1) x {pointer, the row's own index (position -> row)}
     // 4-byte "filter postings", same order as the postings proper (only for cosine-like B):
     //   bits [0, L) column inside the tile (L = tile_log2), [L, 24) bq, [24, 32) fq   with
     //   b <= bq / bq_max * norm_up   and

@@ -216,14 +216,18 @@ __global__ void __launch_bounds__(1024) postings_fill_lds(const int64_t *__restr
 }
 
 // Packed copy of B's rows for the pruned multiply (one 16-byte load = two f32 entries or one f64 entry): a thread per
-// entry, and a thread per row for the 32-bit row pointers.
+// entry, and a thread per row for its {32-bit row pointer, the row's own index} -- the index rides with the pointer
+// because the multiply needs both for every pair it scores: as a table of its own (orig_of[j]) it cost a cache line per
+// pair, 4 GB of the kernel's 55 GB at 663 k.
 template <typename T>
 __global__ void __launch_bounds__(256) fwd_pack(const int64_t *__restrict__ indptr, const int32_t *__restrict__ indices,
                                                 const T *__restrict__ data, int64_t n_rows, int64_t nnz,
-                                                uint32_t *__restrict__ fwd_ptr, void *__restrict__ fwd) {
+                                                const uint32_t *__restrict__ orig_of /* position -> row; null: identity */,
+                                                uint32_t *__restrict__ fwd_ptr /* uint2 per row: {pointer, row} */, void *__restrict__ fwd) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t base = indptr[0];
-    if (i <= n_rows) fwd_ptr[i] = (uint32_t)(indptr[i] - base);
+    if (i <= n_rows)
+        reinterpret_cast<uint2 *>(fwd_ptr)[i] = make_uint2((uint32_t)(indptr[i] - base), i < n_rows ? (orig_of ? orig_of[i] : (uint32_t)i) : 0u);
     if (i >= nnz) return;
     const int64_t p = base + i;
     if (sizeof(T) == 4) {
@@ -434,7 +438,7 @@ extern "C" int sg_postings_build_flags(sg_ctx *ctx, const sg_csr *B_in, int32_t 
     if (st == SG_OK && want_pruned && sg_pruned_supports_tile(tile_log2) &&
         (B->n_cols + 1) * ((n_tiles64 + 3) & ~(int64_t)3) < ((int64_t)1 << 30)) {
         st = ctx->alloc(((size_t)B->nnz + 8) * (B->dtype == SG_F64 ? 16 : 8), &p->d_fwd);
-        if (st == SG_OK) st = sg_alloc(ctx, (size_t)B->n_rows + 2, &p->d_fwd_ptr);
+        if (st == SG_OK) st = sg_alloc(ctx, 2 * ((size_t)B->n_rows + 2), &p->d_fwd_ptr);   // uint2 per row
         // slack: the pruned multiply loads a lane's four slots of a segment unconditionally (<= 4 * 63 entries past it)
         if (st == SG_OK) st = sg_alloc(ctx, (size_t)B->nnz + 512, &p->d_filt);
         p->nt_pad = (int32_t)((n_tiles64 + 3) & ~(int64_t)3);
@@ -559,10 +563,10 @@ extern "C" int sg_postings_build_flags(sg_ctx *ctx, const sg_csr *B_in, int32_t 
             const unsigned g2 = (unsigned)((work + 255) / 256);
             if (B->dtype == SG_F64)
                 hipLaunchKernelGGL(fwd_pack<double>, dim3(g2), dim3(256), 0, ctx->stream, B->d_indptr, B->d_indices,
-                                   (const double *)B->d_data, B->n_rows, B->nnz, p->d_fwd_ptr, p->d_fwd);
+                                   (const double *)B->d_data, B->n_rows, B->nnz, (const uint32_t *)p->d_orig_of, p->d_fwd_ptr, p->d_fwd);
             else
                 hipLaunchKernelGGL(fwd_pack<float>, dim3(g2), dim3(256), 0, ctx->stream, B->d_indptr, B->d_indices,
-                                   (const float *)B->d_data, B->n_rows, B->nnz, p->d_fwd_ptr, p->d_fwd);
+                                   (const float *)B->d_data, B->n_rows, B->nnz, (const uint32_t *)p->d_orig_of, p->d_fwd_ptr, p->d_fwd);
             if (hipGetLastError() != hipSuccess) st = SG_ERR_HIP;
         }
     }

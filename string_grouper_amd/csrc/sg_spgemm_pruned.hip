@@ -143,11 +143,15 @@ __device__ __forceinline__ T row_value(const int *hk, const T *ha, int key, int 
 // values are non-negative), so absent terms and the padding of a round need no branch.
 template <typename T, bool WIDE>
 __device__ __forceinline__ T exact_score(int j, const int *hk, const T *ha, int nnz, const uint32_t *__restrict__ fwd_ptr,
-                                         const void *__restrict__ fwd) {
+                                         const void *__restrict__ fwd, int &row_of_j) {
     T sum = (T)0;
+    row_of_j = j;
     if (j >= 0) {
-        const uint32_t pb = fwd_ptr[j];
-        const uint32_t pe = fwd_ptr[j + 1];
+        // {first entry, the row's own index} of positions j and j + 1: sixteen contiguous bytes
+        const uint2 m0 = reinterpret_cast<const uint2 *>(fwd_ptr)[j], m1 = reinterpret_cast<const uint2 *>(fwd_ptr)[j + 1];
+        const uint32_t pb = m0.x;
+        const uint32_t pe = m1.x;
+        row_of_j = (int)m0.y;
         SG_WD_DECL(wd_v);
         for (uint32_t q = pb & ~1u; q < pe; q += 8) {
             SG_WD(wd_v, 1 << 20, 21)
@@ -179,11 +183,10 @@ __device__ __noinline__ TopList<T> drain_survivors(int nnz, T thr, uint32_t row,
     int *surv = reinterpret_cast<int *>(smem + TILE * 2 + 512 + 1024);
     const int lane = threadIdx.x;
     const int j = (uint32_t)lane < n_surv ? surv[lane] : -1;   // a POSITION: the index is built over a permutation of B's rows
-    const uint32_t *const orig_of = sc->orig_of;
-    const T sum = exact_score<T, WIDE>(j, hk, ha, nnz, sc->fwd_ptr, sc->fwd);
-    uint64_t hm = __ballot(j >= 0 && sum > thr);
     // what leaves the kernel is the row itself: the top list orders equal scores by the ORIGINAL column, the pairs name rows
-    const int jo = (orig_of && j >= 0) ? (int)orig_of[j] : j;
+    int jo;
+    const T sum = exact_score<T, WIDE>(j, hk, ha, nnz, sc->fwd_ptr, sc->fwd, jo);
+    uint64_t hm = __ballot(j >= 0 && sum > thr);
     if (SYM) {
         // row i keeps its own matches j <= i in its top list like the one-sided form; what row j < i has to learn -- that
         // i matches it -- goes to the pair list (pass 2 merges it into row j's list).  The diagonal is nobody's mirror.
@@ -211,7 +214,7 @@ __device__ __noinline__ TopList<T> drain_survivors(int nnz, T thr, uint32_t row,
             }
             if (((mm >> lane) & 1ull) && (pos >> 9) < pair_chunks) {   // past the capacity nothing is written: the caller falls back
                 const size_t o = (size_t)(pos >> 9) * SG_PAIR_CHUNK + (pos & 511u) + (uint32_t)__popcll(mm & ((1ull << lane) - 1ull));
-                pair_i[o] = orig_of ? orig_of[row] : row;   // the left row's own name
+                pair_i[o] = reinterpret_cast<const uint2 *>(sc->fwd_ptr)[row].y;   // the left row's own name (self-join: A is B)
                 pair_j[o] = (uint32_t)jo;
                 pair_s[o] = sum;
                 atomicAdd(&pair_row_count[jo], 1u);   // how many mirrored matches row j will receive (pass 2 scans these)
