@@ -40,17 +40,23 @@
 // float conversions for x and tq, a select + shift + compare per speculative load, register rotation of the
 // prefetched batches.  Now: the loop is unrolled four tiles deep with four statically named batches (the
 // batch of tile t + 3 is issued while tile t is applied -- no register moves, so no waits on loads in
-// flight); a batch is four unconditional loads at base, base + G, base + 2G, base + 3G (K3 leaves slack
-// behind the postings) plus ONE signed remainder `rem` = bytes of the segment at and after the lane's first
-// entry, slot e is valid iff e * 4G < rem; the segment ends come four tiles per 16-byte load from the
-// padded table K3 writes; x and tq are 24-bit integer multiplies (v_mul_hi_u32_u24, v_mul_i32_i24 with a
-// byte select).  ~12 VALU per round, ~2.5 rounds per tile.
+// flight); a batch is ONE unconditional 16-byte load -- lane u of the g lanes of a term owns entries 4u .. 4u + 3 of
+// the term's segment in every tile (K3 leaves slack behind the postings) -- plus ONE signed remainder `rem` = bytes
+// of the segment at and after the lane's first entry, slot e is valid iff 4e < rem; the segment ends come four
+// tiles per 16-byte load from the padded table K3 writes; x and tq are 24-bit integer multiplies (v_mul_hi_u32_u24,
+// v_mul_i32_i24 with a byte select).  ~12 VALU per slot, four slots per tile.
 //
 // Self-join ("symmetric") mode: score(i, j) and score(j, i) are the same float (same products, same
 // ascending-k order), so when A is the matrix the postings were built from, row i only walks the tiles
-// up to its own column and scores the pairs j <= i; every pair above the threshold is appended to a
-// global list and a second pass builds both rows' candidate lists from it and takes each row's top-n
-// with the canonical order.  Half the (row, tile) visits, half the exact scorings, identical result.
+// up to its own column and scores the pairs j <= i: its own matches go into its register top-n list and out to its
+// result row, the MIRRORED pairs (that i matches j < i) into a chunked global list, and a second pass merges them
+// into the rows they point at (pairs_fill / pairs_select).  Half the (row, tile) visits, half the exact scorings,
+// identical result.
+//
+// Position space: "column", "tile" and "row i of the self-join" mean POSITIONS of a fixed permutation of the right-hand
+// rows (sg_postings.hip: a sorted name list piles a row's candidates into a few tiles otherwise); what leaves the
+// kernel -- the result row, the columns kept, the pairs -- names rows again ({pointer, row} per position rides with
+// the packed rows; equal scores are ordered and cut by the ORIGINAL column).
 //
 // One 64-lane wave per left row, single-wave workgroups, persistent waves fed by a global row
 // counter, as K4.  LDS per wave: the tile's 4096 u16 accumulators (two per word), row i as a term ->
