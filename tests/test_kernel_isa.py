@@ -1,0 +1,114 @@
+"""CPU guard on the code hipcc generates for the pruned multiply's tile loop (no GPU needed: hipcc cross-compiles gfx950).
+
+The kernel (string_grouper_amd/csrc/sg_spgemm_pruned.hip) is VALU-issue bound and sits at the 128-VGPR limit of four
+waves per SIMD; every round of work on it has shown the same failure: an innocent edit makes the register allocator
+spill something INSIDE the tile loop -- typically a prefetched batch, stored to scratch right behind its load, which
+turns the loop's `s_waitcnt vmcnt(3..5)` into `vmcnt(0)` and costs 10-40 % on the GPU (DESIGN.md section 4,
+profiles/r02_sessionAH_AI_*, r02_sessionAL_*).  None of that is visible without a GPU run -- except in the ISA.  This
+test compiles the file to assembly and checks, for the four kernels that carry the headline paths (f32 / f64, self-join
+form / one-sided, 4096-column tile):
+  * the fast path of the tile loop (the block with four LDS adds and four re-zeroing stores) touches no scratch memory
+    and keeps its size;
+  * no value is spilled right behind its load anywhere in the tile loop (`s_waitcnt vmcnt(0)` + `scratch_store`);
+  * the tile loop still waits with a COUNT for its prefetched batches (vmcnt(3) or more somewhere in it);
+  * spills stay at the few the row set-up has always had.
+"""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, "string_grouper_amd", "csrc", "sg_spgemm_pruned.hip")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+
+# template arguments <T, TILE_LOG2, SYM, WIDE> -> mangled fragment
+KERNELS = {
+    "f32 self-join": "IfLi12ELb1ELb0EE",
+    "f32 one-sided": "IfLi12ELb0ELb0EE",
+    "f64 self-join": "IdLi12ELb1ELb0EE",
+    "f64 one-sided": "IdLi12ELb0ELb0EE",
+}
+# (vgpr spills allowed, instructions of the fast-path block allowed)
+LIMITS = {"f32 self-join": (8, 95), "f32 one-sided": (8, 95), "f64 self-join": (16, 95), "f64 one-sided": (16, 95)}
+
+
+@pytest.fixture(scope="module")
+def asm(tmp_path_factory):
+    if not (os.path.exists(HIPCC) or shutil.which(HIPCC)):
+        pytest.skip("hipcc not available")
+    out = tmp_path_factory.mktemp("isa") / "pruned.s"
+    cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wno-unused-function",
+           "-S", "--cuda-device-only", "-o", str(out), SRC]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    return out.read_text()
+
+
+def kernel_body(asm, frag):
+    m = re.search(r"^(_Z25spgemm_topn_pruned_kernel%s\w*):" % frag, asm, re.M)
+    assert m, frag
+    start = m.start()
+    end = asm.index("s_endpgm", start)
+    return m.group(1), asm[start:end]
+
+
+def blocks_of(body):
+    """[(label, [instruction lines], in_tile_loop)]; the tile loop = the blocks annotated with loop depth >= 3 whose
+    header is the loop that holds the fast path (found from the fast path itself)."""
+    out, cur = [], None
+    for line in body.split("\n"):
+        m = re.match(r"^(\.LBB\S+):(.*)$", line)
+        if m:
+            cur = {"label": m.group(1), "ins": [], "note": m.group(2)}
+            out.append(cur)
+            continue
+        s = line.strip()
+        if cur is None or not s or s.startswith(";") or s.startswith("."):
+            if cur is not None and "Loop" in s and not cur["note"]:
+                cur["note"] = s
+            continue
+        cur["ins"].append(s.split(";")[0].strip())
+        if ";" in s and "Loop" in s and not cur["note"]:
+            cur["note"] = s
+    return out
+
+
+def is_fast_path(b):
+    adds = [i for i, x in enumerate(b["ins"]) if x.startswith("ds_add_rtn_u32")]
+    zeros = [i for i, x in enumerate(b["ins"]) if x.startswith("ds_write_b32")]
+    return len(adds) == 4 and len(zeros) >= 4
+
+
+@pytest.mark.timeout(1200)
+@pytest.mark.parametrize("which", list(KERNELS))
+def test_tile_loop_of_the_pruned_kernel_keeps_its_shape(asm, which):
+    name, body = kernel_body(asm, KERNELS[which])
+    meta = asm[asm.index(".name:           " + name):]
+    spills = int(re.search(r"\.vgpr_spill_count:\s*(\d+)", meta).group(1))
+    vgprs = int(re.search(r"\.vgpr_count:\s*(\d+)", meta).group(1))
+    max_spills, max_fast = LIMITS[which]
+    assert vgprs <= 128, (which, vgprs)                      # four waves per SIMD
+    assert spills <= max_spills, (which, spills)
+
+    blocks = blocks_of(body)
+    fast = [b for b in blocks if is_fast_path(b)]
+    assert len(fast) == 4, (which, len(fast))                # the loop is unrolled four tiles deep
+    for b in fast:
+        assert not any(x.startswith("scratch_") for x in b["ins"]), (which, b["label"], "scratch access in the fast path")
+        assert len(b["ins"]) <= max_fast, (which, b["label"], len(b["ins"]))
+        valu = sum(1 for x in b["ins"] if x.startswith("v_"))
+        assert valu <= 66, (which, b["label"], valu)
+
+    # the tile loop: everything between the first and the last fast-path block
+    i0, i1 = blocks.index(fast[0]), blocks.index(fast[-1])
+    loop = blocks[max(0, i0 - 12): i1 + 1]
+    flat = [x for b in loop for x in b["ins"]]
+    for k, a in enumerate(flat):
+        if a.startswith("s_waitcnt vmcnt(0)"):
+            assert not any(b.startswith("scratch_store") for b in flat[k + 1:k + 4]), \
+                (which, "a value is spilled right behind its load inside the tile loop")
+    counts = [int(m.group(1)) for x in flat for m in [re.match(r"s_waitcnt vmcnt\((\d+)\)", x)] if m]
+    assert max(counts) >= 3, (which, counts)                 # the prefetched batches are waited for by count
