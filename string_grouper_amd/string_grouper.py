@@ -264,6 +264,18 @@ class StringGrouper(object):
         n = cfg.ngram_size
         return [string[i:i + n] for i in range(len(string) - n + 1)]
 
+    # ---- the reference's vectoriser helpers (string_grouper.py:305-308, :699-707).  The reference fits an sklearn
+    #      vectoriser when the instance is built and again inside fit(); here vocabulary, idf and both matrices come out
+    #      of ONE pass on the device inside fit() (_tfidf_on_engine), so these two only exist for callers of the private
+    #      surface: they run that pass and hand back the fitted vectoriser.
+    def _fit_vectorizer(self):
+        self._tfidf_on_engine()
+        return self._vectorizer
+
+    def _build_corpus(self):
+        self._vectorizer = self._fit_vectorizer()
+        self.is_build = False
+
     def _tfidf_on_engine(self):
         cfg = self._config
         eng = _engine_mod.get_engine()
@@ -398,10 +410,10 @@ class StringGrouper(object):
         return sp.coo_matrix((vals, (rows, cols)), shape=coo.shape)
 
     @staticmethod
-    def _symmetrize_matrix(m):
+    def _symmetrize_matrix(m_symmetric):
         """If (r, c) is stored so is (c, r) with the same value (string_grouper.py:960-964); rows come
         back sorted by column, as the reference's lil round trip leaves them."""
-        coo = sp.coo_matrix(m)
+        coo = sp.coo_matrix(m_symmetric)
         n_cols = np.int64(coo.shape[1])
         r = coo.row.astype(np.int64)
         c = coo.col.astype(np.int64)
@@ -546,8 +558,7 @@ class StringGrouper(object):
         m_idx, d_idx = self._get_indices_of(master_side, dupe_side)
         earlier = self._matches_list.master_side[self._matches_list.dupe_side.isin(d_idx)]
         d_idx = pd.concat([d_idx, earlier]).drop_duplicates()
-        grid = pd.MultiIndex.from_product([m_idx, d_idx, [1]], names=['master_side', 'dupe_side', 'similarity'])
-        new_pairs = pd.DataFrame(index=grid).reset_index()
+        new_pairs = StringGrouper._cross_join(d_idx, m_idx, [1])
         if self._duplicates is None:
             new_pairs = StringGrouper._make_symmetric(new_pairs)
         self._matches_list = pd.concat([self._matches_list.drop_duplicates(), new_pairs], ignore_index=True)
@@ -569,13 +580,25 @@ class StringGrouper(object):
                                 'similarity': new_matches.similarity})
         return pd.concat([new_matches, flipped])
 
+    @staticmethod
+    def _cross_join(dupe_indices, master_indices, similarities) -> pd.DataFrame:
+        """Every (master index, duplicate index, similarity) combination as match-list rows (string_grouper.py:974-978)."""
+        grid = pd.MultiIndex.from_product([master_indices, dupe_indices, similarities],
+                                          names=['master_side', 'dupe_side', 'similarity'])
+        return pd.DataFrame(index=grid).reset_index()
+
+    @staticmethod
+    def _validate_strings_exist(master_side, dupe_side, master_strings, dupe_strings):
+        """ValueError unless both strings occur in their columns (string_grouper.py:981-985)."""
+        if not master_strings.isin([master_side]).any():
+            raise ValueError(f'{master_side} not found in StringGrouper string series')
+        if not dupe_strings.isin([dupe_side]).any():
+            raise ValueError(f'{dupe_side} not found in StringGrouper dupe string series')
+
     def _get_indices_of(self, master_side: str, dupe_side: str) -> Tuple[pd.Series, pd.Series]:
         m_strings = self._master
         d_strings = self._master if self._duplicates is None else self._duplicates
-        if not m_strings.isin([master_side]).any():
-            raise ValueError(f'{master_side} not found in StringGrouper string series')
-        if not d_strings.isin([dupe_side]).any():
-            raise ValueError(f'{dupe_side} not found in StringGrouper dupe string series')
+        self._validate_strings_exist(master_side, dupe_side, m_strings, d_strings)
         m_idx = m_strings[m_strings == master_side].index.to_series().reset_index(drop=True)
         d_idx = d_strings[d_strings == dupe_side].index.to_series().reset_index(drop=True)
         return m_idx, d_idx

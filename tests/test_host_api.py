@@ -281,3 +281,49 @@ def test_get_groups_through_the_device_reductions_equals_the_host_formulation():
         np.testing.assert_array_equal(sims.to_numpy(), np.asarray(a.multiply(b).sum(axis=1)).squeeze(axis=1))
     finally:
         E.set_engine(old)
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/string_grouper"), reason="reference tree not mounted")
+def test_public_and_private_surface_matches_the_reference():
+    """Every name of the reference module that a user (or the reference's tests) can reach exists here with the same
+    parameters and defaults: module constants, the four top-level functions, StringGrouperConfig, and every method and
+    attribute of StringGrouper incl. the private ones (string_grouper/string_grouper.py)."""
+    import importlib
+    import inspect
+    code = r"""
+import sys, inspect, importlib, json
+sys.path[:0] = [%r, "/root/reference"]
+ref = importlib.import_module("string_grouper.string_grouper")
+out = {"consts": {n: repr(getattr(ref, n)) for n in dir(ref) if n.isupper()},
+       "funcs": {n: [(p.name, repr(p.default), str(p.kind)) for p in inspect.signature(o).parameters.values()]
+                 for n, o in vars(ref).items() if inspect.isfunction(o) and o.__module__ == ref.__name__},
+       "methods": {n: ([(p.name, repr(p.default), str(p.kind)) for p in inspect.signature(o).parameters.values()]
+                       if callable(o) else None)
+                   for n, o in inspect.getmembers(ref.StringGrouper) if not (n.startswith("__") and n != "__init__")},
+       "config": [list(ref.StringGrouperConfig._fields), {k: repr(v) for k, v in ref.StringGrouperConfig._field_defaults.items()}]}
+print(json.dumps(out))
+""" % os.path.join(ROOT, "tests", "ref_shims")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, cwd="/tmp")
+    assert r.returncode == 0, r.stderr[-2000:]
+    import json
+    want = json.loads(r.stdout.strip().splitlines()[-1])
+    import string_grouper_amd.string_grouper as mine
+
+    def params(o):
+        return [[p.name, repr(p.default), str(p.kind)] for p in inspect.signature(o).parameters.values()]
+
+    for n, v in want["consts"].items():
+        assert hasattr(mine, n) and repr(getattr(mine, n)) == v, n
+    for n, sig in want["funcs"].items():
+        if n == "validate_is_fit":                      # a decorator: its one parameter's name is nobody's interface
+            assert hasattr(mine, n)
+            continue
+        assert hasattr(mine, n), n
+        assert params(getattr(mine, n)) == sig, (n, params(getattr(mine, n)), sig)
+    for n, sig in want["methods"].items():
+        assert hasattr(mine.StringGrouper, n), n
+        if sig is not None:
+            assert params(getattr(mine.StringGrouper, n)) == sig, (n, params(getattr(mine.StringGrouper, n)), sig)
+    assert [list(mine.StringGrouperConfig._fields), {k: repr(v) for k, v in mine.StringGrouperConfig._field_defaults.items()}] \
+        == want["config"]
+
