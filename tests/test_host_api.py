@@ -327,3 +327,91 @@ print(json.dumps(out))
     assert [list(mine.StringGrouperConfig._fields), {k: repr(v) for k, v in mine.StringGrouperConfig._field_defaults.items()}] \
         == want["config"]
 
+
+_INDEX_CASES = """
+import numpy as np, pandas as pd
+base = ["ACME HOLDINGS INC", "ACME HOLDING INC", "Acme Holdings, Inc.", "ZENITH PARTNERS LP", "ZENITH PARTNER LP",
+        "OMEGA CAPITAL LLC", "OMEGA CAPITAL, LLC", "BOREAL TRUST", "BOREAL TRUST CO", "QUARTZ FUND", "QUARTZ FUNDS",
+        "LONE STRING WITHOUT A MATCH"]
+dup = ["ACME HOLDINGS", "ZENITH PARTNERS", "OMEGA CAPITAL", "NOTHING LIKE THE OTHERS AT ALL", "QUARTZ FUND LP"]
+
+
+def cases():
+    n, m = len(base), len(dup)
+    yield "default index", pd.Series(base), None, None, None, {}
+    yield "named series, range index with start and step", pd.Series(base, index=pd.RangeIndex(10, 10 + 3 * n, 3), name="name"), None, None, None, {}
+    yield "string index with a name", pd.Series(base, index=pd.Index([f"k{i:02d}" for i in range(n)], name="key")), None, None, None, {}
+    yield "unsorted integer index", pd.Series(base, index=np.arange(n)[::-1] * 7 + 1), None, None, None, {}
+    yield "datetime index", pd.Series(base, index=pd.date_range("2020-01-01", periods=n, freq="D")), None, None, None, {}
+    yield "float index", pd.Series(base, index=np.linspace(0.5, 6.0, n)), None, None, None, {}
+    yield "multi index", pd.Series(base, index=pd.MultiIndex.from_arrays([np.arange(n) // 3, np.arange(n) % 3], names=["a", "b"])), None, None, None, {}
+    yield "series named index", pd.Series(base, name="index"), None, None, None, {}
+    yield "ignore_index", pd.Series(base, index=[f"k{i}" for i in range(n)]), None, None, None, {"ignore_index": True}
+    yield "with ids", pd.Series(base, name="nm"), None, pd.Series(np.arange(n) + 100, name="uid"), None, {}
+    yield "master x duplicates", pd.Series(base, index=pd.RangeIndex(5, 5 + n)), pd.Series(dup, index=[f"d{i}" for i in range(m)], name="dupe"), None, None, {}
+    yield "master x duplicates with ids", pd.Series(base), pd.Series(dup), pd.Series(np.arange(n) * 2, name="mid"), pd.Series([f"x{i}" for i in range(m)], name="did"), {}
+    yield "string dtype", pd.Series(base, dtype="string", name="s"), None, None, None, {}
+    yield "arrow string dtype", pd.Series(base, dtype="string[pyarrow]", index=[f"r{i}" for i in range(n)]), pd.Series(dup, dtype="string[pyarrow]"), None, None, {}
+    yield "zeroes included", pd.Series(base[:6], index=pd.RangeIndex(3, 9)), None, None, None, {"min_similarity": 0.0, "include_zeroes": True, "max_n_matches": 6}
+"""
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/string_grouper"), reason="reference tree not mounted")
+def test_frames_equal_the_references_for_every_kind_of_index():
+    """get_matches() / get_groups() assemble their frames without pandas' take + reset_index on the common shapes
+    (string_grouper_amd/string_grouper.py: side()).  Whatever the index of the input Series is -- default, a range with
+    start and step, strings, unsorted integers, datetimes, floats, a MultiIndex, names that collide with reset_index's --
+    the frames must be the unmodified reference's: values, dtypes, column names and order."""
+    import pickle
+    d = tempfile.mkdtemp()
+    try:
+        with open(os.path.join(d, "cases.py"), "w") as f:
+            f.write(_INDEX_CASES)
+        ref_code = (
+            "import sys, pickle\n"
+            "sys.path[:0] = [%r, %r, '/root/reference']\n"
+            "import os\nos.environ['SG_SHIM_BACKEND'] = 'oracle'\n"
+            "from cases import cases\n"
+            "from string_grouper import match_strings, group_similar_strings, match_most_similar\n"
+            "out = {}\n"
+            "for name, m, dd, mid, did, kw in cases():\n"
+            "    out[name, 'match'] = match_strings(m, dd, mid, did, **kw)\n"
+            "    if dd is None and 'include_zeroes' not in kw:\n"
+            "        out[name, 'groups'] = group_similar_strings(m, mid, **kw)\n"
+            "    if dd is not None:\n"
+            "        out[name, 'nearest'] = match_most_similar(m, dd, mid, did, **kw)\n"
+            "pickle.dump(out, open(%r, 'wb'))\n"
+        ) % (d, os.path.join(ROOT, "tests", "ref_shims"), os.path.join(d, "ref.pkl"))
+        r = subprocess.run([sys.executable, "-c", ref_code], cwd=d, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+        want = pickle.load(open(os.path.join(d, "ref.pkl"), "rb"))
+        sys.path.insert(0, d)
+        try:
+            import importlib
+            cases_mod = importlib.import_module("cases")
+        finally:
+            sys.path.remove(d)
+        import string_grouper_amd as sga
+        import string_grouper_amd.engine as E
+        old = E._engine
+        E.set_engine(OracleEngine())
+        try:
+            for name, m, dd, mid, did, kw in cases_mod.cases():
+                got = sga.match_strings(m, dd, mid, did, **kw)
+                pd.testing.assert_frame_equal(got, want[name, "match"], obj=f"match_strings, {name}")
+                if dd is None and "include_zeroes" not in kw:
+                    g = sga.group_similar_strings(m, mid, **kw)
+                    w = want[name, "groups"]
+                    (pd.testing.assert_frame_equal if isinstance(w, pd.DataFrame) else pd.testing.assert_series_equal)(
+                        g, w, obj=f"group_similar_strings, {name}")
+                if dd is not None:
+                    g = sga.match_most_similar(m, dd, mid, did, **kw)
+                    w = want[name, "nearest"]
+                    (pd.testing.assert_frame_equal if isinstance(w, pd.DataFrame) else pd.testing.assert_series_equal)(
+                        g, w, obj=f"match_most_similar, {name}")
+        finally:
+            E.set_engine(old)
+            sys.modules.pop("cases", None)
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+
