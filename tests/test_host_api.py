@@ -415,3 +415,52 @@ def test_frames_equal_the_references_for_every_kind_of_index():
     finally:
         shutil.rmtree(d, ignore_errors=True)
 
+
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/string_grouper"), reason="reference tree not mounted")
+def test_seeded_fuzz_of_the_public_api_against_the_reference():
+    """150 random small jobs -- options drawn at random (thresholds, max_n_matches, n-gram sizes, regexes incl. ones that
+    are not character classes, case / ASCII handling on strings with accents, sharp s, Greek final sigma, dtypes,
+    n_blocks, ids, group representatives, replace_na) -- through all five entry points: the frames / Series (or the
+    exception) must be the unmodified reference's."""
+    import pickle
+    d = tempfile.mkdtemp()
+    try:
+        ref_code = (
+            "import sys, pickle, os\n"
+            "sys.path[:0] = [%r, %r, '/root/reference']\n"
+            "sys.path.append(%r)\n"
+            "os.environ['SG_SHIM_BACKEND'] = 'oracle'\n"
+            "import string_grouper as api\n"
+            "assert api.__file__.startswith('/root/reference'), api.__file__\n"
+            "from tests._fuzz_cases import cases, run\n"
+            "out = {c: run(api, kind, m, dd, mid, did, kw) for c, kind, m, dd, mid, did, kw in cases()}\n"
+            "pickle.dump(out, open(%r, 'wb'))\n"
+        ) % (d, os.path.join(ROOT, "tests", "ref_shims"), ROOT, os.path.join(d, "ref.pkl"))
+        r = subprocess.run([sys.executable, "-c", ref_code], cwd=d, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+        want = pickle.load(open(os.path.join(d, "ref.pkl"), "rb"))
+        from tests import _fuzz_cases as fz
+        import string_grouper_amd as sga
+        import string_grouper_amd.engine as E
+        old = E._engine
+        E.set_engine(OracleEngine())
+        try:
+            n_raised = 0
+            for c, kind, m, dd, mid, did, kw in fz.cases():
+                got, w = fz.run(sga, kind, m, dd, mid, did, kw), want[c]
+                what = f"case {c}: {kind} {kw}"
+                if isinstance(w, tuple):
+                    n_raised += 1
+                    assert isinstance(got, tuple) and got[:2] == w[:2], (what, got, w)
+                elif isinstance(w, pd.DataFrame):
+                    pd.testing.assert_frame_equal(got, w, obj=what)
+                else:
+                    pd.testing.assert_series_equal(got, w, obj=what)
+            assert n_raised < 50
+        finally:
+            E.set_engine(old)
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+

@@ -654,6 +654,33 @@ def test_config5_asymmetric_10M_x_1M_one_of_eight_row_blocks(ctx):
     ctx.trim()
 
 
+def test_seeded_fuzz_of_the_public_api_hip_engine_equals_oracle_engine(ctx):
+    """The 150 random small jobs of tests/_fuzz_cases.py (options drawn at random; all five entry points; on the CPU they
+    are compared with the unmodified reference through the oracle engine, tests/test_host_api.py) through the HIP
+    engine: frames, Series and exceptions must be what the oracle engine gives, bit for bit."""
+    import pandas as pd
+    import string_grouper_amd as sga
+    import string_grouper_amd.engine as E
+    from tests import _fuzz_cases as fz
+    from tests._oracle_engine import OracleEngine
+    old = E._engine
+    try:
+        for c, kind, m, dd, mid, did, kw in fz.cases():
+            E.set_engine(OracleEngine())
+            want = fz.run(sga, kind, m, dd, mid, did, kw)
+            E.set_engine(E.HipEngine(ctx))
+            got = fz.run(sga, kind, m, dd, mid, did, kw)
+            what = f"case {c}: {kind} {kw}"
+            if isinstance(want, tuple):
+                assert isinstance(got, tuple) and got[:2] == want[:2], (what, got, want)
+            elif isinstance(want, pd.DataFrame):
+                pd.testing.assert_frame_equal(got, want, obj=what)
+            else:
+                pd.testing.assert_series_equal(got, want, obj=what)
+    finally:
+        E.set_engine(old)
+
+
 def test_vectoriser_fuzz_against_python_semantics(ctx):
     """Seeded fuzz of K1/K2 against the reference's analyzer + sklearn: every ASCII byte (controls,
     punctuation, the \\x1c-\\x1f separators \\s matches), case, non-ASCII that NFKD folds to ASCII,
