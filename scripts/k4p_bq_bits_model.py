@@ -44,7 +44,7 @@ def main():
     fq = np.minimum(255, np.ceil(np.nextafter(np.sqrt(f2).astype(f32), f32(2)) * inv * f32(255.0) * f32(1.000002))).astype(np.int64)
     rng = np.random.default_rng(11)
     sample = np.sort(rng.choice(n, n_sample, replace=False))
-    out = {}
+    out, alt = {}, {}
     for bits in (11, 8, 6):
         bq_max = (1 << bits) - 1
         bq_t = np.minimum(bq_max, np.ceil(mt.data.astype(f32) * inv * f32(bq_max) * f32(1.000002))).astype(np.int64)
@@ -86,8 +86,15 @@ def main():
             touched = np.flatnonzero(q)
             tq = (T0 - C1 * fq[touched]) >> 8
             surv_total += int((q[touched] >= tq).sum())
+            if bits == 11:
+                # the per-column threshold with an INTEGER slope (no >> 8 per slot): tq' = (T0 >> 8) - ceil(C1 / 256) * fq <= tq
+                tq_i = (T0 >> 8) - (-(-C1 // 256)) * fq[touched] - 1
+                alt["integer slope"] = alt.get("integer slope", 0) + int((q[touched] >= tq_i).sum())
         out[bits] = surv_total / n_sample
         print(f"value field of {bits} bits: {out[bits]:.1f} pairs scored exactly per row ({100 * out[bits] / out[11]:.0f} %)", flush=True)
+        if bits == 11:
+            for k_, v in alt.items():
+                print(f"  {k_}: {v / n_sample:.1f} ({100 * v / n_sample / out[11]:.0f} %)", flush=True)
 
 
 if __name__ == "__main__":
