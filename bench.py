@@ -11,7 +11,9 @@ is quoted on -- 663k-name self-join, 3-grams, ntop=10, min_sim=0.8, fp32 -- on S
 
 ``--gpus N`` with N > 1 and no rank environment re-executes itself under ``torch.distributed.run`` (N ranks,
 one per GPU, RCCL); launched BY torch.distributed.run it reads RANK / LOCAL_RANK / WORLD_SIZE.  N > 1 is strong
-scaling of the same workload: left rows in N contiguous blocks (string_grouper_amd/distributed.py).
+scaling of the same workload (string_grouper_amd/distributed.py): every rank vectorises its block of the rows (one
+all-reduce of the df table, one all-gather of the CSR blocks), builds the index, and scores the pairs (i, j <= i) of its
+range of the self-join form (one all-gather of the mirrored pairs, merge); results stay on the ranks.
 
 Prints ONE JSON line (rank 0):
   value / ms_per_step   the hot path, inputs in HBM (the contract's metric)
