@@ -248,3 +248,42 @@ def build_matches(A: sp.csr_matrix, B: sp.csr_matrix, n_blocks, top_n: int, thre
     Cs = [[sp_matmul_topn(Aj, Bi.T, top_n, threshold, True, n_threads) for Bi in Bs] for Aj in As]
     Czip = [zip_sp_matmul_topn(top_n, Cis) for Cis in Cs]
     return sp.vstack(Czip, dtype=np.float64).tocsr()
+
+
+# --------------------------------------------------------------------------- tie-aware comparison
+def compare_tie_aware(C_a, C_b, top_n: int) -> List[str]:
+    """Compare two results of ``sp_matmul_topn`` that may differ ONLY in what the absent wheel leaves unpinned: which of
+    several candidates with the row's cut score were kept, and the order of equal scores inside a row.
+
+    For every row: the same number of entries; the same multiset of scores (whatever the tie rule, the ``top_n`` best
+    scores are the same numbers); and -- after dropping, in a row that is full (``top_n`` entries), the entries whose
+    score equals the row's lowest kept score (the cut score: other columns with that very score may have been cut) --
+    the same set of (column, score).  A row that is not full was not cut: it must hold the same (column, score) set.
+    Returns a list of human-readable differences (empty = equal in everything a tie rule cannot change)."""
+    A = sp.csr_matrix(C_a)
+    B = sp.csr_matrix(C_b)
+    out: List[str] = []
+    if A.shape != B.shape:
+        return [f"shapes differ: {A.shape} vs {B.shape}"]
+    na, nb = np.diff(A.indptr), np.diff(B.indptr)
+    if not np.array_equal(na, nb):
+        bad = np.nonzero(na != nb)[0]
+        return [f"{len(bad)} rows differ in their number of entries, first: row {bad[0]}: {na[bad[0]]} vs {nb[bad[0]]}"]
+    for i in np.nonzero(na > 0)[0]:
+        ca, va = A.indices[A.indptr[i]:A.indptr[i + 1]], A.data[A.indptr[i]:A.indptr[i + 1]]
+        cb, vb = B.indices[B.indptr[i]:B.indptr[i + 1]], B.data[B.indptr[i]:B.indptr[i + 1]]
+        if not np.array_equal(np.sort(va), np.sort(vb)):
+            out.append(f"row {i}: kept scores differ")
+            continue
+        if len(va) >= top_n:            # full: entries AT the cut score are the tie rule's to choose
+            cut = va.min()
+            ka, kb = va != cut, vb != cut
+        else:
+            ka = kb = slice(None)
+        sa = set(zip(ca[ka].tolist(), va[ka].tolist()))
+        sb = set(zip(cb[kb].tolist(), vb[kb].tolist()))
+        if sa != sb:
+            out.append(f"row {i}: entries above the cut score differ: {sorted(sa ^ sb)[:4]}")
+        if len(out) >= 20:
+            break
+    return out

@@ -43,7 +43,9 @@ def _as_bt_csr(B):
     return Bt
 
 
-def sp_matmul_topn_port(A, B, top_n, threshold=0.0, sort=True, n_threads=None):
+def sp_matmul_topn_port(A, B, top_n, threshold=0.0, sort=True, n_threads=None, tie_rule=0):
+    """tie_rule 0: the canonical order this build defines (score descending, column ascending); 1: the arrival-order
+    variant of sdtn_port.c (what a bounded heap that only replaces on strictly greater values would keep)."""
     A = sp.csr_matrix(A)
     if not A.has_sorted_indices:
         A = A.sorted_indices()
@@ -61,7 +63,7 @@ def sp_matmul_topn_port(A, B, top_n, threshold=0.0, sort=True, n_threads=None):
     thr = ctypes.c_float(float(np.float32(threshold))) if dtype == np.float32 else ctypes.c_double(float(threshold))
     rc = fn(ctypes.c_int64(nL), ctypes.c_int64(nR), _p(a_ip), _p(a_ix), _p(a_d), _p(b_ip), _p(b_ix), _p(b_d),
             ctypes.c_int32(top_n), thr, ctypes.c_int32(1 if sort else 0),
-            ctypes.c_int32(int(n_threads) if n_threads else 1), _p(oc), _p(ov), _p(cnt))
+            ctypes.c_int32(int(n_threads) if n_threads else 1), _p(oc), _p(ov), _p(cnt), ctypes.c_int32(int(tie_rule)))
     if rc != 0:
         raise MemoryError("sdtn_port: allocation failed")
     return fixed_stride_to_csr(oc, ov, cnt, top_n, (nL, nR))

@@ -13,6 +13,14 @@
  * order (score descending, column ascending), exactly as oracle.py does; tests assert
  * port == oracle.py bit-for-bit.
  *
+ * tie_rule = 1 is a SECOND, deliberately different plausible behaviour of the absent wheel, kept
+ * to show what the unpinned tie-break can and cannot change (tests/test_tie_rules.py): the touched
+ * columns are visited in the order of the linked list (last touched first) and a full result
+ * list only admits a candidate that is STRICTLY greater than its current minimum, equal values
+ * keeping their order of arrival -- which of several equal scores survives the cut then depends
+ * on the order in which the columns were touched, not on the column index.  The two rules agree
+ * on every entry whose score differs from the row's cut score (oracle.compare_tie_aware).
+ *
  * Arithmetic: each C[i][j] is accumulated over k in ascending stored order of row i of A,
  * product and sum rounded separately in the value type (built with -ffp-contract=off), which
  * is bit-identical to scipy's csr_matmat.
@@ -32,7 +40,7 @@
     int NAME(int64_t n_left, int64_t n_right, const int64_t *a_indptr, const int32_t *a_indices,    \
              const T *a_data, const int64_t *bt_indptr, const int32_t *bt_indices,                 \
              const T *bt_data, int32_t top_n, T threshold, int32_t sort, int32_t n_threads,        \
-             int32_t *out_cols, T *out_vals, int32_t *out_cnt)                                     \
+             int32_t *out_cols, T *out_vals, int32_t *out_cnt, int32_t tie_rule)                   \
     {                                                                                              \
         int failed = 0;                                                                            \
         if (n_threads < 1) n_threads = 1;                                                          \
@@ -72,6 +80,8 @@
                         if (!(v > threshold)) continue;                                            \
                         /* bounded insertion, order: value desc then column asc */                 \
                         int32_t pos = cnt;                                                         \
+                        if (tie_rule == 1) { while (pos > 0 && ov[pos - 1] < v) --pos; }           \
+                        else                                                                       \
                         while (pos > 0 && (ov[pos - 1] < v || (ov[pos - 1] == v && oc[pos - 1] > j))) --pos; \
                         if (pos >= top_n) continue;                                                \
                         int32_t last = cnt < top_n ? cnt : top_n - 1;                              \

@@ -1,0 +1,64 @@
+#!/bin/bash
+# One GPU session = one gpurun call.  usage: scripts/gpu_session.sh <name> <step> [<step> ...]
+#   steps: tests            pytest -m gpu (whole GPU suite)        -> gpurun_out/<name>_pytest.log
+#          tests:<expr>     pytest -m gpu -k <expr>
+#          smoke            __graft_entry__.smoke()
+#          bench[:args]     python bench.py <args> (no CPU baseline unless asked) -> gpurun_out/<name>_bench*.json
+#          ab:<ENV=a,b>[:bench args]   the bench line once per value of ENV (kernel time, step time, matches)
+#          prof[:args]      rocprofv3 --kernel-trace --stats of the bench command -> gpurun_out/<name>_kernel_stats.csv
+#          pmc[:args]       the HBM traffic passes (FETCH_SIZE / WRITE_SIZE, separate runs, no trace domains)
+#          py:<script args> python <script args> -> gpurun_out/<name>_<script>.log
+# Everything a step prints goes to gpurun_out/<name>.log; what is worth keeping is copied into profiles/ by hand.
+name=$1; shift
+mkdir -p gpurun_out
+export PYTHONPATH=$PWD
+LOG=gpurun_out/${name}.log
+: > $LOG
+short() { python -c "
+import sys, json
+for line in sys.stdin:
+    if not line.startswith('{'): continue
+    d = json.loads(line)
+    r = d.get('roofline', {})
+    print(d['dtype'], 'kernel_ms', r.get('avg_ms'), 'frac', round(r.get('frac', 0), 4), 'step_ms', round(d['ms_per_step'], 3), 'kernels', d.get('kernels_ms'), 'matches', d.get('matches'), 'pruning', d.get('pruning'), 'identical', (d.get('exact_kernel') or {}).get('pruned_result_identical'))"; }
+n=0
+for step in "$@"; do
+  n=$((n+1))
+  kind=${step%%:*}; arg=""; [[ "$step" == *:* ]] && arg=${step#*:}
+  echo "=== [$n] $step" >> $LOG
+  case $kind in
+    tests)
+      if [ -n "$arg" ]; then timeout 1500 python -m pytest tests -m gpu -x -q -k "$arg" > gpurun_out/${name}_pytest$n.log 2>&1
+      else timeout 1500 python -m pytest tests -m gpu -x -q > gpurun_out/${name}_pytest$n.log 2>&1; fi
+      echo "rc=$?" >> $LOG; tail -5 gpurun_out/${name}_pytest$n.log >> $LOG ;;
+    smoke)
+      timeout 300 python -c "import __graft_entry__ as g; g.smoke()" >> $LOG 2>&1; echo "rc=$?" >> $LOG ;;
+    bench)
+      timeout 900 python bench.py $arg > gpurun_out/${name}_bench$n.json 2> gpurun_out/${name}_bench$n.err
+      echo "rc=$?" >> $LOG; short < gpurun_out/${name}_bench$n.json >> $LOG 2>&1 ;;
+    ab)
+      spec=${arg%%:*}; bargs="--steps 6 --warmup 2 --no-cpu-baseline --no-exact-kernel --no-end-to-end"; [[ "$arg" == *:* ]] && bargs=${arg#*:}
+      var=${spec%%=*}; vals=${spec#*=}
+      for rep in 1 2; do for v in ${vals//,/ }; do
+        echo -n "$var=$v : " >> $LOG
+        env $var=$v timeout 600 python bench.py $bargs 2> gpurun_out/${name}_ab$n.err | short >> $LOG 2>&1
+      done; done ;;
+    prof)
+      ( cd /tmp && export TMPDIR=/tmp && timeout 900 rocprofv3 --kernel-trace --stats -d $OLDPWD/gpurun_out/${name}_prof -o run -- python $OLDPWD/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-exact-kernel --no-end-to-end $arg > $OLDPWD/gpurun_out/${name}_prof.json 2> $OLDPWD/gpurun_out/${name}_prof.err )
+      echo "rc=$?" >> $LOG
+      f=$(find gpurun_out/${name}_prof -name "*kernel_stats.csv" | head -1)
+      [ -n "$f" ] && cp $f gpurun_out/${name}_kernel_stats.csv && head -25 $f >> $LOG
+      short < gpurun_out/${name}_prof.json >> $LOG 2>&1 ;;
+    pmc)
+      for c in FETCH_SIZE WRITE_SIZE; do
+        ( cd /tmp && export TMPDIR=/tmp && timeout 900 rocprofv3 --pmc $c -d $OLDPWD/gpurun_out/${name}_pmc_$c -o run -- python $OLDPWD/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-exact-kernel --no-end-to-end $arg > /dev/null 2> $OLDPWD/gpurun_out/${name}_pmc_$c.err )
+        echo "pmc $c rc=$?" >> $LOG
+      done
+      python scripts/pmc_traffic.py gpurun_out/${name}_pmc_FETCH_SIZE gpurun_out/${name}_pmc_WRITE_SIZE gpurun_out/${name}_k4_traffic.json >> $LOG 2>&1 ;;
+    py)
+      base=$(basename ${arg%% *} .py)
+      timeout 1500 python $arg > gpurun_out/${name}_${base}$n.log 2>&1; echo "rc=$?" >> $LOG; tail -40 gpurun_out/${name}_${base}$n.log >> $LOG ;;
+    *) echo "unknown step $step" >> $LOG ;;
+  esac
+done
+cat $LOG

@@ -172,6 +172,14 @@ struct sg_postings {
     // of segment (k, t) (entries past the last tile repeat the end of the list): one 16-byte load = four tiles
     uint32_t *d_ends = nullptr;
     int32_t nt_pad = 0;
+    // Stream form of the pruned multiply: 2^fold_log2 consecutive tiles (a super-tile, one visit of a left row) share one
+    // accumulator tile; the filter postings then carry the tile index mod 2^fold_log2 and a narrower bq
+    // (sg_postings.hip, emit_posting).  d_ends8[k * nv_pad + v] = byte offset into d_filt of the end of term k's postings
+    // in super-tiles 0 .. v (16-byte aligned rows, the tail repeats the end of the list, one all-zero row behind the last
+    // term).  fold_log2 == 0: the tile-by-tile form and its posting format.
+    int32_t fold_log2 = 0;
+    uint32_t *d_ends8 = nullptr;
+    int32_t nv_pad = 0;
     float norm_up = 0.f;                 // max ||row of B||, rounded up
     uint32_t freq_min = 0;               // list length from which a term counts as frequent
     bool cosine_like = false;            // B: values >= 0, sorted rows, row norms <= 1 (sg_csr_props)

@@ -93,6 +93,12 @@ struct TopList {   // lane r holds the r-th best (score, col); empty slots are (
             c = nc;
         }
     }
+    // The same for a candidate that may already be in the list (same column => same pair => same score): entered once.
+    // A repeat of an entry that has dropped off the end ranks behind all 64 entries and is refused like the first time.
+    __device__ __forceinline__ void insert_unique(T ns, int nc, int lane) {
+        if (__ballot(c == nc) != 0) return;
+        insert(ns, nc, lane);
+    }
 };
 
 // Posting entry (written by K3): f32 -> packed {uint32 slot, float value}, one 8-byte load per lane;

@@ -80,17 +80,22 @@ __device__ __forceinline__ uint32_t frequent_norm_q8(const int32_t *__restrict__
 //   [2, AB)    word  (col >> 1): bits [0, AB) masked with ~3 ARE the byte address of the accumulator word in LDS
 //   [AB, 24)   bq    value quantised upwards relative to norm_up
 //   [24, 32)   fq    norm of the row's frequent part, quantised upwards relative to norm_up
+// Stream form (fold_log2 > 0; sg_spgemm_pruned.hip, "stream form"): 2^fold_log2 consecutive tiles share ONE accumulator
+// tile, and the posting says which of them its column lies in:
+//   [AB, AB + fold_log2)   fold   tile index mod 2^fold_log2
+//   [AB + fold_log2, 24)   bq     (8 bits at the default geometry: tile 4096, fold 8)
 template <typename T>
 __device__ __forceinline__ void emit_posting(int32_t *out_rows, T *out_vals, uint32_t *out_filt, uint32_t pos, uint32_t col,
-                                             T v, uint32_t fq, int32_t tile_log2, float inv_norm_up) {
+                                             T v, uint32_t fq, int32_t tile_log2, float inv_norm_up, uint32_t tile,
+                                             int32_t fold_log2) {
     // the multiply wants the byte offset of the accumulator inside its LDS tile, not j itself
     store_posting<T>(out_rows, out_vals, pos, (int32_t)(col * (uint32_t)sizeof(T)), v);
     if (out_filt) {
-        const int32_t ab = tile_log2 + 1;
-        const uint32_t bq_max = (1u << (24 - ab)) - 1u;   // the bits the address and fq leave
+        const int32_t ab = tile_log2 + 1, fb = ab + fold_log2;
+        const uint32_t bq_max = (1u << (24 - fb)) - 1u;   // the bits the address, the fold and fq leave
         uint32_t bq = (uint32_t)ceilf((float)v * inv_norm_up * (float)bq_max * 1.000002f);
         if (bq > bq_max) bq = bq_max;
-        out_filt[pos] = ((col >> 1) << 2) | (col & 1u) | (bq << ab) | (fq << 24);
+        out_filt[pos] = ((col >> 1) << 2) | (col & 1u) | ((tile & ((1u << fold_log2) - 1u)) << ab) | (bq << fb) | (fq << 24);
     }
 }
 
@@ -101,7 +106,7 @@ __global__ void __launch_bounds__(256) postings_fill(const int64_t *__restrict__
                                                      int32_t n_tiles, const uint32_t *__restrict__ seg,
                                                      uint32_t *cursor, int32_t *out_rows, T *out_vals,
                                                      uint32_t *out_filt /* null: no filter postings */,
-                                                     uint32_t freq_min, float inv_norm_up) {
+                                                     uint32_t freq_min, float inv_norm_up, int32_t fold_log2) {
     const int64_t j = row_of_thread((int64_t)blockIdx.x * blockDim.x + threadIdx.x, tile_log2, n_tiles);
     if (j >= n_rows) return;
     const int64_t lo = indptr[j], hi = indptr[j + 1];
@@ -111,7 +116,7 @@ __global__ void __launch_bounds__(256) postings_fill(const int64_t *__restrict__
     for (int64_t p = lo; p < hi; ++p) {
         const int64_t bin = (int64_t)indices[p] * n_tiles + t;
         const uint32_t pos = seg[bin] + atomicAdd(&cursor[bin], 1u);
-        emit_posting<T>(out_rows, out_vals, out_filt, pos, col, data[p], fq, tile_log2, inv_norm_up);
+        emit_posting<T>(out_rows, out_vals, out_filt, pos, col, data[p], fq, tile_log2, inv_norm_up, t, fold_log2);
     }
 }
 
@@ -166,7 +171,7 @@ __global__ void __launch_bounds__(1024) postings_fill_lds(const int64_t *__restr
                                                           int32_t n_tiles, int32_t n_terms, int32_t split,
                                                           const uint32_t *__restrict__ segp,
                                                           const uint8_t *__restrict__ is_frequent, int32_t *out_rows,
-                                                          T *out_vals, uint32_t *out_filt, float inv_norm_up) {
+                                                          T *out_vals, uint32_t *out_filt, float inv_norm_up, int32_t fold_log2) {
     extern __shared__ uint32_t cursor[];   // next free slot of (term k, this tile, this part); then the frequent-term bits
     uint32_t *freq_bits = cursor + n_terms;
     const int64_t t = blockIdx.x / split;
@@ -210,7 +215,7 @@ __global__ void __launch_bounds__(1024) postings_fill_lds(const int64_t *__restr
         const uint32_t col = (uint32_t)(j - (t << tile_log2));
         for (int64_t p = lo + sub; p < hi; p += 16) {
             const uint32_t pos = atomicAdd(&cursor[indices[p]], 1u);
-            emit_posting<T>(out_rows, out_vals, out_filt, pos, col, data[p], fq, tile_log2, inv_norm_up);
+            emit_posting<T>(out_rows, out_vals, out_filt, pos, col, data[p], fq, tile_log2, inv_norm_up, (uint32_t)t, fold_log2);
         }
     }
 }
@@ -251,6 +256,23 @@ __global__ void __launch_bounds__(256) pack_ends_kernel(const uint32_t *__restri
     int32_t t = (int32_t)(i - k * nt_pad);
     if (t >= n_tiles) t = n_tiles - 1;
     ends[i] = seg[k * n_tiles + t + 1] << 2;
+}
+
+// Stream form: the same for SUPER-TILES of 2^fold_log2 tiles (one visit of the stream form): ends8[k * nv_pad + v] = byte
+// offset of the end of term k's postings in tiles [0, (v + 1) << fold_log2); entries past the last super-tile repeat the
+// end of the list; one more all-zero row for lanes without a term.
+__global__ void __launch_bounds__(256) pack_super_ends_kernel(const uint32_t *__restrict__ seg, int64_t n_terms, int32_t n_tiles,
+                                                              int32_t fold_log2, int32_t nv_pad, uint32_t *__restrict__ ends8) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (n_terms + 1) * nv_pad) return;
+    const int64_t k = i / nv_pad;
+    if (k == n_terms) {
+        ends8[i] = 0;
+        return;
+    }
+    int64_t t = ((i - k * nv_pad + 1) << fold_log2);   // first tile past super-tile v
+    if (t > n_tiles) t = n_tiles;
+    ends8[i] = seg[k * n_tiles + t] << 2;
 }
 
 // ---- position space: a fixed permutation of the right-hand rows (see sg_postings in sg_internal.h)
@@ -443,6 +465,14 @@ extern "C" int sg_postings_build_flags(sg_ctx *ctx, const sg_csr *B_in, int32_t 
         if (st == SG_OK) st = sg_alloc(ctx, (size_t)B->nnz + 512, &p->d_filt);
         p->nt_pad = (int32_t)((n_tiles64 + 3) & ~(int64_t)3);
         if (st == SG_OK) st = sg_alloc(ctx, (size_t)(B->n_cols + 1) * (size_t)p->nt_pad + 4, &p->d_ends);
+        // stream form of the pruned multiply (sg_spgemm_pruned.hip): eight tiles share one accumulator tile
+        p->fold_log2 = 0;
+        if (tile_log2 == 12 && !(getenv("SG_K4_STREAM") && getenv("SG_K4_STREAM")[0] == '0')) p->fold_log2 = 3;
+        if (p->fold_log2 > 0) {
+            const int64_t n_super = (n_tiles64 + ((int64_t)1 << p->fold_log2) - 1) >> p->fold_log2;
+            p->nv_pad = (int32_t)((n_super + 3) & ~(int64_t)3);
+            if (st == SG_OK) st = sg_alloc(ctx, (size_t)(B->n_cols + 1) * (size_t)p->nv_pad + 4, &p->d_ends8);
+        }
         p->norm_up = __builtin_nextafterf(sqrtf(max_norm2) * 1.000001f, 2.f);
         // a term is "frequent" when it occurs in at least this share of the right-hand rows: the suffix of a
         // left row is drawn from frequent terms only, which lets the survivor test use each candidate's own
@@ -498,12 +528,12 @@ extern "C" int sg_postings_build_flags(sg_ctx *ctx, const sg_csr *B_in, int32_t 
                         hipLaunchKernelGGL(postings_fill_lds<double>, dim3(wgs), dim3(1024), lds, ctx->stream, B->d_indptr,
                                            B->d_indices, (const double *)B->d_data, B->n_rows, tile_log2, p->n_tiles,
                                            (int32_t)B->n_cols, split, (const uint32_t *)segp, (const uint8_t *)is_frequent,
-                                           p->d_rows, (double *)p->d_vals, p->d_filt, inv_norm);
+                                           p->d_rows, (double *)p->d_vals, p->d_filt, inv_norm, p->fold_log2);
                     else
                         hipLaunchKernelGGL(postings_fill_lds<float>, dim3(wgs), dim3(1024), lds, ctx->stream, B->d_indptr,
                                            B->d_indices, (const float *)B->d_data, B->n_rows, tile_log2, p->n_tiles,
                                            (int32_t)B->n_cols, split, (const uint32_t *)segp, (const uint8_t *)is_frequent,
-                                           p->d_rows, (float *)p->d_vals, p->d_filt, inv_norm);
+                                           p->d_rows, (float *)p->d_vals, p->d_filt, inv_norm, p->fold_log2);
                     if (split > 1)
                         hipLaunchKernelGGL(unsplit_seg_kernel, dim3((unsigned)((n_bins + 256) / 256)), dim3(256), 0, ctx->stream,
                                            (const uint32_t *)segp, n_bins, split, p->d_seg);
@@ -534,11 +564,11 @@ extern "C" int sg_postings_build_flags(sg_ctx *ctx, const sg_csr *B_in, int32_t 
                 if (B->dtype == SG_F64)
                     hipLaunchKernelGGL(postings_fill<double>, dim3(grid), dim3(256), 0, ctx->stream, B->d_indptr,
                                        B->d_indices, (const double *)B->d_data, B->n_rows, tile_log2, p->n_tiles,
-                                       p->d_seg, cursor, p->d_rows, (double *)p->d_vals, p->d_filt, p->freq_min, inv_norm);
+                                       p->d_seg, cursor, p->d_rows, (double *)p->d_vals, p->d_filt, p->freq_min, inv_norm, p->fold_log2);
                 else
                     hipLaunchKernelGGL(postings_fill<float>, dim3(grid), dim3(256), 0, ctx->stream, B->d_indptr,
                                        B->d_indices, (const float *)B->d_data, B->n_rows, tile_log2, p->n_tiles,
-                                       p->d_seg, cursor, p->d_rows, (float *)p->d_vals, p->d_filt, p->freq_min, inv_norm);
+                                       p->d_seg, cursor, p->d_rows, (float *)p->d_vals, p->d_filt, p->freq_min, inv_norm, p->fold_log2);
                 if (hipGetLastError() != hipSuccess) st = SG_ERR_HIP;
             }
             ctx->release(cursor);
@@ -550,6 +580,12 @@ extern "C" int sg_postings_build_flags(sg_ctx *ctx, const sg_csr *B_in, int32_t 
             const int64_t cells = (B->n_cols + 1) * (int64_t)p->nt_pad;
             hipLaunchKernelGGL(pack_ends_kernel, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, ctx->stream,
                                (const uint32_t *)p->d_seg, B->n_cols, p->n_tiles, p->nt_pad, p->d_ends);
+            if (hipGetLastError() != hipSuccess) st = SG_ERR_HIP;
+        }
+        if (st == SG_OK && p->d_ends8 && B->n_cols > 0) {
+            const int64_t cells = (B->n_cols + 1) * (int64_t)p->nv_pad;
+            hipLaunchKernelGGL(pack_super_ends_kernel, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, ctx->stream,
+                               (const uint32_t *)p->d_seg, B->n_cols, p->n_tiles, p->fold_log2, p->nv_pad, p->d_ends8);
             if (hipGetLastError() != hipSuccess) st = SG_ERR_HIP;
         }
         if (st == SG_OK && p->d_fwd) {
@@ -599,6 +635,7 @@ extern "C" int sg_postings_free(sg_postings *p) {
     p->ctx->release(p->d_fwd_ptr);
     p->ctx->release(p->d_filt);
     p->ctx->release(p->d_ends);
+    p->ctx->release(p->d_ends8);
     p->ctx->release(p->d_score_ctx);
     p->ctx->release(p->d_orig_of);
     p->ctx->release(p->d_pos_of);

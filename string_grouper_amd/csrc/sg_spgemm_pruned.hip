@@ -177,7 +177,7 @@ __device__ __forceinline__ T exact_score(int j, const int *hk, const T *ha, int 
 // Scores the columns in surv[0 .. min(n_surv, 64)) and moves the rest of the buffer to the front.  Deliberately
 // not inlined: the tile loop has sixteen unrolled rounds and must not carry sixteen copies of this.
 // (LDS objects are addressed through the kernel's own shared array so that they stay ds_* accesses.)
-template <typename T, bool SYM, int TILE_LOG2, bool WIDE>
+template <typename T, bool SYM, int TILE_LOG2, bool WIDE, bool UNIQ>
 __device__ __noinline__ TopList<T> drain_survivors(int nnz, T thr, uint32_t row,
                                                    const SgScoreCtx *__restrict__ sc /* packed rows of B, position -> row */,
                                                    const SgPairSink *__restrict__ pairs /* SYM: the pair list */,
@@ -234,7 +234,10 @@ __device__ __noinline__ TopList<T> drain_survivors(int nnz, T thr, uint32_t row,
         SG_WD(wd_h, 70, 22)
         const int src = __builtin_ctzll(hm);
         hm &= hm - 1;
-        top.insert(wave_read<T>(sum, src), wave_read<int>(jo, src), lane);
+        // (stream form: a column may be scored twice -- the filter's records are deduplicated by a small table that
+        //  forgets -- and the same (score, column) must not enter the list twice)
+        if (UNIQ) top.insert_unique(wave_read<T>(sum, src), wave_read<int>(jo, src), lane);
+        else top.insert(wave_read<T>(sum, src), wave_read<int>(jo, src), lane);
     }
     if (n_surv > 64) {   // < 64 left: move to the front
         const uint32_t rem = n_surv - 64;
@@ -247,7 +250,7 @@ __device__ __noinline__ TopList<T> drain_survivors(int nnz, T thr, uint32_t row,
 
 // WIDE: the second launch, over the rows the first one could not take because they have 65 .. 128 non-zeros: every lane
 // stages two of the row's terms; still one posting list per lane, so the row's prefix P must fit 64 lanes.
-template <typename T, int TILE_LOG2, bool SYM, bool WIDE>
+template <typename T, int TILE_LOG2, bool SYM, bool WIDE, int FOLD_LOG2>
 __global__ void __launch_bounds__(64, 4)   // 16 single-wave workgroups per CU (the LDS limit) = 4 waves per SIMD: <= 128 VGPRs
 spgemm_topn_pruned_kernel(const int64_t *__restrict__ a_indptr, const int32_t *__restrict__ a_indices,
                           const T *__restrict__ a_data, uint32_t n_left, const uint32_t *__restrict__ seg,
@@ -263,13 +266,19 @@ spgemm_topn_pruned_kernel(const int64_t *__restrict__ a_indptr, const int32_t *_
                           const SgPairSink *__restrict__ pairs /* SYM: the pair list (sg_internal.h), in device memory */,
                           uint32_t pair_chunks /* chunks there are */,
                           uint32_t sym_lo, uint32_t sym_hi /* SYM: the left rows this launch scores (multi-GPU: a rank's range) */,
-                          const uint32_t *__restrict__ row_list /* WIDE: the rows to process */, const uint32_t *row_list_len) {
+                          const uint32_t *__restrict__ row_list /* WIDE: the rows to process */, const uint32_t *row_list_len,
+                          const uint32_t *__restrict__ ends8 /* stream form: ends of the super-tiles */, int32_t nv_pad) {
     constexpr int TILE = 1 << TILE_LOG2;
     constexpr int SLOTS = WIDE ? 2 : 1;   // row terms staged per lane
     constexpr int AB = TILE_LOG2 + 1;                          // address + half bits of a filter posting
     constexpr uint32_t ADDR_MASK = ((1u << AB) - 1u) & ~3u;    // byte address of the accumulator word
-    constexpr uint32_t BQ_BITS = 24 - AB;
+    // stream form (FOLD_LOG2 > 0): 2^FOLD_LOG2 tiles share the accumulator tile; the posting's fold field sits between
+    // the address and bq, and the fixed point is coarser by the same factor so that an accumulator holding the sums of
+    // all the columns folded onto it still fits sixteen bits
+    constexpr int FB = AB + FOLD_LOG2;                         // first bit of bq
+    constexpr uint32_t BQ_BITS = 24 - FB;
     constexpr uint32_t BQ_MAX = (1u << BQ_BITS) - 1u;
+    constexpr float SCALE = (float)(32768 >> FOLD_LOG2);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     // smem: TILE u16 accumulators (address 0), then
     int *hk = reinterpret_cast<int *>(smem + TILE * 2);                       // row i: hash of its terms
@@ -385,8 +394,8 @@ spgemm_topn_pruned_kernel(const int64_t *__restrict__ a_indptr, const int32_t *_
         //      q_ij >= tq_j,  tq_j = floor(((T0 - C1 * fq_j)) / 256)  <=  (thr - 1e-5) * 2^15 - 2 - c1 * fq_j
         //      (T0 = floor(t0 * 256), C1 = floor(c1 * 256) + 1; the 2 covers the float evaluation of t0, c1).
         const float b_s = sqrtf(bs2) * 1.000002f;
-        const float t0 = ((float)thr - 1e-5f) * 32768.0f - 2.0f;
-        const float c1 = b_s * norm_b * (32768.0f / 255.0f) * 1.000002f;
+        const float t0 = ((float)thr - 1e-5f) * SCALE - 2.0f;
+        const float c1 = b_s * norm_b * (SCALE / 255.0f) * 1.000002f;
         const int32_t T0 = (int32_t)floorf(t0 * 256.0f) - 256 * np;   // every add may fall short by < 1, |P| adds at most
         const int32_t C1 = (int32_t)(c1 * 256.0f) + 1;
         if (!(T0 - C1 * 255 >= 256)) {   // delta too small for the fixed-point resolution: exact kernel
@@ -445,8 +454,8 @@ spgemm_topn_pruned_kernel(const int64_t *__restrict__ a_indptr, const int32_t *_
         }
         // upper bound (less one) of a * b * 2^15 from the bq field of a filter posting, left in place:
         // x = (CA * (bq << AB)) >> 32 with CA >= c_a * 2^(32 - AB), c_a = a * norm_b * 2^15 / BQ_MAX
-        const float c_a = (float)my_a * norm_b * (32768.0f / (float)BQ_MAX) * 1.000002f;
-        const uint32_t CA = (uint32_t)(c_a * (float)(1u << (32 - AB))) + 1u;   // < 2^24
+        const float c_a = (float)my_a * norm_b * (SCALE / (float)BQ_MAX) * 1.000002f;
+        const uint32_t CA = (uint32_t)(c_a * (float)(1u << (32 - FB))) + 1u;   // < 2^24
         // lane (term, u of G): byte offset of its first entry inside a segment, stride; idle lanes read the
         // all-zero row K3 appends to the table of segment ends (empty segments, rem == 0) and entry 0
         // Lane u of the g lanes of a term owns entries 4u .. 4u + 3 of the term's segment in every tile: one 16-byte load.
@@ -505,7 +514,7 @@ spgemm_topn_pruned_kernel(const int64_t *__restrict__ a_indptr, const int32_t *_
             if (cross) surv[n_surv + __popcll(cm & lanes_below)] = col;
             n_surv += __popcll(cm);
             if (n_surv >= 64) {
-                top = drain_survivors<T, SYM, TILE_LOG2, WIDE>(nnz, thr, row, sc, pairs, top, n_surv);
+                top = drain_survivors<T, SYM, TILE_LOG2, WIDE, (FOLD_LOG2 > 0)>(nnz, thr, row, sc, pairs, top, n_surv);
                 st_surv += 64;
                 n_surv -= 64;
             }
@@ -517,7 +526,7 @@ spgemm_topn_pruned_kernel(const int64_t *__restrict__ a_indptr, const int32_t *_
         auto round = [&](uint32_t r, bool valid, uint64_t valid_mask, uint32_t t, uint32_t &zaddr) {
             zaddr = r & ADDR_MASK;
             const uint32_t sh = r << 4;   // bit 4 = the half; shifts and bit-field offsets use 5 bits
-            const uint32_t x = (uint32_t)(((uint64_t)(r & (BQ_MAX << AB)) * (uint64_t)(CA & 0xffffffu)) >> 32);
+            const uint32_t x = (uint32_t)(((uint64_t)(r & (BQ_MAX << FB)) * (uint64_t)(CA & 0xffffffu)) >> 32);
             const uint32_t tq1 = (uint32_t)((T0m - __mul24(C1, (int32_t)(r >> 24))) >> 8);
             uint32_t xs;   // x << (16 * half): the hardware shift takes the low five bits of sh by itself
             asm("v_lshlrev_b32 %0, %1, %2" : "=v"(xs) : "v"(sh), "v"(x));
@@ -574,7 +583,7 @@ spgemm_topn_pruned_kernel(const int64_t *__restrict__ a_indptr, const int32_t *_
             Slot s;
             s.z = r & ADDR_MASK;
             s.sh = r << 4;   // bit 4 = the half; shifts and bit-field offsets use 5 bits
-            s.x = (uint32_t)(((uint64_t)(r & (BQ_MAX << AB)) * (uint64_t)(CA & 0xffffffu)) >> 32);
+            s.x = (uint32_t)(((uint64_t)(r & (BQ_MAX << FB)) * (uint64_t)(CA & 0xffffffu)) >> 32);
             s.tq1 = (uint32_t)((T0m - __mul24(C1, (int32_t)(r >> 24))) >> 8);
             // x << (16 * half): the hardware shift takes the low five bits of sh by itself
             asm("v_lshlrev_b32 %0, %1, %2" : "=v"(s.xs) : "v"(s.sh), "v"(s.x));
@@ -650,34 +659,194 @@ spgemm_topn_pruned_kernel(const int64_t *__restrict__ a_indptr, const int32_t *_
 #endif
         };
 
-        // Software pipeline, four tiles per trip: E = segment ends of tiles 4m .. 4m + 3 (byte offsets),
-        // prev = end of tile 4m - 1 (= start of tile 4m); batch j of a trip belongs to tile 4m + j and is
-        // re-issued for tile 4m + j + 4 ... no: the batch of tile t + 3 is issued while tile t is applied.
-        uint4 E0 = ends_at(0);
-        uint4 E1 = ends_at(min(1u, last_group));
-        const uint32_t list_lo = g ? my_lo << 2 : 0u;
-        Batch b0, b1, b2, b3;
-        issue(b0, list_lo, E0.x);
-        issue(b1, E0.x, E0.y);
-        issue(b2, E0.y, E0.z);
-        SG_WD_DECL(wd_t);
-        for (uint32_t t = 0; t < t_end; t += 4) {
-            SG_WD(wd_t, n_tiles + 2, 13)
-            // tiles t .. t + 3 use E0; E1 = the next four; E2 is fetched for the trip after
-            const uint4 E2 = ends_at(min((t >> 2) + 2u, last_group));
-            issue(b3, E0.z, E0.w);
-            apply(b0, t);
-            if (t + 1 >= t_end) break;
-            issue(b0, E0.w, E1.x);
-            apply(b1, t + 1);
-            if (t + 2 >= t_end) break;
-            issue(b1, E1.x, E1.y);
-            apply(b2, t + 2);
-            if (t + 3 >= t_end) break;
-            issue(b2, E1.y, E1.z);
-            apply(b3, t + 3);
-            E0 = E1;
-            E1 = E2;
+        if constexpr (FOLD_LOG2 == 0) {
+            // Software pipeline, four tiles per trip: E = segment ends of tiles 4m .. 4m + 3 (byte offsets),
+            // prev = end of tile 4m - 1 (= start of tile 4m); batch j of a trip belongs to tile 4m + j and is
+            // re-issued for tile 4m + j + 4 ... no: the batch of tile t + 3 is issued while tile t is applied.
+            uint4 E0 = ends_at(0);
+            uint4 E1 = ends_at(min(1u, last_group));
+            const uint32_t list_lo = g ? my_lo << 2 : 0u;
+            Batch b0, b1, b2, b3;
+            issue(b0, list_lo, E0.x);
+            issue(b1, E0.x, E0.y);
+            issue(b2, E0.y, E0.z);
+            SG_WD_DECL(wd_t);
+            for (uint32_t t = 0; t < t_end; t += 4) {
+                SG_WD(wd_t, n_tiles + 2, 13)
+                // tiles t .. t + 3 use E0; E1 = the next four; E2 is fetched for the trip after
+                const uint4 E2 = ends_at(min((t >> 2) + 2u, last_group));
+                issue(b3, E0.z, E0.w);
+                apply(b0, t);
+                if (t + 1 >= t_end) break;
+                issue(b0, E0.w, E1.x);
+                apply(b1, t + 1);
+                if (t + 2 >= t_end) break;
+                issue(b1, E1.x, E1.y);
+                apply(b2, t + 2);
+                if (t + 3 >= t_end) break;
+                issue(b2, E1.y, E1.z);
+                apply(b3, t + 3);
+                E0 = E1;
+                E1 = E2;
+            }
+        } else {
+            // ---- Stream form (round 3).  The tile-by-tile loop above pays ~150 instructions per (row, tile) visit for ~110
+            // postings in 256 slots: lanes are dealt to the terms once per row, a tile's segment of a term is short, and
+            // what a lane's four slots do not hold goes through a slow path (scripts/k4f_fold_model.py: 34 % of the slots
+            // used, 11 % of the visits overflow).  Here a visit covers a SUPER-TILE of 2^FOLD_LOG2 tiles whose columns share
+            // one accumulator tile (column c -> accumulator c mod TILE; K3 writes the tile index mod 2^FOLD_LOG2 into the
+            // posting) and is worked off in ROUNDS of one 16-byte load per lane -- as many as the longest lane stream of the
+            // visit needs -- with the loads of the next three rounds in flight, whichever visit they belong to.  Eight
+            // times fewer visits, twice the postings per round (the relative spread of a segment's length shrinks with its
+            // size), no slow path.
+            //
+            // Sums of several columns in one accumulator are still UPPER bounds of each of them, so nothing is lost as long
+            // as every posting that finds its accumulator at or above ITS column's survivor threshold records the column:
+            // the test is `old + x >= tq_j`, not the crossing `old < tq_j <= old + x` (with two columns in an accumulator
+            // the crossing may be another column's doing).  Price: false positives (two unrelated partial sums adding up;
+            // + 20 % at 663 k) and repeats (every posting of a column after the first that passes); both only cost an exact
+            // scoring.  Repeats are caught by a 128-entry table of the columns recorded last (ds_wrxchg); what it forgets
+            // is scored twice and dropped where results are kept (TopList::insert_unique, pairs_select_kernel).
+            // Accumulators are cleared once per visit (8 KiB, eight ds_write_b128 per lane) instead of per posting: with
+            // more than one round the re-zeroing stores of a round would wipe sums that later rounds add to.
+            constexpr int FOLD = 1 << FOLD_LOG2;
+            constexpr uint32_t COL_MASK = ((1u << (TILE_LOG2 + FOLD_LOG2)) - 1u) & ~1u;
+            uint32_t *dt = reinterpret_cast<uint32_t *>(smem + TILE * 2 + 512 + (sizeof(T) == 4 ? 512 : 1024 + SG_SURV_CAP * 4));
+            dt[lane] = 0xFFFFFFFFu;
+            dt[lane + 64] = 0xFFFFFFFFu;
+            const uint32_t n_visits = (t_end + (uint32_t)FOLD - 1u) >> FOLD_LOG2;
+            const uint32_t erow8 = (g ? (uint32_t)my_k : n_terms) * (uint32_t)nv_pad;
+            auto ends8_at = [&](uint32_t group) {
+                return *reinterpret_cast<const uint4 *>(reinterpret_cast<const char *>(ends8) + ((erow8 + (group << 2)) << 2));
+            };
+            const uint32_t last_group8 = (uint32_t)(nv_pad >> 2) - 1u;
+            // the stream of a lane ends with the row's last tile (self-join form: the row's own tile), which need not be the
+            // end of a super-tile
+            const uint32_t hi_end = ends[(size_t)erow + t_end - 1u];
+            uint4 Ec = ends8_at(0);
+            uint4 En = ends8_at(min(1u, last_group8));
+            uint32_t gv = 0;                                  // the visit whose loads are being issued (wave-uniform)
+            uint32_t hi = min(Ec.x, hi_end);                  // end of the lane's segment in visit gv
+            uint32_t cur = (g ? my_lo << 2 : 0u) + u16;       // the lane's next four entries
+
+            struct SBatch {
+                uint32_t r0, r1, r2, r3;
+                int32_t rem;   // bytes of the segment at and after the lane's first entry of the round (<= 0: none)
+            };
+            struct __attribute__((packed, aligned(4))) Quad {
+                uint32_t x, y, z, w;
+            };
+            // One round's load for every lane.  tv = the visit it belongs to (>= n_visits: past the end), last = the
+            // visit ends with this round.
+            auto issue_s = [&](SBatch &bt, uint32_t &tv, bool &last) {
+                tv = gv;
+                bt.rem = (int32_t)(hi - cur);
+                // unconditional (see the tile-by-tile form), but never past the end of the lane's own segment: a lane that
+                // is through keeps re-reading the four entries behind it while the longest stream of the visit finishes
+                const Quad q = *reinterpret_cast<const Quad *>(reinterpret_cast<const char *>(filt) + min(cur, hi));
+                bt.r0 = q.x;
+                bt.r1 = q.y;
+                bt.r2 = q.z;
+                bt.r3 = q.w;
+                cur += G16;
+                last = ballot64((int32_t)(hi - cur) > 0) == 0;
+                if (last) {   // next visit
+                    ++gv;
+                    const uint32_t c = gv & 3u;
+                    if (c == 0) {
+                        Ec = En;
+                        En = ends8_at(min((gv >> 2) + 1u, last_group8));
+                    }
+                    const uint32_t e = c == 0 ? Ec.x : (c == 1 ? Ec.y : (c == 2 ? Ec.z : Ec.w));
+                    cur = hi + u16;              // the next segment starts where this one ends
+                    hi = min(e, hi_end);
+                }
+            };
+            auto collect_s = [&](uint64_t cm, uint32_t r, uint32_t tv) {
+                bool cross = (cm >> lane) & 1ull;
+                const uint32_t col = (tv << (TILE_LOG2 + FOLD_LOG2)) | ((r >> 1) & COL_MASK) | (r & 1u);
+                if (SYM) cross = cross && col <= row;   // the pair (i, j > i) is row j's to score
+                if (cross) {
+                    const uint32_t prev = __hip_atomic_exchange(&dt[(col * 2654435761u) >> 25], col, __ATOMIC_RELAXED,
+                                                                __HIP_MEMORY_SCOPE_WORKGROUP);
+                    cross = prev != col;
+                }
+                cm = ballot64(cross);
+                if (cm == 0) return;
+                if (cross) surv[n_surv + __popcll(cm & lanes_below)] = (int)col;
+                n_surv += __popcll(cm);
+                if (n_surv >= 64) {
+                    top = drain_survivors<T, SYM, TILE_LOG2, WIDE, true>(nnz, thr, row, sc, pairs, top, n_surv);
+                    st_surv += 64;
+                    n_surv -= 64;
+                }
+            };
+            struct SSlot {
+                uint32_t z, sh, xs;
+                int32_t d;
+            };
+            auto prep_s = [&](uint32_t r) {
+                SSlot q;
+                q.z = r & ADDR_MASK;
+                q.sh = r << 4;   // bit 4 = the half
+                const uint32_t x = (uint32_t)(((uint64_t)(r & (BQ_MAX << FB)) * (uint64_t)(CA & 0xffffffu)) >> 32);
+                // the accumulator must reach tq = (T0 - C1 fq) >> 8; with this posting's x added: old >= tq - x
+                q.d = ((T0 - __mul24(C1, (int32_t)(r >> 24))) >> 8) - (int32_t)x;
+                asm("v_lshlrev_b32 %0, %1, %2" : "=v"(q.xs) : "v"(q.sh), "v"(x));
+                return q;
+            };
+            bool dirty = false;   // accumulators of the current visit hold sums
+            auto apply_s = [&](const SBatch &bt, uint32_t tv, bool last) {
+                const bool v0 = bt.rem > 0, v1 = bt.rem > 4, v2 = bt.rem > 8, v3 = bt.rem > 12;
+                const uint64_t m0 = ballot64(v0), m1 = ballot64(v1), m2 = ballot64(v2), m3 = ballot64(v3);
+                if (m0 != 0) {
+                    dirty = true;
+                    const SSlot s0 = prep_s(bt.r0), s1 = prep_s(bt.r1), s2 = prep_s(bt.r2), s3 = prep_s(bt.r3);
+                    // no lane mask on the adds: a slot without a posting adds 0 to some accumulator of the tile
+                    const uint32_t a0 = v0 ? s0.xs : 0u, a1 = v1 ? s1.xs : 0u, a2 = v2 ? s2.xs : 0u, a3 = v3 ? s3.xs : 0u;
+                    uint32_t o0 = __hip_atomic_fetch_add(tab_at(s0.z), a0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    uint32_t o1 = __hip_atomic_fetch_add(tab_at(s1.z), a1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    uint32_t o2 = __hip_atomic_fetch_add(tab_at(s2.z), a2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    uint32_t o3 = __hip_atomic_fetch_add(tab_at(s3.z), a3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    asm volatile("" : "+v"(o0), "+v"(o1), "+v"(o2), "+v"(o3));   // the one wait
+                    const uint64_t c0 = ballot64((int32_t)__builtin_amdgcn_ubfe(o0, s0.sh, 16u) >= s0.d) & m0;
+                    const uint64_t c1m = ballot64((int32_t)__builtin_amdgcn_ubfe(o1, s1.sh, 16u) >= s1.d) & m1;
+                    const uint64_t c2 = ballot64((int32_t)__builtin_amdgcn_ubfe(o2, s2.sh, 16u) >= s2.d) & m2;
+                    const uint64_t c3 = ballot64((int32_t)__builtin_amdgcn_ubfe(o3, s3.sh, 16u) >= s3.d) & m3;
+                    if (c0 | c1m | c2 | c3) {
+                        if (c0) collect_s(c0, bt.r0, tv);
+                        if (c1m) collect_s(c1m, bt.r1, tv);
+                        if (c2) collect_s(c2, bt.r2, tv);
+                        if (c3) collect_s(c3, bt.r3, tv);
+                    }
+                }
+                if (last && dirty) {   // the visit is through: its accumulators back to zero
+                    for (int x = lane; x < TILE * 2 / 16; x += 64) tab_v[x] = make_uint4(0, 0, 0, 0);
+                    dirty = false;
+                }
+            };
+            SBatch sb0, sb1, sb2, sb3;
+            uint32_t tv0, tv1, tv2, tv3;
+            bool la0, la1, la2, la3;
+            issue_s(sb0, tv0, la0);
+            issue_s(sb1, tv1, la1);
+            issue_s(sb2, tv2, la2);
+            SG_WD_DECL(wd_s);
+            for (;;) {
+                SG_WD(wd_s, 1 << 26, 17)
+                issue_s(sb3, tv3, la3);
+                if (tv0 >= n_visits) break;
+                apply_s(sb0, tv0, la0);
+                issue_s(sb0, tv0, la0);
+                if (tv1 >= n_visits) break;
+                apply_s(sb1, tv1, la1);
+                issue_s(sb1, tv1, la1);
+                if (tv2 >= n_visits) break;
+                apply_s(sb2, tv2, la2);
+                issue_s(sb2, tv2, la2);
+                if (tv3 >= n_visits) break;
+                apply_s(sb3, tv3, la3);
+            }
         }
         {   // postings streamed = entries of P's lists in the tiles visited
             uint32_t mine = 0;
@@ -693,7 +862,7 @@ spgemm_topn_pruned_kernel(const int64_t *__restrict__ a_indptr, const int32_t *_
         if (probe_sink == 0x1234567887654321ull) n_surv = 1;   // keeps the tests alive
 #endif
         if (n_surv > 0) {   // fewer than 64 left
-            top = drain_survivors<T, SYM, TILE_LOG2, WIDE>(nnz, thr, row, sc, pairs, top, n_surv);
+            top = drain_survivors<T, SYM, TILE_LOG2, WIDE, (FOLD_LOG2 > 0)>(nnz, thr, row, sc, pairs, top, n_surv);
             st_surv += n_surv;
         }
         {   // (symmetric mode: the row's matches j <= i; pass 2 merges the mirrored ones in)
@@ -834,17 +1003,28 @@ __global__ void __launch_bounds__(64) pairs_select_kernel(const uint32_t *__rest
                     c = lcol[lo + (uint32_t)(lane - own)];
                 }
                 int rank = 0;
+                bool repeat = false;   // the same pair earlier in the list (the stream form may score a pair twice)
                 for (int q = 0; q < m; ++q) {
                     const T sq = wave_read<T>(s, q);
                     const int cq = wave_read<int>(c, q);
                     rank += (sq > s || (sq == s && cq < c)) ? 1 : 0;
+                    repeat = repeat || (cq == c && q < lane);
+                }
+                uint64_t rm = __ballot(have && repeat);
+                const int distinct = m - __popcll(rm);
+                while (rm) {   // (rare) a repeat ranked ahead of this entry does not count
+                    const int q = __builtin_ctzll(rm);
+                    rm &= rm - 1;
+                    const T sq = wave_read<T>(s, q);
+                    const int cq = wave_read<int>(c, q);
+                    rank -= (sq > s || (sq == s && cq < c)) ? 1 : 0;
                 }
                 __builtin_amdgcn_wave_barrier();   // all of the own list is in registers before it is overwritten
-                if (have && rank < keep) {
+                if (have && !repeat && rank < keep) {
                     out_vals[obase + rank] = s;
                     out_cols[obase + rank] = c;
                 }
-                if (lane == 0) out_cnt[row] = m < keep ? m : keep;
+                if (lane == 0) out_cnt[row] = distinct < keep ? distinct : keep;
                 continue;
             }
             TopList<T> top;
@@ -859,7 +1039,7 @@ __global__ void __launch_bounds__(64) pairs_select_kernel(const uint32_t *__rest
                 const T s = have ? lval[base + lane] : (T)0;
                 const int c = have ? lcol[base + lane] : 0;
                 const int mm = (int)min(64u, hi - base);
-                for (int q = 0; q < mm; ++q) top.insert(wave_read<T>(s, q), wave_read<int>(c, q), lane);
+                for (int q = 0; q < mm; ++q) top.insert_unique(wave_read<T>(s, q), wave_read<int>(c, q), lane);
             }
             int cnt = __popcll(__ballot(top.c != INT32_MAX));
             if (cnt > keep) cnt = keep;
@@ -965,8 +1145,13 @@ struct PairList {   // symmetric mode: the mirrored pairs (i, j < i) above the t
 __global__ void pair_sink_kernel(SgPairSink v, SgPairSink *out) { *out = v; }
 
 // single-wave workgroups of the pruned kernel: as many as the LDS of the chip holds
-static unsigned pruned_grid(const sg_ctx *ctx, int32_t tile_log2, int64_t n_rows) {
-    const size_t lds = ((size_t)2 << tile_log2) + 512 + 1024 + (size_t)SG_SURV_CAP * 4;
+// LDS of one wave: accumulator tile, row hash (keys 512 B, values up to 1 KiB), survivor buffer; the stream form adds its
+// 512-byte table of recorded columns, which for f32 fits the unused half of the value slots
+static size_t pruned_lds(int32_t tile_log2, int32_t fold_log2, int32_t dtype) {
+    return ((size_t)2 << tile_log2) + 512 + 1024 + (size_t)SG_SURV_CAP * 4 + (fold_log2 > 0 && dtype == SG_F64 ? 512 : 0);
+}
+static unsigned pruned_grid(const sg_ctx *ctx, int32_t tile_log2, int64_t n_rows, int32_t fold_log2 = 0, int32_t dtype = SG_F32) {
+    const size_t lds = pruned_lds(tile_log2, fold_log2, dtype);
     int waves_per_cu = (int)(ctx->lds_per_cu / lds);
     if (waves_per_cu > 32) waves_per_cu = 32;
     if (waves_per_cu < 1) waves_per_cu = 1;
@@ -977,21 +1162,21 @@ static unsigned pruned_grid(const sg_ctx *ctx, int32_t tile_log2, int64_t n_rows
     return grid;
 }
 
-template <typename T, int TILE_LOG2, bool SYM, bool WIDE>
+template <typename T, int TILE_LOG2, bool SYM, bool WIDE, int FOLD_LOG2>
 static int launch_pruned(sg_ctx *ctx, const sg_csr *A, const sg_postings *Bt, int32_t keep, sg_topn *r, T thr,
                          float s_budget, uint32_t *row_counter, uint32_t *flagged_count, uint32_t *flagged_rows,
                          unsigned long long *stats, const PairList &pl, const uint32_t *row_list, const uint32_t *row_list_len) {
-    const size_t lds = ((size_t)2 << TILE_LOG2) + 512 + 1024 + (size_t)SG_SURV_CAP * 4;
-    unsigned grid = pruned_grid(ctx, TILE_LOG2, SYM ? (int64_t)(pl.row_hi - pl.row_lo) : A->n_rows);
+    const size_t lds = pruned_lds(TILE_LOG2, FOLD_LOG2, A->dtype);
+    unsigned grid = pruned_grid(ctx, TILE_LOG2, SYM ? (int64_t)(pl.row_hi - pl.row_lo) : A->n_rows, FOLD_LOG2, A->dtype);
     if (WIDE && grid > (unsigned)ctx->num_cu * 4u) grid = (unsigned)ctx->num_cu * 4u;   // few rows, if any: idle waves leave at once
-    hipLaunchKernelGGL((spgemm_topn_pruned_kernel<T, TILE_LOG2, SYM, WIDE>), dim3(grid), dim3(64), lds, ctx->stream, A->d_indptr,
+    hipLaunchKernelGGL((spgemm_topn_pruned_kernel<T, TILE_LOG2, SYM, WIDE, FOLD_LOG2>), dim3(grid), dim3(64), lds, ctx->stream, A->d_indptr,
                        A->d_indices, (const T *)A->d_data, (uint32_t)A->n_rows, (const uint32_t *)Bt->d_seg,
                        (const uint32_t *)Bt->d_ends, Bt->nt_pad, (uint32_t)Bt->n_terms,
                        (const uint32_t *)Bt->d_filt, Bt->n_tiles, (const SgScoreCtx *)Bt->d_score_ctx, keep, r->stride, thr, s_budget,
                        Bt->norm_up, Bt->freq_min, r->d_cols,
                        (T *)r->d_vals,
                        r->d_counts, row_counter, flagged_count, flagged_rows, stats, pl.d_sink, pl.chunks, pl.row_lo, pl.row_hi, row_list,
-                       row_list_len);
+                       row_list_len, (const uint32_t *)Bt->d_ends8, Bt->nv_pad);
     SG_HIP_TRY(hipGetLastError());
     return SG_OK;
 }
@@ -999,7 +1184,7 @@ static int launch_pruned(sg_ctx *ctx, const sg_csr *A, const sg_postings *Bt, in
 // Both launches of one multiply: every row through the 64-term kernel; the rows it passes on (65 .. 128 non-zeros)
 // through the wide one; what THAT passes on (more than 128 non-zeros, more than 64 prefix terms, delta too small for
 // the fixed point) lands in (flagged_count, flagged_rows) for the exact kernel.
-template <typename T, int TILE_LOG2, bool SYM>
+template <typename T, int TILE_LOG2, bool SYM, int FOLD_LOG2>
 static int launch_both(sg_ctx *ctx, const sg_csr *A, const sg_postings *Bt, int32_t keep, sg_topn *r, T thr,
                        float s_budget, uint32_t *row_counter, uint32_t *flagged_count, uint32_t *flagged_rows,
                        unsigned long long *stats, const PairList &pl) {
@@ -1007,10 +1192,10 @@ static int launch_both(sg_ctx *ctx, const sg_csr *A, const sg_postings *Bt, int3
     SG_TRY(sg_alloc(ctx, (size_t)A->n_rows + 8, &l1));
     int st = hipMemsetAsync(l1, 0, 4 * sizeof(uint32_t), ctx->stream) == hipSuccess ? SG_OK : SG_ERR_HIP;
     if (st == SG_OK)
-        st = launch_pruned<T, TILE_LOG2, SYM, false>(ctx, A, Bt, keep, r, thr, s_budget, row_counter, l1, l1 + 4, stats, pl,
+        st = launch_pruned<T, TILE_LOG2, SYM, false, FOLD_LOG2>(ctx, A, Bt, keep, r, thr, s_budget, row_counter, l1, l1 + 4, stats, pl,
                                                      nullptr, nullptr);
     if (st == SG_OK && !(getenv("SG_PRUNE_WIDE") && getenv("SG_PRUNE_WIDE")[0] == '0'))
-        st = launch_pruned<T, TILE_LOG2, SYM, true>(ctx, A, Bt, keep, r, thr, s_budget, l1 + 1, flagged_count, flagged_rows, stats,
+        st = launch_pruned<T, TILE_LOG2, SYM, true, FOLD_LOG2>(ctx, A, Bt, keep, r, thr, s_budget, l1 + 1, flagged_count, flagged_rows, stats,
                                                     pl, l1 + 4, l1);
     else if (st == SG_OK) {   // SG_PRUNE_WIDE=0: the first launch's list goes to the exact kernel as it is
         if (hipMemcpyAsync(flagged_count, l1, 4, hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess ||
@@ -1026,10 +1211,18 @@ template <typename T, bool SYM>
 static int dispatch_pruned(sg_ctx *ctx, const sg_csr *A, const sg_postings *Bt, int32_t keep, sg_topn *r, T thr,
                            float s_budget, uint32_t *row_counter, uint32_t *flagged_count, uint32_t *flagged_rows,
                            unsigned long long *stats, const PairList &pl) {
+    if (Bt->fold_log2 > 0) {   // stream form: the postings were written for it (sg_postings.hip)
+        if (Bt->fold_log2 != 3 || Bt->tile_log2 != 12 || !Bt->d_ends8) {
+            sg_set_error("postings folded 2^%d over tiles of 2^%d columns are not supported by the pruned multiply", Bt->fold_log2,
+                         Bt->tile_log2);
+            return SG_ERR_UNSUPPORTED;
+        }
+        return launch_both<T, 12, SYM, 3>(ctx, A, Bt, keep, r, thr, s_budget, row_counter, flagged_count, flagged_rows, stats, pl);
+    }
     switch (Bt->tile_log2) {
-        case 11: return launch_both<T, 11, SYM>(ctx, A, Bt, keep, r, thr, s_budget, row_counter, flagged_count, flagged_rows, stats, pl);
-        case 12: return launch_both<T, 12, SYM>(ctx, A, Bt, keep, r, thr, s_budget, row_counter, flagged_count, flagged_rows, stats, pl);
-        case 13: return launch_both<T, 13, SYM>(ctx, A, Bt, keep, r, thr, s_budget, row_counter, flagged_count, flagged_rows, stats, pl);
+        case 11: return launch_both<T, 11, SYM, 0>(ctx, A, Bt, keep, r, thr, s_budget, row_counter, flagged_count, flagged_rows, stats, pl);
+        case 12: return launch_both<T, 12, SYM, 0>(ctx, A, Bt, keep, r, thr, s_budget, row_counter, flagged_count, flagged_rows, stats, pl);
+        case 13: return launch_both<T, 13, SYM, 0>(ctx, A, Bt, keep, r, thr, s_budget, row_counter, flagged_count, flagged_rows, stats, pl);
         default:
             sg_set_error("postings tile of 2^%d columns is not supported by the pruned multiply (2^11..2^13)", Bt->tile_log2);
             return SG_ERR_UNSUPPORTED;
@@ -1094,7 +1287,7 @@ int sg_spgemm_pruned_symmetric(sg_ctx *ctx, const sg_csr *A, const sg_postings *
     if (cap >= ((int64_t)1 << 31)) cap = ((int64_t)1 << 31) - 1;   // list offsets are 32-bit
     // every wave of the kernel holds one open chunk: count those in
     pl.chunks = (uint32_t)(cap / SG_PAIR_CHUNK);
-    if (!cap_forced) pl.chunks += pruned_grid(ctx, Bt->tile_log2, n) + (uint32_t)ctx->num_cu * 4u + sg_spgemm_exact_selfjoin_grid(ctx);
+    if (!cap_forced) pl.chunks += pruned_grid(ctx, Bt->tile_log2, n, Bt->fold_log2, A->dtype) + (uint32_t)ctx->num_cu * 4u + sg_spgemm_exact_selfjoin_grid(ctx);
     if (pl.chunks < 1) pl.chunks = 1;
     cap = (int64_t)pl.chunks * SG_PAIR_CHUNK;
     // [0] row counter [1] flagged count [2..3] pairs [4] chunks handed out [5] row counter of the exact kernel's launch;

@@ -24,13 +24,21 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "string_grouper_amd", "csrc", "sg_spgemm_pruned.hip")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 
-# template arguments <T, TILE_LOG2, SYM, WIDE> -> mangled fragment
+# template arguments <T, TILE_LOG2, SYM, WIDE, FOLD_LOG2> -> mangled fragment (FOLD_LOG2 = 0: the tile-by-tile form)
 KERNELS = {
-    "f32 self-join": "IfLi12ELb1ELb0EE",
-    "f32 one-sided": "IfLi12ELb0ELb0EE",
-    "f64 self-join": "IdLi12ELb1ELb0EE",
-    "f64 one-sided": "IdLi12ELb0ELb0EE",
+    "f32 self-join": "IfLi12ELb1ELb0ELi0EE",
+    "f32 one-sided": "IfLi12ELb0ELb0ELi0EE",
+    "f64 self-join": "IdLi12ELb1ELb0ELi0EE",
+    "f64 one-sided": "IdLi12ELb0ELb0ELi0EE",
 }
+# the stream form (FOLD_LOG2 = 3): rounds of four adds, no per-posting re-zeroing
+STREAM_KERNELS = {
+    "f32 self-join": "IfLi12ELb1ELb0ELi3EE",
+    "f32 one-sided": "IfLi12ELb0ELb0ELi3EE",
+    "f64 self-join": "IdLi12ELb1ELb0ELi3EE",
+    "f64 one-sided": "IdLi12ELb0ELb0ELi3EE",
+}
+STREAM_LIMITS = {"f32 self-join": 8, "f32 one-sided": 8, "f64 self-join": 16, "f64 one-sided": 16}   # vgpr spills allowed
 # (vgpr spills allowed, instructions of the fast-path block allowed)
 LIMITS = {"f32 self-join": (8, 95), "f32 one-sided": (8, 95), "f64 self-join": (16, 95), "f64 one-sided": (16, 95)}
 
@@ -112,3 +120,33 @@ def test_tile_loop_of_the_pruned_kernel_keeps_its_shape(asm, which):
                 (which, "a value is spilled right behind its load inside the tile loop")
     counts = [int(m.group(1)) for x in flat for m in [re.match(r"s_waitcnt vmcnt\((\d+)\)", x)] if m]
     assert max(counts) >= 3, (which, counts)                 # the prefetched batches are waited for by count
+
+
+def is_stream_round(b):
+    adds = [i for i, x in enumerate(b["ins"]) if x.startswith("ds_add_rtn_u32")]
+    return len(adds) == 4
+
+
+@pytest.mark.timeout(1200)
+@pytest.mark.parametrize("which", list(STREAM_KERNELS))
+def test_round_loop_of_the_stream_form_keeps_its_shape(asm, which):
+    """The stream form's loop: four unrolled rounds, each one block with the four LDS adds of a round and no scratch
+    access; the prefetched rounds are waited for by count; spills stay out of the loop."""
+    name, body = kernel_body(asm, STREAM_KERNELS[which])
+    meta = asm[asm.index(".name:           " + name):]
+    spills = int(re.search(r"\.vgpr_spill_count:\s*(\d+)", meta).group(1))
+    vgprs = int(re.search(r"\.vgpr_count:\s*(\d+)", meta).group(1))
+    assert vgprs <= 128, (which, vgprs)
+    assert spills <= STREAM_LIMITS[which], (which, spills)
+    blocks = blocks_of(body)
+    rounds = [b for b in blocks if is_stream_round(b)]
+    assert len(rounds) == 4, (which, len(rounds))
+    for b in rounds:
+        assert not any(x.startswith("scratch_") for x in b["ins"]), (which, b["label"], "scratch access in a round")
+        assert not any(x.startswith("ds_write_b32") for x in b["ins"]), (which, b["label"], "per-posting re-zeroing is back")
+        valu = sum(1 for x in b["ins"] if x.startswith("v_"))
+        assert valu <= 70, (which, b["label"], valu)
+    i0, i1 = blocks.index(rounds[0]), blocks.index(rounds[-1])
+    flat = [x for b in blocks[max(0, i0 - 12): i1 + 1] for x in b["ins"]]
+    counts = [int(m.group(1)) for x in flat for m in [re.match(r"s_waitcnt vmcnt\((\d+)\)", x)] if m]
+    assert max(counts) >= 3, (which, counts)

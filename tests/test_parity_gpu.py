@@ -1270,3 +1270,20 @@ def test_postings_built_with_lds_and_with_global_counters_give_the_same_multiply
             assert_csr_identical(res.to_scipy(), want, f"{dtype.__name__} lds={lds} prune={prune}")
             res.free()
             post.free()
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("top_n,thr", [(10, 0.8), (5, 0.6)])
+def test_hip_equals_the_canonical_tie_rule_exactly_and_the_arrival_rule_tie_aware(ctx, dtype, top_n, thr):
+    """Hubs of identical names larger than top_n: the HIP path equals the canonical port bit for bit, and differs from
+    the arrival-order variant (tests/test_tie_rules.py) only in which entries AT a row's cut score it keeps -- what a
+    user coming from the real wheel can see change (README, "ties")."""
+    from string_grouper_amd.sparse_dot_topn import sp_matmul_topn
+    from tests.test_tie_rules import hub_names
+    names = hub_names(30000, 11)
+    A = _tfidf(names, dtype)
+    C_dev = sp_matmul_topn(A, A.T, top_n, thr, sort=True, ctx=ctx)
+    assert_csr_identical(C_dev, P.sp_matmul_topn_port(A, A.T, top_n, thr, True, 8), "canonical rule")
+    arrival = P.sp_matmul_topn_port(A, A.T, top_n, thr, True, 8, tie_rule=1)
+    assert (C_dev != arrival).nnz > 0
+    assert O.compare_tie_aware(C_dev, arrival, top_n) == []

@@ -95,3 +95,105 @@ def test_survivors_cover_every_oracle_match(thr, delta, freq):
         total_surv += len(surv)
         total_full += int((mt.indptr[m.indices[lo:hi] + 1] - mt.indptr[m.indices[lo:hi]]).sum())
     assert total_streamed < total_full   # the filter does prune
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Stream form (round 3): eight tiles of 4096 columns share ONE accumulator tile (column c -> accumulator c mod 4096),
+# bq has 8 bits, the fixed point is 2^12, and a posting records its column when `old + x >= tq_j` -- whatever the
+# other columns folded onto the accumulator have added before.  The model runs the accumulation in a RANDOM order of
+# the postings (the kernel's order depends on how the lanes are dealt) and must still record every oracle match.
+FOLD_LOG2 = 3
+FB = AB + FOLD_LOG2
+BQ_MAX_S = (1 << (24 - FB)) - 1
+SCALE_S = 32768 >> FOLD_LOG2
+
+
+def quantise_right_stream(m, mt, freq_min, norm_up):
+    df = np.diff(mt.indptr)
+    inv = f32(1.0) / f32(norm_up)
+    frequent = df[m.indices] >= freq_min
+    f2 = np.zeros(m.shape[0])
+    np.add.at(f2, np.repeat(np.arange(m.shape[0]), np.diff(m.indptr))[frequent],
+              m.data[frequent].astype(np.float64) ** 2)
+    fq = np.minimum(255, np.ceil(np.nextafter(np.sqrt(f2).astype(f32), f32(2)) * inv * f32(255.0) * f32(1.000002)))
+    bq_t = np.minimum(BQ_MAX_S, np.ceil(mt.data.astype(f32) * inv * f32(BQ_MAX_S) * f32(1.000002)))
+    return fq.astype(np.int64), bq_t.astype(np.int64)
+
+
+def records_of_row_stream(a_idx, a_val, Bt_indptr, Bt_rows, bq_t, fq, thr, delta, norm_up, freq_min, rng, tile=4096):
+    """Columns the stream form records for one left row, repeats and false positives included."""
+    nnz = len(a_idx)
+    df = (Bt_indptr[a_idx + 1] - Bt_indptr[a_idx]).astype(np.int64)
+    beta = thr - delta
+    budget = np.nextafter(f32((beta / norm_up) ** 2 * (1.0 - 1e-6)), f32(0))
+    w = (a_val.astype(f32) * a_val.astype(f32) * f32(1.00001)).astype(f32)
+    cum = np.zeros(nnz, f32)
+    for lane in range(nnz):
+        c = f32(0)
+        for q in range(nnz):
+            if df[q] > df[lane] or (df[q] == df[lane] and q <= lane):
+                c = f32(c + w[q])
+        cum[lane] = c
+    in_s = (cum <= budget) & (df >= freq_min)
+    in_p = ~in_s
+    if not in_p.any():
+        return np.zeros(0, np.int64), 0
+    bs2 = cum[in_s].max() if in_s.any() else f32(0)
+    b_s = f32(f32(np.sqrt(bs2)) * f32(1.000002))
+    t0 = f32(f32(f32(thr) - f32(1e-5)) * f32(SCALE_S)) - f32(2.0)
+    c1 = f32(f32(f32(b_s * f32(norm_up)) * f32(SCALE_S / 255.0)) * f32(1.000002))
+    n_p = int(in_p.sum())
+    T0 = int(np.floor(f32(t0 * f32(256.0)))) - 256 * n_p
+    C1 = int(f32(c1 * f32(256.0))) + 1
+    if T0 - C1 * 255 < 256:
+        return None, 0          # the kernel hands such a row to the exact kernel
+    cols, xs = [], []
+    for t in np.nonzero(in_p)[0]:
+        lo, hi = Bt_indptr[a_idx[t]], Bt_indptr[a_idx[t] + 1]
+        c_a = f32(f32(f32(f32(a_val[t]) * f32(norm_up)) * f32(SCALE_S / BQ_MAX_S)) * f32(1.000002))
+        CA = int(f32(c_a * f32(1 << (32 - FB)))) + 1
+        assert CA < (1 << 24)
+        xs.append((CA * (bq_t[lo:hi].astype(np.int64) << FB)) >> 32)      # v_mul_hi_u32_u24
+        cols.append(Bt_rows[lo:hi])
+    cols = np.concatenate(cols)
+    xs = np.concatenate(xs)
+    order = rng.permutation(len(cols))
+    acc = {}
+    rec = []
+    for j, x in zip(cols[order], xs[order]):
+        key = (int(j) // (tile << FOLD_LOG2), int(j) % tile)     # (visit, accumulator)
+        old = acc.get(key, 0)
+        acc[key] = old + int(x)
+        assert acc[key] < 65536                                  # sixteen bits hold the sums of all folded columns
+        if old + int(x) >= ((T0 - C1 * int(fq[j])) >> 8):
+            rec.append(int(j))
+    return np.array(rec, dtype=np.int64), len(cols)
+
+
+@pytest.mark.parametrize("thr,delta,freq,tile", [(0.8, 0.05, 0.0045, 4096), (0.8, 0.05, 0.0045, 16), (0.5, 0.2, 0.01, 16),
+                                                 (0.95, 0.3, 0.05, 64), (0.6, 0.02, 0.0, 16)])
+def test_stream_form_records_cover_every_oracle_match(thr, delta, freq, tile):
+    """`tile` much smaller than the kernel's 4096 folds 3000 columns as heavily as 663 k columns fold in the kernel."""
+    names = synth_names(3000, 78)
+    (m,), _, _ = O.tfidf_sklearn(names, [names], dtype=np.float32)
+    m = m.tocsr()
+    m.sort_indices()
+    mt = m.T.tocsr()
+    mt.sort_indices()
+    C = O.sp_matmul_topn(m, m.T.tocsr(), 10_000, thr, sort=True)
+    norm_up = np.nextafter(f32(np.sqrt(f32(np.asarray(m.multiply(m).sum(axis=1)).max())) * f32(1.000001)), f32(2))
+    freq_min = max(1, int(freq * m.shape[0]))
+    fq, bq_t = quantise_right_stream(m, mt, freq_min, norm_up)
+    rng = np.random.default_rng(5)
+    n_rec = n_true = 0
+    for i in range(0, m.shape[0], 7):
+        lo, hi = m.indptr[i], m.indptr[i + 1]
+        rec, _ = records_of_row_stream(m.indices[lo:hi], m.data[lo:hi], mt.indptr, mt.indices, bq_t, fq, thr, delta,
+                                       norm_up, freq_min, rng, tile=tile)
+        if rec is None:
+            continue
+        want = C.indices[C.indptr[i]:C.indptr[i + 1]]
+        assert set(want) <= set(rec.tolist()), (i, sorted(set(want) - set(rec.tolist())))
+        n_rec += len(set(rec.tolist()))
+        n_true += len(want)
+    assert n_true > 0 and n_rec >= n_true
