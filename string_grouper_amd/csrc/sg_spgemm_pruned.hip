@@ -723,6 +723,11 @@ spgemm_topn_pruned_kernel(const int64_t *__restrict__ a_indptr, const int32_t *_
             // the stream of a lane ends with the row's last tile (self-join form: the row's own tile), which need not be the
             // end of a super-tile
             const uint32_t hi_end = ends[(size_t)erow + t_end - 1u];
+            typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+            // Ends of the visits, four per 16-byte load, the next four prefetched.  These loads are ordinary ones: the
+            // compiler waits for them with vmcnt(0) -- it does not know of the rounds in flight -- so every fourth visit the
+            // prefetched rounds are drained.  (Loading them by hand as well was tried: the value then flows through the
+            // phi of `if (c == 0)`, which the compiler lowers with copies of registers whose load is still in flight.)
             uint4 Ec = ends8_at(0);
             uint4 En = ends8_at(min(1u, last_group8));
             uint32_t gv = 0;                                  // the visit whose loads are being issued (wave-uniform)
@@ -730,11 +735,8 @@ spgemm_topn_pruned_kernel(const int64_t *__restrict__ a_indptr, const int32_t *_
             uint32_t cur = (g ? my_lo << 2 : 0u) + u16;       // the lane's next four entries
 
             struct SBatch {
-                uint32_t r0, r1, r2, r3;
+                u32x4 q;       // the lane's four entries of the round
                 int32_t rem;   // bytes of the segment at and after the lane's first entry of the round (<= 0: none)
-            };
-            struct __attribute__((packed, aligned(4))) Quad {
-                uint32_t x, y, z, w;
             };
             // One round's load for every lane.  tv = the visit it belongs to (>= n_visits: past the end), last = the
             // visit ends with this round.
@@ -743,11 +745,19 @@ spgemm_topn_pruned_kernel(const int64_t *__restrict__ a_indptr, const int32_t *_
                 bt.rem = (int32_t)(hi - cur);
                 // unconditional (see the tile-by-tile form), but never past the end of the lane's own segment: a lane that
                 // is through keeps re-reading the four entries behind it while the longest stream of the visit finishes
-                const Quad q = *reinterpret_cast<const Quad *>(reinterpret_cast<const char *>(filt) + min(cur, hi));
-                bt.r0 = q.x;
-                bt.r1 = q.y;
-                bt.r2 = q.z;
-                bt.r3 = q.w;
+                //
+                // The load and its wait are written by hand.  With ordinary loads the compiler's own wait counts come out
+                // as vmcnt(0) / vmcnt(1) at the head of every trip whatever the shape of the loop (its merge of the loop's
+                // entry and back edge, profiles/r03_stream_waitcnt.md), i.e. the rounds in flight are drained once per trip
+                // and the kernel runs at the latency of its loads (11.1 ms; the tile-by-tile form: 12.2).  An asm load is
+                // invisible to that bookkeeping; apply_s waits for it with the exact count -- three younger rounds are in
+                // flight whenever a round is applied; loads the compiler issues itself in between (segment ends) only make
+                // the wait stricter, never too lax (loads return in order).  tests/test_kernel_isa.py checks that nothing
+                // reads a round's registers between its load and its wait.
+                {
+                    const uint32_t at = min(cur, hi);
+                    asm volatile("global_load_dwordx4 %0, %1, %2" : "+v"(bt.q) : "v"(at), "s"(filt) : "memory");
+                }
                 cur += G16;
                 last = ballot64((int32_t)(hi - cur) > 0) == 0;
                 if (last) {   // next visit
@@ -762,24 +772,24 @@ spgemm_topn_pruned_kernel(const int64_t *__restrict__ a_indptr, const int32_t *_
                     hi = min(e, hi_end);
                 }
             };
+            // A posting that finds its accumulator at or above its column's threshold records the column: appended to the
+            // survivor buffer, nothing else -- no LDS read, no call inside the pipelined loop (either one makes the compiler
+            // wait for all but one or two of the loads in flight at the head of every trip: profiles/r03_stream_waitcnt.md).
+            // Repeats are removed and full waves of survivors scored between trips (below).  A row that records more
+            // than the buffer holds within one trip (hubs of a thousand near-identical names) is handed to the exact kernel.
+            bool overflow = false;
             auto collect_s = [&](uint64_t cm, uint32_t r, uint32_t tv) {
                 bool cross = (cm >> lane) & 1ull;
                 const uint32_t col = (tv << (TILE_LOG2 + FOLD_LOG2)) | ((r >> 1) & COL_MASK) | (r & 1u);
-                if (SYM) cross = cross && col <= row;   // the pair (i, j > i) is row j's to score
-                if (cross) {
-                    const uint32_t prev = __hip_atomic_exchange(&dt[(col * 2654435761u) >> 25], col, __ATOMIC_RELAXED,
-                                                                __HIP_MEMORY_SCOPE_WORKGROUP);
-                    cross = prev != col;
+                if (SYM) {
+                    cross = cross && col <= row;   // the pair (i, j > i) is row j's to score
+                    cm = ballot64(cross);
                 }
-                cm = ballot64(cross);
-                if (cm == 0) return;
-                if (cross) surv[n_surv + __popcll(cm & lanes_below)] = (int)col;
-                n_surv += __popcll(cm);
-                if (n_surv >= 64) {
-                    top = drain_survivors<T, SYM, TILE_LOG2, WIDE, true>(nnz, thr, row, sc, pairs, top, n_surv);
-                    st_surv += 64;
-                    n_surv -= 64;
-                }
+                const uint32_t n_new = (uint32_t)__popcll(cm);
+                const bool fits = n_surv + n_new <= (uint32_t)SG_SURV_CAP - 1u;
+                overflow = overflow || !fits;
+                if (cross && fits) surv[n_surv + __popcll(cm & lanes_below)] = (int)col;
+                n_surv += fits ? n_new : 0u;
             };
             struct SSlot {
                 uint32_t z, sh, xs;
@@ -796,12 +806,15 @@ spgemm_topn_pruned_kernel(const int64_t *__restrict__ a_indptr, const int32_t *_
                 return q;
             };
             bool dirty = false;   // accumulators of the current visit hold sums
-            auto apply_s = [&](const SBatch &bt, uint32_t tv, bool last) {
+            auto apply_s = [&](SBatch &bt, uint32_t tv, bool last) {
+                // the round's load is waited for HERE, on every path (also when no lane has a posting)
+                asm volatile("s_waitcnt vmcnt(3) ; round %0" : "+v"(bt.q)::"memory");
+                const u32x4 q = bt.q;
                 const bool v0 = bt.rem > 0, v1 = bt.rem > 4, v2 = bt.rem > 8, v3 = bt.rem > 12;
                 const uint64_t m0 = ballot64(v0), m1 = ballot64(v1), m2 = ballot64(v2), m3 = ballot64(v3);
                 if (m0 != 0) {
                     dirty = true;
-                    const SSlot s0 = prep_s(bt.r0), s1 = prep_s(bt.r1), s2 = prep_s(bt.r2), s3 = prep_s(bt.r3);
+                    const SSlot s0 = prep_s(q.x), s1 = prep_s(q.y), s2 = prep_s(q.z), s3 = prep_s(q.w);
                     // no lane mask on the adds: a slot without a posting adds 0 to some accumulator of the tile
                     const uint32_t a0 = v0 ? s0.xs : 0u, a1 = v1 ? s1.xs : 0u, a2 = v2 ? s2.xs : 0u, a3 = v3 ? s3.xs : 0u;
                     uint32_t o0 = __hip_atomic_fetch_add(tab_at(s0.z), a0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -814,10 +827,10 @@ spgemm_topn_pruned_kernel(const int64_t *__restrict__ a_indptr, const int32_t *_
                     const uint64_t c2 = ballot64((int32_t)__builtin_amdgcn_ubfe(o2, s2.sh, 16u) >= s2.d) & m2;
                     const uint64_t c3 = ballot64((int32_t)__builtin_amdgcn_ubfe(o3, s3.sh, 16u) >= s3.d) & m3;
                     if (c0 | c1m | c2 | c3) {
-                        if (c0) collect_s(c0, bt.r0, tv);
-                        if (c1m) collect_s(c1m, bt.r1, tv);
-                        if (c2) collect_s(c2, bt.r2, tv);
-                        if (c3) collect_s(c3, bt.r3, tv);
+                        if (c0) collect_s(c0, q.x, tv);
+                        if (c1m) collect_s(c1m, q.y, tv);
+                        if (c2) collect_s(c2, q.z, tv);
+                        if (c3) collect_s(c3, q.w, tv);
                     }
                 }
                 if (last && dirty) {   // the visit is through: its accumulators back to zero
@@ -826,26 +839,79 @@ spgemm_topn_pruned_kernel(const int64_t *__restrict__ a_indptr, const int32_t *_
                 }
             };
             SBatch sb0, sb1, sb2, sb3;
+            sb0.q = sb1.q = sb2.q = sb3.q = u32x4{0u, 0u, 0u, 0u};   // (the loads name their registers as read-write operands)
             uint32_t tv0, tv1, tv2, tv3;
             bool la0, la1, la2, la3;
             issue_s(sb0, tv0, la0);
             issue_s(sb1, tv1, la1);
             issue_s(sb2, tv2, la2);
+            issue_s(sb3, tv3, la3);
             SG_WD_DECL(wd_s);
             for (;;) {
-                SG_WD(wd_s, 1 << 26, 17)
-                issue_s(sb3, tv3, la3);
-                if (tv0 >= n_visits) break;
-                apply_s(sb0, tv0, la0);
-                issue_s(sb0, tv0, la0);
-                if (tv1 >= n_visits) break;
-                apply_s(sb1, tv1, la1);
-                issue_s(sb1, tv1, la1);
-                if (tv2 >= n_visits) break;
-                apply_s(sb2, tv2, la2);
-                issue_s(sb2, tv2, la2);
-                if (tv3 >= n_visits) break;
-                apply_s(sb3, tv3, la3);
+                bool finished = false;
+                for (;;) {   // trips of four rounds; left at the end of a trip when survivors are waiting
+                    SG_WD(wd_s, 1 << 26, 17)
+                    // (every batch is re-issued right behind its use: all four are in flight across the trip's end, none of
+                    //  them lives in the registers a call clobbers)
+                    finished = true;
+                    if (tv0 >= n_visits) break;
+                    apply_s(sb0, tv0, la0);
+                    issue_s(sb0, tv0, la0);
+                    if (tv1 >= n_visits) break;
+                    apply_s(sb1, tv1, la1);
+                    issue_s(sb1, tv1, la1);
+                    if (tv2 >= n_visits) break;
+                    apply_s(sb2, tv2, la2);
+                    issue_s(sb2, tv2, la2);
+                    if (tv3 >= n_visits) break;
+                    apply_s(sb3, tv3, la3);
+                    issue_s(sb3, tv3, la3);
+                    finished = false;
+                    if (n_surv >= 64u || overflow) break;
+                }
+                if (overflow) break;
+                // ---- between trips: drop the columns recorded before (128-entry table of the columns recorded last;
+                // what it forgets is scored twice and dropped where results are kept), close the gaps, score full waves
+                if (n_surv > 0) {
+                    const uint32_t n_before = n_surv;
+                    int c0 = 0, c1 = 0;
+                    bool k0 = false, k1 = false;
+                    if ((uint32_t)lane < n_before) {
+                        c0 = surv[lane];
+                        k0 = __hip_atomic_exchange(&dt[((uint32_t)c0 * 2654435761u) >> 25], (uint32_t)c0, __ATOMIC_RELAXED,
+                                                   __HIP_MEMORY_SCOPE_WORKGROUP) != (uint32_t)c0;
+                    }
+                    if ((uint32_t)lane + 64u < n_before) {
+                        c1 = surv[lane + 64];
+                        k1 = __hip_atomic_exchange(&dt[((uint32_t)c1 * 2654435761u) >> 25], (uint32_t)c1, __ATOMIC_RELAXED,
+                                                   __HIP_MEMORY_SCOPE_WORKGROUP) != (uint32_t)c1;
+                    }
+                    const uint64_t m0 = ballot64(k0), m1 = ballot64(k1);
+                    const uint32_t n0 = (uint32_t)__popcll(m0);
+                    __builtin_amdgcn_wave_barrier();
+                    if (k0) surv[__popcll(m0 & lanes_below)] = c0;
+                    if (k1) surv[n0 + __popcll(m1 & lanes_below)] = c1;
+                    __builtin_amdgcn_wave_barrier();
+                    n_surv = (uint32_t)__builtin_amdgcn_readfirstlane((int)(n0 + (uint32_t)__popcll(m1)));   // (explicitly wave-uniform)
+                    if (n_surv >= 64u) {
+                        // the rounds in flight land before the call: the callee saves and restores the registers they are
+                        // loaded into, and the compiler does not know that they are in flight
+                        asm volatile("s_waitcnt vmcnt(0) ; rounds %0 %1 %2 %3" : "+v"(sb0.q), "+v"(sb1.q), "+v"(sb2.q), "+v"(sb3.q)::"memory");
+                        top = drain_survivors<T, SYM, TILE_LOG2, WIDE, true>(nnz, thr, row, sc, pairs, top, n_surv);
+                        st_surv += 64;
+                        n_surv -= 64;
+                    }
+                }
+                if (finished) break;
+            }
+            // rounds issued past the end of the stream are still in flight: they must land before their registers are reused
+            asm volatile("s_waitcnt vmcnt(0) ; rounds %0 %1 %2 %3" : "+v"(sb0.q), "+v"(sb1.q), "+v"(sb2.q), "+v"(sb3.q)::"memory");
+            if (overflow) {   // more records than the buffer holds within one trip: the exact kernel takes the row
+                // (the accumulator tile may hold sums of the visit that was cut short)
+                for (int x = lane; x < TILE * 2 / 16; x += 64) tab_v[x] = make_uint4(0, 0, 0, 0);
+                if (lane == 0) flagged_rows[atomicAdd(flagged_count, 1u)] = row;
+                --st_rows;
+                continue;
             }
         }
         {   // postings streamed = entries of P's lists in the tiles visited

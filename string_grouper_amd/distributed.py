@@ -138,18 +138,36 @@ def all_gather_csr(indptr, indices, data, n_cols: int, group=None):
 
 
 # ---------------------------------------------------------------------------------------------- the sharded path
+class ShardedFitNotApplicable(Exception):
+    """Raised by ``sharded_tfidf`` on EVERY rank of the group alike (the decision is taken from exchanged facts, before
+    any collective on the data): some rank's block is coded in a way the others cannot add up -- n-gram keys over the
+    alphabet of the LOCAL strings (``ngram_size`` > 3, ``normalize_to_ascii=False`` with non-ASCII characters on some
+    ranks only), or a sorted vocabulary without a dense table.  The caller vectorises the whole column on every rank
+    instead (``DistributedHipEngine.tfidf``, ``sharded_self_join_replicated``)."""
+
+
 def sharded_tfidf(ops, local_sets: Sequence, group=None):
     """Steps 1-3: TF-IDF of the LOCAL blocks of every string column with the vocabulary / idf of ALL ranks' strings
     (TfidfVectorizer.fit(concat(all strings)) + transform, string_grouper.py:685-707).
     ``local_sets``: this rank's block of each column, e.g. [master block] or [master block, duplicates block].
-    Returns (fit state, [local CSR of each set])."""
+    Returns (fit state, [local CSR of each set]).  Raises ``ShardedFitNotApplicable`` -- on all ranks or on none."""
     state = ops.fit_begin(local_sets)
+    world = dist.get_world_size(group)
+    if world > 1:
+        # Whether the document-frequency tables can be added up is a property of EVERY rank's block (a block that is
+        # pure ASCII gets the shared 7-bit coding, a block with other characters its own alphabet): all ranks learn all
+        # ranks' answers from one small exchange and take the same branch -- a rank that raised on its own while the
+        # others entered the all-reduce would hang the job until the collective timed out.
+        shareable, entries = ops.fit_info(state)
+        facts = all_headers([1 if shareable else 0, int(entries)], ops.device, group)
+        if not all(f[0] == 1 for f in facts) or len({f[1] for f in facts}) != 1:
+            raise ShardedFitNotApplicable(
+                "the n-gram keys of some rank's strings are coded over the alphabet of its LOCAL strings (ngram_size > 3, "
+                "or non-ASCII characters kept by normalize_to_ascii=False), or the vocabulary is a sorted one: the document "
+                f"frequencies of the ranks cannot be added up (shareable, table entries per rank: {facts})")
     df = ops.df_tensor(state)                                   # dense int32 table over the n-gram key space
     n_docs = torch.tensor([sum(ops.n_strings(s) for s in local_sets)], dtype=torch.int64, device=df.device)
-    if dist.get_world_size(group) > 1:
-        if not ops.df_shareable(state):
-            raise NotImplementedError("ngram_size > 3 codes characters by their rank among the LOCAL strings; "
-                                      "the sharded vectoriser needs the shared 7-bit coding (ngram_size <= 3)")
+    if world > 1:
         dist.all_reduce(df, op=dist.ReduceOp.SUM, group=group)
         dist.all_reduce(n_docs, op=dist.ReduceOp.SUM, group=group)
     ops.fit_end(state, int(n_docs.item()))
@@ -362,6 +380,12 @@ class HipOps:
 
     def df_shareable(self, vec) -> bool:
         return vec.df_table()[2]
+
+    def fit_info(self, vec):
+        """(the table can be added to other ranks' tables, its entries) -- without touching the table (a sorted vocabulary
+        has none)."""
+        _, n, ok = vec.df_table()
+        return bool(ok), int(n)
 
     def fit_end(self, vec, n_docs_total: int):
         self._sync()

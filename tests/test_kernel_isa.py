@@ -38,6 +38,13 @@ STREAM_KERNELS = {
     "f64 self-join": "IdLi12ELb1ELb0ELi3EE",
     "f64 one-sided": "IdLi12ELb0ELb0ELi3EE",
 }
+# ... and the second launch over rows of 65 .. 128 non-zeros (WIDE): same loop, checked for its hand-written loads
+STREAM_WIDE_KERNELS = {
+    "f32 self-join wide": "IfLi12ELb1ELb1ELi3EE",
+    "f32 one-sided wide": "IfLi12ELb0ELb1ELi3EE",
+    "f64 self-join wide": "IdLi12ELb1ELb1ELi3EE",
+    "f64 one-sided wide": "IdLi12ELb0ELb1ELi3EE",
+}
 STREAM_LIMITS = {"f32 self-join": 8, "f32 one-sided": 8, "f64 self-join": 16, "f64 one-sided": 16}   # vgpr spills allowed
 # (vgpr spills allowed, instructions of the fast-path block allowed)
 LIMITS = {"f32 self-join": (8, 95), "f32 one-sided": (8, 95), "f64 self-join": (16, 95), "f64 one-sided": (16, 95)}
@@ -143,10 +150,57 @@ def test_round_loop_of_the_stream_form_keeps_its_shape(asm, which):
     assert len(rounds) == 4, (which, len(rounds))
     for b in rounds:
         assert not any(x.startswith("scratch_") for x in b["ins"]), (which, b["label"], "scratch access in a round")
-        assert not any(x.startswith("ds_write_b32") for x in b["ins"]), (which, b["label"], "per-posting re-zeroing is back")
         valu = sum(1 for x in b["ins"] if x.startswith("v_"))
         assert valu <= 70, (which, b["label"], valu)
     i0, i1 = blocks.index(rounds[0]), blocks.index(rounds[-1])
     flat = [x for b in blocks[max(0, i0 - 12): i1 + 1] for x in b["ins"]]
     counts = [int(m.group(1)) for x in flat for m in [re.match(r"s_waitcnt vmcnt\((\d+)\)", x)] if m]
     assert max(counts) >= 3, (which, counts)
+
+
+def _regs_of(text):
+    """VGPR numbers an instruction line mentions (v7, v[8:11])."""
+    out = set()
+    for a, b in re.findall(r"\bv\[(\d+):(\d+)\]", text):
+        out.update(range(int(a), int(b) + 1))
+    for a in re.findall(r"\bv(\d+)\b", text):
+        out.add(int(a))
+    return out
+
+
+@pytest.mark.timeout(1200)
+@pytest.mark.parametrize("which", list(STREAM_KERNELS) + list(STREAM_WIDE_KERNELS))
+def test_nothing_reads_a_round_between_its_hand_written_load_and_its_wait(asm, which):
+    """The stream form loads its rounds with `global_load_dwordx4` in inline assembly and waits for them with a hand-counted
+    `s_waitcnt vmcnt(3)`: the compiler does not know that these registers are in flight, so a copy or a spill of one of
+    them between the load and the wait would read garbage -- silently.  Every such load must be followed (in layout
+    order) by its own wait before anything else names its registers, and there must be exactly four round variables."""
+    name, body = kernel_body(asm, {**STREAM_KERNELS, **STREAM_WIDE_KERNELS}[which])
+    raw = body.split("\n")
+    loads = []
+    for i, x in enumerate(raw):
+        if x.strip().startswith("global_load_dwordx4") and i > 0 and "#ASMSTART" in raw[i - 1]:
+            m = re.match(r"global_load_dwordx4 v\[(\d+):(\d+)\]", x.strip())
+            assert m, x
+            loads.append((i, int(m.group(1)), int(m.group(2))))
+    assert len(loads) >= 8, (which, len(loads))            # four in the prologue, four in the loop
+    assert len({(a, b) for _, a, b in loads}) == 4, (which, sorted({(a, b) for _, a, b in loads}))
+    for i, a, b in loads:
+        regs = set(range(a, b + 1))
+        want = "s_waitcnt vmcnt(3) ; round v[%d:%d]" % (a, b)
+        for j in list(range(i + 1, len(raw))) + list(range(0, i)):   # (the loop wraps: a round loaded at its end is waited for at its head)
+            t = raw[j].strip()
+            if t.startswith(want) or t.startswith("s_waitcnt vmcnt(0) ; rounds"):
+                break
+            if not t or t.startswith(";") or t.startswith(".") or t.startswith("s_waitcnt vmcnt(3) ; round") or \
+                    t.startswith("s_endpgm"):
+                continue
+            ins = t.split(";")[0]
+            if ins.startswith("global_load_dwordx4") and "#ASMSTART" in raw[j - 1]:
+                assert not (_regs_of(ins.split(",")[0]) & regs), (which, j, t)
+                touched = _regs_of(",".join(ins.split(",")[1:]))
+            else:
+                touched = _regs_of(ins)
+            assert not (touched & regs), (which, "line %d names v[%d:%d] before its wait: %s" % (j, a, b, t))
+        else:
+            raise AssertionError((which, "no wait found for the load at line %d" % i))
