@@ -8,6 +8,7 @@
 #          prof[:args]      rocprofv3 --kernel-trace --stats of the bench command -> gpurun_out/<name>_kernel_stats.csv
 #          pmc[:args]       the HBM traffic passes (FETCH_SIZE / WRITE_SIZE, separate runs, no trace domains)
 #          py:<script args> python <script args> -> gpurun_out/<name>_<script>.log
+#          sh:<command>     any shell command -> gpurun_out/<name>_sh<n>.log
 # Everything a step prints goes to gpurun_out/<name>.log; what is worth keeping is copied into profiles/ by hand.
 name=$1; shift
 mkdir -p gpurun_out
@@ -58,6 +59,8 @@ for step in "$@"; do
     py)
       base=$(basename ${arg%% *} .py)
       timeout 1500 python $arg > gpurun_out/${name}_${base}$n.log 2>&1; echo "rc=$?" >> $LOG; tail -40 gpurun_out/${name}_${base}$n.log >> $LOG ;;
+    sh)
+      timeout 1500 bash -c "$arg" > gpurun_out/${name}_sh$n.log 2>&1; echo "rc=$?" >> $LOG; tail -15 gpurun_out/${name}_sh$n.log >> $LOG ;;
     *) echo "unknown step $step" >> $LOG ;;
   esac
 done

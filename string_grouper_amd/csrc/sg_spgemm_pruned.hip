@@ -756,7 +756,11 @@ spgemm_topn_pruned_kernel(const int64_t *__restrict__ a_indptr, const int32_t *_
                 // reads a round's registers between its load and its wait.
                 {
                     const uint32_t at = min(cur, hi);
+#ifdef SG_STREAM_PLAIN_LOADS   // (A/B: the compiler's own loads and wait counts)
+                    bt.q = *reinterpret_cast<const u32x4 __attribute__((aligned(4))) *>(reinterpret_cast<const char *>(filt) + at);
+#else
                     asm volatile("global_load_dwordx4 %0, %1, %2" : "+v"(bt.q) : "v"(at), "s"(filt) : "memory");
+#endif
                 }
                 cur += G16;
                 last = ballot64((int32_t)(hi - cur) > 0) == 0;
@@ -772,24 +776,31 @@ spgemm_topn_pruned_kernel(const int64_t *__restrict__ a_indptr, const int32_t *_
                     hi = min(e, hi_end);
                 }
             };
-            // A posting that finds its accumulator at or above its column's threshold records the column: appended to the
-            // survivor buffer, nothing else -- no LDS read, no call inside the pipelined loop (either one makes the compiler
-            // wait for all but one or two of the loads in flight at the head of every trip: profiles/r03_stream_waitcnt.md).
-            // Repeats are removed and full waves of survivors scored between trips (below).  A row that records more
-            // than the buffer holds within one trip (hubs of a thousand near-identical names) is handed to the exact kernel.
-            bool overflow = false;
+            SBatch sb0, sb1, sb2, sb3;
+            sb0.q = sb1.q = sb2.q = sb3.q = u32x4{0u, 0u, 0u, 0u};   // (the loads name their registers as read-write operands)
+            // A posting that finds its accumulator at or above its column's threshold records the column -- unless the table
+            // of the columns recorded last says it has been recorded before.  A full wave of survivors is scored at once;
+            // the rounds in flight land first: the callee saves and restores the registers they are loaded into, and the
+            // compiler does not know that they are in flight.
             auto collect_s = [&](uint64_t cm, uint32_t r, uint32_t tv) {
                 bool cross = (cm >> lane) & 1ull;
                 const uint32_t col = (tv << (TILE_LOG2 + FOLD_LOG2)) | ((r >> 1) & COL_MASK) | (r & 1u);
-                if (SYM) {
-                    cross = cross && col <= row;   // the pair (i, j > i) is row j's to score
-                    cm = ballot64(cross);
+                if (SYM) cross = cross && col <= row;   // the pair (i, j > i) is row j's to score
+                if (cross) {
+                    const uint32_t prev = __hip_atomic_exchange(&dt[(col * 2654435761u) >> 25], col, __ATOMIC_RELAXED,
+                                                                __HIP_MEMORY_SCOPE_WORKGROUP);
+                    cross = prev != col;
                 }
-                const uint32_t n_new = (uint32_t)__popcll(cm);
-                const bool fits = n_surv + n_new <= (uint32_t)SG_SURV_CAP - 1u;
-                overflow = overflow || !fits;
-                if (cross && fits) surv[n_surv + __popcll(cm & lanes_below)] = (int)col;
-                n_surv += fits ? n_new : 0u;
+                cm = ballot64(cross);
+                if (cm == 0) return;
+                if (cross) surv[n_surv + __popcll(cm & lanes_below)] = (int)col;
+                n_surv += __popcll(cm);
+                if (n_surv >= 64) {
+                    asm volatile("s_waitcnt vmcnt(0) ; rounds %0 %1 %2 %3" : "+v"(sb0.q), "+v"(sb1.q), "+v"(sb2.q), "+v"(sb3.q)::"memory");
+                    top = drain_survivors<T, SYM, TILE_LOG2, WIDE, true>(nnz, thr, row, sc, pairs, top, n_surv);
+                    st_surv += 64;
+                    n_surv -= 64;
+                }
             };
             struct SSlot {
                 uint32_t z, sh, xs;
@@ -808,7 +819,11 @@ spgemm_topn_pruned_kernel(const int64_t *__restrict__ a_indptr, const int32_t *_
             bool dirty = false;   // accumulators of the current visit hold sums
             auto apply_s = [&](SBatch &bt, uint32_t tv, bool last) {
                 // the round's load is waited for HERE, on every path (also when no lane has a posting)
+#ifdef SG_STREAM_PLAIN_LOADS
+                asm volatile("" : "+v"(bt.q)::"memory");
+#else
                 asm volatile("s_waitcnt vmcnt(3) ; round %0" : "+v"(bt.q)::"memory");
+#endif
                 const u32x4 q = bt.q;
                 const bool v0 = bt.rem > 0, v1 = bt.rem > 4, v2 = bt.rem > 8, v3 = bt.rem > 12;
                 const uint64_t m0 = ballot64(v0), m1 = ballot64(v1), m2 = ballot64(v2), m3 = ballot64(v3);
@@ -838,8 +853,6 @@ spgemm_topn_pruned_kernel(const int64_t *__restrict__ a_indptr, const int32_t *_
                     dirty = false;
                 }
             };
-            SBatch sb0, sb1, sb2, sb3;
-            sb0.q = sb1.q = sb2.q = sb3.q = u32x4{0u, 0u, 0u, 0u};   // (the loads name their registers as read-write operands)
             uint32_t tv0, tv1, tv2, tv3;
             bool la0, la1, la2, la3;
             issue_s(sb0, tv0, la0);
@@ -847,72 +860,23 @@ spgemm_topn_pruned_kernel(const int64_t *__restrict__ a_indptr, const int32_t *_
             issue_s(sb2, tv2, la2);
             issue_s(sb3, tv3, la3);
             SG_WD_DECL(wd_s);
-            for (;;) {
-                bool finished = false;
-                for (;;) {   // trips of four rounds; left at the end of a trip when survivors are waiting
-                    SG_WD(wd_s, 1 << 26, 17)
-                    // (every batch is re-issued right behind its use: all four are in flight across the trip's end, none of
-                    //  them lives in the registers a call clobbers)
-                    finished = true;
-                    if (tv0 >= n_visits) break;
-                    apply_s(sb0, tv0, la0);
-                    issue_s(sb0, tv0, la0);
-                    if (tv1 >= n_visits) break;
-                    apply_s(sb1, tv1, la1);
-                    issue_s(sb1, tv1, la1);
-                    if (tv2 >= n_visits) break;
-                    apply_s(sb2, tv2, la2);
-                    issue_s(sb2, tv2, la2);
-                    if (tv3 >= n_visits) break;
-                    apply_s(sb3, tv3, la3);
-                    issue_s(sb3, tv3, la3);
-                    finished = false;
-                    if (n_surv >= 64u || overflow) break;
-                }
-                if (overflow) break;
-                // ---- between trips: drop the columns recorded before (128-entry table of the columns recorded last;
-                // what it forgets is scored twice and dropped where results are kept), close the gaps, score full waves
-                if (n_surv > 0) {
-                    const uint32_t n_before = n_surv;
-                    int c0 = 0, c1 = 0;
-                    bool k0 = false, k1 = false;
-                    if ((uint32_t)lane < n_before) {
-                        c0 = surv[lane];
-                        k0 = __hip_atomic_exchange(&dt[((uint32_t)c0 * 2654435761u) >> 25], (uint32_t)c0, __ATOMIC_RELAXED,
-                                                   __HIP_MEMORY_SCOPE_WORKGROUP) != (uint32_t)c0;
-                    }
-                    if ((uint32_t)lane + 64u < n_before) {
-                        c1 = surv[lane + 64];
-                        k1 = __hip_atomic_exchange(&dt[((uint32_t)c1 * 2654435761u) >> 25], (uint32_t)c1, __ATOMIC_RELAXED,
-                                                   __HIP_MEMORY_SCOPE_WORKGROUP) != (uint32_t)c1;
-                    }
-                    const uint64_t m0 = ballot64(k0), m1 = ballot64(k1);
-                    const uint32_t n0 = (uint32_t)__popcll(m0);
-                    __builtin_amdgcn_wave_barrier();
-                    if (k0) surv[__popcll(m0 & lanes_below)] = c0;
-                    if (k1) surv[n0 + __popcll(m1 & lanes_below)] = c1;
-                    __builtin_amdgcn_wave_barrier();
-                    n_surv = (uint32_t)__builtin_amdgcn_readfirstlane((int)(n0 + (uint32_t)__popcll(m1)));   // (explicitly wave-uniform)
-                    if (n_surv >= 64u) {
-                        // the rounds in flight land before the call: the callee saves and restores the registers they are
-                        // loaded into, and the compiler does not know that they are in flight
-                        asm volatile("s_waitcnt vmcnt(0) ; rounds %0 %1 %2 %3" : "+v"(sb0.q), "+v"(sb1.q), "+v"(sb2.q), "+v"(sb3.q)::"memory");
-                        top = drain_survivors<T, SYM, TILE_LOG2, WIDE, true>(nnz, thr, row, sc, pairs, top, n_surv);
-                        st_surv += 64;
-                        n_surv -= 64;
-                    }
-                }
-                if (finished) break;
+            for (;;) {   // trips of four rounds; every round is re-issued right behind its use
+                SG_WD(wd_s, 1 << 26, 17)
+                if (tv0 >= n_visits) break;
+                apply_s(sb0, tv0, la0);
+                issue_s(sb0, tv0, la0);
+                if (tv1 >= n_visits) break;
+                apply_s(sb1, tv1, la1);
+                issue_s(sb1, tv1, la1);
+                if (tv2 >= n_visits) break;
+                apply_s(sb2, tv2, la2);
+                issue_s(sb2, tv2, la2);
+                if (tv3 >= n_visits) break;
+                apply_s(sb3, tv3, la3);
+                issue_s(sb3, tv3, la3);
             }
             // rounds issued past the end of the stream are still in flight: they must land before their registers are reused
             asm volatile("s_waitcnt vmcnt(0) ; rounds %0 %1 %2 %3" : "+v"(sb0.q), "+v"(sb1.q), "+v"(sb2.q), "+v"(sb3.q)::"memory");
-            if (overflow) {   // more records than the buffer holds within one trip: the exact kernel takes the row
-                // (the accumulator tile may hold sums of the visit that was cut short)
-                for (int x = lane; x < TILE * 2 / 16; x += 64) tab_v[x] = make_uint4(0, 0, 0, 0);
-                if (lane == 0) flagged_rows[atomicAdd(flagged_count, 1u)] = row;
-                --st_rows;
-                continue;
-            }
         }
         {   // postings streamed = entries of P's lists in the tiles visited
             uint32_t mine = 0;

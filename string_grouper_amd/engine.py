@@ -278,18 +278,47 @@ class DistributedHipEngine(HipEngine):
             ranges.append((lo, hi))
             blocks.append(probe.prepare(series.iloc[lo:hi] if hasattr(series, "iloc") else series[lo:hi]))
         t = self._tick("prepare_and_upload_s", t)
-        vec, mats = D.sharded_tfidf(ops, blocks, self.group)
+        try:
+            vec, mats = D.sharded_tfidf(ops, blocks, self.group)
+        except D.ShardedFitNotApplicable:
+            # (raised on every rank alike.)  n-gram keys coded over the alphabet of the strings at hand -- ngram_size > 3,
+            # characters kept by normalize_to_ascii=False -- mean something else on every rank: every rank vectorises the
+            # WHOLE columns (it holds them: the public API runs the same script on the same Series everywhere), and only
+            # the multiply is shared: this rank's rows on the left, the whole matrix, which is already here, on the right.
+            return self._tfidf_replicated(master, duplicates, factory, ops, ranges, t)
         self._tick("vectorise_s", t)
         A = ShardedMatrix(mats[0], len(master), ranges[0], ops, self.group)
         B = A if duplicates is None else ShardedMatrix(mats[1], len(duplicates), ranges[1], ops, self.group)
         return A, B, vec
 
+    def _tfidf_replicated(self, master, duplicates, factory, ops, ranges, t):
+        vec = factory()
+        sets = [vec.prepare(master)] + ([] if duplicates is None else [vec.prepare(duplicates)])
+        vec.fit_prepared(sets)
+        full = [vec.transform_prepared(s) for s in sets]
+        self._tick("vectorise_s", t)
+        out = []
+        for csr, (lo, hi) in zip(full, ranges):
+            m = ShardedMatrix(csr.row_block(lo, hi), csr.dims()[0], (lo, hi), ops, self.group)
+            m._full = csr                      # no all-gather: the whole matrix is this rank's own work
+            out.append(m)
+        return out[0], (out[0] if duplicates is None else out[1]), vec
+
     def _topn_device(self, A, B, top_n: int, threshold: float) -> "N.TopN":
         if not isinstance(A, ShardedMatrix):
-            return super()._topn_device(A, B, top_n, threshold)      # replicated inputs: every rank does it all
+            # replicated left side: every rank does it all -- against the WHOLE right-hand side, not this rank's block of it
+            if isinstance(B, ShardedMatrix):
+                B = DeviceMatrix(B.full())
+            return super()._topn_device(A, B, top_n, threshold)
         from . import distributed as D
         right = B.full() if isinstance(B, ShardedMatrix) else B.csr
-        res_local = D.sharded_topn(A._ops, A.csr, right, top_n, threshold, self_join=B is A, group=self.group)
+        try:
+            res_local = D.sharded_topn(A._ops, A.csr, right, top_n, threshold, self_join=B is A, group=self.group)
+        except OverflowError:
+            # the right-hand side does not fit one inverted index (on every rank alike: it is the same matrix): the local
+            # rows against row blocks of it, merged on the device (K5), as on one GPU and as fit() expects of the engine
+            # (string_grouper.py:397-413)
+            res_local = HipEngine._topn_device(self, DeviceMatrix(A.csr), DeviceMatrix(right), top_n, threshold)
         cols, vals, counts = D.gather_topn(A._ops, res_local, self.group)
         res_local.free()
         return self.ctx.topn_from_host(cols, vals, counts, B.shape[0])

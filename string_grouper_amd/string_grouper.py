@@ -732,13 +732,20 @@ class StringGrouper(object):
             return False
         # the reference tests every element with isinstance(x, str) (string_grouper.py:351-362); pandas' C-level type
         # inference answers the same question ("string" only when every element is a str, no missing values)
+        if len(series_to_test) == 0:
+            return True                       # nothing in it that is not a str (the reference: any() of nothing)
         kind = pd.api.types.infer_dtype(series_to_test, skipna=False)
         if kind == "string":
             # an extension string dtype may hold pd.NA, which the inference does not report
             return series_to_test.dtype == object or not bool(series_to_test.isna().any())
         if kind == "empty":
             return len(series_to_test) == 0
-        return False
+        if kind in ("mixed", "mixed-integer", "floating", "integer", "boolean", "bytes", "decimal", "complex",
+                    "datetime64", "datetime", "date", "timedelta64", "timedelta", "time", "period", "interval"):
+            return False                      # some element is not a str (an object column of anything but str included)
+        # whatever else the inference calls it ("categorical", "unknown-array", ...): the reference's own element-wise
+        # test -- a categorical Series of str passes it
+        return all(isinstance(x, str) for x in series_to_test.to_numpy(dtype=object))
 
     @staticmethod
     def _is_input_data_combination_valid(duplicates, master_id, duplicates_id) -> bool:

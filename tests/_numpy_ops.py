@@ -58,6 +58,15 @@ class NumpyOps:
     def df_shareable(self, st):
         return True
 
+    # test hook: ranks for which fit_info reports a table that cannot be added to the others' (a block coded over the
+    # alphabet of its own strings)
+    not_shareable_on = ()
+
+    def fit_info(self, st):
+        import torch.distributed as dist
+        rank = dist.get_rank() if dist.is_initialized() else 0
+        return rank not in self.not_shareable_on, KEY_SPACE
+
     def fit_end(self, st, n_docs_total):
         df = st.df.numpy()
         present = np.flatnonzero(df > 0)

@@ -164,6 +164,18 @@ def _sharded_worker(rank, world, port, ret):
         ok["match_counts"] = np.array_equal(np.diff(got.indptr), np.diff(C.indptr))
         ok["match_indices"] = np.array_equal(got.indices, C.indices)
         ok["match_scores"] = np.array_equal(got.data, C.data)
+        # ---- a block that cannot share its document-frequency table on ONE rank only (that rank used to raise
+        #      on its own while the other entered the all-reduce): every rank learns it from the exchange and raises alike
+        for bad in ((1,), (0, 1)):
+            ops.not_shareable_on = bad
+            try:
+                D.distributed_self_join(ops, names[lo:hi], 10, 0.8)
+                ok["not_shareable_%s" % len(bad)] = False
+            except D.ShardedFitNotApplicable:
+                ok["not_shareable_%s" % len(bad)] = True
+        ops.not_shareable_on = ()
+        res, _ = D.distributed_self_join(ops, names[lo:hi], 10, 0.8)          # ... and the group is still in step
+        ok["in_step_after_refusal"] = len(res[2]) == hi - lo
         # ---- gather_counts with cost-weighted (uneven) cuts
         cuts = D.weighted_row_blocks(np.arange(1, 101) ** 2, world)
         mine = torch.arange(int(cuts[rank]), int(cuts[rank + 1]), dtype=torch.int32)

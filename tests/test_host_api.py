@@ -464,3 +464,46 @@ def test_seeded_fuzz_of_the_public_api_against_the_reference():
     finally:
         shutil.rmtree(d, ignore_errors=True)
 
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/string_grouper"), reason="reference tree not mounted")
+def test_series_validation_answers_as_the_reference_does():
+    """``_is_series_of_strings`` (string_grouper.py:988-995 of the reference) on every kind of Series a caller may pass:
+    object / string / arrow / categorical columns, empty ones of any dtype, missing values, mixed content."""
+    code = r"""
+import sys, json
+sys.path[:0] = [%r, "/root/reference"]
+import numpy as np, pandas as pd
+from string_grouper.string_grouper import StringGrouper as R
+sys.path.insert(0, %r)
+from string_grouper_amd.string_grouper import StringGrouper as M
+cases = {
+    "object str": pd.Series(["a", "b"]), "string dtype": pd.Series(["a", "b"], dtype="string"),
+    "arrow": pd.Series(["a", "b"], dtype="string[pyarrow]"), "categorical of str": pd.Series(["a", "b", "a"], dtype="category"),
+    "categorical of int": pd.Series(pd.Categorical([1, 2])), "mixed": pd.Series(["a", 1]), "none": pd.Series(["a", None]),
+    "nan": pd.Series(["a", np.nan]), "pd.NA in string dtype": pd.Series(["a", pd.NA], dtype="string"),
+    "ints": pd.Series([1, 2]), "floats": pd.Series([1.0]), "bytes": pd.Series([b"a"]),
+    "empty object": pd.Series([], dtype=object), "empty float": pd.Series([], dtype=float),
+    "empty string": pd.Series([], dtype="string"), "empty category": pd.Series([], dtype="category"),
+    "not a series": ["a", "b"], "frame": pd.DataFrame({"a": ["x"]}), "index": pd.Index(["a"]),
+    "datetimes": pd.Series(pd.date_range("2020", periods=2)), "bools": pd.Series([True, False]),
+}
+def ask(f, v):
+    try:
+        return bool(f(v))
+    except Exception as e:           # (the reference's map/any chain raises on some extension dtypes: nothing to compare)
+        return "raises " + type(e).__name__
+print(json.dumps({k: [ask(R._is_series_of_strings, v), ask(M._is_series_of_strings, v)] for k, v in cases.items()}))
+""" % (os.path.join(ROOT, "tests", "ref_shims"), ROOT)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, cwd="/tmp")
+    assert r.returncode == 0, r.stderr[-2000:]
+    import json
+    got = json.loads(r.stdout.strip().splitlines()[-1])
+    assert len(got) > 15
+    compared = 0
+    for k, (ref, mine) in got.items():
+        assert isinstance(mine, bool), (k, mine)                 # the mirror never raises on a Series
+        if isinstance(ref, bool):
+            assert ref == mine, (k, ref, mine)
+            compared += 1
+    assert compared > 15
