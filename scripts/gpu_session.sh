@@ -56,6 +56,17 @@ for step in "$@"; do
         echo "pmc $c rc=$?" >> $LOG
       done
       python scripts/pmc_traffic.py gpurun_out/${name}_pmc_FETCH_SIZE gpurun_out/${name}_pmc_WRITE_SIZE gpurun_out/${name}_k4_traffic.json >> $LOG 2>&1 ;;
+    pmcsq)
+      i=0
+      for ctrs in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS" \
+                  "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_WAVES" \
+                  "TCP_TCC_READ_REQ_sum TCC_HIT_sum TCC_MISS_sum TCC_EA_RDREQ_sum" "TCP_GATE_EN1_sum TCP_GATE_EN2_sum TCP_TA_TCP_STATE_READ_sum TCP_PENDING_STALL_CYCLES_sum"; do
+        i=$((i+1))
+        ( cd /tmp && export TMPDIR=/tmp && timeout 600 rocprofv3 --pmc $ctrs --output-format csv -d $OLDPWD/gpurun_out/${name}_pmcsq$i -o k -- python $OLDPWD/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-exact-kernel --no-end-to-end $arg > /dev/null 2> $OLDPWD/gpurun_out/${name}_pmcsq$i.err )
+        echo "-- pmc pass $i rc=$?: $ctrs" >> $LOG
+        python scripts/pmc_summary.py gpurun_out/${name}_pmcsq$i 2>&1 | grep -A14 "spgemm_topn_pruned" | head -16 >> $LOG
+        rm -rf gpurun_out/${name}_pmcsq$i
+      done ;;
     py)
       base=$(basename ${arg%% *} .py)
       timeout 1500 python $arg > gpurun_out/${name}_${base}$n.log 2>&1; echo "rc=$?" >> $LOG; tail -40 gpurun_out/${name}_${base}$n.log >> $LOG ;;

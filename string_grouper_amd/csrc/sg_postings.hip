@@ -463,6 +463,8 @@ extern "C" int sg_postings_build_flags(sg_ctx *ctx, const sg_csr *B_in, int32_t 
         if (st == SG_OK) st = sg_alloc(ctx, 2 * ((size_t)B->n_rows + 2), &p->d_fwd_ptr);   // uint2 per row
         // slack: the pruned multiply loads a lane's four slots of a segment unconditionally (<= 4 * 63 entries past it)
         if (st == SG_OK) st = sg_alloc(ctx, (size_t)B->nnz + 512, &p->d_filt);
+        // the stream form points lanes without a posting at the slack behind the array: all-zero entries add nothing
+        if (st == SG_OK && hipMemsetAsync(p->d_filt + B->nnz, 0, 512 * sizeof(uint32_t), ctx->stream) != hipSuccess) st = SG_ERR_HIP;
         p->nt_pad = (int32_t)((n_tiles64 + 3) & ~(int64_t)3);
         if (st == SG_OK) st = sg_alloc(ctx, (size_t)(B->n_cols + 1) * (size_t)p->nt_pad + 4, &p->d_ends);
         // stream form of the pruned multiply (sg_spgemm_pruned.hip): eight tiles share one accumulator tile

@@ -248,10 +248,66 @@ __device__ __noinline__ TopList<T> drain_survivors(int nnz, T thr, uint32_t row,
     return top;
 }
 
+// Stream form: the survivor buffer runs full.  Drops the columns recorded before -- a 128-entry table of the columns
+// recorded last (ds_wrxchg); what it forgets is scored twice and dropped where results are kept -- closes the gaps and,
+// if a full wave of survivors is left, scores it.  The first n_clean entries have been through this before (they ARE the
+// table's entries) and stay.  Returns the list and, in .c of the extra lane-uniform word, the entries left (all clean).
+// Not inlined: sixteen call sites in the round loop.  The caller has waited for its rounds in flight (this function and
+// its callee save and restore registers).
+template <typename T>
+struct FlushOut {
+    TopList<T> top;
+    uint32_t n_surv;
+};
+template <typename T, bool SYM, int TILE_LOG2, bool WIDE>
+__device__ __noinline__ FlushOut<T> flush_survivors(int nnz, T thr, uint32_t row, const SgScoreCtx *__restrict__ sc,
+                                                    const SgPairSink *__restrict__ pairs, TopList<T> top, uint32_t n_surv,
+                                                    uint32_t n_clean) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int TILE = 1 << TILE_LOG2;
+    int *surv = reinterpret_cast<int *>(smem + TILE * 2 + 512 + 1024);
+    uint32_t *dt = reinterpret_cast<uint32_t *>(smem + TILE * 2 + 512 + (sizeof(T) == 4 ? 512 : 1024 + SG_SURV_CAP * 4));
+    const int lane = threadIdx.x;
+    const uint64_t lanes_below = (1ull << lane) - 1ull;
+    int c0 = 0, c1 = 0;
+    bool k0 = false, k1 = false;
+    if ((uint32_t)lane < n_surv) {
+        c0 = surv[lane];
+        k0 = (uint32_t)lane < n_clean ||
+             __hip_atomic_exchange(&dt[((uint32_t)c0 * 2654435761u) >> 25], (uint32_t)c0, __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_WORKGROUP) != (uint32_t)c0;
+    }
+    if ((uint32_t)lane + 64u < n_surv) {
+        c1 = surv[lane + 64];
+        k1 = (uint32_t)lane + 64u < n_clean ||
+             __hip_atomic_exchange(&dt[((uint32_t)c1 * 2654435761u) >> 25], (uint32_t)c1, __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_WORKGROUP) != (uint32_t)c1;
+    }
+    const uint64_t f0 = ballot64(k0), f1 = ballot64(k1);
+    const uint32_t n0 = (uint32_t)__popcll(f0);
+    __builtin_amdgcn_wave_barrier();
+    if (k0) surv[__popcll(f0 & lanes_below)] = c0;
+    if (k1) surv[n0 + __popcll(f1 & lanes_below)] = c1;
+    __builtin_amdgcn_wave_barrier();
+    FlushOut<T> out;
+    out.top = top;
+    out.n_surv = (uint32_t)__builtin_amdgcn_readfirstlane((int)(n0 + (uint32_t)__popcll(f1)));
+    if (out.n_surv >= 64u) {
+#ifndef SG_STREAM_PROBE_NO_SCORE
+        out.top = drain_survivors<T, SYM, TILE_LOG2, WIDE, true>(nnz, thr, row, sc, pairs, top, out.n_surv);
+#endif
+        out.n_surv -= 64u;
+    }
+    return out;
+}
+
 // WIDE: the second launch, over the rows the first one could not take because they have 65 .. 128 non-zeros: every lane
 // stages two of the row's terms; still one posting list per lane, so the row's prefix P must fit 64 lanes.
+// 16 single-wave workgroups per CU (the LDS limit) = 4 waves per SIMD: <= 128 VGPRs.  The f64 stream form has 10.5 KiB of LDS
+// per wave (15 per CU) and, at 128 registers, spills the visit ends inside its round loop -- scratch reloads that the
+// compiler waits for with vmcnt(0), i.e. the rounds in flight drained every round: it is built for 3 waves per SIMD.
 template <typename T, int TILE_LOG2, bool SYM, bool WIDE, int FOLD_LOG2>
-__global__ void __launch_bounds__(64, 4)   // 16 single-wave workgroups per CU (the LDS limit) = 4 waves per SIMD: <= 128 VGPRs
+__global__ void __launch_bounds__(64, (sizeof(T) == 8 && FOLD_LOG2 > 0) ? 3 : 4)
 spgemm_topn_pruned_kernel(const int64_t *__restrict__ a_indptr, const int32_t *__restrict__ a_indices,
                           const T *__restrict__ a_data, uint32_t n_left, const uint32_t *__restrict__ seg,
                           const uint32_t *__restrict__ ends, int32_t nt_pad, uint32_t n_terms,
@@ -267,7 +323,8 @@ spgemm_topn_pruned_kernel(const int64_t *__restrict__ a_indptr, const int32_t *_
                           uint32_t pair_chunks /* chunks there are */,
                           uint32_t sym_lo, uint32_t sym_hi /* SYM: the left rows this launch scores (multi-GPU: a rank's range) */,
                           const uint32_t *__restrict__ row_list /* WIDE: the rows to process */, const uint32_t *row_list_len,
-                          const uint32_t *__restrict__ ends8 /* stream form: ends of the super-tiles */, int32_t nv_pad) {
+                          const uint32_t *__restrict__ ends8 /* stream form: ends of the super-tiles */, int32_t nv_pad,
+                          uint32_t null_off /* stream form: byte offset of sixteen all-zero filter postings */) {
     constexpr int TILE = 1 << TILE_LOG2;
     constexpr int SLOTS = WIDE ? 2 : 1;   // row terms staged per lane
     constexpr int AB = TILE_LOG2 + 1;                          // address + half bits of a filter posting
@@ -736,15 +793,18 @@ spgemm_topn_pruned_kernel(const int64_t *__restrict__ a_indptr, const int32_t *_
 
             struct SBatch {
                 u32x4 q;       // the lane's four entries of the round
-                int32_t rem;   // bytes of the segment at and after the lane's first entry of the round (<= 0: none)
             };
             // One round's load for every lane.  tv = the visit it belongs to (>= n_visits: past the end), last = the
             // visit ends with this round.
             auto issue_s = [&](SBatch &bt, uint32_t &tv, bool &last) {
                 tv = gv;
-                bt.rem = (int32_t)(hi - cur);
-                // unconditional (see the tile-by-tile form), but never past the end of the lane's own segment: a lane that
-                // is through keeps re-reading the four entries behind it while the longest stream of the visit finishes
+                // Unconditional (see the tile-by-tile form) and WITHOUT validity masks: a lane that is through with its
+                // segment reads the all-zero entries K3 leaves behind the array -- they add 0 to accumulator 0 -- and the
+                // last load of a segment may bring one to three entries of what follows it (the term's next super-tile,
+                // or the next term's list): whatever they are, they add non-negative amounts to accumulators of this
+                // visit, which keeps every accumulator an UPPER bound (a few false positives more; the columns such
+                // entries record are columns of this visit like any other and are scored exactly).  Four compares, four
+                // selects and four mask operations per round less, and one register per round in flight.
                 //
                 // The load and its wait are written by hand.  With ordinary loads the compiler's own wait counts come out
                 // as vmcnt(0) / vmcnt(1) at the head of every trip whatever the shape of the loop (its merge of the loop's
@@ -755,8 +815,10 @@ spgemm_topn_pruned_kernel(const int64_t *__restrict__ a_indptr, const int32_t *_
                 // the wait stricter, never too lax (loads return in order).  tests/test_kernel_isa.py checks that nothing
                 // reads a round's registers between its load and its wait.
                 {
-                    const uint32_t at = min(cur, hi);
-#ifdef SG_STREAM_PLAIN_LOADS   // (A/B: the compiler's own loads and wait counts)
+                    const uint32_t at = (int32_t)(hi - cur) > 0 ? cur : null_off;
+#if defined(SG_STREAM_PROBE_NO_LOADS)   // timing probes (wrong results): scripts/gpu_session.sh ab:SG_HIP_LIB=...
+                    bt.q = u32x4{at & 0x1ffcu, (at * 5u) & 0x1ffcu, (at * 9u) & 0x1ffcu, (at * 13u) & 0x1ffcu};
+#elif defined(SG_STREAM_PLAIN_LOADS)   // (A/B: the compiler's own loads and wait counts)
                     bt.q = *reinterpret_cast<const u32x4 __attribute__((aligned(4))) *>(reinterpret_cast<const char *>(filt) + at);
 #else
                     asm volatile("global_load_dwordx4 %0, %1, %2" : "+v"(bt.q) : "v"(at), "s"(filt) : "memory");
@@ -778,29 +840,32 @@ spgemm_topn_pruned_kernel(const int64_t *__restrict__ a_indptr, const int32_t *_
             };
             SBatch sb0, sb1, sb2, sb3;
             sb0.q = sb1.q = sb2.q = sb3.q = u32x4{0u, 0u, 0u, 0u};   // (the loads name their registers as read-write operands)
-            // A posting that finds its accumulator at or above its column's threshold records the column -- unless the table
-            // of the columns recorded last says it has been recorded before.  A full wave of survivors is scored at once;
-            // the rounds in flight land first: the callee saves and restores the registers they are loaded into, and the
-            // compiler does not know that they are in flight.
+            // A posting that finds its accumulator at or above its column's threshold records the column: appended to the
+            // survivor buffer and nothing else -- at 663 k a round records five columns on average (every posting of a
+            // column behind the first that passes fires again), so this path is not a rare one, and an LDS round trip per
+            // firing slot (the exchange with the table of recorded columns) cost as much as the rest of the round
+            // (profiles/r03_sessionE_*).  Repeats are removed in bulk when the buffer runs full (flush_s).
+            uint32_t n_clean = 0;   // survivors at the front of the buffer that the repeat filter has seen already
+            // (the rounds in flight land before the call: callees save and restore the registers they are loaded into, and
+            //  the compiler does not know that they are in flight)
+            auto flush_s = [&]() {
+                asm volatile("s_waitcnt vmcnt(0) ; rounds %0 %1 %2 %3" : "+v"(sb0.q), "+v"(sb1.q), "+v"(sb2.q), "+v"(sb3.q)::"memory");
+                const FlushOut<T> fo = flush_survivors<T, SYM, TILE_LOG2, WIDE>(nnz, thr, row, sc, pairs, top, n_surv, n_clean);
+                top = fo.top;
+                st_surv += (n_surv - fo.n_surv) & ~63u;   // 64 if a wave was scored (the rest were repeats)
+                n_surv = n_clean = (uint32_t)__builtin_amdgcn_readfirstlane((int)fo.n_surv);
+            };
             auto collect_s = [&](uint64_t cm, uint32_t r, uint32_t tv) {
                 bool cross = (cm >> lane) & 1ull;
                 const uint32_t col = (tv << (TILE_LOG2 + FOLD_LOG2)) | ((r >> 1) & COL_MASK) | (r & 1u);
-                if (SYM) cross = cross && col <= row;   // the pair (i, j > i) is row j's to score
-                if (cross) {
-                    const uint32_t prev = __hip_atomic_exchange(&dt[(col * 2654435761u) >> 25], col, __ATOMIC_RELAXED,
-                                                                __HIP_MEMORY_SCOPE_WORKGROUP);
-                    cross = prev != col;
+                if (SYM) {
+                    cross = cross && col <= row;   // the pair (i, j > i) is row j's to score
+                    cm = ballot64(cross);
                 }
-                cm = ballot64(cross);
-                if (cm == 0) return;
+                const uint32_t n_new = (uint32_t)__popcll(cm);
+                if (n_surv + n_new > (uint32_t)SG_SURV_CAP - 1u) flush_s();   // (leaves fewer than 64)
                 if (cross) surv[n_surv + __popcll(cm & lanes_below)] = (int)col;
-                n_surv += __popcll(cm);
-                if (n_surv >= 64) {
-                    asm volatile("s_waitcnt vmcnt(0) ; rounds %0 %1 %2 %3" : "+v"(sb0.q), "+v"(sb1.q), "+v"(sb2.q), "+v"(sb3.q)::"memory");
-                    top = drain_survivors<T, SYM, TILE_LOG2, WIDE, true>(nnz, thr, row, sc, pairs, top, n_surv);
-                    st_surv += 64;
-                    n_surv -= 64;
-                }
+                n_surv += n_new;
             };
             struct SSlot {
                 uint32_t z, sh, xs;
@@ -819,28 +884,29 @@ spgemm_topn_pruned_kernel(const int64_t *__restrict__ a_indptr, const int32_t *_
             bool dirty = false;   // accumulators of the current visit hold sums
             auto apply_s = [&](SBatch &bt, uint32_t tv, bool last) {
                 // the round's load is waited for HERE, on every path (also when no lane has a posting)
-#ifdef SG_STREAM_PLAIN_LOADS
+#if defined(SG_STREAM_PLAIN_LOADS) || defined(SG_STREAM_PROBE_NO_LOADS)
                 asm volatile("" : "+v"(bt.q)::"memory");
 #else
                 asm volatile("s_waitcnt vmcnt(3) ; round %0" : "+v"(bt.q)::"memory");
 #endif
                 const u32x4 q = bt.q;
-                const bool v0 = bt.rem > 0, v1 = bt.rem > 4, v2 = bt.rem > 8, v3 = bt.rem > 12;
-                const uint64_t m0 = ballot64(v0), m1 = ballot64(v1), m2 = ballot64(v2), m3 = ballot64(v3);
-                if (m0 != 0) {
+                {
                     dirty = true;
                     const SSlot s0 = prep_s(q.x), s1 = prep_s(q.y), s2 = prep_s(q.z), s3 = prep_s(q.w);
-                    // no lane mask on the adds: a slot without a posting adds 0 to some accumulator of the tile
-                    const uint32_t a0 = v0 ? s0.xs : 0u, a1 = v1 ? s1.xs : 0u, a2 = v2 ? s2.xs : 0u, a3 = v3 ? s3.xs : 0u;
+                    const uint32_t a0 = s0.xs, a1 = s1.xs, a2 = s2.xs, a3 = s3.xs;
+#ifdef SG_STREAM_PROBE_NO_LDS
+                    uint32_t o0 = s0.z + a0, o1 = s1.z + a1, o2 = s2.z + a2, o3 = s3.z + a3;
+#else
                     uint32_t o0 = __hip_atomic_fetch_add(tab_at(s0.z), a0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     uint32_t o1 = __hip_atomic_fetch_add(tab_at(s1.z), a1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     uint32_t o2 = __hip_atomic_fetch_add(tab_at(s2.z), a2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     uint32_t o3 = __hip_atomic_fetch_add(tab_at(s3.z), a3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#endif
                     asm volatile("" : "+v"(o0), "+v"(o1), "+v"(o2), "+v"(o3));   // the one wait
-                    const uint64_t c0 = ballot64((int32_t)__builtin_amdgcn_ubfe(o0, s0.sh, 16u) >= s0.d) & m0;
-                    const uint64_t c1m = ballot64((int32_t)__builtin_amdgcn_ubfe(o1, s1.sh, 16u) >= s1.d) & m1;
-                    const uint64_t c2 = ballot64((int32_t)__builtin_amdgcn_ubfe(o2, s2.sh, 16u) >= s2.d) & m2;
-                    const uint64_t c3 = ballot64((int32_t)__builtin_amdgcn_ubfe(o3, s3.sh, 16u) >= s3.d) & m3;
+                    const uint64_t c0 = ballot64((int32_t)__builtin_amdgcn_ubfe(o0, s0.sh, 16u) >= s0.d);
+                    const uint64_t c1m = ballot64((int32_t)__builtin_amdgcn_ubfe(o1, s1.sh, 16u) >= s1.d);
+                    const uint64_t c2 = ballot64((int32_t)__builtin_amdgcn_ubfe(o2, s2.sh, 16u) >= s2.d);
+                    const uint64_t c3 = ballot64((int32_t)__builtin_amdgcn_ubfe(o3, s3.sh, 16u) >= s3.d);
                     if (c0 | c1m | c2 | c3) {
                         if (c0) collect_s(c0, q.x, tv);
                         if (c1m) collect_s(c1m, q.y, tv);
@@ -848,10 +914,12 @@ spgemm_topn_pruned_kernel(const int64_t *__restrict__ a_indptr, const int32_t *_
                         if (c3) collect_s(c3, q.w, tv);
                     }
                 }
+#ifndef SG_STREAM_PROBE_NO_CLEAR
                 if (last && dirty) {   // the visit is through: its accumulators back to zero
                     for (int x = lane; x < TILE * 2 / 16; x += 64) tab_v[x] = make_uint4(0, 0, 0, 0);
                     dirty = false;
                 }
+#endif
             };
             uint32_t tv0, tv1, tv2, tv3;
             bool la0, la1, la2, la3;
@@ -877,6 +945,7 @@ spgemm_topn_pruned_kernel(const int64_t *__restrict__ a_indptr, const int32_t *_
             }
             // rounds issued past the end of the stream are still in flight: they must land before their registers are reused
             asm volatile("s_waitcnt vmcnt(0) ; rounds %0 %1 %2 %3" : "+v"(sb0.q), "+v"(sb1.q), "+v"(sb2.q), "+v"(sb3.q)::"memory");
+            if (n_surv > n_clean) flush_s();   // repeats out of what is left (scored below)
         }
         {   // postings streamed = entries of P's lists in the tiles visited
             uint32_t mine = 0;
@@ -1206,7 +1275,7 @@ static int launch_pruned(sg_ctx *ctx, const sg_csr *A, const sg_postings *Bt, in
                        Bt->norm_up, Bt->freq_min, r->d_cols,
                        (T *)r->d_vals,
                        r->d_counts, row_counter, flagged_count, flagged_rows, stats, pl.d_sink, pl.chunks, pl.row_lo, pl.row_hi, row_list,
-                       row_list_len, (const uint32_t *)Bt->d_ends8, Bt->nv_pad);
+                       row_list_len, (const uint32_t *)Bt->d_ends8, Bt->nv_pad, (uint32_t)((Bt->nnz + 64) * 4));
     SG_HIP_TRY(hipGetLastError());
     return SG_OK;
 }

@@ -45,7 +45,8 @@ STREAM_WIDE_KERNELS = {
     "f64 self-join wide": "IdLi12ELb1ELb1ELi3EE",
     "f64 one-sided wide": "IdLi12ELb0ELb1ELi3EE",
 }
-STREAM_LIMITS = {"f32 self-join": 8, "f32 one-sided": 8, "f64 self-join": 16, "f64 one-sided": 16}   # vgpr spills allowed
+STREAM_LIMITS = {"f32 self-join": 8, "f32 one-sided": 8, "f64 self-join": 4, "f64 one-sided": 4}   # vgpr spills allowed
+STREAM_VGPRS = {"f32 self-join": 128, "f32 one-sided": 128, "f64 self-join": 168, "f64 one-sided": 168}   # 4 / 3 waves per SIMD
 # (vgpr spills allowed, instructions of the fast-path block allowed)
 LIMITS = {"f32 self-join": (8, 95), "f32 one-sided": (8, 95), "f64 self-join": (16, 95), "f64 one-sided": (16, 95)}
 
@@ -143,7 +144,7 @@ def test_round_loop_of_the_stream_form_keeps_its_shape(asm, which):
     meta = asm[asm.index(".name:           " + name):]
     spills = int(re.search(r"\.vgpr_spill_count:\s*(\d+)", meta).group(1))
     vgprs = int(re.search(r"\.vgpr_count:\s*(\d+)", meta).group(1))
-    assert vgprs <= 128, (which, vgprs)
+    assert vgprs <= STREAM_VGPRS[which], (which, vgprs)
     assert spills <= STREAM_LIMITS[which], (which, spills)
     blocks = blocks_of(body)
     rounds = [b for b in blocks if is_stream_round(b)]
@@ -151,11 +152,12 @@ def test_round_loop_of_the_stream_form_keeps_its_shape(asm, which):
     for b in rounds:
         assert not any(x.startswith("scratch_") for x in b["ins"]), (which, b["label"], "scratch access in a round")
         valu = sum(1 for x in b["ins"] if x.startswith("v_"))
-        assert valu <= 70, (which, b["label"], valu)
+        assert valu <= 80, (which, b["label"], valu)
+    # no spill or reload between the first and the last round of the trip (scratch accesses are vector memory
+    # operations the compiler waits for with vmcnt(0): they would drain the rounds in flight)
     i0, i1 = blocks.index(rounds[0]), blocks.index(rounds[-1])
-    flat = [x for b in blocks[max(0, i0 - 12): i1 + 1] for x in b["ins"]]
-    counts = [int(m.group(1)) for x in flat for m in [re.match(r"s_waitcnt vmcnt\((\d+)\)", x)] if m]
-    assert max(counts) >= 3, (which, counts)
+    for b in blocks[i0:i1 + 1]:
+        assert not any(x.startswith("scratch_") for x in b["ins"]), (which, b["label"], "scratch access inside the trip")
 
 
 def _regs_of(text):
