@@ -275,6 +275,11 @@ __global__ void __launch_bounds__(256) pack_super_ends_kernel(const uint32_t *__
     ends8[i] = seg[k * n_tiles + t] << 2;
 }
 
+__global__ void __launch_bounds__(256) null_postings_kernel(uint32_t *__restrict__ slack) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;   // 512 entries: word i of the accumulator tile, bq = fq = 0
+    slack[i] = i << 2;
+}
+
 // ---- position space: a fixed permutation of the right-hand rows (see sg_postings in sg_internal.h)
 // pos_of[j] = j * M mod n with gcd(M, n) = 1, M ~ 0.618 n: neighbours land 0.618 n apart and any run of rows spreads
 // evenly over the positions (a low-discrepancy sequence) -- what a sorted list needs, and harmless on any other.
@@ -463,8 +468,12 @@ extern "C" int sg_postings_build_flags(sg_ctx *ctx, const sg_csr *B_in, int32_t 
         if (st == SG_OK) st = sg_alloc(ctx, 2 * ((size_t)B->n_rows + 2), &p->d_fwd_ptr);   // uint2 per row
         // slack: the pruned multiply loads a lane's four slots of a segment unconditionally (<= 4 * 63 entries past it)
         if (st == SG_OK) st = sg_alloc(ctx, (size_t)B->nnz + 512, &p->d_filt);
-        // the stream form points lanes without a posting at the slack behind the array: all-zero entries add nothing
-        if (st == SG_OK && hipMemsetAsync(p->d_filt + B->nnz, 0, 512 * sizeof(uint32_t), ctx->stream) != hipSuccess) st = SG_ERR_HIP;
+        // the stream form points lanes without a posting at the slack behind the array: entries that add 0 (bq = 0), each to
+        // an accumulator of its own (64 lanes adding to ONE LDS word are serialised: 3 ms at 663 k)
+        if (st == SG_OK) {
+            hipLaunchKernelGGL(null_postings_kernel, dim3(2), dim3(256), 0, ctx->stream, p->d_filt + B->nnz);
+            if (hipGetLastError() != hipSuccess) st = SG_ERR_HIP;
+        }
         p->nt_pad = (int32_t)((n_tiles64 + 3) & ~(int64_t)3);
         if (st == SG_OK) st = sg_alloc(ctx, (size_t)(B->n_cols + 1) * (size_t)p->nt_pad + 4, &p->d_ends);
         // stream form of the pruned multiply (sg_spgemm_pruned.hip): eight tiles share one accumulator tile

@@ -324,7 +324,7 @@ spgemm_topn_pruned_kernel(const int64_t *__restrict__ a_indptr, const int32_t *_
                           uint32_t sym_lo, uint32_t sym_hi /* SYM: the left rows this launch scores (multi-GPU: a rank's range) */,
                           const uint32_t *__restrict__ row_list /* WIDE: the rows to process */, const uint32_t *row_list_len,
                           const uint32_t *__restrict__ ends8 /* stream form: ends of the super-tiles */, int32_t nv_pad,
-                          uint32_t null_off /* stream form: byte offset of sixteen all-zero filter postings */) {
+                          uint32_t null_off /* stream form: byte offset of 256 filter postings that add nothing, four per lane */) {
     constexpr int TILE = 1 << TILE_LOG2;
     constexpr int SLOTS = WIDE ? 2 : 1;   // row terms staged per lane
     constexpr int AB = TILE_LOG2 + 1;                          // address + half bits of a filter posting
@@ -794,12 +794,13 @@ spgemm_topn_pruned_kernel(const int64_t *__restrict__ a_indptr, const int32_t *_
             struct SBatch {
                 u32x4 q;       // the lane's four entries of the round
             };
+            const uint32_t null_at = null_off + ((uint32_t)lane << 4);   // this lane's four postings that add nothing
             // One round's load for every lane.  tv = the visit it belongs to (>= n_visits: past the end), last = the
             // visit ends with this round.
             auto issue_s = [&](SBatch &bt, uint32_t &tv, bool &last) {
                 tv = gv;
                 // Unconditional (see the tile-by-tile form) and WITHOUT validity masks: a lane that is through with its
-                // segment reads the all-zero entries K3 leaves behind the array -- they add 0 to accumulator 0 -- and the
+                // segment reads four entries K3 leaves behind the array for it -- they add 0 to accumulators of their own -- and the
                 // last load of a segment may bring one to three entries of what follows it (the term's next super-tile,
                 // or the next term's list): whatever they are, they add non-negative amounts to accumulators of this
                 // visit, which keeps every accumulator an UPPER bound (a few false positives more; the columns such
@@ -815,7 +816,7 @@ spgemm_topn_pruned_kernel(const int64_t *__restrict__ a_indptr, const int32_t *_
                 // the wait stricter, never too lax (loads return in order).  tests/test_kernel_isa.py checks that nothing
                 // reads a round's registers between its load and its wait.
                 {
-                    const uint32_t at = (int32_t)(hi - cur) > 0 ? cur : null_off;
+                    const uint32_t at = (int32_t)(hi - cur) > 0 ? cur : null_at;
 #if defined(SG_STREAM_PROBE_NO_LOADS)   // timing probes (wrong results): scripts/gpu_session.sh ab:SG_HIP_LIB=...
                     bt.q = u32x4{at & 0x1ffcu, (at * 5u) & 0x1ffcu, (at * 9u) & 0x1ffcu, (at * 13u) & 0x1ffcu};
 #elif defined(SG_STREAM_PLAIN_LOADS)   // (A/B: the compiler's own loads and wait counts)
@@ -1275,7 +1276,7 @@ static int launch_pruned(sg_ctx *ctx, const sg_csr *A, const sg_postings *Bt, in
                        Bt->norm_up, Bt->freq_min, r->d_cols,
                        (T *)r->d_vals,
                        r->d_counts, row_counter, flagged_count, flagged_rows, stats, pl.d_sink, pl.chunks, pl.row_lo, pl.row_hi, row_list,
-                       row_list_len, (const uint32_t *)Bt->d_ends8, Bt->nv_pad, (uint32_t)((Bt->nnz + 64) * 4));
+                       row_list_len, (const uint32_t *)Bt->d_ends8, Bt->nv_pad, (uint32_t)(Bt->nnz * 4));
     SG_HIP_TRY(hipGetLastError());
     return SG_OK;
 }
