@@ -52,10 +52,20 @@ for step in "$@"; do
       short < gpurun_out/${name}_prof.json >> $LOG 2>&1 ;;
     pmc)
       for c in FETCH_SIZE WRITE_SIZE; do
-        ( cd /tmp && export TMPDIR=/tmp && timeout 900 rocprofv3 --pmc $c -d $OLDPWD/gpurun_out/${name}_pmc_$c -o run -- python $OLDPWD/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-exact-kernel --no-end-to-end $arg > /dev/null 2> $OLDPWD/gpurun_out/${name}_pmc_$c.err )
+        ( cd /tmp && export TMPDIR=/tmp && timeout 900 rocprofv3 --pmc $c --output-format csv -d $OLDPWD/gpurun_out/${name}_pmc${n}_$c -o run -- python $OLDPWD/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-exact-kernel --no-end-to-end $arg > /dev/null 2> $OLDPWD/gpurun_out/${name}_pmc${n}_$c.err )
         echo "pmc $c rc=$?" >> $LOG
       done
-      python scripts/pmc_traffic.py gpurun_out/${name}_pmc_FETCH_SIZE gpurun_out/${name}_pmc_WRITE_SIZE gpurun_out/${name}_k4_traffic.json >> $LOG 2>&1 ;;
+      python scripts/pmc_traffic.py gpurun_out/${name}_pmc${n}_FETCH_SIZE gpurun_out/${name}_pmc${n}_WRITE_SIZE gpurun_out/${name}_k4_traffic$n.json >> $LOG 2>&1
+      rm -rf gpurun_out/${name}_pmc${n}_FETCH_SIZE gpurun_out/${name}_pmc${n}_WRITE_SIZE ;;
+    envpmc)   # envpmc:VAR=value  -- the traffic passes with one environment variable set
+      export ${arg}
+      for c in FETCH_SIZE WRITE_SIZE; do
+        ( cd /tmp && export TMPDIR=/tmp && timeout 900 rocprofv3 --pmc $c --output-format csv -d $OLDPWD/gpurun_out/${name}_pmc${n}_$c -o run -- python $OLDPWD/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-exact-kernel --no-end-to-end > /dev/null 2> $OLDPWD/gpurun_out/${name}_pmc${n}_$c.err )
+        echo "pmc $c ($arg) rc=$?" >> $LOG
+      done
+      python scripts/pmc_traffic.py gpurun_out/${name}_pmc${n}_FETCH_SIZE gpurun_out/${name}_pmc${n}_WRITE_SIZE gpurun_out/${name}_k4_traffic$n.json >> $LOG 2>&1
+      rm -rf gpurun_out/${name}_pmc${n}_FETCH_SIZE gpurun_out/${name}_pmc${n}_WRITE_SIZE
+      unset ${arg%%=*} ;;
     pmcsq)
       i=0
       for ctrs in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS" \

@@ -128,6 +128,13 @@ struct SgScoreCtx {
                                          // row at q = entries [fwd_ptr[2 q], fwd_ptr[2 q + 2])
     const void *fwd = nullptr;
     const uint32_t *orig_of = nullptr;   // position -> row; null: identity
+    // Row blocks (round 3): the same rows at a FIXED stride of blk_bytes (a multiple of 128), 128-byte aligned: entry 0 is
+    // a header {the row's own index, its number of entries}, entries 1 .. nnz follow ({term, value}: 8 bytes f32 / 16
+    // bytes f64), zero padding up to the end of the last 128-byte line the row uses (lines behind it are never read).
+    // Scoring a pair then needs no row pointer first, its lines are aligned, and the line behind the first is requested
+    // as soon as the header is there.  null: no blocks (a row would need more than 1 KiB): the packed rows above are used.
+    const void *blk = nullptr;
+    uint32_t blk_bytes = 0;
 };
 
 struct sg_postings {
@@ -149,8 +156,10 @@ struct sg_postings {
     // rows of B packed for the pruned multiply's exact scoring (built only for cosine-like B):
     // f32: {int32 term, float value} (8 B), f64: {int32 term, pad, double value} (16 B); row j = entries
     // [d_fwd_ptr[j], d_fwd_ptr[j+1])
-    void *d_fwd = nullptr;
+    void *d_fwd = nullptr;               // (null when the row blocks below are built: they replace it)
     uint32_t *d_fwd_ptr = nullptr;       // (n_right + 1) x {pointer, the row's own index (position -> row)}
+    void *d_blk = nullptr;               // row blocks at a fixed stride (SgScoreCtx::blk)
+    uint32_t blk_bytes = 0;
     // 4-byte "filter postings", same order as the postings proper (only for cosine-like B):
     //   bits [0, L) column inside the tile (L = tile_log2), [L, 24) bq, [24, 32) fq   with
     //   b <= bq / bq_max * norm_up   and

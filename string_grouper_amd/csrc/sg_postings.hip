@@ -233,7 +233,7 @@ __global__ void __launch_bounds__(256) fwd_pack(const int64_t *__restrict__ indp
     const int64_t base = indptr[0];
     if (i <= n_rows)
         reinterpret_cast<uint2 *>(fwd_ptr)[i] = make_uint2((uint32_t)(indptr[i] - base), i < n_rows ? (orig_of ? orig_of[i] : (uint32_t)i) : 0u);
-    if (i >= nnz) return;
+    if (i >= nnz || fwd == nullptr) return;   // (fwd null: the row blocks carry the rows, only the pointer table is made)
     const int64_t p = base + i;
     if (sizeof(T) == 4) {
         reinterpret_cast<int2 *>(fwd)[i] = make_int2(indices[p], __float_as_int((float)data[p]));
@@ -241,6 +241,51 @@ __global__ void __launch_bounds__(256) fwd_pack(const int64_t *__restrict__ indp
         const long long bits = __double_as_longlong((double)data[p]);
         reinterpret_cast<int4 *>(fwd)[i] = make_int4(indices[p], 0, (int)(bits & 0xffffffffll), (int)(bits >> 32));
     }
+}
+
+// Row blocks for the exact scoring of the pruned multiply (SgScoreCtx::blk): one thread per 16-byte chunk of the
+// 128-byte lines a row uses.
+template <typename T>
+__global__ void __launch_bounds__(256) row_blocks_kernel(const int64_t *__restrict__ indptr, const int32_t *__restrict__ indices,
+                                                         const T *__restrict__ data, int64_t n_rows,
+                                                         const uint32_t *__restrict__ orig_of /* position -> row; null: identity */,
+                                                         uint32_t blk_bytes, void *__restrict__ blk) {
+    constexpr int ES = sizeof(T) == 4 ? 8 : 16;    // bytes of an entry
+    const int64_t chunks = blk_bytes / 16;
+    const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t p = g / chunks;
+    const int32_t c = (int32_t)(g - p * chunks);
+    if (p >= n_rows) return;
+    const int64_t lo = indptr[p];
+    const int32_t nnz = (int32_t)(indptr[p + 1] - lo);
+    const int32_t used = (((nnz + 1) * ES + 127) / 128) * 128;     // bytes of the lines the row uses
+    if (c * 16 >= used) return;
+    uint4 w = make_uint4(0u, 0u, 0u, 0u);
+    if (sizeof(T) == 4) {   // two entries per chunk: 2c, 2c + 1 (entry 0 = header)
+        const int32_t e0 = 2 * c, e1 = 2 * c + 1;
+        if (e0 == 0) {
+            w.x = orig_of ? orig_of[p] : (uint32_t)p;
+            w.y = (uint32_t)nnz;
+        } else if (e0 <= nnz) {
+            w.x = (uint32_t)indices[lo + e0 - 1];
+            w.y = __float_as_uint((float)data[lo + e0 - 1]);
+        }
+        if (e1 <= nnz) {
+            w.z = (uint32_t)indices[lo + e1 - 1];
+            w.w = __float_as_uint((float)data[lo + e1 - 1]);
+        }
+    } else {                // one entry per chunk
+        if (c == 0) {
+            w.x = orig_of ? orig_of[p] : (uint32_t)p;
+            w.y = (uint32_t)nnz;
+        } else if (c <= nnz) {
+            const long long bits = __double_as_longlong((double)data[lo + c - 1]);
+            w.x = (uint32_t)indices[lo + c - 1];
+            w.z = (uint32_t)(bits & 0xffffffffll);
+            w.w = (uint32_t)(bits >> 32);
+        }
+    }
+    reinterpret_cast<uint4 *>(reinterpret_cast<char *>(blk) + (size_t)p * blk_bytes)[c] = w;
 }
 
 // segment ends of every term as byte offsets into the filter postings, rows padded to a multiple of four tiles
@@ -464,7 +509,22 @@ extern "C" int sg_postings_build_flags(sg_ctx *ctx, const sg_csr *B_in, int32_t 
     if (st == SG_OK) st = ctx->alloc(((size_t)B->nnz + 64) * vs, &p->d_vals);
     if (st == SG_OK && want_pruned && sg_pruned_supports_tile(tile_log2) &&
         (B->n_cols + 1) * ((n_tiles64 + 3) & ~(int64_t)3) < ((int64_t)1 << 30)) {
-        st = ctx->alloc(((size_t)B->nnz + 8) * (B->dtype == SG_F64 ? 16 : 8), &p->d_fwd);
+        {
+            // rows at a fixed stride for the exact scoring, when the longest row fits 1 KiB (127 entries f32 / 63 f64)
+            uint32_t max_nnz = 0;
+            bool cl = false;
+            float n2 = 0.f;
+            st = sg_csr_props(ctx, B, &cl, &n2, &max_nnz);
+            const size_t es = B->dtype == SG_F64 ? 16 : 8;
+            const size_t need = (((size_t)max_nnz + 1) * es + 127) / 128 * 128;
+            const bool want_blk = !(getenv("SG_ROW_BLOCKS") && getenv("SG_ROW_BLOCKS")[0] == '0');
+            if (st == SG_OK && want_blk && need <= 1024 && (double)need * (double)B->n_rows < 3.5e9 &&
+                (ctx->total_mem == 0 || need * (size_t)B->n_rows < ctx->total_mem / 8)) {
+                p->blk_bytes = (uint32_t)need;
+                st = ctx->alloc(need * ((size_t)B->n_rows + 1), &p->d_blk);
+            }
+        }
+        if (st == SG_OK && !p->d_blk) st = ctx->alloc(((size_t)B->nnz + 8) * (B->dtype == SG_F64 ? 16 : 8), &p->d_fwd);
         if (st == SG_OK) st = sg_alloc(ctx, 2 * ((size_t)B->n_rows + 2), &p->d_fwd_ptr);   // uint2 per row
         // slack: the pruned multiply loads a lane's four slots of a segment unconditionally (<= 4 * 63 entries past it)
         if (st == SG_OK) st = sg_alloc(ctx, (size_t)B->nnz + 512, &p->d_filt);
@@ -599,13 +659,24 @@ extern "C" int sg_postings_build_flags(sg_ctx *ctx, const sg_csr *B_in, int32_t 
                                (const uint32_t *)p->d_seg, B->n_cols, p->n_tiles, p->fold_log2, p->nv_pad, p->d_ends8);
             if (hipGetLastError() != hipSuccess) st = SG_ERR_HIP;
         }
-        if (st == SG_OK && p->d_fwd) {
+        if (st == SG_OK && p->d_fwd) {   // (packed rows in use: no row blocks)
             // the exact scoring reads packed rows in rounds of eight entries and multiplies the slots past a row's end by
             // a = 0: the pad behind the LAST row must hold finite values (0 * NaN would poison that row's score)
             const size_t es = B->dtype == SG_F64 ? 16 : 8;
             if (hipMemsetAsync((char *)p->d_fwd + (size_t)B->nnz * es, 0, 8 * es, ctx->stream) != hipSuccess) st = SG_ERR_HIP;
         }
-        if (st == SG_OK && p->d_fwd) {
+        if (st == SG_OK && p->d_blk && B->n_rows > 0) {
+            const int64_t work = B->n_rows * (int64_t)(p->blk_bytes / 16);
+            const unsigned g3 = (unsigned)((work + 255) / 256);
+            if (B->dtype == SG_F64)
+                hipLaunchKernelGGL(row_blocks_kernel<double>, dim3(g3), dim3(256), 0, ctx->stream, B->d_indptr, B->d_indices,
+                                   (const double *)B->d_data, B->n_rows, (const uint32_t *)p->d_orig_of, p->blk_bytes, p->d_blk);
+            else
+                hipLaunchKernelGGL(row_blocks_kernel<float>, dim3(g3), dim3(256), 0, ctx->stream, B->d_indptr, B->d_indices,
+                                   (const float *)B->d_data, B->n_rows, (const uint32_t *)p->d_orig_of, p->blk_bytes, p->d_blk);
+            if (hipGetLastError() != hipSuccess) st = SG_ERR_HIP;
+        }
+        if (st == SG_OK && p->d_fwd_ptr) {
             const int64_t work = B->nnz > B->n_rows + 1 ? B->nnz : B->n_rows + 1;
             const unsigned g2 = (unsigned)((work + 255) / 256);
             if (B->dtype == SG_F64)
@@ -617,12 +688,14 @@ extern "C" int sg_postings_build_flags(sg_ctx *ctx, const sg_csr *B_in, int32_t 
             if (hipGetLastError() != hipSuccess) st = SG_ERR_HIP;
         }
     }
-    if (st == SG_OK && p->d_fwd) {
+    if (st == SG_OK && p->d_fwd_ptr) {
         st = ctx->alloc(256, (void **)&p->d_score_ctx);
         if (st == SG_OK) {
             SgScoreCtx sc;
             sc.fwd_ptr = p->d_fwd_ptr;
             sc.fwd = p->d_fwd;
+            sc.blk = p->d_blk;
+            sc.blk_bytes = p->blk_bytes;
             sc.orig_of = p->d_orig_of;
             hipLaunchKernelGGL(score_ctx_kernel, dim3(1), dim3(1), 0, ctx->stream, sc, p->d_score_ctx);
             if (hipGetLastError() != hipSuccess) st = SG_ERR_HIP;
@@ -643,6 +716,7 @@ extern "C" int sg_postings_free(sg_postings *p) {
     p->ctx->release(p->d_rows);
     p->ctx->release(p->d_vals);
     p->ctx->release(p->d_fwd);
+    p->ctx->release(p->d_blk);
     p->ctx->release(p->d_fwd_ptr);
     p->ctx->release(p->d_filt);
     p->ctx->release(p->d_ends);

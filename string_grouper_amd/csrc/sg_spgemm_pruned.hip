@@ -174,6 +174,65 @@ __device__ __forceinline__ T exact_score(int j, const int *hk, const T *ha, int 
     return sum;
 }
 
+// The same score from the ROW BLOCKS (SgScoreCtx::blk): rows at a fixed stride, 128-byte aligned, header first.  No row
+// pointer to fetch before the row itself, every 128-byte line of a row is one aligned request, and the line behind the one
+// being worked off is touched (one dword) as soon as the header says the row reaches it, so that its 64-byte units arrive
+// from the cache.  The packed rows cost a dependent miss per step -- pointer, eight entries, the next eight ... -- four to
+// six memory latencies per wave of survivors, during which the wave does nothing else.  Deliberately small: ONE buffer of
+// four 16-byte registers -- this routine is called from inside the round loop, and every register it uses is one the
+// loop cannot keep a value in across its call sites (two line buffers made the loop spill: 120 registers here).
+// Same arithmetic: ascending entries, product and sum rounded separately, a = 0 for terms row i does not have.
+template <typename T, bool WIDE>
+__device__ __forceinline__ T exact_score_blocks(int j, const int *hk, const T *ha, int nnz, const SgScoreCtx *__restrict__ sc,
+                                                int &row_of_j) {
+    constexpr int ES = sizeof(T) == 4 ? 8 : 16;
+    constexpr int EPU = 64 / ES;   // entries of a 64-byte unit (four 16-byte loads): 8 / 4; two units per 128-byte line
+    T sum = (T)0;
+    row_of_j = j;
+    const bool have = j >= 0;
+    const uint4 *base = reinterpret_cast<const uint4 *>(reinterpret_cast<const char *>(sc->blk) +
+                                                        (size_t)(have ? j : 0) * (size_t)sc->blk_bytes);
+    uint4 U[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) U[e] = make_uint4(0u, 0u, 0u, 0u);
+    if (have) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) U[e] = base[e];
+    }
+    const int nnz_j = have ? (int)U[0].y : -1;    // header: {the row's own index, its entries}; entries 1 .. nnz_j follow
+    if (have) row_of_j = (int)U[0].x;
+    uint32_t touched = 0;
+    auto use = [&](int idx, uint32_t term, T val) {
+        const bool valid = idx >= 1 && idx <= nnz_j;
+        T a = (T)0;
+        if (valid) a = row_value<T, WIDE>(hk, ha, (int)term, nnz);
+        sum = add_rn<T>(sum, mul_rn<T>(a, valid ? val : (T)0));   // (a unit that was not loaded holds the previous one)
+    };
+    SG_WD_DECL(wd_b);
+    for (int u = 0;; ++u) {
+        SG_WD(wd_b, 64, 24)
+        if ((u & 1) == 0 && have && (u + 2) * EPU <= nnz_j)   // first unit of a line: touch the next line
+            touched |= reinterpret_cast<const uint32_t *>(base)[(u + 2) * 16];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            if (sizeof(T) == 4) {
+                use(u * EPU + 2 * e, U[e].x, (T)__uint_as_float(U[e].y));
+                use(u * EPU + 2 * e + 1, U[e].z, (T)__uint_as_float(U[e].w));
+            } else {
+                use(u * EPU + e, U[e].x, (T)__longlong_as_double((long long)(((unsigned long long)U[e].w << 32) | U[e].z)));
+            }
+        }
+        const bool more = have && (u + 1) * EPU <= nnz_j;   // the row reaches unit u + 1
+        if (__ballot(more) == 0) break;
+        if (more) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) U[e] = base[(u + 1) * 4 + e];
+        }
+    }
+    asm volatile("" ::"v"(touched));
+    return sum;
+}
+
 // Scores the columns in surv[0 .. min(n_surv, 64)) and moves the rest of the buffer to the front.  Deliberately
 // not inlined: the tile loop has sixteen unrolled rounds and must not carry sixteen copies of this.
 // (LDS objects are addressed through the kernel's own shared array so that they stay ds_* accesses.)
@@ -191,7 +250,8 @@ __device__ __noinline__ TopList<T> drain_survivors(int nnz, T thr, uint32_t row,
     const int j = (uint32_t)lane < n_surv ? surv[lane] : -1;   // a POSITION: the index is built over a permutation of B's rows
     // what leaves the kernel is the row itself: the top list orders equal scores by the ORIGINAL column, the pairs name rows
     int jo;
-    const T sum = exact_score<T, WIDE>(j, hk, ha, nnz, sc->fwd_ptr, sc->fwd, jo);
+    const T sum = sc->blk ? exact_score_blocks<T, WIDE>(j, hk, ha, nnz, sc, jo)
+                          : exact_score<T, WIDE>(j, hk, ha, nnz, sc->fwd_ptr, sc->fwd, jo);
     uint64_t hm = __ballot(j >= 0 && sum > thr);
     if (SYM) {
         // row i keeps its own matches j <= i in its top list like the one-sided form; what row j < i has to learn -- that
@@ -324,7 +384,8 @@ spgemm_topn_pruned_kernel(const int64_t *__restrict__ a_indptr, const int32_t *_
                           uint32_t sym_lo, uint32_t sym_hi /* SYM: the left rows this launch scores (multi-GPU: a rank's range) */,
                           const uint32_t *__restrict__ row_list /* WIDE: the rows to process */, const uint32_t *row_list_len,
                           const uint32_t *__restrict__ ends8 /* stream form: ends of the super-tiles */, int32_t nv_pad,
-                          uint32_t null_off /* stream form: byte offset of 256 filter postings that add nothing, four per lane */) {
+                          uint32_t null_off /* stream form: byte offset of 256 filter postings that add nothing, four per lane */,
+                          uint32_t n_right /* right-hand rows (columns of the result) */) {
     constexpr int TILE = 1 << TILE_LOG2;
     constexpr int SLOTS = WIDE ? 2 : 1;   // row terms staged per lane
     constexpr int AB = TILE_LOG2 + 1;                          // address + half bits of a filter posting
@@ -859,10 +920,10 @@ spgemm_topn_pruned_kernel(const int64_t *__restrict__ a_indptr, const int32_t *_
             auto collect_s = [&](uint64_t cm, uint32_t r, uint32_t tv) {
                 bool cross = (cm >> lane) & 1ull;
                 const uint32_t col = (tv << (TILE_LOG2 + FOLD_LOG2)) | ((r >> 1) & COL_MASK) | (r & 1u);
-                if (SYM) {
-                    cross = cross && col <= row;   // the pair (i, j > i) is row j's to score
-                    cm = ballot64(cross);
-                }
+                // SYM: the pair (i, j > i) is row j's to score.  One-sided: entries read past the end of a segment (see
+                // issue_s) may name columns of the last super-tile that do not exist.
+                cross = cross && (SYM ? col <= row : col < n_right);
+                cm = ballot64(cross);
                 const uint32_t n_new = (uint32_t)__popcll(cm);
                 if (n_surv + n_new > (uint32_t)SG_SURV_CAP - 1u) flush_s();   // (leaves fewer than 64)
                 if (cross) surv[n_surv + __popcll(cm & lanes_below)] = (int)col;
@@ -1276,7 +1337,7 @@ static int launch_pruned(sg_ctx *ctx, const sg_csr *A, const sg_postings *Bt, in
                        Bt->norm_up, Bt->freq_min, r->d_cols,
                        (T *)r->d_vals,
                        r->d_counts, row_counter, flagged_count, flagged_rows, stats, pl.d_sink, pl.chunks, pl.row_lo, pl.row_hi, row_list,
-                       row_list_len, (const uint32_t *)Bt->d_ends8, Bt->nv_pad, (uint32_t)(Bt->nnz * 4));
+                       row_list_len, (const uint32_t *)Bt->d_ends8, Bt->nv_pad, (uint32_t)(Bt->nnz * 4), (uint32_t)Bt->n_right);
     SG_HIP_TRY(hipGetLastError());
     return SG_OK;
 }

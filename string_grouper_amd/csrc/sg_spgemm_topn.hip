@@ -726,7 +726,10 @@ static bool pruned_applicable(sg_ctx *ctx, const sg_csr *A, const sg_postings *B
         !sg_pruned_supports_tile(Bt->tile_log2) ||
         !(threshold >= env_double("SG_PRUNE_MIN_THRESHOLD", 0.45)))   // below ~0.4 the filter passes too much (profiles/r01_prune_tuning.log)
         return false;
-    *delta = env_double("SG_PRUNE_DELTA", 0.05);   // tuned at 663 k: profiles/r01_prune_tuning.log
+    // tuned at 663 k: the tile-by-tile form 0.05 (profiles/r01_prune_tuning.log); the stream form, whose rounds are cheaper
+    // next to the exact scorings, 0.03 (profiles/r03_sessionG_H_delta.log: 9.76 / 9.95 / 10.10 / 14.3 ms at 0.03 / 0.04 /
+    // 0.05 / 0.08)
+    *delta = env_double("SG_PRUNE_DELTA", Bt->fold_log2 > 0 ? 0.03 : 0.05);
     if (*delta > 0.5 * threshold) *delta = 0.5 * threshold;
     if (*delta < 0.02) *delta = 0.02;
     bool a_ok = false;
