@@ -76,10 +76,50 @@ def main():
     args = parse_args()
     if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
         respawn_under_torchrun(args)
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        # N > 1 hardening: what a rank writes to stderr is also kept per rank (the launcher interleaves the ranks'
+        # streams), a hung collective ends with an exception after three minutes instead of hanging the job, and rank 0
+        # prints ONE JSON line whatever happens -- with "error" instead of a value when a rank has died.
+        import faulthandler
+        log_dir = os.environ.get("SG_BENCH_LOG_DIR", "/tmp")
+        try:
+            rank_log = open(os.path.join(log_dir, f"sg_bench_rank{rank}.log"), "w")
+            faulthandler.enable(rank_log)
+            faulthandler.dump_traceback_later(900, file=rank_log)      # where a rank sits if the job takes this long
+        except OSError:
+            rank_log = None
+        try:
+            run(args)
+        except BaseException as e:  # noqa: BLE001 -- reported, then re-raised
+            import traceback
+            if rank_log is not None:
+                traceback.print_exc(file=rank_log)
+                rank_log.flush()
+            if rank == 0 and not isinstance(e, SystemExit):
+                sys.stdout.flush()
+                os.write(_JSON_FD[0] if _JSON_FD else 1, (json.dumps({
+                    "metric": "match_strings rows/sec (hot path: tokenise + tf-idf + postings + SpGEMM-topn), "
+                              "663k-name self-join ntop=10 min_sim=0.8",
+                    "value": None, "unit": "rows/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                    "higher_is_better": True, "scaling": "strong", "dtype": args.dtype,
+                    "error": f"{type(e).__name__}: {e}"[:500],
+                    "rank_logs": os.path.join(log_dir, "sg_bench_rank<r>.log")}) + "\n").encode())
+            raise
+        return
+    run(args)
+
+
+_JSON_FD = []      # the descriptor the one JSON line goes to (stdout as it was when the process started)
+
+
+def run(args):
     # RCCL prints a version banner to stdout when the first communicator is created; the contract is ONE
     # JSON line on stdout, so everything else this process (and its libraries) writes goes to stderr
     sys.stdout.flush()
     json_fd = os.dup(1)
+    _JSON_FD.append(json_fd)
     os.dup2(2, 1)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -93,7 +133,9 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        import datetime
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank),
+                                timeout=datetime.timedelta(seconds=int(os.environ.get("SG_BENCH_COLLECTIVE_TIMEOUT", "180"))))
     from string_grouper_amd import _native as N
     from string_grouper_amd.synth import synth_names
     from string_grouper_amd.vectorizer import HipTfidfVectorizer

@@ -171,6 +171,10 @@ int sg_topn_counts_to_host(sg_ctx *ctx, const sg_topn *r, int32_t *counts);   /*
 /* Upload a fixed-stride result held on the host (used to feed host CSR blocks to sg_topn_zip). */
 int sg_topn_from_host(sg_ctx *ctx, int64_t n_rows, int64_t n_cols, int32_t stride, int32_t dtype,
                       const int32_t *cols, const void *vals, const int32_t *counts, sg_topn **out);
+/* The same from DEVICE memory (a device-to-device copy on the context's stream): the multi-GPU path hands its all-gathered
+ * blocks over without a trip through the host (string_grouper.py:750 vstack, on the device). */
+int sg_topn_from_device(sg_ctx *ctx, int64_t n_rows, int64_t n_cols, int32_t stride, int32_t dtype,
+                        const int32_t *d_cols, const void *d_vals, const int32_t *d_counts, sg_topn **out);
 /* zip_sp_matmul_topn: parts[b] = A . B_b^T; columns of part b are offset by col_offsets[b]. */
 int sg_topn_zip(sg_ctx *ctx, const sg_topn *const *parts, const int64_t *col_offsets, int32_t n_parts,
                 int32_t top_n, sg_topn **out);

@@ -79,6 +79,7 @@ ABI = {
     "sg_topn_to_host": (C.c_int, [_P, _P, _P, _P, _P]),
     "sg_topn_counts_to_host": (C.c_int, [_P, _P, _P]),
     "sg_topn_from_host": (C.c_int, [_P, C.c_int64, C.c_int64, C.c_int32, C.c_int32, _P, _P, _P, _PP]),
+    "sg_topn_from_device": (C.c_int, [_P, C.c_int64, C.c_int64, C.c_int32, C.c_int32, _P, _P, _P, _PP]),
     "sg_topn_zip": (C.c_int, [_P, _PP, _P, C.c_int32, C.c_int32, _PP]),
     "sg_topn_free": (C.c_int, [_P]),
     "sg_sp_matmul_topn_host": (C.c_int, [_P, C.c_int64, C.c_int64, C.c_int64, _P, _P, _P, _P, _P, _P, C.c_int32,
@@ -509,6 +510,14 @@ class Context:
         out = C.c_void_p()
         check(lib().sg_topn_from_host(self.h, n_rows, n_cols, stride, np_dtype_code(vals.dtype), _ptr(cols),
                                       _ptr(vals), _ptr(counts), C.byref(out)))
+        return TopN(self, out)
+
+    def topn_from_device(self, n_rows: int, stride: int, n_cols: int, dtype, d_cols: int, d_vals: int, d_counts: int) -> TopN:
+        """A fixed-stride result from device pointers (copied on the context's stream; the caller keeps its buffers
+        alive until the stream has passed the copy, e.g. ``ctx.sync()``)."""
+        out = C.c_void_p()
+        check(lib().sg_topn_from_device(self.h, int(n_rows), int(n_cols), int(stride), np_dtype_code(np.dtype(dtype)),
+                                        C.c_void_p(d_cols), C.c_void_p(d_vals), C.c_void_p(d_counts), C.byref(out)))
         return TopN(self, out)
 
     def topn_zip(self, parts, col_offsets, top_n: int) -> TopN:

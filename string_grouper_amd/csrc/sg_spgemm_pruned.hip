@@ -177,27 +177,29 @@ __device__ __forceinline__ T exact_score(int j, const int *hk, const T *ha, int 
 // The same score from the ROW BLOCKS (SgScoreCtx::blk): rows at a fixed stride, 128-byte aligned, header first.  No row
 // pointer to fetch before the row itself, every 128-byte line of a row is one aligned request, and the line behind the one
 // being worked off is touched (one dword) as soon as the header says the row reaches it, so that its 64-byte units arrive
-// from the cache.  The packed rows cost a dependent miss per step -- pointer, eight entries, the next eight ... -- four to
-// six memory latencies per wave of survivors, during which the wave does nothing else.  Deliberately small: ONE buffer of
-// four 16-byte registers -- this routine is called from inside the round loop, and every register it uses is one the
-// loop cannot keep a value in across its call sites (two line buffers made the loop spill: 120 registers here).
+// from the cache.  The packed rows cost a dependent miss per step -- pointer, eight entries, the next eight ... -- and are
+// gathered in unaligned pieces: 57.9 GB of memory-side traffic per launch at 663 k against 45.2 GB with the blocks
+// (profiles/r03_sessionJ_traffic.log).  Deliberately small: ONE buffer of two 16-byte registers (32 bytes, a quarter of a
+// line) -- this routine is called from inside the round loop, and every register it uses is one the loop cannot keep a
+// value in across its call sites: with four registers per unit it needed 67 and the loop's kernel lost 0.3 ms to spills,
+// with two line buffers 120 (the loop itself spilled).
 // Same arithmetic: ascending entries, product and sum rounded separately, a = 0 for terms row i does not have.
 template <typename T, bool WIDE>
 __device__ __forceinline__ T exact_score_blocks(int j, const int *hk, const T *ha, int nnz, const SgScoreCtx *__restrict__ sc,
                                                 int &row_of_j) {
     constexpr int ES = sizeof(T) == 4 ? 8 : 16;
-    constexpr int EPU = 64 / ES;   // entries of a 64-byte unit (four 16-byte loads): 8 / 4; two units per 128-byte line
+    constexpr int EPU = 32 / ES;   // entries of a 32-byte unit (two 16-byte loads): 4 / 2; four units per 128-byte line
     T sum = (T)0;
     row_of_j = j;
     const bool have = j >= 0;
     const uint4 *base = reinterpret_cast<const uint4 *>(reinterpret_cast<const char *>(sc->blk) +
                                                         (size_t)(have ? j : 0) * (size_t)sc->blk_bytes);
-    uint4 U[4];
+    uint4 U[2];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) U[e] = make_uint4(0u, 0u, 0u, 0u);
+    for (int e = 0; e < 2; ++e) U[e] = make_uint4(0u, 0u, 0u, 0u);
     if (have) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) U[e] = base[e];
+        for (int e = 0; e < 2; ++e) U[e] = base[e];
     }
     const int nnz_j = have ? (int)U[0].y : -1;    // header: {the row's own index, its entries}; entries 1 .. nnz_j follow
     if (have) row_of_j = (int)U[0].x;
@@ -211,10 +213,10 @@ __device__ __forceinline__ T exact_score_blocks(int j, const int *hk, const T *h
     SG_WD_DECL(wd_b);
     for (int u = 0;; ++u) {
         SG_WD(wd_b, 64, 24)
-        if ((u & 1) == 0 && have && (u + 2) * EPU <= nnz_j)   // first unit of a line: touch the next line
-            touched |= reinterpret_cast<const uint32_t *>(base)[(u + 2) * 16];
+        if ((u & 3) == 0 && have && (u + 4) * EPU <= nnz_j)   // first unit of a line: touch the next line
+            touched |= reinterpret_cast<const uint32_t *>(base)[(u + 4) * 8];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
+        for (int e = 0; e < 2; ++e) {
             if (sizeof(T) == 4) {
                 use(u * EPU + 2 * e, U[e].x, (T)__uint_as_float(U[e].y));
                 use(u * EPU + 2 * e + 1, U[e].z, (T)__uint_as_float(U[e].w));
@@ -226,7 +228,7 @@ __device__ __forceinline__ T exact_score_blocks(int j, const int *hk, const T *h
         if (__ballot(more) == 0) break;
         if (more) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) U[e] = base[(u + 1) * 4 + e];
+            for (int e = 0; e < 2; ++e) U[e] = base[(u + 1) * 2 + e];
         }
     }
     asm volatile("" ::"v"(touched));

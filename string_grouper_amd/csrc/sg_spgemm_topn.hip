@@ -729,7 +729,10 @@ static bool pruned_applicable(sg_ctx *ctx, const sg_csr *A, const sg_postings *B
     // tuned at 663 k: the tile-by-tile form 0.05 (profiles/r01_prune_tuning.log); the stream form, whose rounds are cheaper
     // next to the exact scorings, 0.03 (profiles/r03_sessionG_H_delta.log: 9.76 / 9.95 / 10.10 / 14.3 ms at 0.03 / 0.04 /
     // 0.05 / 0.08)
-    *delta = env_double("SG_PRUNE_DELTA", Bt->fold_log2 > 0 ? 0.03 : 0.05);
+    // (0.03 only where rows are sparse next to the vocabulary -- name data; on small vocabularies, the regime of the
+    //  pruned-or-exact pilot below, a tighter bound passes too many candidates: 0.05 as before)
+    const bool sparse_rows = A->n_rows > 0 && (double)A->nnz / (double)A->n_rows <= 0.004 * (double)Bt->n_terms;
+    *delta = env_double("SG_PRUNE_DELTA", Bt->fold_log2 > 0 && sparse_rows ? 0.03 : 0.05);
     if (*delta > 0.5 * threshold) *delta = 0.5 * threshold;
     if (*delta < 0.02) *delta = 0.02;
     bool a_ok = false;
@@ -1061,6 +1064,29 @@ extern "C" int sg_topn_from_host(sg_ctx *ctx, int64_t n_rows, int64_t n_cols, in
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     if (e != hipSuccess) {
         sg_set_error("sg_topn_from_host: %s", hipGetErrorString(e));
+        sg_topn_free(r);
+        return SG_ERR_HIP;
+    }
+    *out = r;
+    return SG_OK;
+}
+
+extern "C" int sg_topn_from_device(sg_ctx *ctx, int64_t n_rows, int64_t n_cols, int32_t stride, int32_t dtype,
+                                   const int32_t *d_cols, const void *d_vals, const int32_t *d_counts, sg_topn **out) {
+    SG_REQUIRE(ctx && d_counts && out && n_rows >= 0 && stride >= 1, "bad argument");
+    SG_REQUIRE(dtype == SG_F32 || dtype == SG_F64, "dtype must be SG_F32 or SG_F64");
+    sg_topn *r = nullptr;
+    SG_TRY(topn_alloc(ctx, n_rows, n_cols, stride, dtype, &r));
+    const size_t cells = (size_t)n_rows * (size_t)stride;
+    const size_t s = dtype == SG_F64 ? 8 : 4;
+    hipError_t e = hipSuccess;
+    if (cells > 0) {
+        e = hipMemcpyAsync(r->d_cols, d_cols, cells * 4, hipMemcpyDeviceToDevice, ctx->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(r->d_vals, d_vals, cells * s, hipMemcpyDeviceToDevice, ctx->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(r->d_counts, d_counts, (size_t)n_rows * 4, hipMemcpyDeviceToDevice, ctx->stream);
+    }
+    if (e != hipSuccess) {
+        sg_set_error("sg_topn_from_device: %s", hipGetErrorString(e));
         sg_topn_free(r);
         return SG_ERR_HIP;
     }

@@ -243,10 +243,11 @@ def sharded_selfjoin_topn(ops, A_full, post, top_n: int, threshold: float, group
     return ops.selfjoin_merge(part, pairs_all, lo, hi)
 
 
-def gather_topn(ops, res, group=None):
-    """Step 5 for the public API: every rank's fixed-stride block, all-gathered and concatenated in row order
-    on the HOST (the reference's vstack, string_grouper.py:750).  Returns (cols [n, stride], vals [n, stride],
-    counts [n]) as numpy arrays, identical on every rank."""
+def gather_topn(ops, res, group=None, on_device: bool = False):
+    """Step 5 for the public API: every rank's fixed-stride block, all-gathered and concatenated in row order (the
+    reference's vstack, string_grouper.py:750).  Returns (cols [n, stride], vals [n, stride], counts [n]), identical on
+    every rank: numpy arrays on the HOST, or -- ``on_device`` -- the torch tensors in HBM as they come out of the
+    all-gather (the fused tail of fit(), K6-K8, runs on the device: no reason to cross PCIe twice)."""
     cols, vals, counts = ops.topn_tensors(res)
     stride = cols.shape[1] if cols.dim() == 2 else 1
     if dist.get_world_size(group) > 1:
@@ -267,6 +268,8 @@ def gather_topn(ops, res, group=None):
         cols = torch.empty_like(cols).index_copy_(0, orig_of, cols)
         vals = torch.empty_like(vals).index_copy_(0, orig_of, vals)
         counts = torch.empty_like(counts).index_copy_(0, orig_of, counts)
+    if on_device:
+        return cols.contiguous(), vals.contiguous(), counts.contiguous()
     return cols.cpu().numpy(), vals.cpu().numpy(), counts.cpu().numpy()
 
 
@@ -449,6 +452,15 @@ class HipOps:
                 n = part["res"].dims()[0]
                 orig_of = torch.as_tensor(DeviceTensorView(p_orig, n, "<i4"), device=self.device)[:n].to(torch.int64)
         return TopNRows(part["res"], lo, hi, orig_of)
+
+    def topn_from_tensors(self, cols, vals, counts, n_cols: int):
+        """The gathered result as a library object, without leaving HBM."""
+        self._sync()                                  # the tensors are torch's: written before the library copies them
+        r = self.ctx.topn_from_device(cols.shape[0], cols.shape[1] if cols.dim() == 2 else 1, n_cols,
+                                      np.float64 if vals.dtype == torch.float64 else np.float32,
+                                      cols.data_ptr(), vals.data_ptr(), counts.data_ptr())
+        self.ctx.sync()                               # ... and copied before torch may free them
+        return r
 
     def topn_tensors(self, res):
         import ctypes as C

@@ -319,9 +319,9 @@ class DistributedHipEngine(HipEngine):
             # rows against row blocks of it, merged on the device (K5), as on one GPU and as fit() expects of the engine
             # (string_grouper.py:397-413)
             res_local = HipEngine._topn_device(self, DeviceMatrix(A.csr), DeviceMatrix(right), top_n, threshold)
-        cols, vals, counts = D.gather_topn(A._ops, res_local, self.group)
+        cols, vals, counts = D.gather_topn(A._ops, res_local, self.group, on_device=True)
         res_local.free()
-        return self.ctx.topn_from_host(cols, vals, counts, B.shape[0])
+        return A._ops.topn_from_tensors(cols, vals, counts, B.shape[0])
 
     def rowwise_dot(self, A, B) -> np.ndarray:
         """Row-wise similarity: local rows on the device (K9), the ranks' pieces concatenated."""
