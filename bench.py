@@ -293,7 +293,7 @@ def run(args):
     if world == 1 and pruned and not args.no_exact_kernel:
         # the exact kernel (K4) on the same input, timed live beside the pruned one: it is what runs when the
         # data is not cosine-like or top_n > 64, and the pruned result must equal it bit for bit
-        os.environ["SG_PRUNE"] = "0"
+        ctx.set_option("SG_PRUNE", "0")          # (an option of this context, set explicitly -- the environment is not touched)
         vec = make_vec()
         vec.fit_prepared([prepared])
         A = vec.transform_prepared(prepared)
@@ -306,7 +306,7 @@ def run(args):
             ex_ms.append(st_ex["ms_spgemm_topn"])
             if len(ex_ms) < 2:
                 r_ex.free()
-        os.environ.pop("SG_PRUNE")
+        ctx.set_option("SG_PRUNE", None)
         r_pr = step()
         h_ex, h_pr = r_ex.to_host(), r_pr.to_host()
         mask = np.arange(h_ex[0].shape[1])[None, :] < h_ex[2][:, None]

@@ -66,6 +66,14 @@ int sg_ctx_destroy(sg_ctx *ctx);
 int sg_ctx_sync(sg_ctx *ctx);
 /* Release cached scratch back to the driver. */
 int sg_ctx_trim(sg_ctx *ctx);
+/* Tuning switches (SG_PRUNE, SG_SYM, SG_PRUNE_DELTA ... -- README, "tuning knobs").  The library reads the SG_* variables
+ * of the environment ONCE, in sg_ctx_create; afterwards only these calls change them (value NULL: unset), and nothing
+ * inside an API call looks at the environment.  sg_ctx_options writes the active set as NAME=VALUE lines into buf and
+ * returns the bytes needed (0-terminated); sg_ctx_reset_options re-reads the environment (test hook).  Not to be
+ * called while another thread has a call in flight on the same context. */
+int sg_ctx_set_option(sg_ctx *ctx, const char *name, const char *value);
+int sg_ctx_reset_options(sg_ctx *ctx);
+int sg_ctx_options(sg_ctx *ctx, char *buf, int64_t len);
 
 /* ------------------------------------------------------------------ strings (input of seam b1) */
 /* Arrow large_string layout: string i = bytes[offsets[i] .. offsets[i+1]). */

@@ -110,7 +110,8 @@ def main():
             pair_counts.append(n_pairs)
             per_rank.append({"rank": r, "rows": hi - lo, "range": [plo, phi], "vectorise_ms_wall": t_vec,
                              "vectorise_ms_kernels": k_vec.get("tokenize", 0) + k_vec.get("vocab", 0) + k_vec.get("weight", 0),
-                             "pass1_ms_wall": t_p1, "pass1_ms_kernel": k_p1.get("spgemm_topn", 0.0), "pairs": int(n_pairs),
+                             "pass1_ms_wall": t_p1, "pass1_ms_kernel": k_p1.get("spgemm_topn", 0.0),
+                             "pass1_ms_kernel_alone": k_p1.get("spgemm_kernel", 0.0), "pairs": int(n_pairs),
                              "_res": res, "_ptr": ptr, "_words": words})
         # the merge needs ALL ranks' pairs: concatenate them on the device (what the all-gather delivers)
         import torch
@@ -153,7 +154,8 @@ def main():
         print(f"N={world}: critical path {crit:7.3f} ms (kernels only {crit_kernels:7.3f})  = vectorise "
               f"{max(p['vectorise_ms_wall'] for p in per_rank):.3f} + index {t_post:.3f} + slowest range {slow['pass1_ms_wall']:.3f} "
               f"+ merge {max(p['merge_ms_wall'] for p in per_rank):.3f} + collectives (model) {coll_ms:.3f}   "
-              f"speed-up {one_gpu / crit:.2f}x;  ranges' pass 1: {[round(p['pass1_ms_wall'], 2) for p in per_rank]}")
+              f"speed-up {one_gpu / crit:.2f}x;  ranges' pass 1: {[round(p['pass1_ms_wall'], 2) for p in per_rank]}"
+              f" (kernel alone: {[round(p['pass1_ms_kernel_alone'], 2) for p in per_rank]})")
     print("JSON " + json.dumps(report))
 
 

@@ -42,6 +42,9 @@ ABI = {
     "sg_abi_version": (C.c_int, []),
     "sg_device_count": (C.c_int, [C.POINTER(C.c_int)]),
     "sg_ctx_create": (C.c_int, [C.c_int, _P, _PP]),
+    "sg_ctx_set_option": (C.c_int, [_P, C.c_char_p, C.c_char_p]),
+    "sg_ctx_reset_options": (C.c_int, [_P]),
+    "sg_ctx_options": (C.c_int, [_P, C.c_char_p, C.c_int64]),
     "sg_ctx_destroy": (C.c_int, [_P]),
     "sg_ctx_sync": (C.c_int, [_P]),
     "sg_ctx_trim": (C.c_int, [_P]),
@@ -320,6 +323,21 @@ class Context:
 
     def trim(self):
         check(lib().sg_ctx_trim(self.h))
+
+    # ---- tuning switches: read from the environment once, when the context is created (include/sg_hip.h)
+    def set_option(self, name: str, value=None) -> None:
+        """Set (or, with None, unset) one SG_* switch of THIS context."""
+        check(lib().sg_ctx_set_option(self.h, name.encode(), None if value is None else str(value).encode()))
+
+    def reset_options(self) -> None:
+        """Re-read the SG_* variables of the environment (tests)."""
+        check(lib().sg_ctx_reset_options(self.h))
+
+    def options(self) -> dict:
+        n = lib().sg_ctx_options(self.h, None, 0)
+        buf = C.create_string_buffer(max(int(n), 1))
+        lib().sg_ctx_options(self.h, buf, len(buf))
+        return dict(line.split("=", 1) for line in buf.value.decode().splitlines() if "=" in line)
 
     def stats(self) -> dict:
         st = SgStats()

@@ -34,9 +34,17 @@ extern "C" int sg_device_count(int *count) {
 // SG_POISON_ALLOC=1 (test hook): every block handed out is filled with 0xFF bytes (NaN as a float, -1 as an index)
 // first, so that a kernel reading memory it never wrote shows up as a wrong result instead of depending on what
 // the pool happened to hold (tests/test_parity_gpu.py::test_results_do_not_depend_on_uninitialised_memory).
-static bool poison_allocations() {
-    const char *v = getenv("SG_POISON_ALLOC");
-    return v && v[0] == '1';
+extern char **environ;
+static void snapshot_options(sg_ctx *ctx) {
+    ctx->opts.clear();
+    for (char **e = environ; e && *e; ++e) {
+        if (strncmp(*e, "SG_", 3) != 0) continue;
+        const char *eq = strchr(*e, '=');
+        if (!eq) continue;
+        ctx->opts[std::string(*e, (size_t)(eq - *e))] = std::string(eq + 1);
+    }
+    const char *v = ctx->opt("SG_POISON_ALLOC");
+    ctx->poison = v && v[0] == '1';
 }
 
 int sg_ctx::alloc(size_t bytes, void **out) {
@@ -50,7 +58,7 @@ int sg_ctx::alloc(size_t bytes, void **out) {
             const size_t have = it->first;
             live_blocks[it->second] = it->first;
             free_blocks.erase(it);
-            if (poison_allocations()) (void)hipMemsetAsync(*out, 0xFF, have, stream);
+            if (poison) (void)hipMemsetAsync(*out, 0xFF, have, stream);
             return SG_OK;
         }
     }
@@ -66,7 +74,7 @@ int sg_ctx::alloc(size_t bytes, void **out) {
             return SG_ERR_OOM;
         }
     }
-    if (poison_allocations()) (void)hipMemsetAsync(p, 0xFF, bytes, stream);
+    if (poison) (void)hipMemsetAsync(p, 0xFF, bytes, stream);
     std::lock_guard<std::mutex> g(mu);
     live_blocks[p] = bytes;
     *out = p;
@@ -94,6 +102,38 @@ void sg_ctx::trim() {
 }
 
 // ------------------------------------------------------------------------------------ context
+extern "C" int sg_ctx_set_option(sg_ctx *ctx, const char *name, const char *value) {
+    SG_REQUIRE(ctx && name && strncmp(name, "SG_", 3) == 0, "option names start with SG_");
+    std::lock_guard<std::mutex> g(ctx->mu);
+    if (value) ctx->opts[name] = value;
+    else ctx->opts.erase(name);
+    const char *v = ctx->opt("SG_POISON_ALLOC");
+    ctx->poison = v && v[0] == '1';
+    return SG_OK;
+}
+
+extern "C" int sg_ctx_reset_options(sg_ctx *ctx) {
+    SG_REQUIRE(ctx != nullptr, "context is null");
+    std::lock_guard<std::mutex> g(ctx->mu);
+    snapshot_options(ctx);
+    return SG_OK;
+}
+
+extern "C" int sg_ctx_options(sg_ctx *ctx, char *buf, int64_t len) {
+    if (!ctx) return 0;
+    std::string all;
+    {
+        std::lock_guard<std::mutex> g(ctx->mu);
+        for (auto &kv : ctx->opts) all += kv.first + "=" + kv.second + "\n";
+    }
+    if (buf && len > 0) {
+        const size_t n = all.size() < (size_t)(len - 1) ? all.size() : (size_t)(len - 1);
+        memcpy(buf, all.data(), n);
+        buf[n] = 0;
+    }
+    return (int)all.size() + 1;
+}
+
 extern "C" int sg_ctx_create(int device, void *hip_stream, sg_ctx **out) {
     SG_REQUIRE(out != nullptr, "out is null");
     int n = 0;
@@ -112,6 +152,7 @@ extern "C" int sg_ctx_create(int device, void *hip_stream, sg_ctx **out) {
     }
     sg_ctx *ctx = new (std::nothrow) sg_ctx();
     if (!ctx) return SG_ERR_OOM;
+    snapshot_options(ctx);
     ctx->device = device;
     ctx->num_cu = prop.multiProcessorCount;
     ctx->total_mem = prop.totalGlobalMem;

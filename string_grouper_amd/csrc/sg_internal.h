@@ -68,6 +68,16 @@ struct sg_ctx {
     int64_t *d_stat_words = nullptr;             // [0]=macs [1]=out_nnz [2..4]=pruned rows/postings/survivors [5]=rows handed to K4
     int64_t *h_stat_words = nullptr;             // pinned mirror
 
+    // Tuning switches (SG_*): read from the environment ONCE, when the context is created, changed only through
+    // sg_ctx_set_option, listed by sg_ctx_options -- nothing inside an API call looks at the environment (a variable left
+    // in a user's shell must not silently change what a later call does: SG_PRUNE=0 is a 23 x slower multiply).
+    std::map<std::string, std::string> opts;
+    const char *opt(const char *name) const {    // value of a switch, or null: not set
+        auto it = opts.find(name);
+        return it == opts.end() ? nullptr : it->second.c_str();
+    }
+    bool poison = false;                         // SG_POISON_ALLOC=1 (copied out of opts: read under the pool's lock)
+
     int alloc(size_t bytes, void **out);         // pooled hipMalloc
     void release(void *p);                       // back to the pool
     void trim();

@@ -372,7 +372,7 @@ static int build_permuted(sg_ctx *ctx, const sg_csr *B, int64_t tile_cols, sg_cs
                           uint32_t **out_pos_of) {
     *out_perm = nullptr;
     *out_orig_of = *out_pos_of = nullptr;
-    const char *e = getenv("SG_PERMUTE");
+    const char *e = ctx->opt("SG_PERMUTE");
     if ((e && e[0] == '0') || B->n_rows <= 2 * tile_cols || B->n_rows >= ((int64_t)1 << 31) || B->nnz <= 0) return SG_OK;
     const uint64_t n = (uint64_t)B->n_rows;
     uint64_t mult = (uint64_t)(0.6180339887498949 * (double)n) | 1ull;
@@ -445,19 +445,19 @@ extern "C" int sg_postings_build_flags(sg_ctx *ctx, const sg_csr *B_in, int32_t 
     bool cosine_like = false;
     float max_norm2 = 0.f;
     SG_TRY(sg_csr_props(ctx, B, &cosine_like, &max_norm2));
-    const char *pr = getenv("SG_PRUNE");
+    const char *pr = ctx->opt("SG_PRUNE");
     const bool want_pruned = cosine_like && !(pr && pr[0] == '0');
     if (tile_cols == 0) {
         tile_cols = B->dtype == SG_F64 ? 1024 : 2048;
         if (want_pruned) {
             tile_cols = 4096;
-            if (const char *v = getenv("SG_PRUNE_TILE")) tile_cols = atoi(v) == 13 ? 8192 : (atoi(v) == 11 ? 2048 : 4096);
+            if (const char *v = ctx->opt("SG_PRUNE_TILE")) tile_cols = atoi(v) == 13 ? 8192 : (atoi(v) == 11 ? 2048 : 4096);
         }
     }
     SG_REQUIRE(tile_cols >= 256 && tile_cols <= 32768 && (tile_cols & (tile_cols - 1)) == 0,
                "tile_cols must be a power of two in [256, 32768]");
     int64_t max_entries = (int64_t)1 << 29;   // the multiply addresses postings with 32-bit BYTE offsets (8 B entries)
-    if (const char *v = getenv("SG_MAX_POSTINGS")) {   // test hook: force the right-hand split at small sizes
+    if (const char *v = ctx->opt("SG_MAX_POSTINGS")) {   // test hook: force the right-hand split at small sizes
         const long long o = atoll(v);
         if (o > 0 && o < max_entries) max_entries = o;
     }
@@ -521,7 +521,7 @@ extern "C" int sg_postings_build_flags(sg_ctx *ctx, const sg_csr *B_in, int32_t 
             // launch at 663 k) but not its time -- the kernel is not bound by bytes -- and their scorer's extra loop
             // trips cost 0.3 - 0.7 ms (9.76 ms packed / 10.08 ms with 64-byte units / 10.50 ms with 32-byte units:
             // profiles/r03_row_blocks_ab.log); the index build pays 0.11 ms for them.
-            const bool want_blk = getenv("SG_ROW_BLOCKS") && getenv("SG_ROW_BLOCKS")[0] == '1';
+            const bool want_blk = ctx->opt("SG_ROW_BLOCKS") && ctx->opt("SG_ROW_BLOCKS")[0] == '1';
             if (st == SG_OK && want_blk && need <= 1024 && (double)need * (double)B->n_rows < 3.5e9 &&
                 (ctx->total_mem == 0 || need * (size_t)B->n_rows < ctx->total_mem / 8)) {
                 p->blk_bytes = (uint32_t)need;
@@ -542,7 +542,7 @@ extern "C" int sg_postings_build_flags(sg_ctx *ctx, const sg_csr *B_in, int32_t 
         if (st == SG_OK) st = sg_alloc(ctx, (size_t)(B->n_cols + 1) * (size_t)p->nt_pad + 4, &p->d_ends);
         // stream form of the pruned multiply (sg_spgemm_pruned.hip): eight tiles share one accumulator tile
         p->fold_log2 = 0;
-        if (tile_log2 == 12 && !(getenv("SG_K4_STREAM") && getenv("SG_K4_STREAM")[0] == '0')) p->fold_log2 = 3;
+        if (tile_log2 == 12 && !(ctx->opt("SG_K4_STREAM") && ctx->opt("SG_K4_STREAM")[0] == '0')) p->fold_log2 = 3;
         if (p->fold_log2 > 0) {
             const int64_t n_super = (n_tiles64 + ((int64_t)1 << p->fold_log2) - 1) >> p->fold_log2;
             p->nv_pad = (int32_t)((n_super + 3) & ~(int64_t)3);
@@ -553,7 +553,7 @@ extern "C" int sg_postings_build_flags(sg_ctx *ctx, const sg_csr *B_in, int32_t 
         // left row is drawn from frequent terms only, which lets the survivor test use each candidate's own
         // frequent-part norm instead of 1 (profiles/r01_prune_tuning.log)
         double frac = 0.0045;
-        if (const char *v = getenv("SG_PRUNE_FREQ")) frac = atof(v);
+        if (const char *v = ctx->opt("SG_PRUNE_FREQ")) frac = atof(v);
         const double fm = frac * (double)B->n_rows;
         p->freq_min = fm < 1.0 ? 1u : (uint32_t)fm;
     }
@@ -567,7 +567,7 @@ extern "C" int sg_postings_build_flags(sg_ctx *ctx, const sg_csr *B_in, int32_t 
         // the tile's counters fit in LDS: one workgroup per tile (part), LDS atomics (otherwise global ones)
         const size_t lds = (size_t)B->n_cols * 4 + ((size_t)(B->n_cols + 31) / 32) * 4;
         bool in_lds = B->n_rows > 0 && lds <= 124 * 1024 && B->n_cols > 0;
-        if (const char *e = getenv("SG_POSTINGS_LDS")) in_lds = in_lds && e[0] != '0';
+        if (const char *e = ctx->opt("SG_POSTINGS_LDS")) in_lds = in_lds && e[0] != '0';
         const float inv_norm = p->d_filt ? 1.0f / p->norm_up : 0.f;
         if (in_lds) {
             static bool attr_done = false;
@@ -582,7 +582,7 @@ extern "C" int sg_postings_build_flags(sg_ctx *ctx, const sg_csr *B_in, int32_t 
             while (split < 4 && (int64_t)p->n_tiles * split < ctx->num_cu && (tile_cols / (split * 2)) >= 1024 &&
                    (n_bins * split * 2 + 1) < ((int64_t)1 << 31))
                 split *= 2;
-            if (const char *e = getenv("SG_POSTINGS_SPLIT")) {
+            if (const char *e = ctx->opt("SG_POSTINGS_SPLIT")) {
                 const int o = atoi(e);
                 if ((o == 1 || o == 2 || o == 4) && tile_cols / o >= 64 && n_bins * o + 1 < ((int64_t)1 << 31)) split = o;
             }

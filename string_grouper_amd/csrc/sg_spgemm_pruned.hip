@@ -1318,7 +1318,7 @@ static unsigned pruned_grid(const sg_ctx *ctx, int32_t tile_log2, int64_t n_rows
     int waves_per_cu = (int)(ctx->lds_per_cu / lds);
     if (waves_per_cu > 32) waves_per_cu = 32;
     if (waves_per_cu < 1) waves_per_cu = 1;
-    if (const char *v = getenv("SG_PRUNE_WAVES_PER_CU"))
+    if (const char *v = ctx->opt("SG_PRUNE_WAVES_PER_CU"))
         if (atoi(v) > 0) waves_per_cu = atoi(v);
     unsigned grid = (unsigned)ctx->num_cu * (unsigned)waves_per_cu;
     if ((int64_t)grid > n_rows) grid = (unsigned)(n_rows > 0 ? n_rows : 1);
@@ -1357,7 +1357,7 @@ static int launch_both(sg_ctx *ctx, const sg_csr *A, const sg_postings *Bt, int3
     if (st == SG_OK)
         st = launch_pruned<T, TILE_LOG2, SYM, false, FOLD_LOG2>(ctx, A, Bt, keep, r, thr, s_budget, row_counter, l1, l1 + 4, stats, pl,
                                                      nullptr, nullptr);
-    if (st == SG_OK && !(getenv("SG_PRUNE_WIDE") && getenv("SG_PRUNE_WIDE")[0] == '0'))
+    if (st == SG_OK && !(ctx->opt("SG_PRUNE_WIDE") && ctx->opt("SG_PRUNE_WIDE")[0] == '0'))
         st = launch_pruned<T, TILE_LOG2, SYM, true, FOLD_LOG2>(ctx, A, Bt, keep, r, thr, s_budget, l1 + 1, flagged_count, flagged_rows, stats,
                                                     pl, l1 + 4, l1);
     else if (st == SG_OK) {   // SG_PRUNE_WIDE=0: the first launch's list goes to the exact kernel as it is
@@ -1442,7 +1442,7 @@ int sg_spgemm_pruned_symmetric(sg_ctx *ctx, const sg_csr *A, const sg_postings *
     }
     if (cap < 8 * n + ((int64_t)1 << 20)) cap = 8 * n + ((int64_t)1 << 20);
     bool cap_forced = false;
-    if (const char *v = getenv("SG_SYM_PAIR_CAP"))   // test hook: a list that is too small
+    if (const char *v = ctx->opt("SG_SYM_PAIR_CAP"))   // test hook: a list that is too small
         if (atoll(v) > 0) {
             cap = atoll(v);
             cap_forced = true;

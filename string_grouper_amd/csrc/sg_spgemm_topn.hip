@@ -531,14 +531,14 @@ __global__ void __launch_bounds__(64) topn_zip_kernel(const ZipPart<T> *__restri
 // ================================================================================================
 // host side
 // ================================================================================================
-static double env_double(const char *name, double dflt) {
-    const char *v = getenv(name);
+static double env_double(const sg_ctx *ctx, const char *name, double dflt) {
+    const char *v = ctx->opt(name);
     if (!v || !*v) return dflt;
     return atof(v);
 }
 
-static int env_int(const char *name, int dflt) {
-    const char *v = getenv(name);
+static int env_int(const sg_ctx *ctx, const char *name, int dflt) {
+    const char *v = ctx->opt(name);
     if (!v || !*v) return dflt;
     return atoi(v);
 }
@@ -579,7 +579,7 @@ template <typename T>
 static int dispatch_spgemm(sg_ctx *ctx, const sg_csr *A, const sg_postings *Bt, int32_t tile_begin, int32_t tile_end,
                            int32_t keep, int32_t pass_off, sg_topn *r, T thr, uint32_t *counter, unsigned grid,
                            const uint32_t *row_list = nullptr, const uint32_t *row_list_len = nullptr) {
-    const int depth = env_int("SG_DEPTH", 8);
+    const int depth = env_int(ctx, "SG_DEPTH", 8);
     switch (Bt->tile_log2) {
         case 10: return dispatch_depth<T, 10>(ctx, A, Bt, tile_begin, tile_end, keep, pass_off, r, thr, counter, grid, depth, row_list, row_list_len);
         case 11: return dispatch_depth<T, 11>(ctx, A, Bt, tile_begin, tile_end, keep, pass_off, r, thr, counter, grid, depth, row_list, row_list_len);
@@ -721,10 +721,10 @@ static bool pruned_applicable(sg_ctx *ctx, const sg_csr *A, const sg_postings *B
                               bool *symmetric, int *status, bool any_size = false) {
     *symmetric = false;
     *status = SG_OK;
-    const char *pr = getenv("SG_PRUNE");
+    const char *pr = ctx->opt("SG_PRUNE");
     if ((pr && pr[0] == '0') || !Bt->cosine_like || !Bt->d_filt || stride > SG_TOPN_LANES || A->n_rows <= 0 || Bt->nnz <= 0 ||
         !sg_pruned_supports_tile(Bt->tile_log2) ||
-        !(threshold >= env_double("SG_PRUNE_MIN_THRESHOLD", 0.45)))   // below ~0.4 the filter passes too much (profiles/r01_prune_tuning.log)
+        !(threshold >= env_double(ctx, "SG_PRUNE_MIN_THRESHOLD", 0.45)))   // below ~0.4 the filter passes too much (profiles/r01_prune_tuning.log)
         return false;
     // tuned at 663 k: the tile-by-tile form 0.05 (profiles/r01_prune_tuning.log); the stream form, whose rounds are cheaper
     // next to the exact scorings, 0.03 (profiles/r03_sessionG_H_delta.log: 9.76 / 9.95 / 10.10 / 14.3 ms at 0.03 / 0.04 /
@@ -732,7 +732,7 @@ static bool pruned_applicable(sg_ctx *ctx, const sg_csr *A, const sg_postings *B
     // (0.03 only where rows are sparse next to the vocabulary -- name data; on small vocabularies, the regime of the
     //  pruned-or-exact pilot below, a tighter bound passes too many candidates: 0.05 as before)
     const bool sparse_rows = A->n_rows > 0 && (double)A->nnz / (double)A->n_rows <= 0.004 * (double)Bt->n_terms;
-    *delta = env_double("SG_PRUNE_DELTA", Bt->fold_log2 > 0 && sparse_rows ? 0.03 : 0.05);
+    *delta = env_double(ctx, "SG_PRUNE_DELTA", Bt->fold_log2 > 0 && sparse_rows ? 0.03 : 0.05);
     if (*delta > 0.5 * threshold) *delta = 0.5 * threshold;
     if (*delta < 0.02) *delta = 0.02;
     bool a_ok = false;
@@ -743,13 +743,13 @@ static bool pruned_applicable(sg_ctx *ctx, const sg_csr *A, const sg_postings *B
     // self-join (A is the matrix the postings were built from): score every pair once, from the row with the larger
     // index (sg_spgemm_pruned.hip, symmetric mode; rows the pruned kernel cannot take go through the exact kernel's
     // self-join launch inside the same pass)
-    const char *sy = getenv("SG_SYM");
+    const char *sy = ctx->opt("SG_SYM");
     // ... from the size at which halving the (row, tile) visits outweighs the second pass over the pair list
     // and its host round trip: 0.58 vs 0.57 ms at 50 k rows, 0.95 vs 1.20 at 100 k, 14.0 vs 26.8 at 663 k
     // (profiles/r02_sessionM_sym_sweep.log)
     *symmetric = !(sy && sy[0] == '0') && A->n_rows == Bt->n_right && A->d_indptr == Bt->b_indptr &&
                  A->d_indices == Bt->b_indices && A->d_data == Bt->b_data &&
-                 (any_size || A->n_rows >= (int64_t)env_int("SG_SYM_MIN_ROWS", 65536) || (sy && sy[0] == '1'));
+                 (any_size || A->n_rows >= (int64_t)env_int(ctx, "SG_SYM_MIN_ROWS", 65536) || (sy && sy[0] == '1'));
     return true;
 }
 
@@ -779,7 +779,7 @@ extern "C" int sg_spgemm_topn(sg_ctx *ctx, const sg_csr *A, const sg_postings *B
     // Tile groups (separate launches over a few tiles each, running state kept in the output arrays)
     // exist for right-hand sides whose postings exceed the 256 MiB Infinity Cache; below that one launch
     // is faster (measured: 280 ms vs 415 ms at 663 k -- every launch has a tail and a state round trip).
-    int group = env_int("SG_TILE_GROUP", 0);
+    int group = env_int(ctx, "SG_TILE_GROUP", 0);
     if (group <= 0) {
         const double bytes = (double)Bt->nnz * (double)(4 + s);
         const double budget = 192.0 * 1024 * 1024;
@@ -795,7 +795,7 @@ extern "C" int sg_spgemm_topn(sg_ctx *ctx, const sg_csr *A, const sg_postings *B
     int waves_per_cu = (int)(ctx->lds_per_cu / lds);
     if (waves_per_cu > 32) waves_per_cu = 32;
     if (waves_per_cu < 1) waves_per_cu = 1;
-    waves_per_cu = env_int("SG_WAVES_PER_CU", waves_per_cu);
+    waves_per_cu = env_int(ctx, "SG_WAVES_PER_CU", waves_per_cu);
     unsigned grid = (unsigned)ctx->num_cu * (unsigned)waves_per_cu;
     if ((int64_t)grid > A->n_rows) grid = (unsigned)(A->n_rows > 0 ? A->n_rows : 1);
 
@@ -817,7 +817,7 @@ extern "C" int sg_spgemm_topn(sg_ctx *ctx, const sg_csr *A, const sg_postings *B
     //      blocks of 512 left rows are run through the pruned kernel first and the two costs are priced from what
     //      they did (prune_pilot; constants fitted on the family sweep in profiles/r02_profile_k4p_v9b_sym.log).
     if (prune && A->n_rows >= 32768 && A->nnz > 0 && Bt->n_terms > 0 &&
-        (double)A->nnz / (double)A->n_rows > 0.004 * (double)Bt->n_terms && env_int("SG_PRUNE_PILOT", 1) != 0) {
+        (double)A->nnz / (double)A->n_rows > 0.004 * (double)Bt->n_terms && env_int(ctx, "SG_PRUNE_PILOT", 1) != 0) {
         bool keep_pruned = true;
         const int pst = prune_pilot(ctx, A, Bt, stride, threshold, delta, symmetric, &keep_pruned);
         if (pst != SG_OK) {

@@ -979,7 +979,7 @@ static int fit_begin(sg_ctx *ctx, const sg_strings *const *sets, int32_t n_sets,
             st = SG_ERR_UNSUPPORTED;
         }
         v->sorted_mode = key_bits > 30;
-        if (const char *e = getenv("SG_VOCAB_SORTED"))      // test hook: the sorted vocabulary at any size
+        if (const char *e = ctx->opt("SG_VOCAB_SORTED"))      // test hook: the sorted vocabulary at any size
             if (e[0] == '1') v->sorted_mode = true;
         v->key_space = v->sorted_mode ? 0 : (int64_t)1 << key_bits;
     }
@@ -996,10 +996,10 @@ static int fit_begin(sg_ctx *ctx, const sg_strings *const *sets, int32_t n_sets,
             // df table: `replicas` copies (row mod replicas picks one) while they stay small, summed afterwards
             df_stride = v->key_space + 1;
             replicas = 8;
-            if (const char *e = getenv("SG_DF_REPLICAS")) replicas = atoi(e);
+            if (const char *e = ctx->opt("SG_DF_REPLICAS")) replicas = atoi(e);
             while (replicas > 1 && df_stride * replicas > ((int64_t)1 << 25)) replicas >>= 1;   // <= 128 MiB of counters
             if (replicas < 1) replicas = 1;
-            if (const char *e = getenv("SG_DF_MARKS")) df_marks = df_marks && e[0] != '0';   // A/B hook
+            if (const char *e = ctx->opt("SG_DF_MARKS")) df_marks = df_marks && e[0] != '0';   // A/B hook
             im->df_marks = df_marks;
             const int64_t copies = df_marks ? 1 : replicas;
             if (df_marks) replicas = 0;   // what the tokeniser kernels take as "mark, do not count"
@@ -1282,7 +1282,7 @@ extern "C" int sg_vocab_free(sg_vocab *v) {
 template <typename T, typename KeyT, typename Lookup>
 static void launch_weight(sg_ctx *ctx, const TokenCache *tc, Lookup lookup, const sg_vocab *v, int64_t n, const int64_t *indptr,
                           int32_t *idx, void *val, uint32_t *props) {
-    const char *pe = getenv("SG_K2_PLAIN");   // A/B and test hook: the thread-per-row statement of the arithmetic
+    const char *pe = ctx->opt("SG_K2_PLAIN");   // A/B and test hook: the thread-per-row statement of the arithmetic
     const bool plain = pe && pe[0] == '1';
     if (plain)
         hipLaunchKernelGGL((weight_normalize_kernel<T, KeyT, Lookup>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream,

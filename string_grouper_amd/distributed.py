@@ -534,14 +534,16 @@ def broadcast_strings(ctx, t_bytes, t_offs, src: int = 0, group=None):
 
 
 # ---------------------------------------------------------------------------------------------- round-1 forms
-def pruned_multiply_expected(top_n: int, threshold: float) -> bool:
+def pruned_multiply_expected(top_n: int, threshold: float, ctx=None) -> bool:
     """The library's rule for taking the pruned multiply on TF-IDF input (sg_spgemm_topn).
     Its cost per left row is nearly uniform (the column-tile loop dominates), whereas the exact kernel's
-    follows the row's intermediate products -- which decides how left rows are best cut across ranks."""
+    follows the row's intermediate products -- which decides how left rows are best cut across ranks.
+    ``ctx``: the context whose switches apply (its frozen copy of SG_PRUNE / SG_PRUNE_MIN_THRESHOLD)."""
     import os
-    if os.environ.get("SG_PRUNE", "1").startswith("0"):
+    opts = ctx.options() if ctx is not None else os.environ
+    if opts.get("SG_PRUNE", "1").startswith("0"):
         return False
-    return top_n <= 64 and threshold >= float(os.environ.get("SG_PRUNE_MIN_THRESHOLD", "0.45"))
+    return top_n <= 64 and threshold >= float(opts.get("SG_PRUNE_MIN_THRESHOLD", "0.45"))
 
 
 def sharded_self_join_replicated(ctx, prepared_dev, vectorizer_factory, top_n: int, threshold: float,
@@ -553,7 +555,7 @@ def sharded_self_join_replicated(ctx, prepared_dev, vectorizer_factory, top_n: i
     rows.  Returns (TopN of the local block, (row_lo, row_hi), n_rows_total)."""
     rank, world = dist.get_rank(group), dist.get_world_size(group)
     if balance is None:
-        balance = not pruned_multiply_expected(top_n, threshold)
+        balance = not pruned_multiply_expected(top_n, threshold, ctx)
     vec = vectorizer_factory()
     vec.fit_prepared([prepared_dev])
     A = vec.transform_prepared(prepared_dev)

@@ -363,13 +363,13 @@ def test_headline_663k_selfjoin_every_row_equals_sklearn_and_the_port(ctx):
     assert st["prune_rows"] > 0 and st["exact_rows"] == 0
     assert_csr_identical(C_sym, C_ref, "663k self-join, symmetric pruned multiply")
     assert st["prune_postings"] < 0.06 * st["macs"]       # the symmetric pass streams half of the one-sided 8 %
-    os.environ["SG_SYM"] = "0"
+    ctx.set_option("SG_SYM", "0")
     try:
         res = ctx.spgemm_topn(dA, post, 10, 0.8, True)
         C_one = res.to_scipy()
         res.free()
     finally:
-        os.environ.pop("SG_SYM")
+        ctx.set_option("SG_SYM", None)
     assert_csr_identical(C_one, C_ref, "663k self-join, one-sided pruned multiply")
     post.free()
     # properties that hold at any size: every non-empty row finds itself with a score of 1 (+- rounding), rows are
