@@ -161,8 +161,10 @@ struct sg_postings {
     const void *b_data = nullptr;
     uint32_t *d_seg = nullptr;           // n_terms * n_tiles + 1
     uint32_t *d_term_len = nullptr;      // n_terms: entries of term k's list (= seg[(k+1) * n_tiles] - seg[k * n_tiles])
-    int32_t *d_rows = nullptr;           // nnz   (row j of B)
-    void *d_vals = nullptr;              // nnz   (value B[j, k])
+    int32_t *d_rows = nullptr;           // nnz   (row j of B)                  } null until sg_postings_ensure_full when the
+    void *d_vals = nullptr;              // nnz   (value B[j, k])               } build left the postings proper out
+    sg_csr src;                          // the matrix the index was built over (rows in position order; not owned)
+    int32_t split = 1;                   // parts a tile was counted in (sg_postings.hip, LDS path)
     // rows of B packed for the pruned multiply's exact scoring (built only for cosine-like B):
     // f32: {int32 term, float value} (8 B), f64: {int32 term, pad, double value} (16 B); row j = entries
     // [d_fwd_ptr[j], d_fwd_ptr[j+1])
@@ -238,6 +240,7 @@ int sg_matchlist_device_view(const sg_matchlist *ml, int64_t *n_rows, int64_t *n
 // sg_spgemm_pruned.hip
 int sg_csr_props(sg_ctx *ctx, const sg_csr *m, bool *cosine_like, float *max_norm2, uint32_t *max_nnz = nullptr);
 bool sg_pruned_supports_tile(int32_t tile_log2);
+int sg_postings_ensure_full(sg_ctx *ctx, const sg_postings *p);   // sg_postings.hip: the exact kernel's postings, on demand
 int sg_spgemm_pruned_launch(sg_ctx *ctx, const sg_csr *A, const sg_postings *Bt, int32_t keep, sg_topn *r,
                             double threshold, double delta, uint32_t *row_counter,
                             uint32_t *flagged_count, uint32_t *flagged_rows, unsigned long long *stats);

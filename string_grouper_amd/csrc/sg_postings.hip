@@ -89,7 +89,7 @@ __device__ __forceinline__ void emit_posting(int32_t *out_rows, T *out_vals, uin
                                              T v, uint32_t fq, int32_t tile_log2, float inv_norm_up, uint32_t tile,
                                              int32_t fold_log2) {
     // the multiply wants the byte offset of the accumulator inside its LDS tile, not j itself
-    store_posting<T>(out_rows, out_vals, pos, (int32_t)(col * (uint32_t)sizeof(T)), v);
+    if (out_vals) store_posting<T>(out_rows, out_vals, pos, (int32_t)(col * (uint32_t)sizeof(T)), v);   // (null: filter postings only)
     if (out_filt) {
         const int32_t ab = tile_log2 + 1, fb = ab + fold_log2;
         const uint32_t bq_max = (1u << (24 - fb)) - 1u;   // the bits the address, the fold and fq leave
@@ -505,10 +505,22 @@ extern "C" int sg_postings_build_flags(sg_ctx *ctx, const sg_csr *B_in, int32_t 
     const size_t vs = 8;   // f64 value, or packed {row, f32 value}
     int st = sg_alloc(ctx, (size_t)n_bins + 1, &p->d_seg);
     if (st == SG_OK) st = sg_alloc(ctx, (size_t)B->n_cols + 1, &p->d_term_len);
-    if (st == SG_OK && B->dtype == SG_F64) st = sg_alloc(ctx, (size_t)B->nnz + 64, &p->d_rows);
-    if (st == SG_OK) st = ctx->alloc(((size_t)B->nnz + 64) * vs, &p->d_vals);
-    if (st == SG_OK && want_pruned && sg_pruned_supports_tile(tile_log2) &&
-        (B->n_cols + 1) * ((n_tiles64 + 3) & ~(int64_t)3) < ((int64_t)1 << 30)) {
+    // The postings proper ({accumulator slot, value}: 8 bytes each, 100 MB at 663 k) are what the EXACT kernel streams.  When
+    // the pruned multiply will take the product they are only needed for the rows it hands over (wider than 128 non-zeros
+    // ...: none in a list of names), and scattering them is half of the index build: they are then written on demand
+    // (sg_postings_ensure_full), from the same segment table.
+    const bool will_filter = want_pruned && sg_pruned_supports_tile(tile_log2) &&
+                             (B->n_cols + 1) * ((n_tiles64 + 3) & ~(int64_t)3) < ((int64_t)1 << 30);
+    const size_t lds_need = (size_t)B->n_cols * 4 + ((size_t)(B->n_cols + 31) / 32) * 4;
+    bool lds_path = B->n_rows > 0 && lds_need <= 124 * 1024 && B->n_cols > 0;
+    if (const char *e = ctx->opt("SG_POSTINGS_LDS")) lds_path = lds_path && e[0] != '0';
+    const bool lazy_full = will_filter && lds_path && !(ctx->opt("SG_POSTINGS_LAZY") && ctx->opt("SG_POSTINGS_LAZY")[0] == '0');
+    p->src = *B;
+    p->src.owned = false;
+    p->src.d_props_words = nullptr;
+    if (st == SG_OK && !lazy_full && B->dtype == SG_F64) st = sg_alloc(ctx, (size_t)B->nnz + 64, &p->d_rows);
+    if (st == SG_OK && !lazy_full) st = ctx->alloc(((size_t)B->nnz + 64) * vs, &p->d_vals);
+    if (st == SG_OK && will_filter) {
         {
             // rows at a fixed stride for the exact scoring, when the longest row fits 1 KiB (127 entries f32 / 63 f64)
             uint32_t max_nnz = 0;
@@ -586,6 +598,7 @@ extern "C" int sg_postings_build_flags(sg_ctx *ctx, const sg_csr *B_in, int32_t 
                 const int o = atoi(e);
                 if ((o == 1 || o == 2 || o == 4) && tile_cols / o >= 64 && n_bins * o + 1 < ((int64_t)1 << 31)) split = o;
             }
+            p->split = split;
             uint32_t *segp = p->d_seg;          // counters with the parts; the table itself when split == 1
             uint8_t *is_frequent = nullptr;
             if (split > 1) st = sg_alloc(ctx, (size_t)(n_bins * split) + 1, &segp);
@@ -711,6 +724,48 @@ extern "C" int sg_postings_build_flags(sg_ctx *ctx, const sg_csr *B_in, int32_t 
     }
     *out = p;
     return SG_OK;
+}
+
+// The postings proper, when the build left them out (see sg_postings_build_flags): same two passes, values only.
+int sg_postings_ensure_full(sg_ctx *ctx, const sg_postings *cp) {
+    sg_postings *p = const_cast<sg_postings *>(cp);
+    if (p->d_vals || p->nnz <= 0) return SG_OK;
+    const sg_csr *B = &p->src;
+    const int64_t n_bins = p->n_terms * (int64_t)p->n_tiles;
+    const int32_t split = p->split > 0 ? p->split : 1;
+    int st = SG_OK;
+    if (B->dtype == SG_F64) st = sg_alloc(ctx, (size_t)B->nnz + 64, &p->d_rows);
+    if (st == SG_OK) st = ctx->alloc(((size_t)B->nnz + 64) * 8, &p->d_vals);
+    uint32_t *segp = nullptr;
+    if (st == SG_OK) st = sg_alloc(ctx, (size_t)(n_bins * split) + 1, &segp);
+    if (st == SG_OK) {
+        const unsigned wgs = (unsigned)(p->n_tiles * split);
+        const size_t lds = (size_t)B->n_cols * 4 + ((size_t)(B->n_cols + 31) / 32) * 4;
+        hipLaunchKernelGGL(postings_count_lds, dim3(wgs), dim3(1024), (size_t)B->n_cols * 4, ctx->stream, B->d_indptr, B->d_indices,
+                           B->n_rows, p->tile_log2, p->n_tiles, (int32_t)B->n_cols, split, segp);
+        st = sg_exclusive_scan_u32(ctx, segp, segp, n_bins * split, segp + n_bins * split);
+        if (st == SG_OK) {
+            if (B->dtype == SG_F64)
+                hipLaunchKernelGGL(postings_fill_lds<double>, dim3(wgs), dim3(1024), lds, ctx->stream, B->d_indptr, B->d_indices,
+                                   (const double *)B->d_data, B->n_rows, p->tile_log2, p->n_tiles, (int32_t)B->n_cols, split,
+                                   (const uint32_t *)segp, (const uint8_t *)nullptr, p->d_rows, (double *)p->d_vals,
+                                   (uint32_t *)nullptr, 0.f, 0);
+            else
+                hipLaunchKernelGGL(postings_fill_lds<float>, dim3(wgs), dim3(1024), lds, ctx->stream, B->d_indptr, B->d_indices,
+                                   (const float *)B->d_data, B->n_rows, p->tile_log2, p->n_tiles, (int32_t)B->n_cols, split,
+                                   (const uint32_t *)segp, (const uint8_t *)nullptr, p->d_rows, (float *)p->d_vals,
+                                   (uint32_t *)nullptr, 0.f, 0);
+            if (hipGetLastError() != hipSuccess) st = SG_ERR_HIP;
+        }
+    }
+    ctx->release(segp);
+    if (st != SG_OK) {
+        ctx->release(p->d_vals);
+        ctx->release(p->d_rows);
+        p->d_vals = nullptr;
+        p->d_rows = nullptr;
+    }
+    return st;
 }
 
 extern "C" int sg_postings_free(sg_postings *p) {

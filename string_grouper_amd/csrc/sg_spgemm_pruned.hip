@@ -424,8 +424,16 @@ spgemm_topn_pruned_kernel(const int64_t *__restrict__ a_indptr, const int32_t *_
     // rows are handed out four at a time: one global atomic per row capped the kernel at ~88 rows/us (larger first
     // helpings were tried -- sixteen rows for the first three quarters -- and changed nothing: profiles/r02_sessionJ6_*.log).
     // Symmetric mode walks the rows from the last to the first: a row's cost grows with its index there.
-    for (uint32_t row0 = next_row(row_counter, lane) * 4u; row0 < n_here; row0 = next_row(row_counter, lane) * 4u) {
-    for (uint32_t rr = row0; rr < min(row0 + 4u, n_here); ++rr) {
+    // The last rows -- two per wave of the launch -- go one at a time: a launch ends with its slowest helping, and when
+    // the launch is a rank's RANGE of the multi-GPU self-join the last rows are not the cheap ones of the whole job but
+    // rows as expensive as the range's first (scripts/sim_scaling.py: the eight ranges of the 663 k job took 25.8 ms in
+    // all against 10.0 ms for the whole -- tails of four-row helpings).
+    const uint32_t n_single = min(n_here, 2u * gridDim.x);
+    const uint32_t n_quads = (n_here - n_single) >> 2;     // helpings [0, n_quads) hold four rows, the rest one
+    for (uint32_t hlp = next_row(row_counter, lane);; hlp = next_row(row_counter, lane)) {
+    const uint32_t row0 = hlp < n_quads ? hlp << 2 : (n_quads << 2) + (hlp - n_quads);
+    if (row0 >= n_here || hlp >= 0x10000000u) break;       // (the second: the pass was called off, see the pair list below)
+    for (uint32_t rr = row0; rr < row0 + (hlp < n_quads ? 4u : 1u); ++rr) {   // (rows behind the quads go singly)
         SG_WD(wd_rows, n_left + 2, 11)
         const uint32_t row = WIDE ? (uint32_t)__builtin_amdgcn_readfirstlane((int)row_list[rr]) : (SYM ? sym_hi - 1u - rr : rr);
         // self-join form: the left matrix IS the permuted one, `row` a position; its result row and its name in the pairs
@@ -1523,21 +1531,25 @@ int sg_spgemm_pruned_symmetric(sg_ctx *ctx, const sg_csr *A, const sg_postings *
         else
             st = dispatch_pruned<float, true>(ctx, A, Bt, keep, r, (float)threshold, s_budget, words, words + 1, flagged_rows,
                                               d_stats3, pl);
-        // the rows neither launch of the pruned kernel could take (more than 128 non-zeros, more than 64 prefix terms, no
-        // room for the fixed-point filter): through the exact kernel, in the same form -- pairs (i, j <= i), mirrored ones
-        // into the pair list.  Launched on the device-side count: without such rows its waves leave at once.
-        if (st == SG_OK) {
-            st = sg_spgemm_exact_selfjoin_rows(ctx, A, Bt, keep, r, threshold, words + 5, flagged_rows, words + 1, sink);
-        }
     }
-    if (st == SG_OK) {
-        // h[0] = {row counter, flagged}, h[1] = pairs, h[2] = chunks handed out
+    // h[0] = {row counter, flagged}, h[1] = pairs, h[2] = chunks handed out
+    auto read_back = [&]() {
         e = hipMemcpyAsync(h, words, 24, hipMemcpyDeviceToHost, ctx->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
         if (e != hipSuccess) {
             sg_set_error("symmetric multiply: %s", hipGetErrorString(e));
             st = SG_ERR_HIP;
         }
+    };
+    if (st == SG_OK) read_back();
+    if (st == SG_OK && (uint32_t)(h[0] >> 32) > 0) {
+        // the rows neither launch of the pruned kernel could take (more than 128 non-zeros, more than 64 prefix terms, no
+        // room for the fixed-point filter, or -- stream form -- none at all): through the exact kernel, in the same form --
+        // pairs (i, j <= i), mirrored ones into the pair list.  Its postings are written now if the index build left them
+        // out (name lists have no such rows), and the counts are read again.
+        st = sg_postings_ensure_full(ctx, Bt);
+        if (st == SG_OK) st = sg_spgemm_exact_selfjoin_rows(ctx, A, Bt, keep, r, threshold, words + 5, flagged_rows, words + 1, sink);
+        if (st == SG_OK) read_back();
     }
     if (st != SG_OK) {
         ctx->release(d_stats3);

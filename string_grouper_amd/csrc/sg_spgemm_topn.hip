@@ -855,9 +855,22 @@ extern "C" int sg_spgemm_topn(sg_ctx *ctx, const sg_csr *A, const sg_postings *B
             st = sg_spgemm_pruned_launch(ctx, A, Bt, stride, r, threshold, delta, counters + n_launch + 1,
                                          handed_count, handed_rows, (unsigned long long *)(ctx->d_stat_words + 2));
         }
+        // The exact kernel: the whole product when the pruned multiply does not apply, or the rows it handed over -- whether
+        // there are any is read back (four bytes), because the index build leaves the exact kernel's postings out when
+        // the pruned multiply is expected to take everything (sg_postings_ensure_full writes them on demand).
+        bool need_exact = !prune && !sym_done;
+        if (prune && !sym_done && st == SG_OK) {
+            uint32_t *h_handed = (uint32_t *)(ctx->h_stat_words + 7);   // pinned
+            *h_handed = 0;
+            if (hipMemcpyAsync(h_handed, handed_count, 4, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+                hipStreamSynchronize(ctx->stream) != hipSuccess)
+                st = SG_ERR_HIP;
+            need_exact = *h_handed > 0;
+        }
+        if (need_exact && st == SG_OK) st = sg_postings_ensure_full(ctx, Bt);
         SgTimer *exact_timer = (!prune && !sym_done) ? new (std::nothrow) SgTimer(ctx, SG_K_SPGEMM_KERNEL) : nullptr;
         int li = 0;
-        for (int pass = 0; pass < n_pass && st == SG_OK && A->n_rows > 0 && !sym_done; ++pass) {
+        for (int pass = 0; pass < n_pass && st == SG_OK && A->n_rows > 0 && need_exact; ++pass) {
             const int pass_off = pass * SG_TOPN_LANES;
             const int keep = stride - pass_off < SG_TOPN_LANES ? stride - pass_off : SG_TOPN_LANES;
             for (int g = 0; g < n_groups && st == SG_OK; ++g, ++li) {
