@@ -46,8 +46,8 @@ HBM_PEAK_GBPS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=0, help="timed steps; 0 (default): as many as fill a timed region of >= 2 s")
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--rows", type=int, default=663000, help="names in the self-join (metric config: 663000)")
     ap.add_argument("--top-n", type=int, default=10)
     ap.add_argument("--min-similarity", type=float, default=0.8)
@@ -58,6 +58,9 @@ def parse_args():
     ap.add_argument("--no-end-to-end", action="store_true", help="skip the match_strings() wall-clock runs (fp32 + fp64)")
     ap.add_argument("--end-to-end", action="store_true", help=argparse.SUPPRESS)      # round-1 flag: now the default
     ap.add_argument("--cpu-cores", type=int, default=4, help="cores of the reference CPU leg (README: 4)")
+    ap.add_argument("--cpu-full", action="store_true", help="CPU baseline: multiply ALL left rows instead of a bounded "
+                                                            "sample (~100 s on 4 cores at 663 k): nothing extrapolated "
+                                                            "but the tokenisation passes and the tail")
     return ap.parse_args()
 
 
@@ -194,6 +197,20 @@ def run(args):
     for _ in range(args.warmup):
         r = step()
         r.free()
+    if args.steps <= 0:
+        # default: a timed region of at least two seconds (0.3 s of a 27 s run is thin) -- one more untimed
+        # step is timed to size it; every rank arrives at the same count (max over ranks)
+        barrier()
+        tc = time.perf_counter()
+        r = step()
+        r.free()
+        barrier()
+        one = time.perf_counter() - tc
+        if distributed:
+            tt = torch.tensor([one], dtype=torch.float64, device="cuda")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            one = float(tt.item())
+        args.steps = int(max(5, min(2000, np.ceil(2.0 / max(one, 1e-4)))))
     barrier()
     t0 = time.perf_counter()
     k4_ms = []
@@ -262,6 +279,8 @@ def run(args):
         # launch groups of one step (HIP events on the library's stream); spgemm_topn = the multiply's whole group (pruned
         # kernel + pair-list pass in the self-join form), of which the dominant kernel alone is roofline.avg_ms
         "kernels_ms": {k[3:]: round(v, 4) for k, v in stats.items() if k.startswith("ms_") and k != "ms_spgemm_kernel"},
+        # SG_* switches in force (read from the environment once, when the context was created; include/sg_hip.h)
+        "options": ctx.options(),
         "matches": int(job_nnz),
         "macs": int(job_macs),
         "roofline": {"bound": "hbm",
@@ -286,6 +305,7 @@ def run(args):
         if (tr.get("workload_rows") == args.rows and tr.get("dtype") == args.dtype and world == 1
                 and tr.get("kernel", "K4") == (("K4p-sym" if symmetric else "K4p") if pruned else "K4")):
             result["roofline"]["traffic"] = tr["traffic_bytes_per_launch_raw"]
+            result["roofline"]["traffic_source"] = "committed PMC pass (profiles/k4_traffic.json, written by scripts/pmc_traffic.py); not measured in this run"
             result["roofline"]["traffic_note"] = tr["source"] + "; " + tr["note"]
     except Exception:
         pass
@@ -369,6 +389,7 @@ def run(args):
                  shape=np.array(A_host.shape))
         common = [sys.executable, "-m", "oracle.baseline", "--matrix", mpath, "--rows", str(args.rows), "--top-n",
                   str(args.top_n), "--min-similarity", str(args.min_similarity), "--dtype", args.dtype,
+                  *(["--multiply-seconds", "100000"] if args.cpu_full else []),
                   "--matches-full", str(result.get("end_to_end", {}).get(args.dtype, {}).get("match_rows", 0))]
         all_cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
         try:
@@ -383,6 +404,9 @@ def run(args):
             all_total = vec_s + ball["multiply"]["seconds_full_estimate"] + tail_s
             result["cpu_baseline"] = {
                 "value": base["value"], "unit": "rows/s", "cores": base["cores"], "kind": "port",
+                # the multiply leg ran on a bounded sample of the left rows unless --cpu-full; the tokenisation passes and
+                # the tail are always scaled from a 40 000-name run
+                "extrapolated": bool(base["multiply"]["sample_left_rows"] < args.rows),
                 "cpu_model": base["cpu_model"], "seconds_full_estimate": base["seconds_full_estimate"],
                 "sample": (f"reference match_strings call sequence restated on sklearn + oracle/sdtn_port.c "
                            f"(oracle/ref_pipeline.py; the Python reference cannot travel to the GPU box), child process "
@@ -426,6 +450,10 @@ def run(args):
                 result["end_to_end"]["speedup_vs_cpu_baseline_4_cores"] = \
                     result["cpu_baseline"]["seconds_full_estimate"] / e2e["seconds"]
 
+    if "end_to_end" in result and args.dtype in result["end_to_end"]:
+        # what BASELINE.json calls match_strings: the public API end to end (host preparation, PCIe, frames); `value` is the
+        # device hot path with its inputs resident in HBM, as the bench contract defines it
+        result["match_strings_rows_per_s"] = result["end_to_end"][args.dtype]["rows_per_s"]
     sys.stdout.flush()
     os.write(json_fd, (json.dumps(result) + "\n").encode())
     if distributed:
