@@ -147,6 +147,17 @@ struct SgScoreCtx {
     uint32_t blk_bytes = 0;
 };
 
+// Groups of identical right-hand rows (sg_collapse.hip): the index is built over one representative per group.
+struct SgCollapse {
+    sg_ctx *ctx = nullptr;
+    int64_t n_orig = 0, n_u = 0;         // rows of the caller's matrix, groups
+    uint32_t *d_gid = nullptr;           // n_orig: group of every row (groups numbered by ascending representative)
+    uint32_t *d_group_ptr = nullptr;     // n_u + 1
+    uint32_t *d_members = nullptr;       // n_orig: rows of group g = members[group_ptr[g] .. group_ptr[g + 1]), ascending
+    uint32_t *d_rep_rows = nullptr;      // n_u: lowest row of every group
+    struct sg_csr *unique = nullptr;     // the representatives' rows (owned)
+};
+
 struct sg_postings {
     sg_ctx *ctx = nullptr;
     int64_t n_right = 0, n_terms = 0, nnz = 0;
@@ -205,6 +216,15 @@ struct sg_postings {
     uint32_t freq_min = 0;               // list length from which a term counts as frequent
     bool cosine_like = false;            // B: values >= 0, sorted rows, row norms <= 1 (sg_csr_props)
     float max_norm2 = 0.f;               // max ||row of B||^2, rounded up
+    // Identical rows collapsed (sg_collapse.hip): everything above indexes the representatives' matrix (n_right = groups);
+    // the caller's matrix is (caller_*), the multiply expands its result to the caller's rows / columns.  `plain`: an index
+    // over all rows, built on demand for what the collapsed one does not serve (top_n > 64, the multi-GPU row ranges).
+    SgCollapse *collapse = nullptr;
+    const sg_csr *caller_b = nullptr;    // (borrowed: outlives the postings, like b_indptr)
+    sg_csr caller_b_copy;                // the struct itself, copied (the caller may free its handle's wrapper, not the arrays)
+    int64_t n_right_caller = 0;
+    mutable sg_postings *plain = nullptr;
+    int32_t build_tile_cols = 0, build_flags = 0;
 };
 
 struct sg_topn {
@@ -274,6 +294,13 @@ int sg_spgemm_exact_selfjoin_rows(sg_ctx *ctx, const sg_csr *A, const sg_posting
                                   double threshold, uint32_t *row_counter, const uint32_t *row_list,
                                   const uint32_t *row_list_len, const SgPairSink &sink);
 
+// sg_collapse.hip
+int sg_collapse_build(sg_ctx *ctx, const sg_csr *B, SgCollapse **out);
+void sg_collapse_free(SgCollapse *c);
+int sg_collapse_expand(sg_ctx *ctx, const SgCollapse *c, const sg_topn *ru, bool rows_are_groups, sg_topn *out);
+// sg_sortvocab.hip: stable sort of (key, value) pairs by key
+int sg_sort_pairs_u64_u32(sg_ctx *ctx, const uint64_t *d_keys, const uint32_t *d_vals, int64_t n, uint64_t *d_keys_out,
+                          uint32_t *d_vals_out);
 // sg_sortvocab.hip: ascending distinct values of d_keys[0 .. n) and how often each occurs (d_keys is overwritten)
 int sg_sort_unique_u64(sg_ctx *ctx, uint64_t *d_keys, int64_t n, uint64_t *d_unique, int32_t *d_counts, int64_t *n_unique);
 

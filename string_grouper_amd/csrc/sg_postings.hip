@@ -436,8 +436,46 @@ extern "C" int sg_postings_build(sg_ctx *ctx, const sg_csr *B, int32_t tile_cols
     return sg_postings_build_flags(ctx, B, tile_cols, 0, out);
 }
 
+// internal flags of sg_postings_build_flags (above the public ones)
+#define SG_POSTINGS_NO_COLLAPSE (1 << 8)   // index every row (the collapse wrapper's own inner call; the on-demand plain index)
+#define SG_POSTINGS_INNER (1 << 9)         // called by the collapse wrapper: the wrapper's timer covers the build
+
 extern "C" int sg_postings_build_flags(sg_ctx *ctx, const sg_csr *B_in, int32_t tile_cols, int32_t flags, sg_postings **out) {
     SG_REQUIRE(ctx && B_in && out, "null argument");
+    if (!(flags & SG_POSTINGS_NO_COLLAPSE)) {
+        // identical rows (identical strings): one representative per group is indexed (sg_collapse.hip)
+        bool cl = false;
+        float n2 = 0.f;
+        SG_TRY(sg_csr_props(ctx, B_in, &cl, &n2));
+        SgCollapse *col = nullptr;
+        SgTimer timer(ctx, SG_K_POSTINGS);   // grouping + the index over the representatives
+        if (cl) SG_TRY(sg_collapse_build(ctx, B_in, &col));
+        if (col) {
+            sg_postings *inner = nullptr;
+            const int st = sg_postings_build_flags(ctx, col->unique, tile_cols, flags | SG_POSTINGS_NO_COLLAPSE | SG_POSTINGS_INNER, &inner);
+            if (st != SG_OK) {
+                sg_collapse_free(col);
+                return st;
+            }
+            inner->collapse = col;
+            inner->caller_b_copy = *B_in;
+            inner->caller_b_copy.owned = false;
+            inner->caller_b_copy.d_props_words = nullptr;
+            inner->caller_b = &inner->caller_b_copy;
+            inner->n_right_caller = B_in->n_rows;
+            inner->build_tile_cols = tile_cols;
+            inner->build_flags = flags;
+            *out = inner;
+            return SG_OK;
+        }
+        flags |= SG_POSTINGS_INNER;          // (no groups: this call goes on under the timer above)
+        const int st = sg_postings_build_flags(ctx, B_in, tile_cols, flags | SG_POSTINGS_NO_COLLAPSE, out);
+        if (st == SG_OK) {
+            (*out)->build_tile_cols = tile_cols;
+            (*out)->build_flags = flags & 0xff;
+        }
+        return st;
+    }
     const sg_csr *B = B_in;
     // cosine-like right-hand sides (non-negative, sorted rows, norms <= 1: TF-IDF) take the pruned multiply,
     // whose 16-bit accumulators make a 4096-column tile 8 KiB; everything else the exact kernel with 8 KiB
@@ -477,7 +515,11 @@ extern "C" int sg_postings_build_flags(sg_ctx *ctx, const sg_csr *B_in, int32_t 
     }
     sg_csr *permuted = nullptr;
     uint32_t *orig_of = nullptr, *pos_of = nullptr;
-    SgTimer timer(ctx, SG_K_POSTINGS);   // the whole build, the permuted copy included
+    SgTimer *timer = (flags & SG_POSTINGS_INNER) ? nullptr : new (std::nothrow) SgTimer(ctx, SG_K_POSTINGS);   // the whole build, the permuted copy included
+    struct TimerGuard {
+        SgTimer *t;
+        ~TimerGuard() { delete t; }
+    } timer_guard{timer};
     if (!(flags & SG_POSTINGS_NO_PERMUTATION)) SG_TRY(build_permuted(ctx, B_in, tile_cols, &permuted, &orig_of, &pos_of));
     if (permuted) B = permuted;   // everything below indexes right-hand rows by POSITION
     sg_postings *p = new (std::nothrow) sg_postings();
@@ -784,6 +826,8 @@ extern "C" int sg_postings_free(sg_postings *p) {
     p->ctx->release(p->d_orig_of);
     p->ctx->release(p->d_pos_of);
     sg_csr_free(p->permuted);
+    sg_collapse_free(p->collapse);
+    if (p->plain) sg_postings_free(p->plain);
     delete p;
     return SG_OK;
 }

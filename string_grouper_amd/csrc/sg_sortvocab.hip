@@ -50,3 +50,19 @@ int sg_sort_unique_u64(sg_ctx *ctx, uint64_t *d_keys, int64_t n, uint64_t *d_uni
     *n_unique = runs;
     return SG_OK;
 }
+
+int sg_sort_pairs_u64_u32(sg_ctx *ctx, const uint64_t *d_keys, const uint32_t *d_vals, int64_t n, uint64_t *d_keys_out,
+                          uint32_t *d_vals_out) {
+    if (n <= 0) return SG_OK;
+    size_t tmp = 0;
+    hipError_t e = rocprim::radix_sort_pairs(nullptr, tmp, d_keys, d_keys_out, d_vals, d_vals_out, (size_t)n, 0, 64, ctx->stream);
+    void *d_tmp = nullptr;
+    int st = e == hipSuccess ? ctx->alloc(tmp ? tmp : 256, &d_tmp) : SG_ERR_HIP;
+    if (st == SG_OK) {
+        e = rocprim::radix_sort_pairs(d_tmp, tmp, d_keys, d_keys_out, d_vals, d_vals_out, (size_t)n, 0, 64, ctx->stream);
+        if (e != hipSuccess) st = SG_ERR_HIP;
+    }
+    ctx->release(d_tmp);   // (stream-ordered reuse)
+    if (st != SG_OK) sg_set_error("sorting (hash, row) pairs failed: %s", hipGetErrorString(e));
+    return st;
+}

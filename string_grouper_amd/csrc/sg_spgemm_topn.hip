@@ -753,9 +753,66 @@ static bool pruned_applicable(sg_ctx *ctx, const sg_csr *A, const sg_postings *B
     return true;
 }
 
+// The index was built over one representative per group of identical right-hand rows (sg_collapse.hip): multiply on the
+// groups, expand to the caller's columns (and, in a self-join, to the caller's rows).
+static int spgemm_topn_collapsed(sg_ctx *ctx, const sg_csr *A, const sg_postings *Bt, int32_t top_n, double threshold,
+                                 int32_t sort, sg_topn **out) {
+    const SgCollapse *c = Bt->collapse;
+    int64_t stride64 = top_n;
+    if (stride64 > c->n_orig) stride64 = c->n_orig > 0 ? c->n_orig : 1;
+    if (stride64 > SG_TOPN_LANES) {
+        // more columns per row than one register list: an index over all rows, built once, serves these calls
+        if (!Bt->plain)
+            SG_TRY(sg_postings_build_flags(ctx, &Bt->caller_b_copy, Bt->build_tile_cols, (Bt->build_flags & 0xff) | (1 << 8), &Bt->plain));
+        return sg_spgemm_topn(ctx, A, Bt->plain, top_n, threshold, sort, out);
+    }
+    const sg_csr *cb = &Bt->caller_b_copy;
+    const bool self = A->n_rows == c->n_orig && A->d_indptr == cb->d_indptr && A->d_indices == cb->d_indices &&
+                      A->d_data == cb->d_data;
+    sg_postings view = *Bt;          // shallow: the same index, seen without the groups
+    view.collapse = nullptr;
+    view.plain = nullptr;
+    sg_topn *ru = nullptr;
+    SG_TRY(sg_spgemm_topn(ctx, self ? c->unique : A, &view, top_n, threshold, 1, &ru));
+    sg_topn *r = nullptr;
+    int st = topn_alloc(ctx, A->n_rows, c->n_orig, (int32_t)stride64, A->dtype, &r);
+    if (st == SG_OK) {
+        SgTimer timer(ctx, SG_K_ZIP);    // the expansion is a merge by column, like the zip of column blocks
+        if (hipMemsetAsync(r->d_counts, 0, sizeof(int32_t) * (size_t)(A->n_rows + 1), ctx->stream) != hipSuccess) st = SG_ERR_HIP;
+        if (st == SG_OK) st = sg_collapse_expand(ctx, c, ru, self, r);
+        if (st == SG_OK && !sort && A->n_rows > 0) {
+            const unsigned g2 = (unsigned)(A->n_rows < 65535 * 16 ? A->n_rows : 65535 * 16);
+            const size_t l2 = (size_t)r->stride * (4 + (A->dtype == SG_F64 ? 8 : 4));
+            if (A->dtype == SG_F64)
+                hipLaunchKernelGGL(topn_sort_by_col_kernel<double>, dim3(g2), dim3(64), l2, ctx->stream, r->d_cols, (double *)r->d_vals,
+                                   r->d_counts, A->n_rows, r->stride);
+            else
+                hipLaunchKernelGGL(topn_sort_by_col_kernel<float>, dim3(g2), dim3(64), l2, ctx->stream, r->d_cols, (float *)r->d_vals,
+                                   r->d_counts, A->n_rows, r->stride);
+        }
+        if (st == SG_OK && A->n_rows > 0) {   // entries kept, counted on the expanded result
+            (void)hipMemsetAsync(ctx->d_stat_words + 1, 0, sizeof(int64_t), ctx->stream);
+            hipLaunchKernelGGL(sum_counts_kernel, dim3(256), dim3(256), 0, ctx->stream, r->d_counts, A->n_rows,
+                               (unsigned long long *)(ctx->d_stat_words + 1));
+            if (hipGetLastError() != hipSuccess) st = SG_ERR_HIP;
+        }
+    }
+    sg_topn_free(ru);
+    if (st != SG_OK) {
+        sg_topn_free(r);
+        return st;
+    }
+    *out = r;
+    return SG_OK;
+}
+
 extern "C" int sg_spgemm_topn(sg_ctx *ctx, const sg_csr *A, const sg_postings *Bt, int32_t top_n, double threshold,
                               int32_t sort, sg_topn **out) {
     SG_REQUIRE(ctx && A && Bt && out, "null argument");
+    if (Bt->collapse) {
+        SG_REQUIRE(A->n_cols == Bt->n_terms && A->dtype == Bt->dtype && top_n >= 1, "A and B differ in columns or value type, or top_n < 1");
+        return spgemm_topn_collapsed(ctx, A, Bt, top_n, threshold, sort, out);
+    }
     SG_REQUIRE(A->n_cols == Bt->n_terms, "A and B have different numbers of columns (vocabulary size)");
     SG_REQUIRE(A->dtype == Bt->dtype, "A and B have different value types");
     SG_REQUIRE(top_n >= 1, "top_n must be >= 1");
@@ -940,6 +997,7 @@ extern "C" int sg_selfjoin_range(sg_ctx *ctx, const sg_csr *A, const sg_postings
     *n_pairs = 0;
     *pair_words = A->dtype == SG_F64 ? 4 : 3;
     *applicable = 0;
+    if (Bt->collapse) return SG_OK;   // (an index over groups of identical rows: the row-block form, through sg_spgemm_topn)
     if (!(threshold > 0.0)) threshold = 0.0;
     int64_t stride64 = top_n;
     if (stride64 > Bt->n_right) stride64 = Bt->n_right > 0 ? Bt->n_right : 1;

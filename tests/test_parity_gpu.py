@@ -1287,3 +1287,56 @@ def test_hip_equals_the_canonical_tie_rule_exactly_and_the_arrival_rule_tie_awar
     arrival = P.sp_matmul_topn_port(A, A.T, top_n, thr, True, 8, tie_rule=1)
     assert (C_dev != arrival).nnz > 0
     assert O.compare_tie_aware(C_dev, arrival, top_n) == []
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("order", ["shuffled", "sorted"])
+def test_identical_rows_are_collapsed_and_the_result_is_the_ports(ctx, dtype, order, monkeypatch):
+    """Hubs of identical names (3 000, 700, 40 and pairs) with near-duplicates around them: the index is built over one
+    representative per group (sg_collapse.hip), the multiply runs on groups and is expanded -- self-join and one-sided,
+    top_n below and above a hub's size, top_n above the register list (the plain index on demand), collapse forced off --
+    always the port's result, bit for bit, ties at the cut included (lowest columns win)."""
+    from string_grouper_amd.sparse_dot_topn import sp_matmul_topn
+    rng = np.random.default_rng(21)
+    names = _names(20000, seed=77)
+    for hub, size in (("ACME HOLDINGS INC", 3000), ("ZENITH CAPITAL PARTNERS LP", 700), ("OMEGA TRUST", 40)):
+        for at in rng.choice(len(names), size, replace=False):
+            names[at] = hub
+    for at in rng.choice(len(names), 300, replace=False):
+        names[at] = "ACME HOLDINGS INC" + rng.choice([".", " 2", "ORPORATED", " LLC"])
+    for at in rng.choice(len(names) - 1, 500, replace=False):
+        names[at + 1] = names[at]                              # pairs
+    if order == "sorted":
+        names = sorted(names)
+    A = _tfidf(names, dtype)
+    for top_n, thr in ((10, 0.8), (5, 0.6), (64, 0.8), (100, 0.8)):
+        want = P.sp_matmul_topn_port(A, A.T, top_n, thr, True, 8)
+        for collapse in ("1", "0"):
+            monkeypatch.setenv("SG_COLLAPSE", collapse)
+            got = sp_matmul_topn(A, A.T, top_n, thr, sort=True, ctx=ctx)
+            assert_csr_identical(got, want, f"self-join top_n={top_n} thr={thr} collapse={collapse} {order}")
+    monkeypatch.setenv("SG_COLLAPSE", "1")
+    left = A[1000:7000]
+    assert_csr_identical(sp_matmul_topn(left, A.T, 10, 0.8, sort=True, ctx=ctx), P.sp_matmul_topn_port(left, A.T, 10, 0.8, True, 8),
+                         "one-sided, columns expanded")
+    assert_csr_identical(sp_matmul_topn(left, A.T, 7, 0.5, sort=False, ctx=ctx), P.sp_matmul_topn_port(left, A.T, 7, 0.5, False, 8),
+                         "one-sided, sorted by column")
+    monkeypatch.delenv("SG_COLLAPSE")
+    # the public API on a list with hubs: groups and frames as on the uncollapsed path (the fuzz and fixture tests cover
+    # the rest; here the hubs are larger than max_n_matches)
+    import pandas as pd
+    import string_grouper_amd as sga
+    import string_grouper_amd.engine as E
+    old = E._engine
+    try:
+        E.set_engine(E.HipEngine(ctx))
+        s = pd.Series(names)
+        monkeypatch.setenv("SG_COLLAPSE", "0")
+        want_g = sga.group_similar_strings(s, min_similarity=0.8, tfidf_matrix_dtype=dtype)
+        want_m = sga.match_strings(s, min_similarity=0.8, max_n_matches=8, tfidf_matrix_dtype=dtype)
+        monkeypatch.setenv("SG_COLLAPSE", "1")
+        pd.testing.assert_frame_equal(pd.DataFrame(sga.group_similar_strings(s, min_similarity=0.8, tfidf_matrix_dtype=dtype)),
+                                      pd.DataFrame(want_g))
+        pd.testing.assert_frame_equal(sga.match_strings(s, min_similarity=0.8, max_n_matches=8, tfidf_matrix_dtype=dtype), want_m)
+    finally:
+        E.set_engine(old)
