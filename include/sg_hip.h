@@ -251,7 +251,22 @@ int sg_selfjoin_range(sg_ctx *ctx, const sg_csr *A, const sg_postings *Bt, int32
                       int32_t *pair_words, int32_t *applicable);
 int sg_selfjoin_merge(sg_ctx *ctx, sg_topn *res, const sg_postings *Bt, const int32_t *d_pairs, int64_t n_pairs,
                       int32_t pair_words, int64_t row_lo, int64_t row_hi);
-/* device tables of Bt's row permutation, n_right entries each: position -> row, row -> position (both null: none) */
+/* Identical rows.  sg_postings_build indexes ONE representative per group of identical right-hand rows (identical
+ * strings; option SG_COLLAPSE=0 switches it off) and sg_spgemm_topn expands its result to the caller's columns, so a
+ * single GPU never sees the groups.  The self-join form over ranges does: with such an index
+ *   - the ranges of sg_selfjoin_range are ranges of the GROUPS' positions, [0, *n_index_rows) of sg_postings_rows; the
+ *     result objects and the permutation tables have one row per group (groups are numbered by ascending lowest member;
+ *     *d_group_of_row: the group of every caller row, device memory of the index, null when nothing was grouped);
+ *   - after sg_selfjoin_merge, sg_topn_expand_groups turns the rows of a rank's groups into the result rows of their
+ *     MEMBERS: output row k is the caller's row d_rows[k] (device array of n_rows row numbers, each a member of a group
+ *     whose row of `groups` is final; null = all rows), columns are the caller's -- bit for bit the rows
+ *     sg_spgemm_topn(A, Bt) returns (sorted by score descending, then column ascending).  The tables it needs (groups'
+ *     members) are part of the index every rank builds, so a rank expands its own groups without any exchange.
+ * (The reference has no analogue: sparse_dot_topn multiplies every duplicate row again, string_grouper.py:728-752.) */
+int sg_postings_rows(const sg_postings *Bt, int64_t *n_index_rows, int64_t *n_caller_rows, const uint32_t **d_group_of_row);
+int sg_topn_expand_groups(sg_ctx *ctx, const sg_postings *Bt, const sg_topn *groups, const int32_t *d_rows, int64_t n_rows,
+                          sg_topn **out);
+/* device tables of Bt's row permutation, one entry per index row: position -> row, row -> position (both null: none) */
 int sg_postings_permutation(const sg_postings *Bt, const uint32_t **d_orig_of, const uint32_t **d_pos_of);
 int sg_device_free(sg_ctx *ctx, void *d_ptr);
 

@@ -7,7 +7,9 @@ makes (string_grouper_amd/distributed.py: distributed_self_join in its self-join
   per rank r of N   tokenise + weight its row block (K1, K2 -- measured on block r of the list)
                     inverted index of the WHOLE matrix (K3 -- replicated work, measured once)
                     pass 1 of the self-join form over ITS range of positions (sg_selfjoin_range -- measured per rank)
-                    merge of the mirrored pairs that point into its range (sg_selfjoin_merge -- measured per rank)
+                    merge of the mirrored pairs that point into its range (sg_selfjoin_merge) and, when the index is one
+                    over groups of identical rows, expansion of its groups into their member rows
+                    (sg_topn_expand_groups) -- measured per rank through HipOps.selfjoin_merge, the driver's call
   collectives       all-reduce of the dense df table, all-gather of the CSR blocks, all-gather of the mirrored pairs:
                     bytes a rank receives / 300 GB/s (7 xGMI links x ~153 GB/s point to point, ring collectives are
                     per-link bound: MI355X_MICROARCH.md) + 20 us per collective -- a MODEL, labelled as such
@@ -68,8 +70,12 @@ def main():
               "postings_ms_kernels": k_post.get("postings", 0.0), "ranks": {}}
     print(f"# {n} rows, nnz {nnz}; inverted index of the whole matrix: {t_post:.3f} ms wall ({k_post.get('postings', 0):.3f} ms kernels)")
     one_gpu = None
+    ops = D.HipOps(ctx, make_vec)
+    n_index, _, grouped = ctx.postings_rows(post)      # (an index over groups of identical rows: ranges of groups)
+    report["index_rows"] = int(n_index)
+    print(f"# index over {n_index} rows" + (" (groups of identical rows)" if grouped else ""))
     for world in (1, 2, 4, 8):
-        bounds = D.selfjoin_row_ranges(n, world)
+        bounds = D.selfjoin_row_ranges(n_index, world)
         per_rank = []
         pair_counts = []
         for r in range(world):
@@ -127,11 +133,14 @@ def main():
             words = pr["_words"]
 
             def merge():
-                ctx.selfjoin_merge(pr["_res"], post, pairs_all.data_ptr(), pairs_all.numel() // words, words, plo, phi)
-            t_m, k_m, _ = ms(merge, reps=1)
+                # the driver's call: merge of the pairs that point into the range + (index over groups) expansion of the
+                # range's groups into their member rows
+                return ops.selfjoin_merge({"res": pr["_res"], "ptr": pr["_ptr"], "n": pr["pairs"], "words": words, "post": post},
+                                          pairs_all, plo, phi)
+            t_m, k_m, blk = ms(merge, reps=1)
             pr["merge_ms_wall"] = t_m
-            pr["_res"].free()
-            ctx.device_free(pr["_ptr"])
+            pr["rows_out"] = int(blk.dims()[0])
+            blk.free()
             for k in ("_res", "_ptr", "_words"):
                 pr.pop(k)
         # collectives (model): df table all-reduce (2 x table x (N-1)/N through the ring), CSR all-gather (a rank receives

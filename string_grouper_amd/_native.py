@@ -97,6 +97,8 @@ ABI = {
     "sg_selfjoin_range": (C.c_int, [_P, _P, _P, C.c_int32, C.c_double, C.c_int64, C.c_int64, _P, _P, _P, _P, _P]),
     "sg_selfjoin_merge": (C.c_int, [_P, _P, _P, _P, C.c_int64, C.c_int32, C.c_int64, C.c_int64]),
     "sg_postings_permutation": (C.c_int, [_P, _PP, _PP]),
+    "sg_postings_rows": (C.c_int, [_P, _P, _P, _PP]),
+    "sg_topn_expand_groups": (C.c_int, [_P, _P, _P, _P, C.c_int64, _PP]),
     "sg_device_free": (C.c_int, [_P, _P]),
     "sg_csr_rowwise_dot": (C.c_int, [_P, _P, _P, _P]),
     "sg_ctx_stats": (C.c_int, [_P, C.POINTER(SgStats)]),
@@ -510,6 +512,20 @@ class Context:
         a, b = C.c_void_p(), C.c_void_p()
         check(lib().sg_postings_permutation(Bt.h, C.byref(a), C.byref(b)))
         return a.value or 0, b.value or 0
+
+    def postings_rows(self, Bt: Postings):
+        """(rows of the index, rows of the matrix it was built from, device pointer of the row -> group table or 0):
+        the first two differ when identical rows were grouped (include/sg_hip.h: sg_postings_rows)."""
+        a, b, g = C.c_int64(), C.c_int64(), C.c_void_p()
+        check(lib().sg_postings_rows(Bt.h, C.byref(a), C.byref(b), C.byref(g)))
+        return a.value, b.value, g.value or 0
+
+    def topn_expand_groups(self, Bt: Postings, groups: "TopN", d_rows: int = 0, n_rows: int = 0) -> "TopN":
+        """The rows ``d_rows`` (device int32 row numbers; 0 = all rows) of the result over the caller's rows, from a
+        result with one row per group of the index (sg_topn_expand_groups)."""
+        out = C.c_void_p()
+        check(lib().sg_topn_expand_groups(self.h, Bt.h, groups.h, C.c_void_p(d_rows) if d_rows else None, int(n_rows), C.byref(out)))
+        return TopN(self, out)
 
     def device_free(self, d_ptr: int) -> None:
         if d_ptr:

@@ -320,13 +320,15 @@ template <typename T>
 __global__ void __launch_bounds__(256) expand_simple_kernel(const int32_t *__restrict__ u_cols, const T *__restrict__ u_vals,
                                                             const int32_t *__restrict__ u_cnt, int32_t u_stride,
                                                             const uint32_t *__restrict__ gid /* null: output row r = row r of u */,
+                                                            const int32_t *__restrict__ row_list /* null: output row r is row r */,
                                                             const uint32_t *__restrict__ group_ptr, const uint32_t *__restrict__ members,
                                                             int64_t n_out, int32_t stride, int32_t *__restrict__ cols,
                                                             T *__restrict__ vals, int32_t *__restrict__ cnt,
                                                             uint32_t *__restrict__ slow_count, uint32_t *__restrict__ slow_rows) {
     const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n_out) return;
-    const int64_t ur = gid ? (int64_t)gid[r] : r;
+    const int64_t row = row_list ? (int64_t)row_list[r] : r;
+    const int64_t ur = gid ? (int64_t)gid[row] : row;
     const int32_t m = u_cnt[ur];
     const int32_t *uc = u_cols + ur * u_stride;
     const T *uv = u_vals + ur * u_stride;
@@ -348,7 +350,8 @@ __global__ void __launch_bounds__(256) expand_simple_kernel(const int32_t *__res
 template <typename T>
 __global__ void __launch_bounds__(64) expand_merge_kernel(const int32_t *__restrict__ u_cols, const T *__restrict__ u_vals,
                                                           const int32_t *__restrict__ u_cnt, int32_t u_stride,
-                                                          const uint32_t *__restrict__ gid, const uint32_t *__restrict__ group_ptr,
+                                                          const uint32_t *__restrict__ gid, const int32_t *__restrict__ row_list,
+                                                          const uint32_t *__restrict__ group_ptr,
                                                           const uint32_t *__restrict__ members, int32_t stride,
                                                           int32_t *__restrict__ cols, T *__restrict__ vals, int32_t *__restrict__ cnt,
                                                           const uint32_t *__restrict__ slow_count, const uint32_t *__restrict__ slow_rows) {
@@ -356,7 +359,8 @@ __global__ void __launch_bounds__(64) expand_merge_kernel(const int32_t *__restr
     const uint32_t n_slow = *slow_count;
     for (uint32_t q = blockIdx.x; q < n_slow; q += gridDim.x) {
         const int64_t r = slow_rows[q];
-        const int64_t ur = gid ? (int64_t)gid[r] : r;
+        const int64_t row = row_list ? (int64_t)row_list[r] : r;
+        const int64_t ur = gid ? (int64_t)gid[row] : row;
         const int32_t m = u_cnt[ur];
         const int32_t *uc = u_cols + ur * u_stride;
         const T *uv = u_vals + ur * u_stride;
@@ -429,7 +433,8 @@ __global__ void __launch_bounds__(64) expand_merge_kernel(const int32_t *__restr
 
 // ru: result over groups (rows: groups if `rows_are_groups`, else the caller's left rows).  out: allocated by the caller
 // (n_out rows, stride), filled here.
-int sg_collapse_expand(sg_ctx *ctx, const SgCollapse *c, const sg_topn *ru, bool rows_are_groups, sg_topn *out) {
+int sg_collapse_expand(sg_ctx *ctx, const SgCollapse *c, const sg_topn *ru, bool rows_are_groups, sg_topn *out,
+                       const int32_t *row_list) {
     const int64_t n_out = out->n_rows;
     if (n_out <= 0) return SG_OK;
     uint32_t *slow = nullptr;
@@ -440,20 +445,20 @@ int sg_collapse_expand(sg_ctx *ctx, const SgCollapse *c, const sg_topn *ru, bool
         const uint32_t *gid = rows_are_groups ? c->d_gid : nullptr;
         if (out->dtype == SG_F64) {
             hipLaunchKernelGGL(expand_simple_kernel<double>, dim3(g1), dim3(256), 0, ctx->stream, (const int32_t *)ru->d_cols,
-                               (const double *)ru->d_vals, (const int32_t *)ru->d_counts, ru->stride, gid,
+                               (const double *)ru->d_vals, (const int32_t *)ru->d_counts, ru->stride, gid, row_list,
                                (const uint32_t *)c->d_group_ptr, (const uint32_t *)c->d_members, n_out, out->stride, out->d_cols,
                                (double *)out->d_vals, out->d_counts, slow, slow + 4);
             hipLaunchKernelGGL(expand_merge_kernel<double>, dim3(2048), dim3(64), 0, ctx->stream, (const int32_t *)ru->d_cols,
-                               (const double *)ru->d_vals, (const int32_t *)ru->d_counts, ru->stride, gid,
+                               (const double *)ru->d_vals, (const int32_t *)ru->d_counts, ru->stride, gid, row_list,
                                (const uint32_t *)c->d_group_ptr, (const uint32_t *)c->d_members, out->stride, out->d_cols,
                                (double *)out->d_vals, out->d_counts, (const uint32_t *)slow, (const uint32_t *)(slow + 4));
         } else {
             hipLaunchKernelGGL(expand_simple_kernel<float>, dim3(g1), dim3(256), 0, ctx->stream, (const int32_t *)ru->d_cols,
-                               (const float *)ru->d_vals, (const int32_t *)ru->d_counts, ru->stride, gid,
+                               (const float *)ru->d_vals, (const int32_t *)ru->d_counts, ru->stride, gid, row_list,
                                (const uint32_t *)c->d_group_ptr, (const uint32_t *)c->d_members, n_out, out->stride, out->d_cols,
                                (float *)out->d_vals, out->d_counts, slow, slow + 4);
             hipLaunchKernelGGL(expand_merge_kernel<float>, dim3(2048), dim3(64), 0, ctx->stream, (const int32_t *)ru->d_cols,
-                               (const float *)ru->d_vals, (const int32_t *)ru->d_counts, ru->stride, gid,
+                               (const float *)ru->d_vals, (const int32_t *)ru->d_counts, ru->stride, gid, row_list,
                                (const uint32_t *)c->d_group_ptr, (const uint32_t *)c->d_members, out->stride, out->d_cols,
                                (float *)out->d_vals, out->d_counts, (const uint32_t *)slow, (const uint32_t *)(slow + 4));
         }

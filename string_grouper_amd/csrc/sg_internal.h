@@ -297,7 +297,8 @@ int sg_spgemm_exact_selfjoin_rows(sg_ctx *ctx, const sg_csr *A, const sg_posting
 // sg_collapse.hip
 int sg_collapse_build(sg_ctx *ctx, const sg_csr *B, SgCollapse **out);
 void sg_collapse_free(SgCollapse *c);
-int sg_collapse_expand(sg_ctx *ctx, const SgCollapse *c, const sg_topn *ru, bool rows_are_groups, sg_topn *out);
+int sg_collapse_expand(sg_ctx *ctx, const SgCollapse *c, const sg_topn *ru, bool rows_are_groups, sg_topn *out,
+                       const int32_t *row_list = nullptr);   // row_list: output row k is the caller's row row_list[k]
 // sg_sortvocab.hip: stable sort of (key, value) pairs by key
 int sg_sort_pairs_u64_u32(sg_ctx *ctx, const uint64_t *d_keys, const uint32_t *d_vals, int64_t n, uint64_t *d_keys_out,
                           uint32_t *d_vals_out);

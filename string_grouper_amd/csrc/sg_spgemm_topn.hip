@@ -997,7 +997,23 @@ extern "C" int sg_selfjoin_range(sg_ctx *ctx, const sg_csr *A, const sg_postings
     *n_pairs = 0;
     *pair_words = A->dtype == SG_F64 ? 4 : 3;
     *applicable = 0;
-    if (Bt->collapse) return SG_OK;   // (an index over groups of identical rows: the row-block form, through sg_spgemm_topn)
+    if (Bt->collapse) {
+        // an index over groups of identical rows: the ranges are ranges of the GROUPS' positions (sg_postings_rows), the
+        // result has one row per group; sg_topn_expand_groups turns the gathered result into the caller's rows
+        const SgCollapse *c = Bt->collapse;
+        const sg_csr *cb = &Bt->caller_b_copy;
+        if (!(A->n_rows == c->n_orig && A->d_indptr == cb->d_indptr && A->d_indices == cb->d_indices && A->d_data == cb->d_data))
+            return SG_OK;                 // not the matrix the index was built from: the row-block form
+        if (row_hi > c->n_u) {
+            sg_set_error("row range [%lld, %lld) outside the %lld groups of the index (sg_postings_rows)", (long long)row_lo,
+                         (long long)row_hi, (long long)c->n_u);
+            return SG_ERR_BADARG;
+        }
+        sg_postings view = *Bt;           // shallow: the same index, seen without the groups
+        view.collapse = nullptr;
+        view.plain = nullptr;
+        return sg_selfjoin_range(ctx, c->unique, &view, top_n, threshold, row_lo, row_hi, out, d_pairs, n_pairs, pair_words, applicable);
+    }
     if (!(threshold > 0.0)) threshold = 0.0;
     int64_t stride64 = top_n;
     if (stride64 > Bt->n_right) stride64 = Bt->n_right > 0 ? Bt->n_right : 1;
@@ -1044,6 +1060,40 @@ extern "C" int sg_selfjoin_merge(sg_ctx *ctx, sg_topn *res, const sg_postings *B
     SG_REQUIRE(row_lo >= 0 && row_lo <= row_hi && row_hi <= res->n_rows, "row range outside the result");
     SgTimer timer(ctx, SG_K_ZIP);
     return sg_selfjoin_merge_pairs(ctx, res, d_pairs, n_pairs, row_lo, row_hi, Bt ? (const uint32_t *)Bt->d_pos_of : nullptr);
+}
+
+extern "C" int sg_postings_rows(const sg_postings *Bt, int64_t *n_index_rows, int64_t *n_caller_rows,
+                                const uint32_t **d_group_of_row) {
+    SG_REQUIRE(Bt != nullptr, "postings are null");
+    if (n_index_rows) *n_index_rows = Bt->n_right;
+    if (n_caller_rows) *n_caller_rows = Bt->collapse ? Bt->collapse->n_orig : Bt->n_right;
+    if (d_group_of_row) *d_group_of_row = Bt->collapse ? Bt->collapse->d_gid : nullptr;
+    return SG_OK;
+}
+
+extern "C" int sg_topn_expand_groups(sg_ctx *ctx, const sg_postings *Bt, const sg_topn *groups, const int32_t *d_rows,
+                                     int64_t n_rows, sg_topn **out) {
+    SG_REQUIRE(ctx && Bt && groups && out, "null argument");
+    SG_REQUIRE(Bt->collapse != nullptr, "the index was not built over groups of identical rows (sg_postings_rows)");
+    const SgCollapse *c = Bt->collapse;
+    SG_REQUIRE(groups->n_rows == c->n_u, "the result does not have one row per group of the index");
+    SG_REQUIRE(groups->dtype == Bt->dtype, "result and index differ in value type");
+    if (!d_rows) n_rows = c->n_orig;
+    SG_REQUIRE(n_rows >= 0 && n_rows <= c->n_orig, "more rows than the matrix has");
+    sg_topn *r = nullptr;
+    SG_TRY(topn_alloc(ctx, n_rows, c->n_orig, groups->stride, groups->dtype, &r));
+    int st = SG_OK;
+    {
+        SgTimer timer(ctx, SG_K_ZIP);
+        if (hipMemsetAsync(r->d_counts, 0, sizeof(int32_t) * (size_t)(n_rows + 1), ctx->stream) != hipSuccess) st = SG_ERR_HIP;
+        if (st == SG_OK) st = sg_collapse_expand(ctx, c, groups, true, r, d_rows);
+    }
+    if (st != SG_OK) {
+        sg_topn_free(r);
+        return st;
+    }
+    *out = r;
+    return SG_OK;
 }
 
 extern "C" int sg_postings_permutation(const sg_postings *Bt, const uint32_t **d_orig_of, const uint32_t **d_pos_of) {

@@ -228,7 +228,7 @@ def sharded_selfjoin_topn(ops, A_full, post, top_n: int, threshold: float, group
     block of the result (rows of its range, in rank order = row order), or None when the form does not apply to the
     input on some rank (then nothing has been changed and the caller multiplies row blocks)."""
     rank, world = dist.get_rank(group), dist.get_world_size(group)
-    n = ops.csr_shape(A_full)[0]
+    n = ops.selfjoin_rows(A_full, post)        # (rows of the INDEX: groups of identical rows, when the library grouped them)
     bounds = selfjoin_row_ranges(n, world)
     lo, hi = int(bounds[rank]), int(bounds[rank + 1])
     part = ops.selfjoin_range(A_full, post, top_n, threshold, lo, hi)
@@ -250,6 +250,11 @@ def gather_topn(ops, res, group=None, on_device: bool = False):
     all-gather (the fused tail of fit(), K6-K8, runs on the device: no reason to cross PCIe twice)."""
     cols, vals, counts = ops.topn_tensors(res)
     stride = cols.shape[1] if cols.dim() == 2 else 1
+    row_ids = getattr(res, "row_ids", None)
+    if row_ids is not None and dist.get_world_size(group) > 1:
+        # the rank's block holds the rows row_ids (members of its groups of identical rows): their numbers travel along
+        sizes = [h[0] for h in all_headers([row_ids.numel()], counts.device, group)]
+        row_ids = torch.cat(all_gather_ragged(row_ids, group, sizes))
     if dist.get_world_size(group) > 1:
         head = all_headers([stride, counts.numel()], counts.device, group)
         strides, rows = [h[0] for h in head], [h[1] for h in head]
@@ -268,6 +273,13 @@ def gather_topn(ops, res, group=None, on_device: bool = False):
         cols = torch.empty_like(cols).index_copy_(0, orig_of, cols)
         vals = torch.empty_like(vals).index_copy_(0, orig_of, vals)
         counts = torch.empty_like(counts).index_copy_(0, orig_of, counts)
+    if row_ids is not None:
+        if counts.numel() != row_ids.numel() or (row_ids.numel() and int(row_ids.max()) >= row_ids.numel()):
+            raise RuntimeError(f"the ranks' blocks hold {counts.numel()} rows for {row_ids.numel()} row numbers")
+        row_ids = row_ids.to(torch.int64)
+        cols = torch.empty_like(cols).index_copy_(0, row_ids, cols)
+        vals = torch.empty_like(vals).index_copy_(0, row_ids, vals)
+        counts = torch.empty_like(counts).index_copy_(0, row_ids, counts)
     if on_device:
         return cols.contiguous(), vals.contiguous(), counts.contiguous()
     return cols.cpu().numpy(), vals.cpu().numpy(), counts.cpu().numpy()
@@ -327,8 +339,11 @@ class TopNRows:
     the range is one of POSITIONS of the library's row permutation (int64 tensor, position -> row): the block's rows are
     orig_of[lo:hi], in that order; the blocks of all ranks concatenated are the result in position order."""
 
-    def __init__(self, res, lo: int, hi: int, orig_of=None):
+    def __init__(self, res, lo: int, hi: int, orig_of=None, row_ids=None):
         self.res, self.lo, self.hi, self.orig_of = res, lo, hi, orig_of
+        # ``row_ids`` given (int tensor): the index was built over GROUPS of identical rows, the rank's range was one of
+        # groups, and the block holds the rows that are members of these groups: block row k is row row_ids[k]
+        self.row_ids = row_ids
         self._keep = None
 
     def free(self):
@@ -451,7 +466,26 @@ class HipOps:
             if p_orig:
                 n = part["res"].dims()[0]
                 orig_of = torch.as_tensor(DeviceTensorView(p_orig, n, "<i4"), device=self.device)[:n].to(torch.int64)
-        return TopNRows(part["res"], lo, hi, orig_of)
+        n_index, n_caller, p_gid = self.ctx.postings_rows(post) if post is not None else (0, 0, 0)
+        if not p_gid:
+            return TopNRows(part["res"], lo, hi, orig_of)
+        # an index over groups of identical rows: the range was one of groups; the rows of this rank are the members of
+        # its groups, expanded here from tables every rank holds (no exchange)
+        mine = torch.zeros(n_index, dtype=torch.bool, device=self.device)
+        if orig_of is not None:
+            mine[orig_of[lo:hi]] = True
+        else:
+            mine[lo:hi] = True
+        gid = torch.as_tensor(DeviceTensorView(p_gid, n_caller, "<i4"), device=self.device)[:n_caller].to(torch.int64)
+        rows = torch.nonzero(mine[gid]).reshape(-1).to(torch.int32).contiguous()
+        torch.cuda.current_stream(self.device).synchronize()   # the row list is torch's: written before the library reads it
+        r = self.ctx.topn_expand_groups(post, part["res"], rows.data_ptr(), rows.numel())
+        self.ctx.sync()
+        part["res"].free()
+        return TopNRows(r, 0, rows.numel(), None, row_ids=rows)
+
+    def selfjoin_rows(self, A_full, post):
+        return self.ctx.postings_rows(post)[0]
 
     def topn_from_tensors(self, cols, vals, counts, n_cols: int):
         """The gathered result as a library object, without leaving HBM."""

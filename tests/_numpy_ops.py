@@ -114,10 +114,43 @@ class NumpyOps:
         orig_of[pos_of] = np.arange(n)
         return orig_of, pos_of
 
+    # The library indexes one representative per group of identical rows (sg_collapse.hip): the ranges of the self-join
+    # form are then ranges of GROUPS, the ranks' blocks hold groups, and the gathered result is expanded to rows
+    # (sg_postings_rows, sg_topn_expand_groups).  ``grouped = True`` restates that contract.
+    grouped = False
+
     def postings(self, m, tile_cols=0, permute=True):
-        return m
+        if not self.grouped:
+            return m
+        return GroupedIndex(m)
+
+    def selfjoin_rows(self, A_full, post):
+        return post.unique.shape[0] if isinstance(post, GroupedIndex) else A_full.shape[0]
+
+    @staticmethod
+    def expand_rows(post, rows, cols, vals, counts):
+        """sg_topn_expand_groups restated: result rows of the caller's ``rows`` from the result over groups."""
+        stride = cols.shape[1]
+        out_c = np.zeros((len(rows), stride), np.int32)
+        out_v = np.zeros((len(rows), stride), vals.dtype)
+        out_n = np.zeros(len(rows), np.int32)
+        for k, i in enumerate(rows):
+            g = post.gid[i]
+            c, v = [], []
+            for e in range(counts[g]):
+                mem = post.members[cols[g, e]]
+                c.extend(mem)
+                v.extend([vals[g, e]] * len(mem))
+            c, v = np.asarray(c, np.int64), np.asarray(v, vals.dtype)
+            order = np.lexsort((c, -v))[:stride]
+            out_n[k] = len(order)
+            out_c[k, :len(order)] = c[order]
+            out_v[k, :len(order)] = v[order]
+        return out_c, out_v, out_n
 
     def multiply(self, left, right, top_n, threshold):
+        if isinstance(right, GroupedIndex):
+            right = right.full
         C = P.sp_matmul_topn_port(left, right.T, top_n, threshold, True, 2)
         stride = max(1, min(top_n, right.shape[0]))
         n = left.shape[0]
@@ -136,6 +169,12 @@ class NumpyOps:
     # ---- the self-join form over row ranges: the contract of sg_selfjoin_range / sg_selfjoin_merge restated with the
     #      oracle's multiply (rows of the range keep their matches j <= i; mirrored pairs (i, j < i, score) go out)
     def selfjoin_range(self, A_full, post, top_n, threshold, lo, hi):
+        if isinstance(post, GroupedIndex):
+            # the result over GROUPS must hold what expansion needs: a row's top_n columns can come from top_n groups at
+            # most, so top_n groups per group are enough (the library's argument, sg_collapse.hip)
+            part = self.selfjoin_range(post.unique, post.unique, top_n, threshold, lo, hi)
+            part["groups_of"] = post
+            return part
         n = A_full.shape[0]
         orig_of, pos_of = self.permutation(n) if self.permuted else (np.arange(n), np.arange(n))
         rows = orig_of[lo:hi]                               # the rows of the range (of positions)
@@ -186,6 +225,13 @@ class NumpyOps:
             cnt[row] = len(order)
             cols[row, :len(order)] = c[order]
             vals[row, :len(order)] = v[order]
+        post = part.get("groups_of")
+        if post is not None:
+            # the range was one of groups: the rank's rows are the members of its groups, expanded from the tables of the
+            # index (which every rank holds)
+            mine = set(int(g) for g in orig_of[lo:hi])
+            rows = np.array([i for i in range(post.full.shape[0]) if int(post.gid[i]) in mine], np.int64)
+            return PermutedBlock(self.expand_rows(post, rows, cols, vals, cnt), None, torch.from_numpy(rows.astype(np.int32)))
         if self.permuted:
             ids = orig_of[lo:hi]
             return PermutedBlock((cols[ids], vals[ids], cnt[ids]), torch.from_numpy(orig_of))
@@ -201,8 +247,26 @@ class PermutedBlock:
     """A rank's block of the self-join form when the ranges are ranges of positions: rows orig_of[lo:hi] in that order
     (what distributed.TopNRows is for the device library)."""
 
-    def __init__(self, arrays, orig_of):
-        self.arrays, self.orig_of = arrays, orig_of
+    def __init__(self, arrays, orig_of, row_ids=None):
+        self.arrays, self.orig_of, self.row_ids = arrays, orig_of, row_ids
 
     def __getitem__(self, k):
         return self.arrays[k]
+
+
+class GroupedIndex:
+    """The index over one representative per group of identical rows: groups numbered by ascending lowest member."""
+
+    def __init__(self, m):
+        m = sp.csr_matrix(m)
+        self.full = m
+        key_to_group, self.members, self.gid = {}, [], np.zeros(m.shape[0], np.int64)
+        for i in range(m.shape[0]):
+            a, b = m.indptr[i], m.indptr[i + 1]
+            key = (m.indices[a:b].tobytes(), m.data[a:b].tobytes())
+            g = key_to_group.setdefault(key, len(self.members))
+            if g == len(self.members):
+                self.members.append([])
+            self.members[g].append(i)
+            self.gid[i] = g
+        self.unique = m[[mem[0] for mem in self.members]]

@@ -13,10 +13,17 @@ def pytest_configure(config):
 
 
 @pytest.fixture(scope="session")
-def ctx():
-    """Device context of the HIP library; GPU tests fail (not skip) if it cannot be created."""
+def _session_ctx():
     from string_grouper_amd import _native as N
     return N.default_context(0)
+
+
+@pytest.fixture
+def ctx(_session_ctx):
+    """Device context of the HIP library; GPU tests fail (not skip) if it cannot be created.  One per session; options a
+    test sets (``ctx.set_option``) end with the test."""
+    yield _session_ctx
+    _session_ctx.reset_options()
 
 
 @pytest.fixture

@@ -152,6 +152,25 @@ def _sharded_worker(rank, world, port, ret):
         ok["positions_counts"] = np.array_equal(np.diff(got.indptr), np.diff(C.indptr))
         ok["positions_indices"] = np.array_equal(got.indices, C.indices)
         ok["positions_scores"] = np.array_equal(got.data, C.data)
+        # ---- ... and with the index over one representative per group of identical rows (what the library builds by
+        #      default): the ranges are ranges of GROUPS, a rank's block holds the rows that are members of its groups
+        #      (expanded on the rank), gather_topn puts the gathered rows where their numbers say -- with and without the row permutation
+        for permuted in (False, True):
+            ops.grouped, ops.permuted = True, permuted
+            os.environ["SG_DIST_SYM"] = "1"
+            res, _ = D.distributed_self_join(ops, hubs[lo2:hi2], 10, 0.8)
+            os.environ["SG_DIST_SYM"] = "0"
+            ops.grouped = ops.permuted = False
+            tag = "groups_permuted" if permuted else "groups"
+            ok[tag + "_block_is_rows_of_my_groups"] = res.row_ids is not None and len(res[2]) == res.row_ids.numel()
+            n_mine = torch.tensor([res.row_ids.numel()])
+            dist.all_reduce(n_mine)
+            ok[tag + "_every_row_once"] = int(n_mine) == len(hubs)
+            cols, vals, counts = D.gather_topn(ops, res)
+            got = _csr_of(cols, vals, counts, len(hubs))
+            ok[tag + "_counts"] = np.array_equal(np.diff(got.indptr), np.diff(C.indptr))
+            ok[tag + "_indices"] = np.array_equal(got.indices, C.indices)
+            ok[tag + "_scores"] = np.array_equal(got.data, C.data)
         # ---- master x duplicates (configs[4]): both columns sharded, vocabulary from both, duplicates replicated
         master = synth_names(1800, 7)
         dups = synth_names(901, 8, perturb_of=master, perturb_frac=0.5)

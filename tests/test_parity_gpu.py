@@ -1019,8 +1019,10 @@ def test_selfjoin_form_over_row_ranges_equals_the_whole(ctx, dtype):
         inverse = np.argsort(blk_orig_of.cpu().numpy(), kind="stable")
         return C[inverse]
 
+    ctx.set_option("SG_COLLAPSE", "0")            # (an index over every row first; over groups of identical rows below)
     for permute in (False, True):
         post = ctx.postings_build(dA, permute=permute)
+        assert ctx.postings_rows(post) == (n, n, 0)
         for world in (1, 2, 3, 5):
             bounds = D.selfjoin_row_ranges(n, world)
             assert bounds[0] == 0 and bounds[-1] == n
@@ -1037,6 +1039,34 @@ def test_selfjoin_form_over_row_ranges_equals_the_whole(ctx, dtype):
                 blk.free()
             assert_csr_identical(stacked(rows, orig_of), want, f"{world} ranges, permutation {permute}")
         post.free()
+    # ---- the index over one representative per group of identical rows (the default when enough rows repeat): the
+    #      ranges are ranges of the groups' positions, a rank's block holds groups, the gathered blocks are expanded
+    ctx.set_option("SG_COLLAPSE", "1")
+    for permute in (False, True):
+        post = ctx.postings_build(dA, permute=permute)
+        n_groups, n_rows, p_gid = ctx.postings_rows(post)
+        assert p_gid and n_rows == n and n_groups == len({(A.indices[a:b].tobytes(), A.data[a:b].tobytes())
+                                                for a, b in zip(A.indptr[:-1], A.indptr[1:])}) < n - 230
+        for world in (1, 2, 5):
+            bounds = D.selfjoin_row_ranges(n_groups, world)
+            parts = [ops.selfjoin_range(dA, post, 10, 0.75, int(bounds[r]), int(bounds[r + 1])) for r in range(world)]
+            assert all(p is not None for p in parts)
+            pairs_all = torch.cat([ops.selfjoin_pairs(p).clone() for p in parts])
+            blocks = [ops.selfjoin_merge(parts[r], pairs_all, int(bounds[r]), int(bounds[r + 1])) for r in range(world)]
+            # a rank's block: the rows that are members of its groups, expanded on the rank (sg_topn_expand_groups)
+            assert all(b.row_ids is not None and b.orig_of is None and b.dims()[0] == b.row_ids.numel() for b in blocks)
+            ids = torch.cat([b.row_ids for b in blocks]).to(torch.int64)
+            assert ids.numel() == n and torch.equal(torch.sort(ids).values.cpu(), torch.arange(n))
+            # what gather_topn does with the ranks' blocks: concatenate, put every row where its number says
+            cols, vals, counts = (torch.cat(t) for t in zip(*[ops.topn_tensors(b) for b in blocks]))
+            cols, vals, counts = (torch.empty_like(t).index_copy_(0, ids, t).cpu().numpy() for t in (cols, vals, counts))
+            mask = np.arange(cols.shape[1])[None, :] < counts[:, None]
+            got = sp.csr_matrix((vals[mask], cols[mask], np.concatenate([[0], np.cumsum(counts)])), shape=(n, n))
+            assert_csr_identical(got, want, f"{world} ranges of groups, permutation {permute}")
+            for b in blocks:
+                b.free()
+        post.free()
+    ctx.set_option("SG_COLLAPSE", "0")
     # rows for the exact kernel (more than 128 terms) are scored inside the range's pass by that kernel's self-join launch
     extra = ["".join(rng.choice(list("ABCDEFGHIJKLMNOPQRSTUVWXYZ"), 180)) for _ in range(3)]
     long_names = names[:4000] + extra + names[4000:] + [extra[1][:170], extra[2]]
