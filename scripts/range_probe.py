@@ -19,7 +19,9 @@ p = vec.prepare(names)
 vec.fit_prepared([p])
 A = vec.transform_prepared(p)
 post = ctx.postings_build(A)
-for width in (4096, 16384, 65536):
+n = ctx.postings_rows(post)[0]      # (rows of the index: groups of identical rows when the library grouped them)
+print(f"index over {n} rows")
+for width in (256, 4096, 16384, 65536):
     out = []
     for frac in (0.1, 0.3, 0.5, 0.7, 0.9, 1.0):
         hi = int(frac * n)

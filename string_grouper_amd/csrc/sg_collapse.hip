@@ -314,8 +314,8 @@ int sg_collapse_build(sg_ctx *ctx, const sg_csr *B, SgCollapse **out) {
 }
 
 // ------------------------------------------------------------------------------------------------ expansion
-// Thread per output row: when every group the row matches has one member the row is a relabelling (group -> its row);
-// otherwise the row is queued for the wave-per-row kernel.
+// Thread per output row: the row's groups written out member by member; rows in which a group of several members ties
+// with another group are queued for the wave-per-row kernel.
 template <typename T>
 __global__ void __launch_bounds__(256) expand_simple_kernel(const int32_t *__restrict__ u_cols, const T *__restrict__ u_vals,
                                                             const int32_t *__restrict__ u_cnt, int32_t u_stride,
@@ -332,17 +332,26 @@ __global__ void __launch_bounds__(256) expand_simple_kernel(const int32_t *__res
     const int32_t m = u_cnt[ur];
     const int32_t *uc = u_cols + ur * u_stride;
     const T *uv = u_vals + ur * u_stride;
-    bool simple = m <= stride;
-    for (int32_t e = 0; simple && e < m; ++e) simple = group_ptr[uc[e] + 1] - group_ptr[uc[e]] == 1u;
-    if (!simple) {
-        slow_rows[atomicAdd(slow_count, 1u)] = (uint32_t)r;
-        return;
+    // A group of several members whose score no other group of the row shares is written member by member (members
+    // ascend); groups of one member that share a score are in column order already (groups are numbered by ascending
+    // lowest member, and the row over groups is sorted by score, then group).  Only a group of several members that
+    // TIES with another group needs the merge by column: the wave-per-row kernel rewrites such rows from scratch.
+    int32_t out = 0;
+    T prev = (T)0;
+    for (int32_t e = 0; e < m && out < stride; ++e) {
+        const uint32_t lo = group_ptr[uc[e]], hi = group_ptr[uc[e] + 1];
+        const T v = uv[e];
+        if (hi - lo != 1u && ((e > 0 && prev == v) || (e + 1 < m && uv[e + 1] == v))) {
+            slow_rows[atomicAdd(slow_count, 1u)] = (uint32_t)r;
+            return;
+        }
+        for (uint32_t p = lo; p < hi && out < stride; ++p, ++out) {
+            cols[r * stride + out] = (int32_t)members[p];
+            vals[r * stride + out] = v;
+        }
+        prev = v;
     }
-    for (int32_t e = 0; e < m; ++e) {
-        cols[r * stride + e] = (int32_t)members[group_ptr[uc[e]]];
-        vals[r * stride + e] = uv[e];
-    }
-    cnt[r] = m;
+    cnt[r] = out;
 }
 
 // Wave per queued row: the groups of one score are merged by column (every lane holds one group's next member, the
