@@ -74,6 +74,9 @@ def main():
     n_index, _, grouped = ctx.postings_rows(post)      # (an index over groups of identical rows: ranges of groups)
     report["index_rows"] = int(n_index)
     print(f"# index over {n_index} rows" + (" (groups of identical rows)" if grouped else ""))
+    # warm-up of the driver's calls (torch's first kernels, the library's pools): one whole pass + merge, thrown away
+    w = ops.selfjoin_range(A, post, 10, 0.8, 0, n_index)
+    ops.selfjoin_merge(w, ops.selfjoin_pairs(w).clone(), 0, n_index).free()
     for world in (1, 2, 4, 8):
         bounds = D.selfjoin_row_ranges(n_index, world)
         per_rank = []

@@ -68,6 +68,8 @@
 #include "sg_k4_device.h"
 
 // (SG_PAIR_CHUNK, the entries of a chunk of the symmetric mode's pair list: sg_internal.h)
+#define SG_ROW_PARTS_LOG2 4
+#define SG_ROW_PARTS 16u       // parts of a row in the launch over parts (stream + self-join form)
 #define SG_SURV_CAP 128   // survivors buffered per wave (scored 64 at a time as soon as 64 are there)
 
 // lane mask of a predicate as a wave-uniform scalar (s_and of the compare result, no VALU round trip)
@@ -363,6 +365,41 @@ __device__ __noinline__ FlushOut<T> flush_survivors(int nnz, T thr, uint32_t row
     return out;
 }
 
+// Launch over parts: the matches a part of a row kept (lane l: the l-th best, cnt of them) appended to the pair list as
+// {column, row, score} -- "row receives column" -- through the wave's chunk like the mirrored pairs of drain_survivors.
+template <typename T, int TILE_LOG2>
+__device__ __noinline__ void emit_part_matches(const SgPairSink *__restrict__ pairs, T s, int c, int cnt, uint32_t row_out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int TILE = 1 << TILE_LOG2;
+    int *surv = reinterpret_cast<int *>(smem + TILE * 2 + 512 + 1024);
+    const int lane = threadIdx.x;
+    if (cnt <= 0) return;
+    uint32_t pos = (uint32_t)surv[SG_SURV_CAP - 1];
+    const uint32_t pair_chunks = pairs->chunks;
+    if (pos == SG_PAIR_NO_CHUNK || (pos & 511u) + (uint32_t)cnt > SG_PAIR_CHUNK) {
+        uint32_t ch = 0;
+        if (lane == 0) {
+            if (pos != SG_PAIR_NO_CHUNK && (pos >> 9) < pair_chunks) {
+                pairs->d_chunk_count[pos >> 9] = pos & 511u;
+                atomicAdd(pairs->d_totals, (unsigned long long)(pos & 511u));
+            }
+            ch = atomicAdd(pairs->d_chunks_used, 1u);
+        }
+        pos = (uint32_t)__builtin_amdgcn_readfirstlane((int)ch) << 9;
+    }
+    if ((pos >> 9) < pair_chunks) {   // past the capacity nothing is written: the caller falls back
+        if (lane < cnt) {
+            const size_t o = (size_t)(pos >> 9) * SG_PAIR_CHUNK + (pos & 511u) + (uint32_t)lane;
+            pairs->d_i[o] = (uint32_t)c;
+            pairs->d_j[o] = row_out;
+            reinterpret_cast<T *>(pairs->d_s)[o] = s;
+        }
+        if (lane == 0) atomicAdd(&pairs->d_row_count[row_out], (uint32_t)cnt);
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0) surv[SG_SURV_CAP - 1] = (int)(pos + (uint32_t)cnt);
+}
+
 // WIDE: the second launch, over the rows the first one could not take because they have 65 .. 128 non-zeros: every lane
 // stages two of the row's terms; still one posting list per lane, so the row's prefix P must fit 64 lanes.
 // 16 single-wave workgroups per CU (the LDS limit) = 4 waves per SIMD: <= 128 VGPRs.  The f64 stream form has 10.5 KiB of LDS
@@ -387,7 +424,10 @@ spgemm_topn_pruned_kernel(const int64_t *__restrict__ a_indptr, const int32_t *_
                           const uint32_t *__restrict__ row_list /* WIDE: the rows to process */, const uint32_t *row_list_len,
                           const uint32_t *__restrict__ ends8 /* stream form: ends of the super-tiles */, int32_t nv_pad,
                           uint32_t null_off /* stream form: byte offset of 256 filter postings that add nothing, four per lane */,
-                          uint32_t n_right /* right-hand rows (columns of the result) */) {
+                          uint32_t n_right /* right-hand rows (columns of the result) */,
+                          uint32_t *heavy_count, uint32_t *heavy_rows /* stream + self-join form: rows set aside for the launch over parts */,
+                          uint32_t part_cfg /* 0: every row whole; < 2^31: rows of at least this many rounds are set aside;
+                                               bit 31: this IS the launch over parts (rows in row_list, SG_ROW_PARTS items each) */) {
     constexpr int TILE = 1 << TILE_LOG2;
     constexpr int SLOTS = WIDE ? 2 : 1;   // row terms staged per lane
     constexpr int AB = TILE_LOG2 + 1;                          // address + half bits of a filter posting
@@ -420,7 +460,15 @@ spgemm_topn_pruned_kernel(const int64_t *__restrict__ a_indptr, const int32_t *_
     };
 
     SG_WD_DECL(wd_rows);
-    const uint32_t n_here = WIDE ? (uint32_t)__builtin_amdgcn_readfirstlane((int)*row_list_len) : (SYM ? sym_hi - sym_lo : n_left);
+    // Launch over PARTS (stream + self-join form, sg_spgemm_pruned_symmetric): an item is one sixteenth of the visits of a row
+    // the first launch set aside -- a row of thousands of rounds is a chain of dependent loads in ONE wave (3.4 ms for the
+    // slowest row of the 663 k job when the whole pass takes 6), which is what a rank's range of the multi-GPU form ends
+    // with (scripts/range_probe.py).  A part keeps its matches in its list like a row and hands them to the pair list,
+    // addressed to its own row; the second pass merges the parts' lists like mirrored matches.
+    constexpr bool CAN_SPLIT = SYM && !WIDE && FOLD_LOG2 > 0;
+    const bool part_mode = CAN_SPLIT && (part_cfg >> 31) != 0u;
+    const uint32_t n_here = (WIDE || part_mode) ? (uint32_t)__builtin_amdgcn_readfirstlane((int)*row_list_len) << (part_mode ? SG_ROW_PARTS_LOG2 : 0)
+                                                : (SYM ? sym_hi - sym_lo : n_left);
     // rows are handed out four at a time: one global atomic per row capped the kernel at ~88 rows/us (larger first
     // helpings were tried -- sixteen rows for the first three quarters -- and changed nothing: profiles/r02_sessionJ6_*.log).
     // Symmetric mode walks the rows from the last to the first: a row's cost grows with its index there.
@@ -435,7 +483,17 @@ spgemm_topn_pruned_kernel(const int64_t *__restrict__ a_indptr, const int32_t *_
     if (row0 >= n_here || hlp >= 0x10000000u) break;       // (the second: the pass was called off, see the pair list below)
     for (uint32_t rr = row0; rr < row0 + (hlp < n_quads ? 4u : 1u); ++rr) {   // (rows behind the quads go singly)
         SG_WD(wd_rows, n_left + 2, 11)
-        const uint32_t row = WIDE ? (uint32_t)__builtin_amdgcn_readfirstlane((int)row_list[rr]) : (SYM ? sym_hi - 1u - rr : rr);
+        const uint32_t row = WIDE ? (uint32_t)__builtin_amdgcn_readfirstlane((int)row_list[rr])
+                                  : part_mode ? (uint32_t)__builtin_amdgcn_readfirstlane((int)row_list[rr >> SG_ROW_PARTS_LOG2])
+                                              : (SYM ? sym_hi - 1u - rr : rr);
+        uint32_t part_lo = 0, part_hi = 0;   // part mode: the visits [part_lo, part_hi) of the row
+        if (CAN_SPLIT && part_mode) {
+            const uint32_t nv = ((row >> TILE_LOG2) + (1u << FOLD_LOG2)) >> FOLD_LOG2;   // visits of the row (self-join form)
+            const uint32_t part = rr & (SG_ROW_PARTS - 1u);
+            part_lo = (part * nv) >> SG_ROW_PARTS_LOG2;
+            part_hi = ((part + 1u) * nv) >> SG_ROW_PARTS_LOG2;
+            if (part_lo == part_hi) continue;
+        }
         // self-join form: the left matrix IS the permuted one, `row` a position; its result row and its name in the pairs
         // are the original row's.  (One-sided form: the left rows are the caller's, only the columns are positions.)
         uint32_t row_out = row;
@@ -507,7 +565,7 @@ spgemm_topn_pruned_kernel(const int64_t *__restrict__ a_indptr, const int32_t *_
             if (lane == 0) flagged_rows[atomicAdd(flagged_count, 1u)] = row;
             continue;
         }
-        ++st_rows;
+        if (!part_mode) ++st_rows;
 #pragma unroll
         for (int d = 32; d > 0; d >>= 1) {
             bs2 = fmaxf(bs2, __shfl_xor(bs2, d, 64));
@@ -856,11 +914,32 @@ spgemm_topn_pruned_kernel(const int64_t *__restrict__ a_indptr, const int32_t *_
             // compiler waits for them with vmcnt(0) -- it does not know of the rounds in flight -- so every fourth visit the
             // prefetched rounds are drained.  (Loading them by hand as well was tried: the value then flows through the
             // phi of `if (c == 0)`, which the compiler lowers with copies of registers whose load is still in flight.)
-            uint4 Ec = ends8_at(0);
-            uint4 En = ends8_at(min(1u, last_group8));
-            uint32_t gv = 0;                                  // the visit whose loads are being issued (wave-uniform)
-            uint32_t hi = min(Ec.x, hi_end);                  // end of the lane's segment in visit gv
+            uint32_t v_lo = 0, v_end = n_visits;              // the visits this item covers
+            uint32_t hi_stop = hi_end;                        // where the lane's stream ends
             uint32_t cur = (g ? my_lo << 2 : 0u) + u16;       // the lane's next four entries
+            if (CAN_SPLIT) {
+                if (part_mode) {
+                    v_lo = part_lo;
+                    v_end = part_hi;
+                    const uint32_t *e8 = ends8 + erow8;
+                    if (v_end < n_visits) hi_stop = min(hi_end, e8[v_end - 1u]);
+                    if (v_lo) cur = e8[v_lo - 1u] + u16;
+                } else if (part_cfg != 0u && n_visits >= 2u) {
+                    // rounds of the row = the longest lane stream; from part_cfg rounds on the row is set aside
+                    float rl = g ? (float)(hi_end - (my_lo << 2)) / (float)G16 : 0.f;
+#pragma unroll
+                    for (int d = 32; d > 0; d >>= 1) rl = fmaxf(rl, __shfl_xor(rl, d, 64));
+                    if (wave_read<float>(rl, 0) >= (float)part_cfg) {
+                        if (lane == 0) heavy_rows[atomicAdd(heavy_count, 1u)] = row;
+                        continue;
+                    }
+                }
+            }
+            uint4 Ec = ends8_at(v_lo >> 2);
+            uint4 En = ends8_at(min((v_lo >> 2) + 1u, last_group8));
+            uint32_t gv = v_lo;                               // the visit whose loads are being issued (wave-uniform)
+            const uint32_t c_lo = v_lo & 3u;
+            uint32_t hi = min(c_lo == 0 ? Ec.x : (c_lo == 1 ? Ec.y : (c_lo == 2 ? Ec.z : Ec.w)), hi_stop);   // end of the lane's segment in visit gv
 
             struct SBatch {
                 u32x4 q;       // the lane's four entries of the round
@@ -907,7 +986,7 @@ spgemm_topn_pruned_kernel(const int64_t *__restrict__ a_indptr, const int32_t *_
                     }
                     const uint32_t e = c == 0 ? Ec.x : (c == 1 ? Ec.y : (c == 2 ? Ec.z : Ec.w));
                     cur = hi + u16;              // the next segment starts where this one ends
-                    hi = min(e, hi_end);
+                    hi = min(e, hi_stop);
                 }
             };
             SBatch sb0, sb1, sb2, sb3;
@@ -1002,16 +1081,16 @@ spgemm_topn_pruned_kernel(const int64_t *__restrict__ a_indptr, const int32_t *_
             SG_WD_DECL(wd_s);
             for (;;) {   // trips of four rounds; every round is re-issued right behind its use
                 SG_WD(wd_s, 1 << 26, 17)
-                if (tv0 >= n_visits) break;
+                if (tv0 >= v_end) break;
                 apply_s(sb0, tv0, la0);
                 issue_s(sb0, tv0, la0);
-                if (tv1 >= n_visits) break;
+                if (tv1 >= v_end) break;
                 apply_s(sb1, tv1, la1);
                 issue_s(sb1, tv1, la1);
-                if (tv2 >= n_visits) break;
+                if (tv2 >= v_end) break;
                 apply_s(sb2, tv2, la2);
                 issue_s(sb2, tv2, la2);
-                if (tv3 >= n_visits) break;
+                if (tv3 >= v_end) break;
                 apply_s(sb3, tv3, la3);
                 issue_s(sb3, tv3, la3);
             }
@@ -1021,7 +1100,7 @@ spgemm_topn_pruned_kernel(const int64_t *__restrict__ a_indptr, const int32_t *_
         }
         {   // postings streamed = entries of P's lists in the tiles visited
             uint32_t mine = 0;
-            if (g && u == 0) {
+            if (g && u == 0 && part_lo == 0u) {   // (a row in parts: counted with its first part)
                 const uint32_t *erp = ends + (size_t)erow;
                 mine = (erp[t_end - 1u] >> 2) - my_lo;
             }
@@ -1036,7 +1115,12 @@ spgemm_topn_pruned_kernel(const int64_t *__restrict__ a_indptr, const int32_t *_
             top = drain_survivors<T, SYM, TILE_LOG2, WIDE, (FOLD_LOG2 > 0)>(nnz, thr, row, sc, pairs, top, n_surv);
             st_surv += n_surv;
         }
-        {   // (symmetric mode: the row's matches j <= i; pass 2 merges the mirrored ones in)
+        if (CAN_SPLIT && part_mode) {
+            // a part's matches go to the pair list, addressed to the part's own row: pass 2 merges the parts like mirrored matches
+            int cnt = __popcll(__ballot(top.c != INT32_MAX));
+            if (cnt > keep) cnt = keep;
+            emit_part_matches<T, TILE_LOG2>(pairs, top.s, top.c, cnt, row_out);
+        } else {   // (symmetric mode: the row's matches j <= i; pass 2 merges the mirrored ones in)
             int cnt = __popcll(__ballot(top.c != INT32_MAX));
             if (cnt > keep) cnt = keep;
             const size_t obase = (size_t)row_out * (size_t)out_stride;
@@ -1336,7 +1420,8 @@ static unsigned pruned_grid(const sg_ctx *ctx, int32_t tile_log2, int64_t n_rows
 template <typename T, int TILE_LOG2, bool SYM, bool WIDE, int FOLD_LOG2>
 static int launch_pruned(sg_ctx *ctx, const sg_csr *A, const sg_postings *Bt, int32_t keep, sg_topn *r, T thr,
                          float s_budget, uint32_t *row_counter, uint32_t *flagged_count, uint32_t *flagged_rows,
-                         unsigned long long *stats, const PairList &pl, const uint32_t *row_list, const uint32_t *row_list_len) {
+                         unsigned long long *stats, const PairList &pl, const uint32_t *row_list, const uint32_t *row_list_len,
+                         uint32_t *heavy_count = nullptr, uint32_t *heavy_rows = nullptr, uint32_t part_cfg = 0) {
     const size_t lds = pruned_lds(TILE_LOG2, FOLD_LOG2, A->dtype);
     unsigned grid = pruned_grid(ctx, TILE_LOG2, SYM ? (int64_t)(pl.row_hi - pl.row_lo) : A->n_rows, FOLD_LOG2, A->dtype);
     if (WIDE && grid > (unsigned)ctx->num_cu * 4u) grid = (unsigned)ctx->num_cu * 4u;   // few rows, if any: idle waves leave at once
@@ -1347,7 +1432,8 @@ static int launch_pruned(sg_ctx *ctx, const sg_csr *A, const sg_postings *Bt, in
                        Bt->norm_up, Bt->freq_min, r->d_cols,
                        (T *)r->d_vals,
                        r->d_counts, row_counter, flagged_count, flagged_rows, stats, pl.d_sink, pl.chunks, pl.row_lo, pl.row_hi, row_list,
-                       row_list_len, (const uint32_t *)Bt->d_ends8, Bt->nv_pad, (uint32_t)(Bt->nnz * 4), (uint32_t)Bt->n_right);
+                       row_list_len, (const uint32_t *)Bt->d_ends8, Bt->nv_pad, (uint32_t)(Bt->nnz * 4), (uint32_t)Bt->n_right,
+                       heavy_count, heavy_rows, part_cfg);
     SG_HIP_TRY(hipGetLastError());
     return SG_OK;
 }
@@ -1362,9 +1448,30 @@ static int launch_both(sg_ctx *ctx, const sg_csr *A, const sg_postings *Bt, int3
     uint32_t *l1 = nullptr;
     SG_TRY(sg_alloc(ctx, (size_t)A->n_rows + 8, &l1));
     int st = hipMemsetAsync(l1, 0, 4 * sizeof(uint32_t), ctx->stream) == hipSuccess ? SG_OK : SG_ERR_HIP;
+    // Stream + self-join form: rows that need many rounds -- a chain of dependent loads in one wave, milliseconds for the
+    // slowest -- are set aside by the first launch and worked off in SG_ROW_PARTS parts each by a launch of their own
+    // (see the kernel).  The whole-matrix pass hides such rows behind the others; a rank's RANGE of the multi-GPU form
+    // ends with its slowest row (scripts/range_probe.py, scripts/sim_scaling.py).  SG_HEAVY_ROUNDS: rounds from which a
+    // row is set aside (0: never).
+    uint32_t *heavy = nullptr;   // [0] count [1] the parts' row counter [4 ..) rows
+    uint32_t heavy_rounds = 0;
+    if (SYM && FOLD_LOG2 > 0 && st == SG_OK) {
+        // (the whole matrix in one pass: 6.0 ms without, 6.35 with the second launch at 663 k -- it has a ramp and a tail of
+        //  its own; a range of an eighth: 3.2 -> 2.25 ms, profiles/r03_sessionS_*)
+        heavy_rounds = (pl.row_lo > 0 || (int64_t)pl.row_hi < A->n_rows) ? 256 : 0;
+        if (const char *v = ctx->opt("SG_HEAVY_ROUNDS")) heavy_rounds = (uint32_t)atoi(v) & 0x7fffffffu;
+        if (heavy_rounds) {
+            st = sg_alloc(ctx, (size_t)A->n_rows + 8, &heavy);
+            if (st == SG_OK && hipMemsetAsync(heavy, 0, 4 * sizeof(uint32_t), ctx->stream) != hipSuccess) st = SG_ERR_HIP;
+        }
+    }
     if (st == SG_OK)
         st = launch_pruned<T, TILE_LOG2, SYM, false, FOLD_LOG2>(ctx, A, Bt, keep, r, thr, s_budget, row_counter, l1, l1 + 4, stats, pl,
-                                                     nullptr, nullptr);
+                                                     nullptr, nullptr, heavy, heavy ? heavy + 4 : nullptr, heavy ? heavy_rounds : 0u);
+    if (st == SG_OK && heavy)
+        st = launch_pruned<T, TILE_LOG2, SYM, false, FOLD_LOG2>(ctx, A, Bt, keep, r, thr, s_budget, heavy + 1, l1, l1 + 4, stats, pl,
+                                                     heavy + 4, heavy, nullptr, nullptr, 0x80000000u);
+    if (heavy) ctx->release(heavy);   // stream-ordered, like l1 below
     if (st == SG_OK && !(ctx->opt("SG_PRUNE_WIDE") && ctx->opt("SG_PRUNE_WIDE")[0] == '0'))
         st = launch_pruned<T, TILE_LOG2, SYM, true, FOLD_LOG2>(ctx, A, Bt, keep, r, thr, s_budget, l1 + 1, flagged_count, flagged_rows, stats,
                                                     pl, l1 + 4, l1);
@@ -1458,7 +1565,7 @@ int sg_spgemm_pruned_symmetric(sg_ctx *ctx, const sg_csr *A, const sg_postings *
     if (cap >= ((int64_t)1 << 31)) cap = ((int64_t)1 << 31) - 1;   // list offsets are 32-bit
     // every wave of the kernel holds one open chunk: count those in
     pl.chunks = (uint32_t)(cap / SG_PAIR_CHUNK);
-    if (!cap_forced) pl.chunks += pruned_grid(ctx, Bt->tile_log2, n, Bt->fold_log2, A->dtype) + (uint32_t)ctx->num_cu * 4u + sg_spgemm_exact_selfjoin_grid(ctx);
+    if (!cap_forced) pl.chunks += 2u * pruned_grid(ctx, Bt->tile_log2, n, Bt->fold_log2, A->dtype) + (uint32_t)ctx->num_cu * 4u + sg_spgemm_exact_selfjoin_grid(ctx);
     if (pl.chunks < 1) pl.chunks = 1;
     cap = (int64_t)pl.chunks * SG_PAIR_CHUNK;
     // [0] row counter [1] flagged count [2..3] pairs [4] chunks handed out [5] row counter of the exact kernel's launch;

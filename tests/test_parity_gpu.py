@@ -1091,6 +1091,47 @@ def test_selfjoin_form_over_row_ranges_equals_the_whole(ctx, dtype):
     postL.free(); dL.free(); dA.free()
 
 
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_rows_worked_off_in_parts_give_the_same_rows(ctx, dtype):
+    """Stream + self-join form: rows that need many rounds are set aside and worked off in sixteen parts each by a second
+    launch (a part hands its matches to the pair list, addressed to its own row).  With the bar at 2 rounds nearly every
+    row of more than one super-tile goes that way: the result must not change by a bit -- whole matrix and ranges --
+    and equals the port's."""
+    import torch
+    from string_grouper_amd import distributed as D
+    from string_grouper_amd.vectorizer import HipTfidfVectorizer
+    base = list(_names(90000, 33))
+    names = base + [base[7]] * 120 + [base[70001] + " CO"] * 80 + ["A INC", "B INC", "AB INC", "INC"]
+    A = _tfidf(names, dtype)
+    dA = ctx.csr_from_scipy(A)
+    n = len(names)
+    want = P.sp_matmul_topn_port(A, A.T, 10, 0.8, True, 16)
+    ctx.set_option("SG_COLLAPSE", "0")
+    ctx.set_option("SG_SYM", "1")
+    ops = D.HipOps(ctx, lambda: HipTfidfVectorizer(dtype=dtype, ctx=ctx))
+    for bar in ("0", "2", "40"):
+        ctx.set_option("SG_HEAVY_ROUNDS", bar)
+        post = ctx.postings_build(dA)
+        res = ctx.spgemm_topn(dA, post, 10, 0.8, True)
+        assert ctx.stats()["prune_symmetric"] == 1
+        assert_csr_identical(res.to_scipy(), want, f"whole matrix, rows of >= {bar} rounds in parts")
+        res.free()
+        bounds = D.selfjoin_row_ranges(n, 3)
+        parts = [ops.selfjoin_range(dA, post, 10, 0.8, int(bounds[r]), int(bounds[r + 1])) for r in range(3)]
+        assert all(p is not None for p in parts)
+        pairs_all = torch.cat([ops.selfjoin_pairs(p).clone() for p in parts])
+        rows, orig_of = [], None
+        for r in range(3):
+            blk = ops.selfjoin_merge(parts[r], pairs_all, int(bounds[r]), int(bounds[r + 1]))
+            orig_of = blk.orig_of
+            rows.append(blk.to_scipy())
+            blk.free()
+        C = sp.vstack(rows).tocsr()[np.argsort(orig_of.cpu().numpy(), kind="stable")]
+        assert_csr_identical(C, want, f"three ranges, rows of >= {bar} rounds in parts")
+        post.free()
+    dA.free()
+
+
 def test_selfjoin_form_with_a_pair_list_that_is_too_small_falls_back(ctx, monkeypatch):
     """The self-join form collects the mirrored pairs in a list of bounded size (chunks handed to the waves); hubs of
     duplicates can outgrow it.  Then nothing of that pass may survive: the one-sided form runs and the result is the
