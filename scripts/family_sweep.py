@@ -13,6 +13,8 @@ from string_grouper_amd.synth import synth_names  # noqa: E402
 from string_grouper_amd.vectorizer import HipTfidfVectorizer  # noqa: E402
 
 ctx = N.default_context(0)
+OPTIONS = dict(a.split("=", 1) for a in sys.argv[1:] if "=" in a and not a.startswith("only="))   # e.g. SG_PRUNE_MIN_THRESHOLD=0.3
+ONLY = [a[5:] for a in sys.argv[1:] if a.startswith("only=")]
 rng = np.random.default_rng(1)
 
 
@@ -22,6 +24,8 @@ def long_names(n, seed):
 
 
 def run(label, master, dups, top_n, thr, **kw):
+    if ONLY and not any(o in label for o in ONLY):
+        return
     vec = HipTfidfVectorizer(dtype=np.float32, ctx=ctx, **kw)
     pm = vec.prepare(master)
     sets = [pm] + ([vec.prepare(dups)] if dups is not None else [])
@@ -31,8 +35,8 @@ def run(label, master, dups, top_n, thr, **kw):
     post = ctx.postings_build(B)
     out = {}
     for mode, env in (("pruned", {}), ("one-sided", {"SG_SYM": "0"}), ("exact", {"SG_PRUNE": "0"})):
-        for k, v in env.items():
-            os.environ[k] = v
+        for k, v in list(env.items()) + list(OPTIONS.items()):
+            ctx.set_option(k, v)          # (the library reads its switches when a context is created)
         if mode == "exact":
             post.free()
             post = ctx.postings_build(B)
@@ -46,8 +50,7 @@ def run(label, master, dups, top_n, thr, **kw):
             res = r.to_host()
             r.free()
         out[mode] = (best, res)
-        for k in env:
-            os.environ.pop(k)
+        ctx.reset_options()
     ref = out["exact"][1]
     for mode in ("pruned", "one-sided"):
         got = out[mode][1]
@@ -70,6 +73,8 @@ run("SynthNames 200k 2-grams ntop10 0.8", names, None, 10, 0.8, ngram_size=2)
 run("SynthNames 200k 4-grams ntop10 0.8", names, None, 10, 0.8, ngram_size=4)
 run("SynthNames 200k 3-grams ntop20 0.6", names, None, 20, 0.6)
 run("SynthNames 200k 3-grams ntop5 0.9", names, None, 5, 0.9)
+for low in (0.45, 0.4, 0.35, 0.3):       # below 0.45 the pruned kernel only runs with SG_PRUNE_MIN_THRESHOLD=<lower>
+    run(f"low threshold: 200k 3-grams ntop10 {low}", names, None, 10, low)
 run("long names (3 joined) 100k 3-grams ntop10 0.8", long_names(100000, 5), None, 10, 0.8)
 digits = ["%09d" % int(x) for x in rng.integers(0, 10 ** 9, 200000)]
 run("9-digit numbers 200k 3-grams (V<=1000) 0.8", digits, None, 10, 0.8)
