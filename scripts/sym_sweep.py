@@ -13,7 +13,7 @@ for n in (5000, 20000, 50000, 100000, 200000, 400000):
     vec.fit_prepared([p]); A = vec.transform_prepared(p); post = ctx.postings_build(A)
     out = {"n": n}
     for sym in ("1", "0"):
-        os.environ["SG_SYM"] = sym
+        ctx.set_option("SG_SYM", sym)        # (the library reads its switches when a context is created)
         best = 1e9
         for rep in range(3):
             r = ctx.spgemm_topn(A, post, 10, 0.8, True); ctx.sync()
@@ -23,4 +23,5 @@ for n in (5000, 20000, 50000, 100000, 200000, 400000):
         out["symmetric_ran" if sym == "1" else "_"] = st["prune_symmetric"]
     out.pop("_", None)
     print(json.dumps(out), flush=True)
+    ctx.reset_options()
     post.free(); A.free()
