@@ -467,7 +467,10 @@ class Context:
 
     # ---- multiply
     def postings_build(self, B: Csr, tile_cols: int = 0, permute: bool = True) -> Postings:
-        """``permute=False``: the index in row order (SG_POSTINGS_NO_PERMUTATION; the multi-GPU self-join form needs it)."""
+        """The inverted index of B (sg_postings_build_flags).  By default it is built over the library's fixed row
+        permutation -- the ranges of the multi-GPU self-join form are then ranges of POSITIONS (``postings_permutation``,
+        ``postings_rows``) -- ``permute=False`` builds it in row order (SG_POSTINGS_NO_PERMUTATION; tests).  All ranks of a
+        job must build their index the same way: ``distributed.sharded_selfjoin_topn`` checks it."""
         out = C.c_void_p()
         check(lib().sg_postings_build_flags(self.h, B.h, int(tile_cols), 0 if permute else 1, C.byref(out)))
         return Postings(self, out)

@@ -233,8 +233,14 @@ def sharded_selfjoin_topn(ops, A_full, post, top_n: int, threshold: float, group
     lo, hi = int(bounds[rank]), int(bounds[rank + 1])
     part = ops.selfjoin_range(A_full, post, top_n, threshold, lo, hi)
     pairs = ops.selfjoin_pairs(part) if part is not None else None
-    # one exchange tells every rank the lengths of all pair lists AND whether every range was applicable (-1: not)
-    sizes = [h[0] for h in all_headers([pairs.numel() if pairs is not None else -1], ops.device, group)]
+    # one exchange tells every rank the lengths of all pair lists AND whether every range was applicable (-1: not) -- and
+    # that all ranks built the same index: ranges and merge are in the index's position space, so an index over the row
+    # permutation on one rank and in row order on another (or over groups on one only) would give rows that look fine
+    permuted = int(bool(ops.index_is_permuted(post))) if hasattr(ops, "index_is_permuted") else 0
+    heads = all_headers([pairs.numel() if pairs is not None else -1, n, permuted], ops.device, group)
+    if len({(h[1], h[2]) for h in heads}) != 1:
+        raise RuntimeError(f"ranks built different indexes (rows of the index, permuted): {[(h[1], h[2]) for h in heads]}")
+    sizes = [h[0] for h in heads]
     if min(sizes) < 0:
         if part is not None:
             ops.selfjoin_discard(part)
@@ -486,6 +492,9 @@ class HipOps:
 
     def selfjoin_rows(self, A_full, post):
         return self.ctx.postings_rows(post)[0]
+
+    def index_is_permuted(self, post):
+        return self.ctx.postings_permutation(post)[0] != 0
 
     def topn_from_tensors(self, cols, vals, counts, n_cols: int):
         """The gathered result as a library object, without leaving HBM."""

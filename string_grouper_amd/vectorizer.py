@@ -145,7 +145,10 @@ class HipTfidfVectorizer:
     def _remember(self, sets, dev_sets):
         # transform_prepared() of a column that was part of the fit must reuse the fit's tokens: the library
         # recognises the device handle, so keep the (possibly converted) device column of every input column
+        # (the ORIGINAL columns are kept alive too: the table is keyed by id(), and the id of a freed column can be handed
+        #  to a later one -- which would then silently get the fit column's matrix)
         self._fit_sets = list(dev_sets)
+        self._fit_originals = list(sets)
         self._dev_of = {id(s): d for s, d in zip(sets, dev_sets)}
 
     def _finish_fit(self) -> "HipTfidfVectorizer":

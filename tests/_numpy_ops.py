@@ -124,6 +124,9 @@ class NumpyOps:
             return m
         return GroupedIndex(m)
 
+    def index_is_permuted(self, post):
+        return self.permuted
+
     def selfjoin_rows(self, A_full, post):
         return post.unique.shape[0] if isinstance(post, GroupedIndex) else A_full.shape[0]
 
