@@ -225,6 +225,9 @@ def run(args):
         out_nnz = stats["out_nnz"]
     barrier()
     elapsed = time.perf_counter() - t0
+    index_rows = None
+    if not distributed:
+        index_rows = int(ctx.postings_rows(last._keep[1])[0])    # < rows: identical rows indexed once (include/sg_hip.h)
     if distributed and dist_mode == "sharded":
         # (the multi-GPU self-join form merges the mirrored pairs after the multiply's own count: count the rank's rows)
         out_nnz = int(ops.topn_tensors(last)[2].sum().item())
@@ -297,6 +300,11 @@ def run(args):
         result["pruning"] = {"rows": stats["prune_rows"], "postings_streamed": stats["prune_postings"],
                              "of_intermediate_products": stats["macs"], "pairs_scored_exactly": stats["prune_survivors"],
                              "rows_handed_to_exact_kernel": stats["exact_rows"], "self_join_form": symmetric}
+        if index_rows is not None and index_rows != args.rows:
+            # identical strings give identical rows: the index holds one representative per group, the multiply runs on
+            # the groups and its result is expanded to all rows (sg_collapse.hip; SG_COLLAPSE=0 switches it off).  Exact:
+            # the matches of all `rows` rows are the reference's, bit for bit.
+            result["pruning"]["identical_rows_indexed_once"] = {"rows": args.rows, "index_rows": index_rows}
 
     # measured HBM-side traffic of the same kernel on the same workload, from the committed PMC passes
     try:

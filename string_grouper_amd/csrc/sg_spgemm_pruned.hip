@@ -1458,7 +1458,21 @@ static int launch_both(sg_ctx *ctx, const sg_csr *A, const sg_postings *Bt, int3
     if (SYM && FOLD_LOG2 > 0 && st == SG_OK) {
         // (the whole matrix in one pass: 6.0 ms without, 6.35 with the second launch at 663 k -- it has a ramp and a tail of
         //  its own; a range of an eighth: 3.2 -> 2.25 ms, profiles/r03_sessionS_*)
-        heavy_rounds = (pl.row_lo > 0 || (int64_t)pl.row_hi < A->n_rows) ? 256 : 0;
+        if (pl.row_lo > 0 || (int64_t)pl.row_hi < A->n_rows) {
+            // A row is worth parts when it is a noticeable share of what ONE wave of the range does.  Rounds per wave,
+            // estimated: rows per wave x rounds per row at the range's position (a row's stream grows with its position
+            // and with the lists, i.e. with n: 40 rounds per row on average at 553 k index rows, 290 at 3.9 M --
+            // 7.2e-5 n).  A fixed bar of 256 rounds sent nearly every row of the 5 M job through parts: eight ranges took
+            // 278 ms in all against 204 ms for the whole (profiles/r03_sessionV_sim_scaling_5M.log).
+            const double n_idx = (double)A->n_rows;
+            const double rows_per_wave =
+                (double)(pl.row_hi - pl.row_lo) / (double)pruned_grid(ctx, TILE_LOG2, (int64_t)(pl.row_hi - pl.row_lo), FOLD_LOG2, A->dtype);
+            const double rounds_per_row = 2.0 * 7.2e-5 * n_idx * (0.5 * ((double)pl.row_lo + (double)pl.row_hi) / n_idx);
+            // (a twentieth: the tail a row of `bar` rounds can leave is then ~5 % of the range's time.  A quarter was
+            //  tried first: two of eight ranges of the 5 M job then ended 10-15 ms after the others, on single rows)
+            const double bar = 0.05 * rows_per_wave * rounds_per_row;
+            heavy_rounds = bar < 256.0 ? 256u : (bar > 1.0e9 ? 1000000000u : (uint32_t)bar);
+        }
         if (const char *v = ctx->opt("SG_HEAVY_ROUNDS")) heavy_rounds = (uint32_t)atoi(v) & 0x7fffffffu;
         if (heavy_rounds) {
             st = sg_alloc(ctx, (size_t)A->n_rows + 8, &heavy);

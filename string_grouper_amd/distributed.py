@@ -199,13 +199,18 @@ def sharded_topn(ops, left_local, right_full, top_n: int, threshold: float, tile
     return res
 
 
+# cumulative cost of the self-join form's rows [0, x n): measured on eight ranges of the 663 k and the 5 M job, it is
+# x^2.15 at both sizes (profiles/r03_sessionV_sim_scaling_5M.log, r03_sessionS_sim_scaling.log) -- a row's stream AND its
+# candidates grow with its position, and the higher positions' postings no longer sit in the caches.  (Round 2 cut by
+# x^2 / 2 + 0.03 x: the first of eight ranges then took 27 ms where the last took 38.)
+SELFJOIN_COST_EXPONENT = 2.15
+
+
 def selfjoin_row_ranges(n_rows: int, world: int) -> np.ndarray:
     """Left-row ranges of the self-join form across ranks: rank r scores the rows [b[r], b[r + 1]) against the columns
-    j <= i, so a row's cost grows with its index (the tiles up to its own + a constant ~3 % of the last row's cost,
-    profiles/r02_sessionM_sym_sweep.log): cumulative cost ~ x^2 / 2 + c x, cut into equal shares."""
-    c = 0.03
+    j <= i, so a row's cost grows with its index: cumulative cost ~ x^2.15, cut into equal shares."""
     share = np.arange(world + 1, dtype=np.float64) / world
-    x = -c + np.sqrt(c * c + 2.0 * share * (0.5 + c))
+    x = share ** (1.0 / SELFJOIN_COST_EXPONENT)
     b = np.minimum(np.round(x * n_rows).astype(np.int64), n_rows)
     b[0], b[-1] = 0, n_rows
     return np.maximum.accumulate(b)
