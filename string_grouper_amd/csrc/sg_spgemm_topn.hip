@@ -727,8 +727,8 @@ static bool pruned_applicable(sg_ctx *ctx, const sg_csr *A, const sg_postings *B
         !(threshold >= env_double(ctx, "SG_PRUNE_MIN_THRESHOLD", 0.45)))   // below ~0.4 the filter passes too much (profiles/r01_prune_tuning.log)
         return false;
     // tuned at 663 k: the tile-by-tile form 0.05 (profiles/r01_prune_tuning.log); the stream form, whose rounds are cheaper
-    // next to the exact scorings, 0.03 (profiles/r03_sessionG_H_delta.log: 9.76 / 9.95 / 10.10 / 14.3 ms at 0.03 / 0.04 /
-    // 0.05 / 0.08)
+    // next to the exact scorings, 0.03 (profiles/r03_sessionG_H_delta.log: 9.76 / 9.95 / 10.10 ms at 0.03 / 0.04 / 0.05;
+    // with identical rows grouped the optimum is flat from 0.02 to 0.04: profiles/r03_sessionU_delta_freq_ab.log)
     // (0.03 only where rows are sparse next to the vocabulary -- name data; on small vocabularies, the regime of the
     //  pruned-or-exact pilot below, a tighter bound passes too many candidates: 0.05 as before)
     const bool sparse_rows = A->n_rows > 0 && (double)A->nnz / (double)A->n_rows <= 0.004 * (double)Bt->n_terms;
