@@ -554,6 +554,26 @@ def test_device_resident_inputs_and_rccl_plumbing(ctx):
                    sga.match_most_similar(s_m, s_d, min_similarity=0.7)]
             for w, g in zip(want, got):
                 pd.testing.assert_frame_equal(pd.DataFrame(w), pd.DataFrame(g))
+            # a list long enough, and repetitive enough, for the library to index identical names once: the distributed
+            # engine's self-join then runs over ranges of GROUPS, the rank expands its groups into rows, and the gathered
+            # rows are put in place by their numbers (distributed.gather_topn) -- forced onto the one rank
+            big = list(_names(12000, seed=13))
+            s_b = pd.Series(big + big[:700] + [big[5]] * 300, name="name")
+            E.set_engine(E.HipEngine(ctx))
+            want_b = sga.match_strings(s_b, min_similarity=0.8, max_n_matches=10, tfidf_matrix_dtype=np.float32)
+            os.environ["SG_DIST_SYM"] = "1"
+            try:
+                E.set_engine(E.DistributedHipEngine(ctx))
+                got_b = sga.match_strings(s_b, min_similarity=0.8, max_n_matches=10, tfidf_matrix_dtype=np.float32)
+            finally:
+                os.environ["SG_DIST_SYM"] = "0"
+            pd.testing.assert_frame_equal(want_b, got_b)
+            vb = HipTfidfVectorizer(dtype=np.float32, ctx=ctx)
+            pb = vb.prepare(list(s_b))
+            vb.fit_prepared([pb])
+            post_b = ctx.postings_build(vb.transform_prepared(pb))
+            assert ctx.postings_rows(post_b)[0] < len(s_b) - 900, "the list was meant to be indexed over groups"
+            post_b.free()
         finally:
             E.set_engine(old)
     finally:
