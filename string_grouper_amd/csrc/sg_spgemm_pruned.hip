@@ -68,6 +68,11 @@
 #include "sg_k4_device.h"
 
 // (SG_PAIR_CHUNK, the entries of a chunk of the symmetric mode's pair list: sg_internal.h)
+#ifdef SG_STREAM_NO_SCHED_FENCE   // (A/B: the compiler's own order of a round's four slots)
+#define SG_SCHED_FENCE()
+#else
+#define SG_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+#endif
 #define SG_ROW_PARTS_LOG2 4
 #define SG_ROW_PARTS 16u       // parts of a row in the launch over parts (stream + self-join form)
 #define SG_SURV_CAP 128   // survivors buffered per wave (scored 64 at a time as soon as 64 are there)
@@ -1003,7 +1008,9 @@ spgemm_topn_pruned_kernel(const int64_t *__restrict__ a_indptr, const int32_t *_
                 asm volatile("s_waitcnt vmcnt(0) ; rounds %0 %1 %2 %3" : "+v"(sb0.q), "+v"(sb1.q), "+v"(sb2.q), "+v"(sb3.q)::"memory");
                 const FlushOut<T> fo = flush_survivors<T, SYM, TILE_LOG2, WIDE>(nnz, thr, row, sc, pairs, top, n_surv, n_clean);
                 top = fo.top;
+#ifndef SG_STREAM_PROBE_COUNT_ROUNDS
                 st_surv += (n_surv - fo.n_surv) & ~63u;   // 64 if a wave was scored (the rest were repeats)
+#endif
                 n_surv = n_clean = (uint32_t)__builtin_amdgcn_readfirstlane((int)fo.n_surv);
             };
             auto collect_s = [&](uint64_t cm, uint32_t r, uint32_t tv) {
@@ -1019,19 +1026,22 @@ spgemm_topn_pruned_kernel(const int64_t *__restrict__ a_indptr, const int32_t *_
                 n_surv += n_new;
             };
             struct SSlot {
-                uint32_t z, sh, xs;
+                uint32_t z, sh, xs, x;
                 int32_t d;
             };
+            // what the LDS add needs (address, amount) ...
             auto prep_s = [&](uint32_t r) {
                 SSlot q;
                 q.z = r & ADDR_MASK;
                 q.sh = r << 4;   // bit 4 = the half
-                const uint32_t x = (uint32_t)(((uint64_t)(r & (BQ_MAX << FB)) * (uint64_t)(CA & 0xffffffu)) >> 32);
-                // the accumulator must reach tq = (T0 - C1 fq) >> 8; with this posting's x added: old >= tq - x
-                q.d = ((T0 - __mul24(C1, (int32_t)(r >> 24))) >> 8) - (int32_t)x;
-                asm("v_lshlrev_b32 %0, %1, %2" : "=v"(q.xs) : "v"(q.sh), "v"(x));
+                q.x = (uint32_t)(((uint64_t)(r & (BQ_MAX << FB)) * (uint64_t)(CA & 0xffffffu)) >> 32);
+                asm("v_lshlrev_b32 %0, %1, %2" : "=v"(q.xs) : "v"(q.sh), "v"(q.x));
+                q.d = 0;
                 return q;
             };
+            // ... and what only the test of its result needs: the accumulator must reach tq = (T0 - C1 fq) >> 8; with this
+            // posting's x added: old >= tq - x.  Computed while the adds are on their way (SG_STREAM_TEST_EARLY: before).
+            auto bar_s = [&](uint32_t r, uint32_t x) { return ((T0 - __mul24(C1, (int32_t)(r >> 24))) >> 8) - (int32_t)x; };
             bool dirty = false;   // accumulators of the current visit hold sums
             auto apply_s = [&](SBatch &bt, uint32_t tv, bool last) {
                 // the round's load is waited for HERE, on every path (also when no lane has a posting)
@@ -1041,18 +1051,37 @@ spgemm_topn_pruned_kernel(const int64_t *__restrict__ a_indptr, const int32_t *_
                 asm volatile("s_waitcnt vmcnt(3) ; round %0" : "+v"(bt.q)::"memory");
 #endif
                 const u32x4 q = bt.q;
+#ifdef SG_STREAM_PROBE_COUNT_ROUNDS   // (probe: the statistics' "pairs scored" word counts ROUNDS instead)
+                ++st_surv;
+#endif
                 {
                     dirty = true;
-                    const SSlot s0 = prep_s(q.x), s1 = prep_s(q.y), s2 = prep_s(q.z), s3 = prep_s(q.w);
-                    const uint32_t a0 = s0.xs, a1 = s1.xs, a2 = s2.xs, a3 = s3.xs;
+                    // every add leaves as soon as its address and amount are there; the thresholds of the four tests are
+                    // computed behind the last add, i.e. inside the LDS round trip (the scheduler, left alone, computes
+                    // all four slots first, then sends the four adds, and one threshold behind the wait -- which costs the
+                    // same time: profiles/r03_sessionAA_slot_order_ab.log; kept because the ISA now reads as the source)
 #ifdef SG_STREAM_PROBE_NO_LDS
-                    uint32_t o0 = s0.z + a0, o1 = s1.z + a1, o2 = s2.z + a2, o3 = s3.z + a3;
+                    SSlot s0 = prep_s(q.x), s1 = prep_s(q.y), s2 = prep_s(q.z), s3 = prep_s(q.w);
+                    uint32_t o0 = s0.z + s0.xs, o1 = s1.z + s1.xs, o2 = s2.z + s2.xs, o3 = s3.z + s3.xs;
 #else
-                    uint32_t o0 = __hip_atomic_fetch_add(tab_at(s0.z), a0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    uint32_t o1 = __hip_atomic_fetch_add(tab_at(s1.z), a1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    uint32_t o2 = __hip_atomic_fetch_add(tab_at(s2.z), a2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    uint32_t o3 = __hip_atomic_fetch_add(tab_at(s3.z), a3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    SSlot s0 = prep_s(q.x);
+                    uint32_t o0 = __hip_atomic_fetch_add(tab_at(s0.z), s0.xs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    SG_SCHED_FENCE();
+                    SSlot s1 = prep_s(q.y);
+                    uint32_t o1 = __hip_atomic_fetch_add(tab_at(s1.z), s1.xs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    SG_SCHED_FENCE();
+                    SSlot s2 = prep_s(q.z);
+                    uint32_t o2 = __hip_atomic_fetch_add(tab_at(s2.z), s2.xs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    SG_SCHED_FENCE();
+                    SSlot s3 = prep_s(q.w);
+                    uint32_t o3 = __hip_atomic_fetch_add(tab_at(s3.z), s3.xs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    SG_SCHED_FENCE();
 #endif
+                    s0.d = bar_s(q.x, s0.x);
+                    s1.d = bar_s(q.y, s1.x);
+                    s2.d = bar_s(q.z, s2.x);
+                    s3.d = bar_s(q.w, s3.x);
+                    asm volatile("" : "+v"(s0.d), "+v"(s1.d), "+v"(s2.d), "+v"(s3.d));   // (before the wait, not behind it)
                     asm volatile("" : "+v"(o0), "+v"(o1), "+v"(o2), "+v"(o3));   // the one wait
                     const uint64_t c0 = ballot64((int32_t)__builtin_amdgcn_ubfe(o0, s0.sh, 16u) >= s0.d);
                     const uint64_t c1m = ballot64((int32_t)__builtin_amdgcn_ubfe(o1, s1.sh, 16u) >= s1.d);
@@ -1113,7 +1142,9 @@ spgemm_topn_pruned_kernel(const int64_t *__restrict__ a_indptr, const int32_t *_
 #endif
         if (n_surv > 0) {   // fewer than 64 left
             top = drain_survivors<T, SYM, TILE_LOG2, WIDE, (FOLD_LOG2 > 0)>(nnz, thr, row, sc, pairs, top, n_surv);
+#ifndef SG_STREAM_PROBE_COUNT_ROUNDS
             st_surv += n_surv;
+#endif
         }
         if (CAN_SPLIT && part_mode) {
             // a part's matches go to the pair list, addressed to the part's own row: pass 2 merges the parts like mirrored matches
