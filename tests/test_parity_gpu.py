@@ -609,6 +609,27 @@ def _check_slice_properties(res, lo, n_left_block, n_right, top_n, thr, self_joi
         assert np.array_equal(cols[i, :cnt[i]], ref_c) and np.array_equal(vals[i, :cnt[i]], ref_v), f"{what}: row {lo + i}"
 
 
+def _all_rows_equal_the_exact_kernel(ctx, res, A, B, top_n, thr, what):
+    """Full size, ALL rows: the product path's result against the exact kernel K4 run on every row of the same matrices
+    (no pruning, identical rows not grouped) -- the kernel that the sampled rows and the smaller sizes pin on the CPU port
+    (the port itself on every row of these sizes would take a quarter of an hour of the box's host cores)."""
+    ctx.set_option("SG_PRUNE", "0")
+    ctx.set_option("SG_COLLAPSE", "0")
+    post = ctx.postings_build(B)
+    ex = ctx.spgemm_topn(A, post, top_n, thr, True)
+    st = ctx.stats()
+    ctx.reset_options()
+    assert st["prune_rows"] == 0, what
+    c0, v0, n0 = res.to_host()
+    c1, v1, n1 = ex.to_host()
+    ex.free()
+    post.free()
+    np.testing.assert_array_equal(n0, n1, err_msg=what)
+    mask = np.arange(c0.shape[1])[None, :] < n0[:, None]
+    assert np.array_equal(c0[mask], c1[mask]) and np.array_equal(v0[mask], v1[mask]), what
+    print(f"{what}: all {len(n0)} rows, {int(n0.sum())} matches, identical to the exact kernel ({st['ms_spgemm_topn']:.0f} ms)")
+
+
 @pytest.mark.timeout(900)
 def test_config4_5M_selfjoin_one_of_eight_row_blocks(ctx):
     """BASELINE.json configs[3]: 5M synthetic names self-join, left CSR row-blocked over 8 GPUs -- here
@@ -632,7 +653,14 @@ def test_config4_5M_selfjoin_one_of_eight_row_blocks(ctx):
           f"{st['spgemm_bytes'] / st['ms_spgemm_topn'] / 1e9:.2f} TB/s (stream model of the exact kernel); pruned rows "
           f"{st['prune_rows']}, postings streamed {st['prune_postings']:.3e}, pairs scored {st['prune_survivors']:.3e}")
     _check_slice_properties(res, lo, hi - lo, n, 10, 0.8, True, A_host, A_host, 300, "config4")
-    for h in (res, blk, post, A):
+    res.free()
+    blk.free()
+    del A_host
+    # the whole self-join on this one GPU (self-join form on the groups of identical rows), every row against the exact kernel
+    res = ctx.spgemm_topn(A, post, 10, 0.8, True)
+    assert ctx.stats()["prune_symmetric"] == 1
+    _all_rows_equal_the_exact_kernel(ctx, res, A, A, 10, 0.8, "configs[3], 5 M self-join")
+    for h in (res, post, A):
         h.free()
     ctx.trim()
 
@@ -669,7 +697,13 @@ def test_config5_asymmetric_10M_x_1M_one_of_eight_row_blocks(ctx):
         def __getitem__(self, idx):
             return self.m[np.asarray(idx) - self.lo]
     _check_slice_properties(res, lo, hi - lo, n_d, 20, 0.7, False, _Shift(A_blk_host, lo), B_host, 300, "config5")
-    for h in (res, blk, post, A, B):
+    res.free()
+    blk.free()
+    del A_blk_host, B_host
+    # all 10 M master rows on this one GPU, every row against the exact kernel
+    res = ctx.spgemm_topn(A, post, 20, 0.7, True)
+    _all_rows_equal_the_exact_kernel(ctx, res, A, B, 20, 0.7, "configs[4], 10 M x 1 M")
+    for h in (res, post, A, B):
         h.free()
     ctx.trim()
 
