@@ -421,6 +421,15 @@ __global__ void __launch_bounds__(256) count_macs_kernel(const int64_t *__restri
     block_add_u64(local, out_macs);
 }
 
+// ... of a self-join (A is the matrix the index was built over): the sum of the squared list lengths
+__global__ void __launch_bounds__(256) count_macs_selfjoin_kernel(const uint32_t *__restrict__ term_len, int64_t n_terms,
+                                                                  unsigned long long *out_macs) {
+    unsigned long long local = 0;
+    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n_terms; k += (int64_t)gridDim.x * blockDim.x)
+        local += (unsigned long long)term_len[k] * (unsigned long long)term_len[k];
+    block_add_u64(local, out_macs);
+}
+
 __global__ void __launch_bounds__(256) row_cost_kernel(const int64_t *__restrict__ a_indptr,
                                                        const int32_t *__restrict__ a_indices, int64_t n_left,
                                                        const uint32_t *__restrict__ term_len,
@@ -962,7 +971,12 @@ extern "C" int sg_spgemm_topn(sg_ctx *ctx, const sg_csr *A, const sg_postings *B
     // measurement words: MACs and kept entries of this multiply
     if (st == SG_OK) {
         (void)hipMemsetAsync(ctx->d_stat_words, 0, 2 * sizeof(int64_t), ctx->stream);
-        if (A->nnz > 0)
+        const bool own = A->n_rows == Bt->n_right && A->d_indptr == Bt->b_indptr && A->d_indices == Bt->b_indices &&
+                         A->d_data == Bt->b_data;
+        if (A->nnz > 0 && own)      // (10 M gathers less per multiply: 54 -> 3 us at 663 k)
+            hipLaunchKernelGGL(count_macs_selfjoin_kernel, dim3(64), dim3(256), 0, ctx->stream, (const uint32_t *)Bt->d_term_len,
+                               Bt->n_terms, (unsigned long long *)ctx->d_stat_words);
+        else if (A->nnz > 0)
             hipLaunchKernelGGL(count_macs_kernel, dim3(512), dim3(256), 0, ctx->stream, A->d_indptr, A->d_indices,
                                A->n_rows, (const uint32_t *)Bt->d_term_len, (unsigned long long *)ctx->d_stat_words);
         if (A->n_rows > 0)

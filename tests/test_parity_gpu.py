@@ -1431,15 +1431,33 @@ def test_identical_rows_are_collapsed_and_the_result_is_the_ports(ctx, dtype, or
         names[at] = "ACME HOLDINGS INC" + rng.choice([".", " 2", "ORPORATED", " LLC"])
     for at in rng.choice(len(names) - 1, 500, replace=False):
         names[at + 1] = names[at]                              # pairs
+    # rows the pruned kernel hands on (more than 128 terms: the exact kernel's rows), some of them identical too
+    longs = ["".join(rng.choice(list("ABCDEFGHIJKLMNOPQRSTUVWXYZ "), 170)) for _ in range(4)]
+    for k, at in enumerate(rng.choice(len(names), 12, replace=False)):
+        names[at] = longs[k % 4] if k < 10 else longs[0][:160]
     if order == "sorted":
         names = sorted(names)
     A = _tfidf(names, dtype)
+    assert int((np.diff(A.indptr) > 128).sum()) >= 10
     for top_n, thr in ((10, 0.8), (5, 0.6), (64, 0.8), (100, 0.8)):
         want = P.sp_matmul_topn_port(A, A.T, top_n, thr, True, 8)
         for collapse in ("1", "0"):
             monkeypatch.setenv("SG_COLLAPSE", collapse)
             got = sp_matmul_topn(A, A.T, top_n, thr, sort=True, ctx=ctx)
             assert_csr_identical(got, want, f"self-join top_n={top_n} thr={thr} collapse={collapse} {order}")
+    # ... and in the self-join form (forced at this size): groups + rows for the exact kernel's self-join launch + the
+    # postings proper written on demand
+    monkeypatch.setenv("SG_COLLAPSE", "1")
+    monkeypatch.setenv("SG_SYM", "1")
+    dA = ctx.csr_from_scipy(A)               # (the form needs the left matrix to BE the matrix of the index)
+    post = ctx.postings_build(dA)
+    res = ctx.spgemm_topn(dA, post, 10, 0.8, True)
+    st = ctx.stats()
+    assert st["prune_symmetric"] == 1 and st["exact_rows"] >= 3 and st["prune_rows"] < A.shape[0] - 4000, st
+    assert_csr_identical(res.to_scipy(), P.sp_matmul_topn_port(A, A.T, 10, 0.8, True, 8), f"self-join form on groups, {order}")
+    for h in (res, post, dA):
+        h.free()
+    monkeypatch.delenv("SG_SYM")
     monkeypatch.setenv("SG_COLLAPSE", "1")
     left = A[1000:7000]
     assert_csr_identical(sp_matmul_topn(left, A.T, 10, 0.8, sort=True, ctx=ctx), P.sp_matmul_topn_port(left, A.T, 10, 0.8, True, 8),
