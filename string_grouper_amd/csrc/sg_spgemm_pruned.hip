@@ -1502,7 +1502,9 @@ static int launch_both(sg_ctx *ctx, const sg_csr *A, const sg_postings *Bt, int3
             // (a twentieth: the tail a row of `bar` rounds can leave is then ~5 % of the range's time.  A quarter was
             //  tried first: two of eight ranges of the 5 M job then ended 10-15 ms after the others, on single rows)
             const double bar = 0.05 * rows_per_wave * rounds_per_row;
-            heavy_rounds = bar < 256.0 ? 256u : (bar > 1.0e9 ? 1000000000u : (uint32_t)bar);
+            // (never below 128 rounds: at 663 k, eight ranges, bars of 64 / 128 / 256 / 512 rounds give 2.10 / 2.03 / 2.19 /
+            //  2.57 ms for the slowest range -- profiles/r03_sessionAG_heavy_bar_ranges.log)
+            heavy_rounds = bar < 128.0 ? 128u : (bar > 1.0e9 ? 1000000000u : (uint32_t)bar);
         }
         if (const char *v = ctx->opt("SG_HEAVY_ROUNDS")) heavy_rounds = (uint32_t)atoi(v) & 0x7fffffffu;
         if (heavy_rounds) {
