@@ -749,7 +749,7 @@ spgemm_topn_pruned_kernel(const int64_t *__restrict__ a_indptr, const int32_t *_
             struct __attribute__((packed, aligned(4))) Quad {
                 uint32_t x, y, z, w;
             };
-#ifdef SG_K4P_PROBE_NO_LOADS   // timing probes (wrong results): scripts/gpu_r02_q.sh
+#ifdef SG_K4P_PROBE_NO_LOADS   // timing probes (wrong results): a build of the library per probe, A/B through SG_HIP_LIB (scripts/gpu_session.sh ab:)
             Quad q;
             q.x = q.y = q.z = q.w = bt.base & 0x1ffcu;
 #else
