@@ -73,6 +73,8 @@ run("SynthNames 200k 2-grams ntop10 0.8", names, None, 10, 0.8, ngram_size=2)
 run("SynthNames 200k 4-grams ntop10 0.8", names, None, 10, 0.8, ngram_size=4)
 run("SynthNames 200k 3-grams ntop20 0.6", names, None, 20, 0.6)
 run("SynthNames 200k 3-grams ntop5 0.9", names, None, 5, 0.9)
+run("SynthNames 200k 3-grams ntop100 0.8", names, None, 100, 0.8)    # 65 .. 128: pruned, rows with full lists to the exact kernel
+run("SynthNames 200k 3-grams ntop100 0.6", names, None, 100, 0.6)
 for low in (0.45, 0.4, 0.35, 0.3):       # below 0.45 the pruned kernel only runs with SG_PRUNE_MIN_THRESHOLD=<lower>
     run(f"low threshold: 200k 3-grams ntop10 {low}", names, None, 10, low)
 run("long names (3 joined) 100k 3-grams ntop10 0.8", long_names(100000, 5), None, 10, 0.8)

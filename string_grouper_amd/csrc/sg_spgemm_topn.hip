@@ -421,6 +421,14 @@ __global__ void __launch_bounds__(256) count_macs_kernel(const int64_t *__restri
     block_add_u64(local, out_macs);
 }
 
+// top_n above the pruned kernel's register list: rows whose list came out full may have more matches -- the exact kernel
+// redoes them (their result rows are overwritten pass by pass)
+__global__ void __launch_bounds__(256) rows_with_full_lists_kernel(const int32_t *__restrict__ cnt, int64_t n_rows, int32_t full,
+                                                                   uint32_t *handed_count, uint32_t *__restrict__ handed_rows) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_rows && cnt[i] >= full) handed_rows[atomicAdd(handed_count, 1u)] = (uint32_t)i;
+}
+
 // ... of a self-join (A is the matrix the index was built over): the sum of the squared list lengths
 __global__ void __launch_bounds__(256) count_macs_selfjoin_kernel(const uint32_t *__restrict__ term_len, int64_t n_terms,
                                                                   unsigned long long *out_macs) {
@@ -689,7 +697,8 @@ static int prune_pilot(sg_ctx *ctx, const sg_csr *A, const sg_postings *Bt, int3
         e = hipMemsetAsync(words, 0, 8 * sizeof(uint32_t), ctx->stream);
         if (e == hipSuccess) e = hipMemsetAsync(scratch->d_counts, 0, sizeof(int32_t) * (size_t)block, ctx->stream);
         if (e == hipSuccess)
-            st = sg_spgemm_pruned_launch(ctx, &view, Bt, stride, scratch, threshold, delta, words, words + 1, words + 8, d_stats);
+            st = sg_spgemm_pruned_launch(ctx, &view, Bt, stride < SG_TOPN_LANES ? stride : SG_TOPN_LANES, scratch, threshold, delta, words,
+                                         words + 1, words + 8, d_stats);
     }
     if (st == SG_OK && e == hipSuccess) {
         hipLaunchKernelGGL(count_macs_kernel, dim3(512), dim3(256), 0, ctx->stream, A->d_indptr, A->d_indices, A->n_rows,
@@ -731,7 +740,9 @@ static bool pruned_applicable(sg_ctx *ctx, const sg_csr *A, const sg_postings *B
     *symmetric = false;
     *status = SG_OK;
     const char *pr = ctx->opt("SG_PRUNE");
-    if ((pr && pr[0] == '0') || !Bt->cosine_like || !Bt->d_filt || stride > SG_TOPN_LANES || A->n_rows <= 0 || Bt->nnz <= 0 ||
+    // (top_n of 65 .. 128: the pruned kernel keeps a row's best 64 in its register list; a row that fills the list may have
+    //  more matches and is handed to the exact kernel, which runs a pass per 64 entries -- rows_with_full_lists_kernel)
+    if ((pr && pr[0] == '0') || !Bt->cosine_like || !Bt->d_filt || stride > 2 * SG_TOPN_LANES || A->n_rows <= 0 || Bt->nnz <= 0 ||
         !sg_pruned_supports_tile(Bt->tile_log2) ||
         !(threshold >= env_double(ctx, "SG_PRUNE_MIN_THRESHOLD", 0.45)))   // below ~0.4 the filter passes too much (profiles/r01_prune_tuning.log)
         return false;
@@ -756,7 +767,7 @@ static bool pruned_applicable(sg_ctx *ctx, const sg_csr *A, const sg_postings *B
     // ... from the size at which halving the (row, tile) visits outweighs the second pass over the pair list
     // and its host round trip: 0.58 vs 0.57 ms at 50 k rows, 0.95 vs 1.20 at 100 k, 14.0 vs 26.8 at 663 k
     // (profiles/r02_sessionM_sym_sweep.log)
-    *symmetric = !(sy && sy[0] == '0') && A->n_rows == Bt->n_right && A->d_indptr == Bt->b_indptr &&
+    *symmetric = !(sy && sy[0] == '0') && stride <= SG_TOPN_LANES && A->n_rows == Bt->n_right && A->d_indptr == Bt->b_indptr &&
                  A->d_indices == Bt->b_indices && A->d_data == Bt->b_data &&
                  (any_size || A->n_rows >= (int64_t)env_int(ctx, "SG_SYM_MIN_ROWS", 65536) || (sy && sy[0] == '1'));
     return true;
@@ -918,8 +929,14 @@ extern "C" int sg_spgemm_topn(sg_ctx *ctx, const sg_csr *A, const sg_postings *B
         ctx->prune_symmetric = sym_done;
         if (prune && !sym_done && st == SG_OK) {
             SgTimer kt(ctx, SG_K_SPGEMM_KERNEL);
-            st = sg_spgemm_pruned_launch(ctx, A, Bt, stride, r, threshold, delta, counters + n_launch + 1,
-                                         handed_count, handed_rows, (unsigned long long *)(ctx->d_stat_words + 2));
+            st = sg_spgemm_pruned_launch(ctx, A, Bt, stride < SG_TOPN_LANES ? stride : SG_TOPN_LANES, r, threshold, delta,
+                                         counters + n_launch + 1, handed_count, handed_rows,
+                                         (unsigned long long *)(ctx->d_stat_words + 2));
+            if (st == SG_OK && stride > SG_TOPN_LANES && A->n_rows > 0) {
+                hipLaunchKernelGGL(rows_with_full_lists_kernel, dim3((unsigned)((A->n_rows + 255) / 256)), dim3(256), 0, ctx->stream,
+                                   (const int32_t *)r->d_counts, A->n_rows, (int32_t)SG_TOPN_LANES, handed_count, handed_rows);
+                if (hipGetLastError() != hipSuccess) st = SG_ERR_HIP;
+            }
         }
         // The exact kernel: the whole product when the pruned multiply does not apply, or the rows it handed over -- whether
         // there are any is read back (four bytes), because the index build leaves the exact kernel's postings out when

@@ -47,6 +47,36 @@ def test_spgemm_topn_selfjoin_matches_oracle(ctx, mats, dtype, top_n, thr, sort)
     assert_csr_identical(C_dev, C_ref, f"{dtype.__name__} top_n={top_n} thr={thr} sort={sort}")
 
 
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_top_n_above_the_register_list_takes_the_pruned_kernel_and_hands_full_rows_on(ctx, dtype, monkeypatch):
+    """max_n_matches of 65 .. 128 at a name-matching threshold: the pruned kernel keeps a row's best 64; rows whose list
+    comes out full (hubs of more than 64 near-identical names) are redone by the exact kernel, a pass per 64 entries.
+    Self-join and master x duplicates, identical rows grouped or not -- the port's result, bit for bit."""
+    from string_grouper_amd.sparse_dot_topn import sp_matmul_topn
+    rng = np.random.default_rng(8)
+    names = list(_names(15000, seed=3))
+    for hub, size in (("NORTHERN LIGHTS HOLDING CO", 150), ("BLUE RIVER PARTNERS", 70), ("KAPPA LTD", 64)):
+        for k, at in enumerate(rng.choice(len(names), size, replace=False)):
+            names[at] = hub + (" " + "ABCDEFGH"[k % 8] if k % 3 == 0 else "")      # identical and near-identical members
+    A = _tfidf(names, dtype)
+    for collapse in ("0", "1"):
+        monkeypatch.setenv("SG_COLLAPSE", collapse)
+        for top_n, thr in ((100, 0.8), (65, 0.6), (128, 0.7)):
+            got = sp_matmul_topn(A, A.T, top_n, thr, sort=True, ctx=ctx)
+            st = ctx.stats()
+            assert_csr_identical(got, P.sp_matmul_topn_port(A, A.T, top_n, thr, True, 8), f"top_n={top_n} thr={thr} collapse={collapse}")
+            if collapse == "0":
+                assert st["prune_rows"] > 14000 and 60 < st["exact_rows"] < 2000, st      # pruned, hub rows handed on
+        left = A[2000:9000]
+        assert_csr_identical(sp_matmul_topn(left, A.T, 90, 0.75, sort=False, ctx=ctx), P.sp_matmul_topn_port(left, A.T, 90, 0.75, False, 8),
+                             f"one-sided, sorted by column, collapse={collapse}")
+    # 129 and more: the exact kernel, as before
+    monkeypatch.setenv("SG_COLLAPSE", "0")
+    got = sp_matmul_topn(A, A.T, 129, 0.8, sort=True, ctx=ctx)
+    assert ctx.stats()["prune_rows"] == 0
+    assert_csr_identical(got, P.sp_matmul_topn_port(A, A.T, 129, 0.8, True, 8), "top_n=129")
+
+
 @pytest.mark.parametrize("tile_cols", [1024, 2048, 4096, 8192])
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
 def test_spgemm_tile_sizes_and_groups(ctx, mats, dtype, tile_cols, monkeypatch):
