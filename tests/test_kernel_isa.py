@@ -45,8 +45,11 @@ STREAM_WIDE_KERNELS = {
     "f64 self-join wide": "IdLi12ELb1ELb1ELi3EE",
     "f64 one-sided wide": "IdLi12ELb0ELb1ELi3EE",
 }
-STREAM_LIMITS = {"f32 self-join": 16, "f32 one-sided": 16, "f64 self-join": 8, "f64 one-sided": 8}   # vgpr spills allowed (all outside the trip)
-STREAM_VGPRS = {"f32 self-join": 128, "f32 one-sided": 128, "f64 self-join": 168, "f64 one-sided": 168}   # 4 / 3 waves per SIMD
+# vgpr spills allowed (all outside the trip).  f64 -- the reference's DEFAULT dtype -- is built for three waves per SIMD
+# (168 registers) and must keep head-room: no scratch at all and at least 8 spare registers, so that an unrelated edit
+# cannot push its round loop into spills (round 2: 14.9 -> 16.4 ms from one, profiles/r02_sessionAL_f64_bisect.log)
+STREAM_LIMITS = {"f32 self-join": 16, "f32 one-sided": 16, "f64 self-join": 0, "f64 one-sided": 0}
+STREAM_VGPRS = {"f32 self-join": 128, "f32 one-sided": 128, "f64 self-join": 160, "f64 one-sided": 160}   # 4 / 3 waves per SIMD
 # (vgpr spills allowed, instructions of the fast-path block allowed)
 LIMITS = {"f32 self-join": (16, 95), "f32 one-sided": (16, 95), "f64 self-join": (24, 95), "f64 one-sided": (24, 95)}
 
