@@ -77,6 +77,49 @@ def test_top_n_above_the_register_list_takes_the_pruned_kernel_and_hands_full_ro
     assert_csr_identical(got, P.sp_matmul_topn_port(A, A.T, 129, 0.8, True, 8), "top_n=129")
 
 
+def test_random_lists_with_repeats_equal_the_port(ctx):
+    """Seeded random jobs around the switches of round 3 -- size on both sides of the grouping's threshold, share and size of
+    the repeats, near-duplicates of the hubs (ties at the cut between a group and single rows), top_n from 1 to 128,
+    thresholds from 0.5 to 0.95, both dtypes, sorted or shuffled, self-join (as the library sees it: the same device
+    matrix on both sides, so the self-join form can run) and one-sided -- against the port, bit for bit."""
+    import os
+    rng = np.random.default_rng(int(os.environ.get("SG_TEST_RANDOM_SEED", "2024")))
+    for job in range(int(os.environ.get("SG_TEST_RANDOM_JOBS", "24"))):     # (a longer soak: SG_TEST_RANDOM_JOBS=200)
+        n = int(rng.choice([6000, 9000, 14000, 30000, 70000]))
+        names = list(_names(n, seed=100 + job))
+        for _ in range(int(rng.integers(0, 6))):                         # hubs
+            hub = names[int(rng.integers(0, n))]
+            size = int(rng.choice([3, 20, 64, 65, 200, 1500]))
+            for k, at in enumerate(rng.choice(n, min(size, n // 4), replace=False)):
+                names[at] = hub if k % 4 else hub + " " + "XYZW"[k % 3]
+        share = float(rng.choice([0.0, 0.02, 0.05, 0.3]))                # plain repeats
+        for at in rng.choice(n - 1, int(share * n), replace=False):
+            names[at + 1] = names[at]
+        if rng.random() < 0.5:
+            names = sorted(names)
+        dtype = np.float32 if rng.random() < 0.6 else np.float64
+        top_n = int(rng.choice([1, 2, 10, 10, 20, 63, 64, 65, 100, 128]))
+        thr = float(rng.choice([0.5, 0.6, 0.75, 0.8, 0.8, 0.9, 0.95]))
+        sym = str(rng.choice(["", "0", "1"]))
+        what = f"job {job}: n={n} top_n={top_n} thr={thr} {dtype.__name__} SG_SYM={sym!r} repeats={share}"
+        A = _tfidf(names, dtype)
+        dA = ctx.csr_from_scipy(A)
+        if sym:
+            ctx.set_option("SG_SYM", sym)
+        post = ctx.postings_build(dA)
+        res = ctx.spgemm_topn(dA, post, top_n, thr, True)
+        assert_csr_identical(res.to_scipy(), P.sp_matmul_topn_port(A, A.T, top_n, thr, True, 16), what)
+        res.free()
+        lo = int(rng.integers(0, n // 2))
+        left = A[lo:lo + n // 3]
+        dL = ctx.csr_from_scipy(left)
+        res = ctx.spgemm_topn(dL, post, top_n, thr, True)
+        assert_csr_identical(res.to_scipy(), P.sp_matmul_topn_port(left, A.T, top_n, thr, True, 16), what + " one-sided")
+        for h in (res, dL, post, dA):
+            h.free()
+        ctx.reset_options()
+
+
 @pytest.mark.parametrize("tile_cols", [1024, 2048, 4096, 8192])
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
 def test_spgemm_tile_sizes_and_groups(ctx, mats, dtype, tile_cols, monkeypatch):
