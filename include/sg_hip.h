@@ -266,6 +266,10 @@ int sg_selfjoin_merge(sg_ctx *ctx, sg_topn *res, const sg_postings *Bt, const in
 int sg_postings_rows(const sg_postings *Bt, int64_t *n_index_rows, int64_t *n_caller_rows, const uint32_t **d_group_of_row);
 int sg_topn_expand_groups(sg_ctx *ctx, const sg_postings *Bt, const sg_topn *groups, const int32_t *d_rows, int64_t n_rows,
                           sg_topn **out);
+/* ... the same for the rows of the groups at the positions [pos_lo, pos_hi) -- a rank's range: the library makes the list
+ * (ascending row numbers; *d_rows, *n_rows: device memory of the library, sg_device_free) and expands it. */
+int sg_topn_expand_range(sg_ctx *ctx, const sg_postings *Bt, const sg_topn *groups, int64_t pos_lo, int64_t pos_hi,
+                         sg_topn **out, int32_t **d_rows, int64_t *n_rows);
 /* device tables of Bt's row permutation, one entry per index row: position -> row, row -> position (both null: none) */
 int sg_postings_permutation(const sg_postings *Bt, const uint32_t **d_orig_of, const uint32_t **d_pos_of);
 int sg_device_free(sg_ctx *ctx, void *d_ptr);

@@ -99,6 +99,7 @@ ABI = {
     "sg_postings_permutation": (C.c_int, [_P, _PP, _PP]),
     "sg_postings_rows": (C.c_int, [_P, _P, _P, _PP]),
     "sg_topn_expand_groups": (C.c_int, [_P, _P, _P, _P, C.c_int64, _PP]),
+    "sg_topn_expand_range": (C.c_int, [_P, _P, _P, C.c_int64, C.c_int64, _PP, _PP, _P]),
     "sg_device_free": (C.c_int, [_P, _P]),
     "sg_csr_rowwise_dot": (C.c_int, [_P, _P, _P, _P]),
     "sg_ctx_stats": (C.c_int, [_P, C.POINTER(SgStats)]),
@@ -529,6 +530,13 @@ class Context:
         out = C.c_void_p()
         check(lib().sg_topn_expand_groups(self.h, Bt.h, groups.h, C.c_void_p(d_rows) if d_rows else None, int(n_rows), C.byref(out)))
         return TopN(self, out)
+
+    def topn_expand_range(self, Bt: Postings, groups: "TopN", pos_lo: int, pos_hi: int):
+        """(result rows, device pointer of their int32 row numbers -- ``device_free`` it --, how many) for the rows of the
+        groups at the positions [pos_lo, pos_hi) of the index (sg_topn_expand_range)."""
+        out, rows, n = C.c_void_p(), C.c_void_p(), C.c_int64()
+        check(lib().sg_topn_expand_range(self.h, Bt.h, groups.h, int(pos_lo), int(pos_hi), C.byref(out), C.byref(rows), C.byref(n)))
+        return TopN(self, out), rows.value or 0, n.value
 
     def device_free(self, d_ptr: int) -> None:
         if d_ptr:

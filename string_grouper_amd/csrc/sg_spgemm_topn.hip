@@ -1127,6 +1127,66 @@ extern "C" int sg_topn_expand_groups(sg_ctx *ctx, const sg_postings *Bt, const s
     return SG_OK;
 }
 
+// rows whose group sits at a position of [pos_lo, pos_hi)
+__global__ void __launch_bounds__(256) rows_of_range_flag_kernel(const uint32_t *__restrict__ gid, const uint32_t *__restrict__ pos_of,
+                                                                 int64_t n_rows, uint32_t pos_lo, uint32_t pos_hi,
+                                                                 uint32_t *__restrict__ flag) {
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_rows) return;
+    const uint32_t g = gid[r];
+    const uint32_t p = pos_of ? pos_of[g] : g;
+    flag[r] = (p >= pos_lo && p < pos_hi) ? 1u : 0u;
+}
+__global__ void __launch_bounds__(256) rows_of_range_fill_kernel(const uint32_t *__restrict__ flag, const uint32_t *__restrict__ at,
+                                                                 int64_t n_rows, int32_t *__restrict__ rows) {
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < n_rows && flag[r]) rows[at[r]] = (int32_t)r;
+}
+
+extern "C" int sg_topn_expand_range(sg_ctx *ctx, const sg_postings *Bt, const sg_topn *groups, int64_t pos_lo, int64_t pos_hi,
+                                    sg_topn **out, int32_t **d_rows, int64_t *n_rows) {
+    SG_REQUIRE(ctx && Bt && groups && out && d_rows && n_rows, "null argument");
+    SG_REQUIRE(Bt->collapse != nullptr, "the index was not built over groups of identical rows (sg_postings_rows)");
+    const SgCollapse *c = Bt->collapse;
+    SG_REQUIRE(pos_lo >= 0 && pos_lo <= pos_hi && pos_hi <= c->n_u, "range outside the groups of the index");
+    *out = nullptr;
+    *d_rows = nullptr;
+    *n_rows = 0;
+    const int64_t n = c->n_orig;
+    uint32_t *flag = nullptr, *at = nullptr, *total = nullptr;
+    int32_t *rows = nullptr;
+    int st = sg_alloc(ctx, (size_t)n + 1, &flag);
+    if (st == SG_OK) st = sg_alloc(ctx, (size_t)n + 1, &at);
+    if (st == SG_OK) st = sg_alloc(ctx, (size_t)4, &total);
+    uint32_t n_mine = 0;
+    if (st == SG_OK && n > 0) {
+        const unsigned g1 = (unsigned)((n + 255) / 256);
+        hipLaunchKernelGGL(rows_of_range_flag_kernel, dim3(g1), dim3(256), 0, ctx->stream, (const uint32_t *)c->d_gid,
+                           (const uint32_t *)Bt->d_pos_of, n, (uint32_t)pos_lo, (uint32_t)pos_hi, flag);
+        st = sg_exclusive_scan_u32(ctx, flag, at, n, total);
+        if (st == SG_OK && (hipMemcpyAsync(&n_mine, total, 4, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+                            hipStreamSynchronize(ctx->stream) != hipSuccess))
+            st = SG_ERR_HIP;
+        if (st == SG_OK) st = sg_alloc(ctx, (size_t)n_mine + 1, &rows);
+        if (st == SG_OK) {
+            hipLaunchKernelGGL(rows_of_range_fill_kernel, dim3(g1), dim3(256), 0, ctx->stream, (const uint32_t *)flag,
+                               (const uint32_t *)at, n, rows);
+            if (hipGetLastError() != hipSuccess) st = SG_ERR_HIP;
+        }
+    }
+    ctx->release(flag);
+    ctx->release(at);
+    ctx->release(total);
+    if (st == SG_OK) st = sg_topn_expand_groups(ctx, Bt, groups, rows, (int64_t)n_mine, out);
+    if (st != SG_OK) {
+        ctx->release(rows);
+        return st;
+    }
+    *d_rows = rows;
+    *n_rows = (int64_t)n_mine;
+    return SG_OK;
+}
+
 extern "C" int sg_postings_permutation(const sg_postings *Bt, const uint32_t **d_orig_of, const uint32_t **d_pos_of) {
     SG_REQUIRE(Bt != nullptr, "postings are null");
     if (d_orig_of) *d_orig_of = Bt->d_orig_of;

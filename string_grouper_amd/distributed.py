@@ -482,16 +482,11 @@ class HipOps:
             return TopNRows(part["res"], lo, hi, orig_of)
         # an index over groups of identical rows: the range was one of groups; the rows of this rank are the members of
         # its groups, expanded here from tables every rank holds (no exchange)
-        mine = torch.zeros(n_index, dtype=torch.bool, device=self.device)
-        if orig_of is not None:
-            mine[orig_of[lo:hi]] = True
-        else:
-            mine[lo:hi] = True
-        gid = torch.as_tensor(DeviceTensorView(p_gid, n_caller, "<i4"), device=self.device)[:n_caller].to(torch.int64)
-        rows = torch.nonzero(mine[gid]).reshape(-1).to(torch.int32).contiguous()
-        torch.cuda.current_stream(self.device).synchronize()   # the row list is torch's: written before the library reads it
-        r = self.ctx.topn_expand_groups(post, part["res"], rows.data_ptr(), rows.numel())
+        r, p_rows, n_mine = self.ctx.topn_expand_range(post, part["res"], lo, hi)
         self.ctx.sync()
+        rows = torch.as_tensor(DeviceTensorView(p_rows, max(n_mine, 1), "<i4"), device=self.device)[:n_mine].clone()
+        torch.cuda.current_stream(self.device).synchronize()   # (copied before the library's list is released)
+        self.ctx.device_free(p_rows)
         part["res"].free()
         return TopNRows(r, 0, rows.numel(), None, row_ids=rows)
 
