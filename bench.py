@@ -276,7 +276,7 @@ def run(args):
                    "parallelism": "single GPU" if world == 1 else
                    f"{world} GPUs, one process each: rows of the string column in {world} contiguous blocks; tokenise local "
                    f"block -> all-reduce df table -> weight local block -> all-gather CSR -> inverted index -> multiply: "
-                   + ("self-join form over left-row ranges (pairs j <= i, one all-gather of the mirrored pairs, merge)"
+                   + ("self-join form over interleaved shares of the rows (pairs j <= i, one all-gather of the mirrored pairs, merge)"
                       if (distributed and dist_mode == "sharded" and D.selfjoin_form_wanted(args.rows, world))
                       else "the local rows against all columns, no collective in the multiply") + f" ({dist_mode})"},
         # launch groups of one step (HIP events on the library's stream); spgemm_topn = the multiply's whole group (pruned

@@ -245,12 +245,17 @@ int sg_row_costs(sg_ctx *ctx, const sg_csr *A, const sg_postings *Bt, int64_t *o
  *   afterwards these rows equal the rows sg_spgemm_topn(A, Bt) would give, bit for bit.
  * When the index is built over the row permutation (the default, sg_postings_build_flags) a range is a range of
  *   POSITIONS: the rows it covers are orig_of[row_lo .. row_hi) (sg_postings_permutation; null tables = row order).
- *   Pass the same Bt to sg_selfjoin_merge. */
+ *   Pass the same Bt to sg_selfjoin_merge.
+ * row_step (round 3): a rank's share need not be contiguous -- with row_step = s it is the rows (positions) row_hi - 1,
+ *   row_hi - 1 - s, row_hi - 1 - 2 s, ... >= row_lo.  Rank r of N takes (0, n - r, N): every rank then holds rows of every
+ *   cost, the shares are equal without a cost model, and a share ends with its CHEAPEST rows like the whole pass does
+ *   (a contiguous range of high positions ends with rows as expensive as its first: + 0.8 ms per range at 663 k).
+ *   row_step <= 1: the contiguous range [row_lo, row_hi).  Pass the same triple to sg_selfjoin_merge / sg_topn_expand_range. */
 int sg_selfjoin_range(sg_ctx *ctx, const sg_csr *A, const sg_postings *Bt, int32_t top_n, double threshold,
                       int64_t row_lo, int64_t row_hi, sg_topn **out, int32_t **d_pairs, int64_t *n_pairs,
-                      int32_t *pair_words, int32_t *applicable);
+                      int32_t *pair_words, int32_t *applicable, int64_t row_step);
 int sg_selfjoin_merge(sg_ctx *ctx, sg_topn *res, const sg_postings *Bt, const int32_t *d_pairs, int64_t n_pairs,
-                      int32_t pair_words, int64_t row_lo, int64_t row_hi);
+                      int32_t pair_words, int64_t row_lo, int64_t row_hi, int64_t row_step);
 /* Identical rows.  sg_postings_build indexes ONE representative per group of identical right-hand rows (identical
  * strings; option SG_COLLAPSE=0 switches it off) and sg_spgemm_topn expands its result to the caller's columns, so a
  * single GPU never sees the groups.  The self-join form over ranges does: with such an index
@@ -269,7 +274,7 @@ int sg_topn_expand_groups(sg_ctx *ctx, const sg_postings *Bt, const sg_topn *gro
 /* ... the same for the rows of the groups at the positions [pos_lo, pos_hi) -- a rank's range: the library makes the list
  * (ascending row numbers; *d_rows, *n_rows: device memory of the library, sg_device_free) and expands it. */
 int sg_topn_expand_range(sg_ctx *ctx, const sg_postings *Bt, const sg_topn *groups, int64_t pos_lo, int64_t pos_hi,
-                         sg_topn **out, int32_t **d_rows, int64_t *n_rows);
+                         sg_topn **out, int32_t **d_rows, int64_t *n_rows, int64_t pos_step);
 /* device tables of Bt's row permutation, one entry per index row: position -> row, row -> position (both null: none) */
 int sg_postings_permutation(const sg_postings *Bt, const uint32_t **d_orig_of, const uint32_t **d_pos_of);
 int sg_device_free(sg_ctx *ctx, void *d_ptr);

@@ -45,15 +45,15 @@ def once(log):
     tick("replicate_csr (world 1: nothing)")
     post = ops.postings(A_full)
     tick("postings (K3)")
-    bounds = D.selfjoin_row_ranges(n, 1)
-    part = ops.selfjoin_range(A_full, post, 10, 0.8, 0, n)
+    n_index = ops.selfjoin_rows(A_full, post)          # (rows of the index: groups of identical rows)
+    part = ops.selfjoin_range(A_full, post, 10, 0.8, 0, n_index)
     tick("selfjoin_range (K4p pass 1)")
     pairs = ops.selfjoin_pairs(part)
     sizes = [h[0] for h in D.all_headers([pairs.numel()], ops.device)]
     tick("header exchange")
     pairs_all = torch.cat(D.all_gather_ragged(pairs, None, sizes))
     tick("all-gather of the pairs")
-    res = ops.selfjoin_merge(part, pairs_all, 0, n)
+    res = ops.selfjoin_merge(part, pairs_all, 0, n_index)
     tick("merge")
     res.free(); post.free(); A_full.free()
     tick("free")

@@ -6,7 +6,8 @@ makes (string_grouper_amd/distributed.py: distributed_self_join in its self-join
 
   per rank r of N   tokenise + weight its row block (K1, K2 -- measured on block r of the list)
                     inverted index of the WHOLE matrix (K3 -- replicated work, measured once)
-                    pass 1 of the self-join form over ITS range of positions (sg_selfjoin_range -- measured per rank)
+                    pass 1 of the self-join form over ITS share of the positions (sg_selfjoin_range -- measured per rank;
+                    distributed.selfjoin_share: interleaved by default, SG_DIST_INTERLEAVE=0 for contiguous ranges)
                     merge of the mirrored pairs that point into its range (sg_selfjoin_merge) and, when the index is one
                     over groups of identical rows, expansion of its groups into their member rows
                     (sg_topn_expand_groups) -- measured per rank through HipOps.selfjoin_merge, the driver's call
@@ -78,7 +79,6 @@ def main():
     w = ops.selfjoin_range(A, post, 10, 0.8, 0, n_index)
     ops.selfjoin_merge(w, ops.selfjoin_pairs(w).clone(), 0, n_index).free()
     for world in (1, 2, 4, 8):
-        bounds = D.selfjoin_row_ranges(n_index, world)
         per_rank = []
         pair_counts = []
         for r in range(world):
@@ -94,10 +94,10 @@ def main():
                 m.free()
                 return None
             t_vec, k_vec, _ = ms(vectorise)
-            plo, phi = int(bounds[r]), int(bounds[r + 1])
+            plo, phi, pstep = (0, n_index, 1) if world == 1 else D.selfjoin_share(n_index, r, world)
 
             def pass1():
-                got = ctx.selfjoin_range(A, post, 10, 0.8, plo, phi)
+                got = ctx.selfjoin_range(A, post, 10, 0.8, plo, phi, pstep)
                 assert got is not None
                 return got
             warm = pass1()                      # (the first call allocates the pair list: not part of a steady step)
@@ -117,7 +117,7 @@ def main():
             t_p1, k_p1, got = best
             res, ptr, n_pairs, words = got
             pair_counts.append(n_pairs)
-            per_rank.append({"rank": r, "rows": hi - lo, "range": [plo, phi], "vectorise_ms_wall": t_vec,
+            per_rank.append({"rank": r, "rows": hi - lo, "range": [plo, phi, pstep], "vectorise_ms_wall": t_vec,
                              "vectorise_ms_kernels": k_vec.get("tokenize", 0) + k_vec.get("vocab", 0) + k_vec.get("weight", 0),
                              "pass1_ms_wall": t_p1, "pass1_ms_kernel": k_p1.get("spgemm_topn", 0.0),
                              "pass1_ms_kernel_alone": k_p1.get("spgemm_kernel", 0.0), "pairs": int(n_pairs),
@@ -132,14 +132,14 @@ def main():
         pairs_all = torch.cat(all_pairs) if all_pairs else torch.zeros(0, dtype=torch.int32, device="cuda")
         torch.cuda.synchronize()
         for pr in per_rank:
-            plo, phi = pr["range"]
+            plo, phi, pstep = pr["range"]
             words = pr["_words"]
 
             def merge():
                 # the driver's call: merge of the pairs that point into the range + (index over groups) expansion of the
                 # range's groups into their member rows
                 return ops.selfjoin_merge({"res": pr["_res"], "ptr": pr["_ptr"], "n": pr["pairs"], "words": words, "post": post},
-                                          pairs_all, plo, phi)
+                                          pairs_all, plo, phi, pstep)
             t_m, k_m, blk = ms(merge, reps=1)
             pr["merge_ms_wall"] = t_m
             pr["rows_out"] = int(blk.dims()[0])

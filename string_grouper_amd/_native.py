@@ -94,12 +94,12 @@ ABI = {
     "sg_matchlist_best_master": (C.c_int, [_P, _P, _P]),
     "sg_matchlist_group_reps": (C.c_int, [_P, _P, C.c_int32, _P]),
     "sg_row_costs": (C.c_int, [_P, _P, _P, _P]),
-    "sg_selfjoin_range": (C.c_int, [_P, _P, _P, C.c_int32, C.c_double, C.c_int64, C.c_int64, _P, _P, _P, _P, _P]),
-    "sg_selfjoin_merge": (C.c_int, [_P, _P, _P, _P, C.c_int64, C.c_int32, C.c_int64, C.c_int64]),
+    "sg_selfjoin_range": (C.c_int, [_P, _P, _P, C.c_int32, C.c_double, C.c_int64, C.c_int64, _P, _P, _P, _P, _P, C.c_int64]),
+    "sg_selfjoin_merge": (C.c_int, [_P, _P, _P, _P, C.c_int64, C.c_int32, C.c_int64, C.c_int64, C.c_int64]),
     "sg_postings_permutation": (C.c_int, [_P, _PP, _PP]),
     "sg_postings_rows": (C.c_int, [_P, _P, _P, _PP]),
     "sg_topn_expand_groups": (C.c_int, [_P, _P, _P, _P, C.c_int64, _PP]),
-    "sg_topn_expand_range": (C.c_int, [_P, _P, _P, C.c_int64, C.c_int64, _PP, _PP, _P]),
+    "sg_topn_expand_range": (C.c_int, [_P, _P, _P, C.c_int64, C.c_int64, _PP, _PP, _P, C.c_int64]),
     "sg_device_free": (C.c_int, [_P, _P]),
     "sg_csr_rowwise_dot": (C.c_int, [_P, _P, _P, _P]),
     "sg_ctx_stats": (C.c_int, [_P, C.POINTER(SgStats)]),
@@ -494,22 +494,23 @@ class Context:
         check(lib().sg_csr_rowwise_dot(self.h, A.h, B.h, _ptr(out)))
         return out[:r]
 
-    def selfjoin_range(self, A: Csr, Bt: Postings, top_n: int, threshold: float, row_lo: int, row_hi: int):
-        """The rows [row_lo, row_hi) of the self-join form (include/sg_hip.h: sg_selfjoin_range).  Returns
+    def selfjoin_range(self, A: Csr, Bt: Postings, top_n: int, threshold: float, row_lo: int, row_hi: int, row_step: int = 1):
+        """The rows [row_lo, row_hi) -- with ``row_step`` s > 1: row_hi - 1, row_hi - 1 - s, ... >= row_lo -- of the
+        self-join form (include/sg_hip.h: sg_selfjoin_range).  Returns
         (TopN over all rows, device pointer of the mirrored pairs, number of pairs, int32 words per pair), or None when
         the form does not apply to this input."""
         out, pairs = C.c_void_p(), C.c_void_p()
         n_pairs, words, ok = C.c_int64(), C.c_int32(), C.c_int32()
         check(lib().sg_selfjoin_range(self.h, A.h, Bt.h, int(top_n), float(threshold), int(row_lo), int(row_hi),
-                                      C.byref(out), C.byref(pairs), C.byref(n_pairs), C.byref(words), C.byref(ok)))
+                                      C.byref(out), C.byref(pairs), C.byref(n_pairs), C.byref(words), C.byref(ok), int(row_step)))
         if not ok.value:
             return None
         return TopN(self, out), pairs.value, n_pairs.value, words.value
 
     def selfjoin_merge(self, res: TopN, Bt: Optional[Postings], d_pairs: int, n_pairs: int, pair_words: int, row_lo: int,
-                       row_hi: int) -> None:
+                       row_hi: int, row_step: int = 1) -> None:
         check(lib().sg_selfjoin_merge(self.h, res.h, Bt.h if Bt is not None else None, C.c_void_p(d_pairs), int(n_pairs),
-                                      int(pair_words), int(row_lo), int(row_hi)))
+                                      int(pair_words), int(row_lo), int(row_hi), int(row_step)))
 
     def postings_permutation(self, Bt: Postings):
         """(device pointer of orig_of, of pos_of), or (0, 0) when the index is in row order."""
@@ -531,11 +532,12 @@ class Context:
         check(lib().sg_topn_expand_groups(self.h, Bt.h, groups.h, C.c_void_p(d_rows) if d_rows else None, int(n_rows), C.byref(out)))
         return TopN(self, out)
 
-    def topn_expand_range(self, Bt: Postings, groups: "TopN", pos_lo: int, pos_hi: int):
+    def topn_expand_range(self, Bt: Postings, groups: "TopN", pos_lo: int, pos_hi: int, pos_step: int = 1):
         """(result rows, device pointer of their int32 row numbers -- ``device_free`` it --, how many) for the rows of the
         groups at the positions [pos_lo, pos_hi) of the index (sg_topn_expand_range)."""
         out, rows, n = C.c_void_p(), C.c_void_p(), C.c_int64()
-        check(lib().sg_topn_expand_range(self.h, Bt.h, groups.h, int(pos_lo), int(pos_hi), C.byref(out), C.byref(rows), C.byref(n)))
+        check(lib().sg_topn_expand_range(self.h, Bt.h, groups.h, int(pos_lo), int(pos_hi), C.byref(out), C.byref(rows), C.byref(n),
+                                         int(pos_step)))
         return TopN(self, out), rows.value or 0, n.value
 
     def device_free(self, d_ptr: int) -> None:

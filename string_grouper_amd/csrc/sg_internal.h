@@ -268,9 +268,10 @@ int sg_spgemm_pruned_launch(sg_ctx *ctx, const sg_csr *A, const sg_postings *Bt,
 int sg_spgemm_pruned_symmetric(sg_ctx *ctx, const sg_csr *A, const sg_postings *Bt, int32_t keep, sg_topn *r,
                                double threshold, double delta, unsigned long long *stats, bool *done, int64_t row_lo = 0,
                                int64_t row_hi = -1 /* the whole matrix */, int32_t **export_pairs = nullptr,
-                               int64_t *export_n = nullptr);
+                               int64_t *export_n = nullptr, int64_t row_step = 1 /* rows row_hi - 1, row_hi - 1 - step, ... */);
 int sg_selfjoin_merge_pairs(sg_ctx *ctx, sg_topn *r, const int32_t *d_pairs, int64_t n_pairs, int64_t row_lo, int64_t row_hi,
-                            const uint32_t *pos_of /* row -> position when the range is one of positions; null: rows */);
+                            const uint32_t *pos_of /* row -> position when the range is one of positions; null: rows */,
+                            int64_t row_step = 1);
 
 // The pair list of the self-join form: the MIRRORED pairs (i, j < i, score) above the threshold, in chunks of
 // SG_PAIR_CHUNK entries that a wave owns while it fills them (one returning atomic per chunk).  Written by the pruned

@@ -425,12 +425,14 @@ spgemm_topn_pruned_kernel(const int64_t *__restrict__ a_indptr, const int32_t *_
                           unsigned long long *stats /* [0] rows [1] postings streamed [2] survivors */,
                           const SgPairSink *__restrict__ pairs /* SYM: the pair list (sg_internal.h), in device memory */,
                           uint32_t pair_chunks /* chunks there are */,
-                          uint32_t sym_lo, uint32_t sym_hi /* SYM: the left rows this launch scores (multi-GPU: a rank's range) */,
+                          uint32_t sym_lo, uint32_t sym_hi /* SYM: the left rows this launch scores: sym_hi - 1, sym_hi - 1 - sym_step, ...
+                                                              >= sym_lo (multi-GPU: a rank's share; sym_step = 1: a contiguous range) */,
                           const uint32_t *__restrict__ row_list /* WIDE: the rows to process */, const uint32_t *row_list_len,
                           const uint32_t *__restrict__ ends8 /* stream form: ends of the super-tiles */, int32_t nv_pad,
                           uint32_t null_off /* stream form: byte offset of 256 filter postings that add nothing, four per lane */,
                           uint32_t n_right /* right-hand rows (columns of the result) */,
                           uint32_t *heavy_count, uint32_t *heavy_rows /* stream + self-join form: rows set aside for the launch over parts */,
+                          uint32_t sym_step,
                           uint32_t part_cfg /* 0: every row whole; < 2^31: rows of at least this many rounds are set aside;
                                                bit 31: this IS the launch over parts (rows in row_list, SG_ROW_PARTS items each) */) {
     constexpr int TILE = 1 << TILE_LOG2;
@@ -473,7 +475,7 @@ spgemm_topn_pruned_kernel(const int64_t *__restrict__ a_indptr, const int32_t *_
     constexpr bool CAN_SPLIT = SYM && !WIDE && FOLD_LOG2 > 0;
     const bool part_mode = CAN_SPLIT && (part_cfg >> 31) != 0u;
     const uint32_t n_here = (WIDE || part_mode) ? (uint32_t)__builtin_amdgcn_readfirstlane((int)*row_list_len) << (part_mode ? SG_ROW_PARTS_LOG2 : 0)
-                                                : (SYM ? sym_hi - sym_lo : n_left);
+                                                : (SYM ? (sym_hi - sym_lo + sym_step - 1u) / sym_step : n_left);
     // rows are handed out four at a time: one global atomic per row capped the kernel at ~88 rows/us (larger first
     // helpings were tried -- sixteen rows for the first three quarters -- and changed nothing: profiles/r02_sessionJ6_*.log).
     // Symmetric mode walks the rows from the last to the first: a row's cost grows with its index there.
@@ -490,7 +492,7 @@ spgemm_topn_pruned_kernel(const int64_t *__restrict__ a_indptr, const int32_t *_
         SG_WD(wd_rows, n_left + 2, 11)
         const uint32_t row = WIDE ? (uint32_t)__builtin_amdgcn_readfirstlane((int)row_list[rr])
                                   : part_mode ? (uint32_t)__builtin_amdgcn_readfirstlane((int)row_list[rr >> SG_ROW_PARTS_LOG2])
-                                              : (SYM ? sym_hi - 1u - rr : rr);
+                                              : (SYM ? sym_hi - 1u - rr * sym_step : rr);
         uint32_t part_lo = 0, part_hi = 0;   // part mode: the visits [part_lo, part_hi) of the row
         if (CAN_SPLIT && part_mode) {
             const uint32_t nv = ((row >> TILE_LOG2) + (1u << FOLD_LOG2)) >> FOLD_LOG2;   // visits of the row (self-join form)
@@ -1226,17 +1228,18 @@ __global__ void __launch_bounds__(SG_PAIR_CHUNK) pairs_export_kernel(const uint3
 
 template <int W>
 __global__ void __launch_bounds__(256) pairs_flat_count_kernel(const int32_t *__restrict__ pairs, int64_t n_pairs, uint32_t lo,
-                                                               uint32_t hi, const uint32_t *__restrict__ pos_of, uint32_t *cnt) {
+                                                               uint32_t hi, uint32_t step, const uint32_t *__restrict__ pos_of,
+                                                               uint32_t *cnt) {
     const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n_pairs) return;
     const uint32_t j = (uint32_t)pairs[p * W + 1];
     const uint32_t at = pos_of ? pos_of[j] : j;   // a rank's range is a range of POSITIONS when the index is permuted
-    if (at >= lo && at < hi) atomicAdd(&cnt[j], 1u);
+    if (at >= lo && at < hi && (hi - 1u - at) % step == 0u) atomicAdd(&cnt[j], 1u);   // (a rank's rows: hi - 1, hi - 1 - step, ...)
 }
 
 template <typename T>
 __global__ void __launch_bounds__(256) pairs_flat_fill_kernel(const int32_t *__restrict__ pairs, int64_t n_pairs, uint32_t lo,
-                                                              uint32_t hi, const uint32_t *__restrict__ pos_of,
+                                                              uint32_t hi, uint32_t step, const uint32_t *__restrict__ pos_of,
                                                               const uint32_t *__restrict__ ptr, uint32_t *cursor,
                                                               int32_t *__restrict__ lcol, T *__restrict__ lval) {
     constexpr int W = sizeof(T) == 8 ? 4 : 3;
@@ -1245,7 +1248,7 @@ __global__ void __launch_bounds__(256) pairs_flat_fill_kernel(const int32_t *__r
     const int32_t *rec = pairs + p * W;
     const uint32_t j = (uint32_t)rec[1];
     const uint32_t pj = pos_of ? pos_of[j] : j;
-    if (pj < lo || pj >= hi) return;
+    if (pj < lo || pj >= hi || (hi - 1u - pj) % step != 0u) return;
     const uint32_t at = ptr[j] + atomicAdd(&cursor[j], 1u);
     lcol[at] = rec[0];
     if (sizeof(T) == 8)
@@ -1424,7 +1427,9 @@ struct PairList {   // symmetric mode: the mirrored pairs (i, j < i) above the t
     uint32_t *d_chunks_used = nullptr;         // chunks handed out
     unsigned long long *d_totals = nullptr;    // pairs
     uint32_t chunks = 0;
-    uint32_t row_lo = 0, row_hi = 0;           // the left rows to score (the whole matrix on one GPU)
+    uint32_t row_lo = 0, row_hi = 0;           // the left rows to score (the whole matrix on one GPU):
+    uint32_t row_step = 1;                     // row_hi - 1, row_hi - 1 - row_step, ... >= row_lo
+    uint32_t rows() const { return (row_hi - row_lo + row_step - 1u) / row_step; }
     const SgPairSink *d_sink = nullptr;        // the same pointers as a struct in device memory: what the kernel is handed
 };
 
@@ -1454,7 +1459,7 @@ static int launch_pruned(sg_ctx *ctx, const sg_csr *A, const sg_postings *Bt, in
                          unsigned long long *stats, const PairList &pl, const uint32_t *row_list, const uint32_t *row_list_len,
                          uint32_t *heavy_count = nullptr, uint32_t *heavy_rows = nullptr, uint32_t part_cfg = 0) {
     const size_t lds = pruned_lds(TILE_LOG2, FOLD_LOG2, A->dtype);
-    unsigned grid = pruned_grid(ctx, TILE_LOG2, SYM ? (int64_t)(pl.row_hi - pl.row_lo) : A->n_rows, FOLD_LOG2, A->dtype);
+    unsigned grid = pruned_grid(ctx, TILE_LOG2, SYM ? (int64_t)pl.rows() : A->n_rows, FOLD_LOG2, A->dtype);
     if (WIDE && grid > (unsigned)ctx->num_cu * 4u) grid = (unsigned)ctx->num_cu * 4u;   // few rows, if any: idle waves leave at once
     hipLaunchKernelGGL((spgemm_topn_pruned_kernel<T, TILE_LOG2, SYM, WIDE, FOLD_LOG2>), dim3(grid), dim3(64), lds, ctx->stream, A->d_indptr,
                        A->d_indices, (const T *)A->d_data, (uint32_t)A->n_rows, (const uint32_t *)Bt->d_seg,
@@ -1464,7 +1469,7 @@ static int launch_pruned(sg_ctx *ctx, const sg_csr *A, const sg_postings *Bt, in
                        (T *)r->d_vals,
                        r->d_counts, row_counter, flagged_count, flagged_rows, stats, pl.d_sink, pl.chunks, pl.row_lo, pl.row_hi, row_list,
                        row_list_len, (const uint32_t *)Bt->d_ends8, Bt->nv_pad, (uint32_t)(Bt->nnz * 4), (uint32_t)Bt->n_right,
-                       heavy_count, heavy_rows, part_cfg);
+                       heavy_count, heavy_rows, pl.row_step, part_cfg);
     SG_HIP_TRY(hipGetLastError());
     return SG_OK;
 }
@@ -1489,18 +1494,20 @@ static int launch_both(sg_ctx *ctx, const sg_csr *A, const sg_postings *Bt, int3
     if (SYM && FOLD_LOG2 > 0 && st == SG_OK) {
         // (the whole matrix in one pass: 6.0 ms without, 6.35 with the second launch at 663 k -- it has a ramp and a tail of
         //  its own; a range of an eighth: 3.2 -> 2.25 ms, profiles/r03_sessionS_*)
-        if (pl.row_lo > 0 || (int64_t)pl.row_hi < A->n_rows) {
+        if (pl.row_lo > 0 || (int64_t)pl.row_hi < A->n_rows || pl.row_step > 1) {
             // A row is worth parts when it is a noticeable share of what ONE wave of the range does.  Rounds per wave,
             // estimated: rows per wave x rounds per row at the range's position (a row's stream grows with its position
             // and with the lists, i.e. with n: 40 rounds per row on average at 553 k index rows, 290 at 3.9 M --
             // 7.2e-5 n).  A fixed bar of 256 rounds sent nearly every row of the 5 M job through parts: eight ranges took
             // 278 ms in all against 204 ms for the whole (profiles/r03_sessionV_sim_scaling_5M.log).
             const double n_idx = (double)A->n_rows;
-            const double rows_per_wave =
-                (double)(pl.row_hi - pl.row_lo) / (double)pruned_grid(ctx, TILE_LOG2, (int64_t)(pl.row_hi - pl.row_lo), FOLD_LOG2, A->dtype);
+            const double rows_per_wave = (double)pl.rows() / (double)pruned_grid(ctx, TILE_LOG2, (int64_t)pl.rows(), FOLD_LOG2, A->dtype);
             const double rounds_per_row = 2.0 * 7.2e-5 * n_idx * (0.5 * ((double)pl.row_lo + (double)pl.row_hi) / n_idx);
-            // (a twentieth: the tail a row of `bar` rounds can leave is then ~5 % of the range's time.  A quarter was
-            //  tried first: two of eight ranges of the 5 M job then ended 10-15 ms after the others, on single rows)
+            // (a twentieth: the tail a row of `bar` rounds can leave is then ~5 % of the launch's time.  A quarter was
+            //  tried twice -- for contiguous ranges and for interleaved shares: shares of the 5 M job then ended 10-15 ms
+            //  after the others, on single rows.  Also tried and dropped, profiles/r03_sessionAR_parts_first.log: a classify
+            //  launch that lists such rows BEFORE the multiply, whose launch then starts with their parts -- 4.5 instead
+            //  of 4.15 ms for a half share at 663 k, 1.94 instead of 1.78 for an eighth)
             const double bar = 0.05 * rows_per_wave * rounds_per_row;
             // (never below 128 rounds: at 663 k, eight ranges, bars of 64 / 128 / 256 / 512 rounds give 2.10 / 2.03 / 2.19 /
             //  2.57 ms for the slowest range -- profiles/r03_sessionAG_heavy_bar_ranges.log)
@@ -1583,7 +1590,7 @@ int sg_spgemm_pruned_launch(sg_ctx *ctx, const sg_csr *A, const sg_postings *Bt,
 // form; the statistics words are untouched then (the result rows are overwritten by that form).
 int sg_spgemm_pruned_symmetric(sg_ctx *ctx, const sg_csr *A, const sg_postings *Bt, int32_t keep, sg_topn *r,
                                double threshold, double delta, unsigned long long *stats, bool *done, int64_t row_lo,
-                               int64_t row_hi, int32_t **export_pairs, int64_t *export_n) {
+                               int64_t row_hi, int32_t **export_pairs, int64_t *export_n, int64_t row_step) {
     *done = false;
     // the self-join runs in position space: its left matrix is the one the index was built over (sg_postings.hip)
     if (Bt->permuted) A = Bt->permuted;
@@ -1593,6 +1600,7 @@ int sg_spgemm_pruned_symmetric(sg_ctx *ctx, const sg_csr *A, const sg_postings *
     PairList pl;
     pl.row_lo = (uint32_t)row_lo;
     pl.row_hi = (uint32_t)row_hi;
+    pl.row_step = row_step > 1 ? (uint32_t)row_step : 1u;
     // A name list has a few matches per row, but hubs of identical names have h^2 / 2 pairs each, and the largest hubs
     // grow with the list (5 M synthetic names: 53 M pairs above 0.8 for 18 M matches kept -- with room for 8 n pairs the
     // pass was thrown away after 630 ms and the one-sided form took another 1300; scripts/full_configs.py).  The list
@@ -1787,7 +1795,8 @@ int sg_spgemm_pruned_symmetric(sg_ctx *ctx, const sg_csr *A, const sg_postings *
 // Second pass of the multi-GPU self-join: merge the mirrored pairs (of all ranks) whose row lies in [row_lo, row_hi)
 // into those rows of `r` (which hold their own matches from sg_spgemm_pruned_symmetric over the same range).
 int sg_selfjoin_merge_pairs(sg_ctx *ctx, sg_topn *r, const int32_t *d_pairs, int64_t n_pairs, int64_t row_lo, int64_t row_hi,
-                            const uint32_t *pos_of) {
+                            const uint32_t *pos_of, int64_t row_step) {
+    const uint32_t step = row_step > 1 ? (uint32_t)row_step : 1u;
     const int64_t n = r->n_rows;
     if (n_pairs <= 0 || row_hi <= row_lo) return SG_OK;
     const size_t vs = r->dtype == SG_F64 ? 8 : 4;
@@ -1807,22 +1816,22 @@ int sg_selfjoin_merge_pairs(sg_ctx *ctx, sg_topn *r, const int32_t *d_pairs, int
         const unsigned pg = (unsigned)((n_pairs + 255) / 256);
         if (r->dtype == SG_F64)
             hipLaunchKernelGGL(pairs_flat_count_kernel<4>, dim3(pg), dim3(256), 0, ctx->stream, d_pairs, n_pairs, (uint32_t)row_lo,
-                               (uint32_t)row_hi, pos_of, cnt);
+                               (uint32_t)row_hi, step, pos_of, cnt);
         else
             hipLaunchKernelGGL(pairs_flat_count_kernel<3>, dim3(pg), dim3(256), 0, ctx->stream, d_pairs, n_pairs, (uint32_t)row_lo,
-                               (uint32_t)row_hi, pos_of, cnt);
+                               (uint32_t)row_hi, step, pos_of, cnt);
         st = sg_exclusive_scan_u32(ctx, cnt, cnt, n + 1, nullptr);
         if (st == SG_OK) {
             const unsigned sgrid = (unsigned)((n + 63) / 64 > 0 ? (n + 63) / 64 : 1);
             if (r->dtype == SG_F64) {
                 hipLaunchKernelGGL(pairs_flat_fill_kernel<double>, dim3(pg), dim3(256), 0, ctx->stream, d_pairs, n_pairs,
-                                   (uint32_t)row_lo, (uint32_t)row_hi, pos_of, cnt, cursor, lcol, (double *)lval);
+                                   (uint32_t)row_lo, (uint32_t)row_hi, step, pos_of, cnt, cursor, lcol, (double *)lval);
                 hipLaunchKernelGGL(pairs_select_kernel<double>, dim3(sgrid), dim3(64), 0, ctx->stream, cnt, lcol,
                                    (const double *)lval, (uint32_t)n, r->stride, r->stride, r->d_cols, (double *)r->d_vals,
                                    r->d_counts);
             } else {
                 hipLaunchKernelGGL(pairs_flat_fill_kernel<float>, dim3(pg), dim3(256), 0, ctx->stream, d_pairs, n_pairs,
-                                   (uint32_t)row_lo, (uint32_t)row_hi, pos_of, cnt, cursor, lcol, (float *)lval);
+                                   (uint32_t)row_lo, (uint32_t)row_hi, step, pos_of, cnt, cursor, lcol, (float *)lval);
                 hipLaunchKernelGGL(pairs_select_kernel<float>, dim3(sgrid), dim3(64), 0, ctx->stream, cnt, lcol,
                                    (const float *)lval, (uint32_t)n, r->stride, r->stride, r->d_cols, (float *)r->d_vals,
                                    r->d_counts);

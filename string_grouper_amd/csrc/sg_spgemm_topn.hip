@@ -1018,7 +1018,8 @@ extern "C" int sg_spgemm_topn(sg_ctx *ctx, const sg_csr *A, const sg_postings *B
 // ---- multi-GPU self-join: the self-join form split over ranks by left-row ranges
 extern "C" int sg_selfjoin_range(sg_ctx *ctx, const sg_csr *A, const sg_postings *Bt, int32_t top_n, double threshold,
                                  int64_t row_lo, int64_t row_hi, sg_topn **out, int32_t **d_pairs, int64_t *n_pairs,
-                                 int32_t *pair_words, int32_t *applicable) {
+                                 int32_t *pair_words, int32_t *applicable, int64_t row_step) {
+    if (row_step < 1) row_step = 1;
     SG_REQUIRE(ctx && A && Bt && out && d_pairs && n_pairs && pair_words && applicable, "null argument");
     SG_REQUIRE(A->n_cols == Bt->n_terms && A->dtype == Bt->dtype, "A and B differ in columns or value type");
     SG_REQUIRE(top_n >= 1, "top_n must be >= 1");
@@ -1043,7 +1044,8 @@ extern "C" int sg_selfjoin_range(sg_ctx *ctx, const sg_csr *A, const sg_postings
         sg_postings view = *Bt;           // shallow: the same index, seen without the groups
         view.collapse = nullptr;
         view.plain = nullptr;
-        return sg_selfjoin_range(ctx, c->unique, &view, top_n, threshold, row_lo, row_hi, out, d_pairs, n_pairs, pair_words, applicable);
+        return sg_selfjoin_range(ctx, c->unique, &view, top_n, threshold, row_lo, row_hi, out, d_pairs, n_pairs, pair_words, applicable,
+                                 row_step);
     }
     if (!(threshold > 0.0)) threshold = 0.0;
     int64_t stride64 = top_n;
@@ -1067,7 +1069,7 @@ extern "C" int sg_selfjoin_range(sg_ctx *ctx, const sg_csr *A, const sg_postings
             st = SG_ERR_HIP;
         if (st == SG_OK)
             st = sg_spgemm_pruned_symmetric(ctx, A, Bt, stride, r, threshold, delta, (unsigned long long *)(ctx->d_stat_words + 2),
-                                            &done, row_lo, row_hi, d_pairs, n_pairs);
+                                            &done, row_lo, row_hi, d_pairs, n_pairs, row_step);
     }
     const size_t s = A->dtype == SG_F64 ? 8 : 4;
     ctx->spgemm_entry_bytes = (int64_t)(4 + s);
@@ -1084,13 +1086,13 @@ extern "C" int sg_selfjoin_range(sg_ctx *ctx, const sg_csr *A, const sg_postings
 }
 
 extern "C" int sg_selfjoin_merge(sg_ctx *ctx, sg_topn *res, const sg_postings *Bt, const int32_t *d_pairs, int64_t n_pairs,
-                                 int32_t pair_words, int64_t row_lo, int64_t row_hi) {
+                                 int32_t pair_words, int64_t row_lo, int64_t row_hi, int64_t row_step) {
     SG_REQUIRE(ctx && res, "null argument");
     SG_REQUIRE(n_pairs == 0 || d_pairs != nullptr, "pairs are null");
     SG_REQUIRE(pair_words == (res->dtype == SG_F64 ? 4 : 3), "pair records do not match the result's value type");
     SG_REQUIRE(row_lo >= 0 && row_lo <= row_hi && row_hi <= res->n_rows, "row range outside the result");
     SgTimer timer(ctx, SG_K_ZIP);
-    return sg_selfjoin_merge_pairs(ctx, res, d_pairs, n_pairs, row_lo, row_hi, Bt ? (const uint32_t *)Bt->d_pos_of : nullptr);
+    return sg_selfjoin_merge_pairs(ctx, res, d_pairs, n_pairs, row_lo, row_hi, Bt ? (const uint32_t *)Bt->d_pos_of : nullptr, row_step);
 }
 
 extern "C" int sg_postings_rows(const sg_postings *Bt, int64_t *n_index_rows, int64_t *n_caller_rows,
@@ -1129,13 +1131,13 @@ extern "C" int sg_topn_expand_groups(sg_ctx *ctx, const sg_postings *Bt, const s
 
 // rows whose group sits at a position of [pos_lo, pos_hi)
 __global__ void __launch_bounds__(256) rows_of_range_flag_kernel(const uint32_t *__restrict__ gid, const uint32_t *__restrict__ pos_of,
-                                                                 int64_t n_rows, uint32_t pos_lo, uint32_t pos_hi,
+                                                                 int64_t n_rows, uint32_t pos_lo, uint32_t pos_hi, uint32_t step,
                                                                  uint32_t *__restrict__ flag) {
     const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n_rows) return;
     const uint32_t g = gid[r];
     const uint32_t p = pos_of ? pos_of[g] : g;
-    flag[r] = (p >= pos_lo && p < pos_hi) ? 1u : 0u;
+    flag[r] = (p >= pos_lo && p < pos_hi && (pos_hi - 1u - p) % step == 0u) ? 1u : 0u;
 }
 __global__ void __launch_bounds__(256) rows_of_range_fill_kernel(const uint32_t *__restrict__ flag, const uint32_t *__restrict__ at,
                                                                  int64_t n_rows, int32_t *__restrict__ rows) {
@@ -1144,7 +1146,8 @@ __global__ void __launch_bounds__(256) rows_of_range_fill_kernel(const uint32_t 
 }
 
 extern "C" int sg_topn_expand_range(sg_ctx *ctx, const sg_postings *Bt, const sg_topn *groups, int64_t pos_lo, int64_t pos_hi,
-                                    sg_topn **out, int32_t **d_rows, int64_t *n_rows) {
+                                    sg_topn **out, int32_t **d_rows, int64_t *n_rows, int64_t pos_step) {
+    if (pos_step < 1) pos_step = 1;
     SG_REQUIRE(ctx && Bt && groups && out && d_rows && n_rows, "null argument");
     SG_REQUIRE(Bt->collapse != nullptr, "the index was not built over groups of identical rows (sg_postings_rows)");
     const SgCollapse *c = Bt->collapse;
@@ -1162,7 +1165,7 @@ extern "C" int sg_topn_expand_range(sg_ctx *ctx, const sg_postings *Bt, const sg
     if (st == SG_OK && n > 0) {
         const unsigned g1 = (unsigned)((n + 255) / 256);
         hipLaunchKernelGGL(rows_of_range_flag_kernel, dim3(g1), dim3(256), 0, ctx->stream, (const uint32_t *)c->d_gid,
-                           (const uint32_t *)Bt->d_pos_of, n, (uint32_t)pos_lo, (uint32_t)pos_hi, flag);
+                           (const uint32_t *)Bt->d_pos_of, n, (uint32_t)pos_lo, (uint32_t)pos_hi, (uint32_t)pos_step, flag);
         st = sg_exclusive_scan_u32(ctx, flag, at, n, total);
         if (st == SG_OK && (hipMemcpyAsync(&n_mine, total, 4, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
                             hipStreamSynchronize(ctx->stream) != hipSuccess))

@@ -216,6 +216,29 @@ def selfjoin_row_ranges(n_rows: int, world: int) -> np.ndarray:
     return np.maximum.accumulate(b)
 
 
+def selfjoin_share(n_rows: int, rank: int, world: int):
+    """(lo, hi, step): the positions rank ``rank`` scores in the self-join form -- hi - 1, hi - 1 - step, ... >= lo
+    (include/sg_hip.h: sg_selfjoin_range).  Interleaved by default: rank r takes (0, n - r, world), i.e. every world-th
+    position counted from the top.  A position's cost grows with the position; interleaved, every rank holds rows of
+    every cost -- equal shares without a cost model -- and its launch ends with its cheapest rows, as the whole pass on
+    one GPU does; a contiguous range of high positions ends with rows as expensive as its first, which cost + 0.8 ms per
+    range at 663 k (scripts/sim_scaling.py).  ``SG_DIST_INTERLEAVE=0``: the contiguous ranges of ``selfjoin_row_ranges``."""
+    import os
+    if world <= 1:
+        return 0, n_rows, 1
+    if os.environ.get("SG_DIST_INTERLEAVE", "1") == "0":
+        b = selfjoin_row_ranges(n_rows, world)
+        return int(b[rank]), int(b[rank + 1]), 1
+    return 0, max(n_rows - rank, 0), world
+
+
+def share_positions(lo: int, hi: int, step: int) -> np.ndarray:
+    """The positions of a share, in the order the blocks list their rows (ascending)."""
+    if step <= 1:
+        return np.arange(lo, hi, dtype=np.int64)
+    return np.arange(hi - 1, lo - 1, -step, dtype=np.int64)[::-1].copy()
+
+
 def selfjoin_form_wanted(n_rows: int, world: int) -> bool:
     """From this size on the self-join form (every pair scored once, mirrored pairs exchanged by one all-gather) beats
     the one-sided multiply of row blocks; ``SG_DIST_SYM=0|1`` forces it off / on."""
@@ -234,9 +257,8 @@ def sharded_selfjoin_topn(ops, A_full, post, top_n: int, threshold: float, group
     input on some rank (then nothing has been changed and the caller multiplies row blocks)."""
     rank, world = dist.get_rank(group), dist.get_world_size(group)
     n = ops.selfjoin_rows(A_full, post)        # (rows of the INDEX: groups of identical rows, when the library grouped them)
-    bounds = selfjoin_row_ranges(n, world)
-    lo, hi = int(bounds[rank]), int(bounds[rank + 1])
-    part = ops.selfjoin_range(A_full, post, top_n, threshold, lo, hi)
+    lo, hi, step = selfjoin_share(n, rank, world)
+    part = ops.selfjoin_range(A_full, post, top_n, threshold, lo, hi, step)
     pairs = ops.selfjoin_pairs(part) if part is not None else None
     # one exchange tells every rank the lengths of all pair lists AND whether every range was applicable (-1: not) -- and
     # that all ranks built the same index: ranges and merge are in the index's position space, so an index over the row
@@ -251,7 +273,7 @@ def sharded_selfjoin_topn(ops, A_full, post, top_n: int, threshold: float, group
             ops.selfjoin_discard(part)
         return None
     pairs_all = torch.cat(all_gather_ragged(pairs, group, sizes))
-    return ops.selfjoin_merge(part, pairs_all, lo, hi)
+    return ops.selfjoin_merge(part, pairs_all, lo, hi, step)
 
 
 def gather_topn(ops, res, group=None, on_device: bool = False):
@@ -350,11 +372,12 @@ class TopNRows:
     the range is one of POSITIONS of the library's row permutation (int64 tensor, position -> row): the block's rows are
     orig_of[lo:hi], in that order; the blocks of all ranks concatenated are the result in position order."""
 
-    def __init__(self, res, lo: int, hi: int, orig_of=None, row_ids=None):
+    def __init__(self, res, lo: int, hi: int, orig_of=None, row_ids=None, sel=None):
         self.res, self.lo, self.hi, self.orig_of = res, lo, hi, orig_of
-        # ``row_ids`` given (int tensor): the index was built over GROUPS of identical rows, the rank's range was one of
-        # groups, and the block holds the rows that are members of these groups: block row k is row row_ids[k]
-        self.row_ids = row_ids
+        # ``row_ids`` given (int tensor): block row k is the caller's row row_ids[k] -- the rank's share was not a contiguous
+        # range of rows (interleaved shares; an index over GROUPS of identical rows, whose members are the block's rows);
+        # ``sel`` given (int64 tensor): the block is the rows sel of ``res`` (else the rows [lo, hi))
+        self.row_ids, self.sel = row_ids, sel
         self._keep = None
 
     def free(self):
@@ -362,10 +385,13 @@ class TopNRows:
 
     def dims(self):
         r, s, d, c = self.res.dims()
-        return self.hi - self.lo, s, d, c
+        return (int(self.sel.numel()) if self.sel is not None else self.hi - self.lo), s, d, c
 
     def to_host(self):
         cols, vals, cnt = self.res.to_host()
+        if self.sel is not None:
+            ids = self.sel.cpu().numpy()
+            return cols[ids], vals[ids], cnt[ids]
         if self.orig_of is not None:
             ids = self.orig_of[self.lo:self.hi].cpu().numpy()
             return cols[ids], vals[ids], cnt[ids]
@@ -444,8 +470,8 @@ class HipOps:
         res._keep = objs
 
     # ---- the self-join form over row ranges (sharded_selfjoin_topn)
-    def selfjoin_range(self, A_full, post, top_n, threshold, lo, hi):
-        got = self.ctx.selfjoin_range(A_full, post, top_n, threshold, lo, hi)
+    def selfjoin_range(self, A_full, post, top_n, threshold, lo, hi, step=1):
+        got = self.ctx.selfjoin_range(A_full, post, top_n, threshold, lo, hi, step)
         if got is None:
             return None
         res, ptr, n_pairs, words = got
@@ -462,12 +488,12 @@ class HipOps:
         self.ctx.device_free(part["ptr"])
         part["res"].free()
 
-    def selfjoin_merge(self, part, pairs_all, lo, hi):
+    def selfjoin_merge(self, part, pairs_all, lo, hi, step=1):
         self._sync()                                  # the gathered list is torch's: ordered before the library reads it
         words = part["words"]
         pairs_all = pairs_all.contiguous()
         post = part.get("post")
-        self.ctx.selfjoin_merge(part["res"], post, pairs_all.data_ptr(), pairs_all.numel() // words, words, lo, hi)
+        self.ctx.selfjoin_merge(part["res"], post, pairs_all.data_ptr(), pairs_all.numel() // words, words, lo, hi, step)
         self.ctx.sync()                               # ... and the library is done with it before torch frees it
         self.ctx.device_free(part["ptr"])
         # the index is built over a permutation of the rows: the range [lo, hi) is one of POSITIONS, its rows are orig_of[lo:hi]
@@ -478,11 +504,16 @@ class HipOps:
                 n = part["res"].dims()[0]
                 orig_of = torch.as_tensor(DeviceTensorView(p_orig, n, "<i4"), device=self.device)[:n].to(torch.int64)
         n_index, n_caller, p_gid = self.ctx.postings_rows(post) if post is not None else (0, 0, 0)
+        if not p_gid and step > 1:
+            # an interleaved share: the block's rows are the rows at the share's positions
+            pos = torch.from_numpy(share_positions(lo, hi, step)).to(self.device)
+            rows = orig_of.index_select(0, pos) if orig_of is not None else pos
+            return TopNRows(part["res"], 0, int(rows.numel()), None, row_ids=rows, sel=rows)
         if not p_gid:
             return TopNRows(part["res"], lo, hi, orig_of)
         # an index over groups of identical rows: the range was one of groups; the rows of this rank are the members of
         # its groups, expanded here from tables every rank holds (no exchange)
-        r, p_rows, n_mine = self.ctx.topn_expand_range(post, part["res"], lo, hi)
+        r, p_rows, n_mine = self.ctx.topn_expand_range(post, part["res"], lo, hi, step)
         self.ctx.sync()
         rows = torch.as_tensor(DeviceTensorView(p_rows, max(n_mine, 1), "<i4"), device=self.device)[:n_mine].clone()
         torch.cuda.current_stream(self.device).synchronize()   # (copied before the library's list is released)
@@ -510,6 +541,8 @@ class HipOps:
         from . import _native as N
         if isinstance(res, TopNRows):
             cols, vals, counts = self.topn_tensors(res.res)
+            if res.sel is not None:
+                return cols.index_select(0, res.sel), vals.index_select(0, res.sel), counts.index_select(0, res.sel)
             if res.orig_of is not None:               # rows of the range in POSITION order
                 ids = res.orig_of[res.lo:res.hi]
                 return cols.index_select(0, ids), vals.index_select(0, ids), counts.index_select(0, ids)

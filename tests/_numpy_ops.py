@@ -171,23 +171,24 @@ class NumpyOps:
 
     # ---- the self-join form over row ranges: the contract of sg_selfjoin_range / sg_selfjoin_merge restated with the
     #      oracle's multiply (rows of the range keep their matches j <= i; mirrored pairs (i, j < i, score) go out)
-    def selfjoin_range(self, A_full, post, top_n, threshold, lo, hi):
+    def selfjoin_range(self, A_full, post, top_n, threshold, lo, hi, step=1):
+        from string_grouper_amd.distributed import share_positions
         if isinstance(post, GroupedIndex):
             # the result over GROUPS must hold what expansion needs: a row's top_n columns can come from top_n groups at
             # most, so top_n groups per group are enough (the library's argument, sg_collapse.hip)
-            part = self.selfjoin_range(post.unique, post.unique, top_n, threshold, lo, hi)
+            part = self.selfjoin_range(post.unique, post.unique, top_n, threshold, lo, hi, step)
             part["groups_of"] = post
             return part
         n = A_full.shape[0]
         orig_of, pos_of = self.permutation(n) if self.permuted else (np.arange(n), np.arange(n))
-        rows = orig_of[lo:hi]                               # the rows of the range (of positions)
+        rows = orig_of[share_positions(lo, hi, step)]       # the rows of the share (of positions)
         C = P.sp_matmul_topn_port(A_full[rows], A_full.T, n, threshold, True, 2)      # every match of the rows
         stride = max(1, min(top_n, n))
         cols = np.zeros((n, stride), np.int32)
         vals = np.zeros((n, stride), self.dtype)
         cnt = np.zeros(n, np.int32)
         pairs = []
-        for r in range(hi - lo):
+        for r in range(len(rows)):
             i = int(rows[r])
             a, b = C.indptr[r], C.indptr[r + 1]
             j, sc = C.indices[a:b], C.data[a:b]
@@ -211,14 +212,16 @@ class NumpyOps:
     def selfjoin_discard(self, part):
         pass
 
-    def selfjoin_merge(self, part, pairs_all, lo, hi):
+    def selfjoin_merge(self, part, pairs_all, lo, hi, step=1):
+        from string_grouper_amd.distributed import share_positions
         cols, vals, cnt = part["res"]
         words, stride = part["words"], part["top_n"]
         rec = pairs_all.numpy().reshape(-1, words)
         scores = np.frombuffer(np.ascontiguousarray(rec[:, 2:]).tobytes(), self.dtype)
         n = cols.shape[0]
         orig_of = self.permutation(n)[0] if self.permuted else np.arange(n)
-        for row in orig_of[lo:hi]:
+        my_rows = orig_of[share_positions(lo, hi, step)]
+        for row in my_rows:
             mine = np.flatnonzero(rec[:, 1] == row)
             if len(mine) == 0:
                 continue
@@ -232,9 +235,11 @@ class NumpyOps:
         if post is not None:
             # the range was one of groups: the rank's rows are the members of its groups, expanded from the tables of the
             # index (which every rank holds)
-            mine = set(int(g) for g in orig_of[lo:hi])
+            mine = set(int(g) for g in my_rows)
             rows = np.array([i for i in range(post.full.shape[0]) if int(post.gid[i]) in mine], np.int64)
             return PermutedBlock(self.expand_rows(post, rows, cols, vals, cnt), None, torch.from_numpy(rows.astype(np.int32)))
+        if step > 1:     # an interleaved share: the block lists its rows
+            return PermutedBlock((cols[my_rows], vals[my_rows], cnt[my_rows]), None, torch.from_numpy(my_rows.astype(np.int64)))
         if self.permuted:
             ids = orig_of[lo:hi]
             return PermutedBlock((cols[ids], vals[ids], cnt[ids]), torch.from_numpy(orig_of))

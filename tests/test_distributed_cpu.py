@@ -125,52 +125,53 @@ def _sharded_worker(rank, world, port, ret):
         # ---- the same self-join in its form over row ranges: every rank scores the pairs (i, j <= i) of its range, the
         #      mirrored pairs are all-gathered, every rank merges those that point into its range (SG_DIST_SYM=1 forces
         #      the form at this size); hubs of duplicates make rows whose top-n is cut inside the merge
-        os.environ["SG_DIST_SYM"] = "1"
         hubs = names + [names[5]] * 40 + [names[9] + " INC"] * 25
         lo2, hi2 = D.row_block(rank, world, len(hubs))
-        res, _ = D.distributed_self_join(ops, hubs[lo2:hi2], 10, 0.8)
-        os.environ["SG_DIST_SYM"] = "0"
+        _, _, C = _expected(hubs, None, 10, 0.8, np.float32)
         bounds = D.selfjoin_row_ranges(len(hubs), world)
         ok["ranges_cover"] = bounds[0] == 0 and bounds[-1] == len(hubs) and bool(np.all(np.diff(bounds) > 0))
-        ok["range_block_is_mine"] = len(res[2]) == int(bounds[rank + 1] - bounds[rank])
-        cols, vals, counts = D.gather_topn(ops, res)
-        _, _, C = _expected(hubs, None, 10, 0.8, np.float32)
-        got = _csr_of(cols, vals, counts, len(hubs))
-        ok["ranges_counts"] = np.array_equal(np.diff(got.indptr), np.diff(C.indptr))
-        ok["ranges_indices"] = np.array_equal(got.indices, C.indices)
-        ok["ranges_scores"] = np.array_equal(got.data, C.data)
-        # ---- ... and with the index over the library's row permutation: the ranges are ranges of POSITIONS, a rank's block
-        #      holds the rows orig_of[lo:hi], gather_topn puts the gathered blocks back into row order
-        ops.permuted = True
-        os.environ["SG_DIST_SYM"] = "1"
-        res, _ = D.distributed_self_join(ops, hubs[lo2:hi2], 10, 0.8)
-        os.environ["SG_DIST_SYM"] = "0"
-        ops.permuted = False
-        ok["position_block_is_mine"] = len(res[2]) == int(bounds[rank + 1] - bounds[rank]) and res.orig_of is not None
-        cols, vals, counts = D.gather_topn(ops, res)
-        got = _csr_of(cols, vals, counts, len(hubs))
-        ok["positions_counts"] = np.array_equal(np.diff(got.indptr), np.diff(C.indptr))
-        ok["positions_indices"] = np.array_equal(got.indices, C.indices)
-        ok["positions_scores"] = np.array_equal(got.data, C.data)
-        # ---- ... and with the index over one representative per group of identical rows (what the library builds by
-        #      default): the ranges are ranges of GROUPS, a rank's block holds the rows that are members of its groups
-        #      (expanded on the rank), gather_topn puts the gathered rows where their numbers say -- with and without the row permutation
-        for permuted in (False, True):
-            ops.grouped, ops.permuted = True, permuted
+        shares = [D.share_positions(*D.selfjoin_share(len(hubs), r, world)) for r in range(world)]
+        ok["interleaved_shares_cover"] = sorted(np.concatenate(shares).tolist()) == list(range(len(hubs)))
+
+        def run_form(tag, permuted, grouped):
+            ops.permuted, ops.grouped = permuted, grouped
             os.environ["SG_DIST_SYM"] = "1"
-            res, _ = D.distributed_self_join(ops, hubs[lo2:hi2], 10, 0.8)
-            os.environ["SG_DIST_SYM"] = "0"
-            ops.grouped = ops.permuted = False
-            tag = "groups_permuted" if permuted else "groups"
-            ok[tag + "_block_is_rows_of_my_groups"] = res.row_ids is not None and len(res[2]) == res.row_ids.numel()
-            n_mine = torch.tensor([res.row_ids.numel()])
-            dist.all_reduce(n_mine)
-            ok[tag + "_every_row_once"] = int(n_mine) == len(hubs)
+            try:
+                res, _ = D.distributed_self_join(ops, hubs[lo2:hi2], 10, 0.8)
+            finally:
+                os.environ["SG_DIST_SYM"] = "0"
+                ops.permuted = ops.grouped = False
             cols, vals, counts = D.gather_topn(ops, res)
             got = _csr_of(cols, vals, counts, len(hubs))
             ok[tag + "_counts"] = np.array_equal(np.diff(got.indptr), np.diff(C.indptr))
             ok[tag + "_indices"] = np.array_equal(got.indices, C.indices)
             ok[tag + "_scores"] = np.array_equal(got.data, C.data)
+            return res
+
+        def every_row_once(tag, res):
+            ok[tag + "_block_lists_its_rows"] = res.row_ids is not None and len(res[2]) == res.row_ids.numel()
+            n_mine = torch.tensor([res.row_ids.numel()])
+            dist.all_reduce(n_mine)
+            ok[tag + "_every_row_once"] = int(n_mine) == len(hubs)
+
+        # (a) contiguous ranges of rows / of positions of the library's row permutation (SG_DIST_INTERLEAVE=0): a rank's block
+        #     holds the rows [lo, hi) / orig_of[lo:hi], gather_topn concatenates and puts the blocks back into row order
+        os.environ["SG_DIST_INTERLEAVE"] = "0"
+        res = run_form("ranges", False, False)
+        ok["range_block_is_mine"] = len(res[2]) == int(bounds[rank + 1] - bounds[rank])
+        res = run_form("positions", True, False)
+        ok["position_block_is_mine"] = len(res[2]) == int(bounds[rank + 1] - bounds[rank]) and res.orig_of is not None
+        # (b) ... over one representative per group of identical rows (what the library builds by default): ranges of GROUPS,
+        #     a rank's block holds the rows that are members of its groups (expanded on the rank), gather_topn puts the
+        #     gathered rows where their numbers say
+        for permuted in (False, True):
+            every_row_once("groups_permuted" if permuted else "groups", run_form("groups_permuted" if permuted else "groups", permuted, True))
+        # (c) the default: INTERLEAVED shares (rank r scores every world-th position from the top): blocks list their rows
+        os.environ.pop("SG_DIST_INTERLEAVE")
+        for permuted in (False, True):
+            for grouped in (False, True):
+                tag = "interleaved" + ("_permuted" if permuted else "") + ("_groups" if grouped else "")
+                every_row_once(tag, run_form(tag, permuted, grouped))
         # ---- master x duplicates (configs[4]): both columns sharded, vocabulary from both, duplicates replicated
         master = synth_names(1800, 7)
         dups = synth_names(901, 8, perturb_of=master, perturb_frac=0.5)

@@ -1193,6 +1193,32 @@ def test_selfjoin_form_over_row_ranges_equals_the_whole(ctx, dtype):
             for b in blocks:
                 b.free()
         post.free()
+    # ---- INTERLEAVED shares (the driver's default: rank r scores every world-th position from the top, sg_selfjoin_range's
+    #      row_step): blocks list their rows; plain index and index over groups, with and without the row permutation
+    for collapse in ("0", "1"):
+        ctx.set_option("SG_COLLAPSE", collapse)
+        for permute in (False, True):
+            post = ctx.postings_build(dA, permute=permute)
+            n_index = ctx.postings_rows(post)[0]
+            assert (n_index < n) == (collapse == "1")
+            for world in (2, 3, 7):
+                shares = [D.selfjoin_share(n_index, r, world) for r in range(world)]
+                assert all(sh[2] == world for sh in shares)
+                parts = [ops.selfjoin_range(dA, post, 10, 0.75, *shares[r]) for r in range(world)]
+                assert all(p is not None for p in parts)
+                pairs_all = torch.cat([ops.selfjoin_pairs(p).clone() for p in parts])
+                blocks = [ops.selfjoin_merge(parts[r], pairs_all, *shares[r]) for r in range(world)]
+                assert all(b.row_ids is not None and b.dims()[0] == b.row_ids.numel() for b in blocks)
+                ids = torch.cat([b.row_ids for b in blocks]).to(torch.int64)
+                assert ids.numel() == n and torch.equal(torch.sort(ids).values.cpu(), torch.arange(n))
+                cols, vals, counts = (torch.cat(t) for t in zip(*[ops.topn_tensors(b) for b in blocks]))
+                cols, vals, counts = (torch.empty_like(t).index_copy_(0, ids, t).cpu().numpy() for t in (cols, vals, counts))
+                mask = np.arange(cols.shape[1])[None, :] < counts[:, None]
+                got = sp.csr_matrix((vals[mask], cols[mask], np.concatenate([[0], np.cumsum(counts)])), shape=(n, n))
+                assert_csr_identical(got, want, f"{world} interleaved shares, groups {collapse}, permutation {permute}")
+                for b in blocks:
+                    b.free()
+            post.free()
     ctx.set_option("SG_COLLAPSE", "0")
     # rows for the exact kernel (more than 128 terms) are scored inside the range's pass by that kernel's self-join launch
     extra = ["".join(rng.choice(list("ABCDEFGHIJKLMNOPQRSTUVWXYZ"), 180)) for _ in range(3)]
