@@ -1494,7 +1494,10 @@ static int launch_both(sg_ctx *ctx, const sg_csr *A, const sg_postings *Bt, int3
     if (SYM && FOLD_LOG2 > 0 && st == SG_OK) {
         // (the whole matrix in one pass: 6.0 ms without, 6.35 with the second launch at 663 k -- it has a ramp and a tail of
         //  its own; a range of an eighth: 3.2 -> 2.25 ms, profiles/r03_sessionS_*)
-        if (pl.row_lo > 0 || (int64_t)pl.row_hi < A->n_rows || pl.row_step > 1) {
+        // ... and a launch over at least half the rows still hides them better than parts do: a half share of the 663 k job
+        // takes 3.6 ms without parts (the longest row: 3.4), 4.06 with; a quarter 3.2 without, 2.8 with
+        // (profiles/r03_sessionAU_shares_without_parts.log)
+        if ((pl.row_lo > 0 || (int64_t)pl.row_hi < A->n_rows || pl.row_step > 1) && 2 * (int64_t)pl.rows() < A->n_rows) {
             // A row is worth parts when it is a noticeable share of what ONE wave of the range does.  Rounds per wave,
             // estimated: rows per wave x rounds per row at the range's position (a row's stream grows with its position
             // and with the lists, i.e. with n: 40 rounds per row on average at 553 k index rows, 290 at 3.9 M --
