@@ -397,12 +397,12 @@ def run(args):
                  shape=np.array(A_host.shape))
         common = [sys.executable, "-m", "oracle.baseline", "--matrix", mpath, "--rows", str(args.rows), "--top-n",
                   str(args.top_n), "--min-similarity", str(args.min_similarity), "--dtype", args.dtype,
-                  *(["--multiply-seconds", "100000"] if args.cpu_full else []),
                   "--matches-full", str(result.get("end_to_end", {}).get(args.dtype, {}).get("match_rows", 0))]
         all_cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
         try:
-            r4 = subprocess.run(common + ["--cores", str(args.cpu_cores), "--multiply-seconds", "10"], cwd=ROOT,
-                                capture_output=True, text=True, timeout=600)
+            # (--cpu-full: no bound on the multiply leg -- every left row, ~85 s on 4 cores)
+            r4 = subprocess.run(common + ["--cores", str(args.cpu_cores), "--multiply-seconds", "100000" if args.cpu_full else "10"],
+                                cwd=ROOT, capture_output=True, text=True, timeout=1500 if args.cpu_full else 600)
             base = json.loads(r4.stdout.strip().splitlines()[-1])
             rall = subprocess.run(common + ["--cores", str(min(all_cores, 64)), "--multiply-seconds", "6",
                                             "--multiply-only"], cwd=ROOT, capture_output=True, text=True, timeout=600)

@@ -1015,16 +1015,21 @@ spgemm_topn_pruned_kernel(const int64_t *__restrict__ a_indptr, const int32_t *_
 #endif
                 n_surv = n_clean = (uint32_t)__builtin_amdgcn_readfirstlane((int)fo.n_surv);
             };
-            auto collect_s = [&](uint64_t cm, uint32_t r, uint32_t tv) {
-                bool cross = (cm >> lane) & 1ull;
+            // `fired`: the lane's own test, `cm` its wave mask.  Written so that nothing of the bookkeeping goes through the
+            // VALU that a scalar can do: the mask of the lanes that record is the AND of two compare masks (the ballot of a
+            // COMBINED predicate is rebuilt through a select and a compare), a lane's slot in the buffer comes from mbcnt,
+            // and the store runs under the two compares' masks.  16 -> 9 VALU per call, two to three calls per round
+            // (profiles/r03_final_sq_counters.log: 128 VALU per round, 50 of them the round's own).
+            auto collect_s = [&](bool fired, uint64_t cm, uint32_t r, uint32_t tv) {
                 const uint32_t col = (tv << (TILE_LOG2 + FOLD_LOG2)) | ((r >> 1) & COL_MASK) | (r & 1u);
                 // SYM: the pair (i, j > i) is row j's to score.  One-sided: entries read past the end of a segment (see
                 // issue_s) may name columns of the last super-tile that do not exist.
-                cross = cross && (SYM ? col <= row : col < n_right);
-                cm = ballot64(cross);
+                const bool mine = SYM ? col <= row : col < n_right;
+                cm &= ballot64(mine);
                 const uint32_t n_new = (uint32_t)__popcll(cm);
                 if (n_surv + n_new > (uint32_t)SG_SURV_CAP - 1u) flush_s();   // (leaves fewer than 64)
-                if (cross) surv[n_surv + __popcll(cm & lanes_below)] = (int)col;
+                const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(cm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)cm, 0u));
+                if (fired && mine) surv[n_surv + below] = (int)col;
                 n_surv += n_new;
             };
             struct SSlot {
@@ -1085,15 +1090,16 @@ spgemm_topn_pruned_kernel(const int64_t *__restrict__ a_indptr, const int32_t *_
                     s3.d = bar_s(q.w, s3.x);
                     asm volatile("" : "+v"(s0.d), "+v"(s1.d), "+v"(s2.d), "+v"(s3.d));   // (before the wait, not behind it)
                     asm volatile("" : "+v"(o0), "+v"(o1), "+v"(o2), "+v"(o3));   // the one wait
-                    const uint64_t c0 = ballot64((int32_t)__builtin_amdgcn_ubfe(o0, s0.sh, 16u) >= s0.d);
-                    const uint64_t c1m = ballot64((int32_t)__builtin_amdgcn_ubfe(o1, s1.sh, 16u) >= s1.d);
-                    const uint64_t c2 = ballot64((int32_t)__builtin_amdgcn_ubfe(o2, s2.sh, 16u) >= s2.d);
-                    const uint64_t c3 = ballot64((int32_t)__builtin_amdgcn_ubfe(o3, s3.sh, 16u) >= s3.d);
+                    const bool f0 = (int32_t)__builtin_amdgcn_ubfe(o0, s0.sh, 16u) >= s0.d;
+                    const bool f1 = (int32_t)__builtin_amdgcn_ubfe(o1, s1.sh, 16u) >= s1.d;
+                    const bool f2 = (int32_t)__builtin_amdgcn_ubfe(o2, s2.sh, 16u) >= s2.d;
+                    const bool f3 = (int32_t)__builtin_amdgcn_ubfe(o3, s3.sh, 16u) >= s3.d;
+                    const uint64_t c0 = ballot64(f0), c1m = ballot64(f1), c2 = ballot64(f2), c3 = ballot64(f3);
                     if (c0 | c1m | c2 | c3) {
-                        if (c0) collect_s(c0, q.x, tv);
-                        if (c1m) collect_s(c1m, q.y, tv);
-                        if (c2) collect_s(c2, q.z, tv);
-                        if (c3) collect_s(c3, q.w, tv);
+                        if (c0) collect_s(f0, c0, q.x, tv);
+                        if (c1m) collect_s(f1, c1m, q.y, tv);
+                        if (c2) collect_s(f2, c2, q.z, tv);
+                        if (c3) collect_s(f3, c3, q.w, tv);
                     }
                 }
 #ifndef SG_STREAM_PROBE_NO_CLEAR
