@@ -221,3 +221,27 @@ def test_sharded_vectoriser_gather_and_match_world2():
     mp.spawn(_sharded_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
     for r in range(world):
         assert all(ret[r].values()), (r, dict(ret[r]))
+
+
+def test_shares_of_the_self_join_form_partition_the_positions(monkeypatch):
+    """distributed.selfjoin_share: interleaved by default (rank r: every world-th position counted from the top) or the
+    contiguous ranges cut by cost (SG_DIST_INTERLEAVE=0) -- either way every position belongs to exactly one rank, for
+    any size, also when there are fewer positions than ranks; and the descending walk of a share (the kernel's order:
+    hi - 1, hi - 1 - step, ...) stays inside [lo, hi)."""
+    for interleave in ("1", "0"):
+        monkeypatch.setenv("SG_DIST_INTERLEAVE", interleave)
+        for n in (0, 1, 2, 7, 8, 9, 63, 64, 1000, 131072, 553497):
+            for world in (1, 2, 3, 5, 8):
+                seen = np.zeros(n, np.int32)
+                for r in range(world):
+                    lo, hi, step = D.selfjoin_share(n, r, world)
+                    assert 0 <= lo <= hi <= n and step >= 1, (n, world, r, lo, hi, step)
+                    pos = D.share_positions(lo, hi, step)
+                    walk = np.arange(hi - 1, lo - 1, -step)            # what the kernel visits
+                    assert sorted(walk.tolist()) == pos.tolist(), (n, world, r)
+                    assert (interleave == "1" and world > 1) == (step > 1) or n == 0 or world == 1
+                    seen[pos] += 1
+                assert (seen == 1).all(), (n, world, interleave)
+                if interleave == "1" and world > 1 and n >= world:
+                    sizes = [len(D.share_positions(*D.selfjoin_share(n, r, world))) for r in range(world)]
+                    assert max(sizes) - min(sizes) <= 1            # equal shares without a cost model
