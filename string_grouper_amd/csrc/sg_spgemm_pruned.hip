@@ -1173,7 +1173,7 @@ spgemm_topn_pruned_kernel(const int64_t *__restrict__ a_indptr, const int32_t *_
             // The pair list is full (this wave was handed a chunk past its end): whatever the pass still does is thrown away,
             // the caller runs the one-sided form.  Push the row counter past the last row so that every wave leaves at its
             // next helping.  (Looking at the shared chunk counter instead -- one load per helping -- cost 3.3 ms at 663 k:
-            // accesses to one word are serialised at ~12 ns each, profiles/r02_sessionZ_*.log.)
+            // accesses to one word are serialised at ~12 ns each, profiles/r02_sessionZ_abort_check_ab.log.)
             const uint32_t pos = (uint32_t)__builtin_amdgcn_readfirstlane(surv[SG_SURV_CAP - 1]);
             if (pos != SG_PAIR_NO_CHUNK && (pos >> 9) >= pair_chunks && lane == 0) atomicMax(row_counter, 0x20000000u);
         }
