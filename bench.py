@@ -41,6 +41,11 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+# `value` is the device hot path with its inputs resident in HBM (the bench contract); BASELINE.json's "match_strings
+# rows/sec" -- the public API end to end, host preparation, PCIe and pandas frames included -- is the SAME line's
+# `match_strings_rows_per_s` (the name must not suggest that `value` is the latter)
+METRIC = ("hot-path rows/sec (the device path of match_strings: tokenise + tf-idf + postings + SpGEMM-topn, inputs resident "
+          "in HBM), 663k-name self-join ntop=10 min_sim=0.8; match_strings end to end: match_strings_rows_per_s")
 
 
 def parse_args():
@@ -57,10 +62,13 @@ def parse_args():
     ap.add_argument("--no-exact-kernel", action="store_true", help="skip the live run of the exact kernel K4")
     ap.add_argument("--no-end-to-end", action="store_true", help="skip the match_strings() wall-clock runs (fp32 + fp64)")
     ap.add_argument("--end-to-end", action="store_true", help=argparse.SUPPRESS)      # round-1 flag: now the default
+    ap.add_argument("--no-side-runs", action="store_true", help="skip the SG_COLLAPSE=0 and other-dtype runs of the step")
     ap.add_argument("--cpu-cores", type=int, default=4, help="cores of the reference CPU leg (README: 4)")
-    ap.add_argument("--cpu-full", action="store_true", help="CPU baseline: multiply ALL left rows instead of a bounded "
-                                                            "sample (~100 s on 4 cores at 663 k): nothing extrapolated "
-                                                            "but the tokenisation passes and the tail")
+    ap.add_argument("--cpu-full", action="store_true", help=argparse.SUPPRESS)        # round-3 flag: now the default
+    ap.add_argument("--cpu-sample", action="store_true", help="CPU baseline: multiply a bounded sample of the left rows "
+                                                              "(~10 s) and extrapolate, instead of ALL left rows (the "
+                                                              "default: ~90 s on 4 cores at 663 k, nothing extrapolated "
+                                                              "but the tokenisation passes and the tail)")
     return ap.parse_args()
 
 
@@ -77,6 +85,7 @@ def respawn_under_torchrun(args) -> None:
 
 def main():
     args = parse_args()
+    args.cpu_full = not args.cpu_sample
     if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
         respawn_under_torchrun(args)
     rank = int(os.environ.get("RANK", "0"))
@@ -103,8 +112,7 @@ def main():
             if rank == 0 and not isinstance(e, SystemExit):
                 sys.stdout.flush()
                 os.write(_JSON_FD[0] if _JSON_FD else 1, (json.dumps({
-                    "metric": "match_strings rows/sec (hot path: tokenise + tf-idf + postings + SpGEMM-topn), "
-                              "663k-name self-join ntop=10 min_sim=0.8",
+                    "metric": METRIC,
                     "value": None, "unit": "rows/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                     "higher_is_better": True, "scaling": "strong", "dtype": args.dtype,
                     "error": f"{type(e).__name__}: {e}"[:500],
@@ -131,14 +139,24 @@ def run(args):
     dtype = np.float32 if args.dtype == "f32" else np.float64
 
     import torch
+    # SG_BENCH_BACKEND=gloo: the N-rank step on a box with fewer GPUs than ranks (the builder's one-GPU box): all ranks on the
+    # devices there are, collectives staged through the host (string_grouper_amd/distributed.py: transport) -- the device ops
+    # of every rank are the real ones, the transport is not RCCL and the ranks share a GPU, so the line says "backend": "gloo"
+    # and its value is no scaling figure.
+    backend = os.environ.get("SG_BENCH_BACKEND", "nccl")
+    if backend == "gloo":
+        local_rank = local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     if distributed:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         import datetime
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank),
-                                timeout=datetime.timedelta(seconds=int(os.environ.get("SG_BENCH_COLLECTIVE_TIMEOUT", "180"))))
+        limit = datetime.timedelta(seconds=int(os.environ.get("SG_BENCH_COLLECTIVE_TIMEOUT", "180")))
+        if backend == "gloo":
+            dist.init_process_group("gloo", rank=rank, world_size=world, timeout=limit)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank), timeout=limit)
     from string_grouper_amd import _native as N
     from string_grouper_amd.synth import synth_names
     from string_grouper_amd.vectorizer import HipTfidfVectorizer
@@ -180,7 +198,10 @@ def run(args):
             local, _, _ = D.broadcast_strings(ctx, *dev_strings)
             res, _, _ = D.sharded_self_join_replicated(ctx, local, make_vec, args.top_n, args.min_similarity)
             return res
-        vec = make_vec()
+        return one_gpu_step(make_vec)
+
+    def one_gpu_step(factory):
+        vec = factory()
         vec.fit_prepared([prepared])
         A = vec.transform_prepared(prepared)
         post = ctx.postings_build(A)
@@ -188,6 +209,22 @@ def run(args):
         ctx.sync()
         res._keep = (A, post, vec)
         return res
+
+    def side_run(factory, k=12):
+        """The same step under another setting (other dtype, a switch of the context), timed like the main region on a
+        shorter one: (ms per step, the dominant kernel's ms, its stats)."""
+        one_gpu_step(factory).free()
+        one_gpu_step(factory).free()
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        kms, st = [], None
+        for _ in range(k):
+            r = one_gpu_step(factory)
+            st = ctx.stats()
+            kms.append(st["ms_spgemm_kernel"] or st["ms_spgemm_topn"])
+            r.free()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t) / k * 1e3, float(np.mean(kms)), st
 
     def barrier():
         if distributed:
@@ -208,7 +245,7 @@ def run(args):
         one = time.perf_counter() - tc
         if distributed:
             tt = torch.tensor([one], dtype=torch.float64, device="cuda")
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            D._all_reduce(tt, dist.ReduceOp.MAX)
             one = float(tt.item())
         args.steps = int(max(5, min(2000, np.ceil(2.0 / max(one, 1e-4)))))
     barrier()
@@ -234,11 +271,11 @@ def run(args):
     last.free()
     if distributed:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        D._all_reduce(t, dist.ReduceOp.MAX)
         elapsed = float(t.item())
         # per-rank K4 work: MACs and bytes are per row block; sum over ranks for the job totals
         w = torch.tensor([stats["macs"], stats["spgemm_bytes"], out_nnz], dtype=torch.float64, device="cuda")
-        dist.all_reduce(w, op=dist.ReduceOp.SUM)
+        D._all_reduce(w, dist.ReduceOp.SUM)
         job_macs, job_bytes, job_nnz = (float(x) for x in w.tolist())
     else:
         job_macs, job_bytes, job_nnz = float(stats["macs"]), float(stats["spgemm_bytes"]), float(out_nnz)
@@ -258,10 +295,12 @@ def run(args):
     k4_bytes = stats["prune_bytes"] if pruned else stats["spgemm_bytes"]
     achieved = k4_bytes / (k4_avg_ms * 1e-3) / 1e9        # this rank's launch group, GB/s
     result = {
-        "metric": "match_strings rows/sec (hot path: tokenise + tf-idf + postings + SpGEMM-topn), "
-                  "663k-name self-join ntop=10 min_sim=0.8",
+        "metric": METRIC,
         "value": args.rows / (elapsed / args.steps),
         "unit": "rows/s",
+        # `value` counts the CALLER's rows; identical strings give identical rows and the library indexes (and multiplies)
+        # one per group, then expands the result to all rows (sg_collapse.hip) -- the line says how many that were
+        "rows_indexed": index_rows, "rows_indexed_per_row": (index_rows / args.rows) if index_rows else None,
         "n_gpus": world,
         "steps": args.steps,
         "warmup": args.warmup,
@@ -270,6 +309,7 @@ def run(args):
         "scaling": "strong",
         "vs_baseline": None,
         "dtype": args.dtype,
+        "backend": (backend if distributed else None),
         "data": "synthetic (SynthNames-v1 seed 1234; sec__edgar names are not distributable)",
         "config": {"workload": f"{args.rows}-name self-join (BASELINE.json configs[2] on the synthetic stand-in)",
                    "ngram_size": 3, "max_n_matches": args.top_n, "min_similarity": args.min_similarity,
@@ -317,6 +357,25 @@ def run(args):
             result["roofline"]["traffic_note"] = tr["source"] + "; " + tr["note"]
     except Exception:
         pass
+
+    if world == 1 and not args.no_side_runs:
+        # the step WITHOUT the collapse of identical rows (every one of the 663 000 rows indexed and multiplied: 16.5 % of
+        # SynthNames-v1's names repeat, a property of the generator, not of sec__edgar) ...
+        ctx.set_option("SG_COLLAPSE", "0")
+        ms, kms, st_nc = side_run(make_vec)
+        ctx.set_option("SG_COLLAPSE", None)
+        nc_bytes = st_nc["prune_bytes"] if st_nc["prune_rows"] > 0 else st_nc["spgemm_bytes"]
+        result["without_row_collapse"] = {"ms_per_step": ms, "rows_per_s": args.rows / (ms * 1e-3), "kernel_ms": kms,
+                                          "kernel_frac_of_hbm_peak": nc_bytes / (kms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                                          "steps": 12, "option": "SG_COLLAPSE=0"}
+        # ... and in the other value type (fp64 is the reference's DEFAULT tfidf_matrix_dtype, string_grouper.py:18)
+        other = "f64" if args.dtype == "f32" else "f32"
+        odt = np.float64 if other == "f64" else np.float32
+        ms, kms, st_o = side_run(lambda: HipTfidfVectorizer(dtype=odt, ctx=ctx))
+        o_bytes = st_o["prune_bytes"] if st_o["prune_rows"] > 0 else st_o["spgemm_bytes"]
+        result[other] = {"ms_per_step": ms, "rows_per_s": args.rows / (ms * 1e-3), "kernel_ms": kms,
+                         "kernel_frac_of_hbm_peak": o_bytes / (kms * 1e-3) / 1e9 / HBM_PEAK_GBPS, "steps": 12,
+                         "matches": st_o["out_nnz"]}
 
     if world == 1 and pruned and not args.no_exact_kernel:
         # the exact kernel (K4) on the same input, timed live beside the pruned one: it is what runs when the

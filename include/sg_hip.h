@@ -57,6 +57,9 @@ typedef struct sg_topn sg_topn;         /* device-resident fixed-stride top-n re
 
 /* ------------------------------------------------------------------ library / context */
 const char *sg_last_error(void);
+/* Bumped whenever a signature or a struct of this header changes (round 4: 2 -- row_step arguments of round 3, sg_stats
+ * grew); a binding compares it with the value it was written for right after loading the library. */
+#define SG_ABI_VERSION 2
 int sg_abi_version(void);
 int sg_device_count(int *count);
 /* hip_stream: a hipStream_t to launch on (e.g. torch.cuda.current_stream().cuda_stream), or NULL

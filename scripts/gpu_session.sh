@@ -38,14 +38,14 @@ for step in "$@"; do
       timeout 900 python bench.py $arg > gpurun_out/${name}_bench$n.json 2> gpurun_out/${name}_bench$n.err
       echo "rc=$?" >> $LOG; short < gpurun_out/${name}_bench$n.json >> $LOG 2>&1 ;;
     ab)
-      spec=${arg%%:*}; bargs="--steps 6 --warmup 2 --no-cpu-baseline --no-exact-kernel --no-end-to-end"; [[ "$arg" == *:* ]] && bargs=${arg#*:}
+      spec=${arg%%:*}; bargs="--steps 6 --warmup 2 --no-cpu-baseline --no-exact-kernel --no-end-to-end --no-side-runs"; [[ "$arg" == *:* ]] && bargs=${arg#*:}
       var=${spec%%=*}; vals=${spec#*=}
       for rep in 1 2; do for v in ${vals//,/ }; do
         echo -n "$var=$v : " >> $LOG
         env $var=$v timeout 600 python bench.py $bargs 2> gpurun_out/${name}_ab$n.err | short >> $LOG 2>&1
       done; done ;;
     prof)
-      ( cd /tmp && export TMPDIR=/tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OLDPWD/gpurun_out/${name}_prof -o run -- python $OLDPWD/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-exact-kernel --no-end-to-end $arg > $OLDPWD/gpurun_out/${name}_prof.json 2> $OLDPWD/gpurun_out/${name}_prof.err )
+      ( cd /tmp && export TMPDIR=/tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OLDPWD/gpurun_out/${name}_prof -o run -- python $OLDPWD/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-exact-kernel --no-end-to-end --no-side-runs $arg > $OLDPWD/gpurun_out/${name}_prof.json 2> $OLDPWD/gpurun_out/${name}_prof.err )
       echo "rc=$?" >> $LOG
       f=$(find gpurun_out/${name}_prof -name "*kernel_stats.csv" | head -1)
       [ -n "$f" ] && cp $f gpurun_out/${name}_kernel_stats.csv && head -25 $f >> $LOG
@@ -53,7 +53,7 @@ for step in "$@"; do
       short < gpurun_out/${name}_prof.json >> $LOG 2>&1 ;;
     pmc)
       for c in FETCH_SIZE WRITE_SIZE; do
-        ( cd /tmp && export TMPDIR=/tmp && timeout 900 rocprofv3 --pmc $c --output-format csv -d $OLDPWD/gpurun_out/${name}_pmc${n}_$c -o run -- python $OLDPWD/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-exact-kernel --no-end-to-end $arg > /dev/null 2> $OLDPWD/gpurun_out/${name}_pmc${n}_$c.err )
+        ( cd /tmp && export TMPDIR=/tmp && timeout 900 rocprofv3 --pmc $c --output-format csv -d $OLDPWD/gpurun_out/${name}_pmc${n}_$c -o run -- python $OLDPWD/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-exact-kernel --no-end-to-end --no-side-runs $arg > /dev/null 2> $OLDPWD/gpurun_out/${name}_pmc${n}_$c.err )
         echo "pmc $c rc=$?" >> $LOG
       done
       python scripts/pmc_traffic.py gpurun_out/${name}_pmc${n}_FETCH_SIZE gpurun_out/${name}_pmc${n}_WRITE_SIZE gpurun_out/${name}_k4_traffic$n.json >> $LOG 2>&1
@@ -61,7 +61,7 @@ for step in "$@"; do
     envpmc)   # envpmc:VAR=value  -- the traffic passes with one environment variable set
       export ${arg}
       for c in FETCH_SIZE WRITE_SIZE; do
-        ( cd /tmp && export TMPDIR=/tmp && timeout 900 rocprofv3 --pmc $c --output-format csv -d $OLDPWD/gpurun_out/${name}_pmc${n}_$c -o run -- python $OLDPWD/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-exact-kernel --no-end-to-end > /dev/null 2> $OLDPWD/gpurun_out/${name}_pmc${n}_$c.err )
+        ( cd /tmp && export TMPDIR=/tmp && timeout 900 rocprofv3 --pmc $c --output-format csv -d $OLDPWD/gpurun_out/${name}_pmc${n}_$c -o run -- python $OLDPWD/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-exact-kernel --no-end-to-end --no-side-runs > /dev/null 2> $OLDPWD/gpurun_out/${name}_pmc${n}_$c.err )
         echo "pmc $c ($arg) rc=$?" >> $LOG
       done
       python scripts/pmc_traffic.py gpurun_out/${name}_pmc${n}_FETCH_SIZE gpurun_out/${name}_pmc${n}_WRITE_SIZE gpurun_out/${name}_k4_traffic$n.json >> $LOG 2>&1
@@ -73,7 +73,7 @@ for step in "$@"; do
                   "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_WAVES" \
                   "TCP_TCC_READ_REQ_sum TCC_HIT_sum TCC_MISS_sum TCC_EA_RDREQ_sum" "TCP_GATE_EN1_sum TCP_GATE_EN2_sum TCP_TA_TCP_STATE_READ_sum TCP_PENDING_STALL_CYCLES_sum"; do
         i=$((i+1))
-        ( cd /tmp && export TMPDIR=/tmp && timeout 600 rocprofv3 --pmc $ctrs --output-format csv -d $OLDPWD/gpurun_out/${name}_pmcsq$i -o k -- python $OLDPWD/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-exact-kernel --no-end-to-end $arg > /dev/null 2> $OLDPWD/gpurun_out/${name}_pmcsq$i.err )
+        ( cd /tmp && export TMPDIR=/tmp && timeout 600 rocprofv3 --pmc $ctrs --output-format csv -d $OLDPWD/gpurun_out/${name}_pmcsq$i -o k -- python $OLDPWD/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-exact-kernel --no-end-to-end --no-side-runs $arg > /dev/null 2> $OLDPWD/gpurun_out/${name}_pmcsq$i.err )
         echo "-- pmc pass $i rc=$?: $ctrs" >> $LOG
         python scripts/pmc_summary.py gpurun_out/${name}_pmcsq$i 2>&1 | grep -A14 "spgemm_topn_pruned" | head -16 >> $LOG
         rm -rf gpurun_out/${name}_pmcsq$i

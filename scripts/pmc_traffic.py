@@ -38,7 +38,7 @@ def main():
            "traffic_bytes_per_launch_raw": read_bytes + write_bytes,
            "read_bytes": read_bytes, "write_bytes": write_bytes, "launches_averaged": [n1, n2],
            "source": "scripts/pmc_traffic.py over two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; separate runs, no trace "
-                     "domains) of `python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-exact-kernel --no-end-to-end`",
+                     "domains) of `python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-exact-kernel --no-end-to-end --no-side-runs`",
            "note": "read = 2 x FETCH_SIZE (gfx950 tallies 128-byte memory-side requests at 64 B: MI355X_MICROARCH.md, HBM); "
                    "WRITE_SIZE uncalibrated; Infinity-Cache hits included"}
     with open(out, "w") as f:

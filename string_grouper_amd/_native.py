@@ -18,6 +18,7 @@ LIB_PATH = os.environ.get("SG_HIP_LIB") or os.path.join(_HERE, "libsg_hip.so")
 
 SG_OK, SG_ERR_BADARG, SG_ERR_OOM, SG_ERR_OVERFLOW, SG_ERR_HIP, SG_ERR_NODEVICE, SG_ERR_UNSUPPORTED = range(7)
 SG_F32, SG_F64 = 0, 1
+ABI_VERSION = 2          # include/sg_hip.h: SG_ABI_VERSION
 SG_K_TOKENIZE, SG_K_WEIGHT, SG_K_POSTINGS, SG_K_SPGEMM, SG_K_ZIP, SG_K_VOCAB, SG_K_SPGEMM_KERNEL, SG_K_COUNT = range(8)
 KERNEL_NAMES = ("tokenize", "weight", "postings", "spgemm_topn", "zip", "vocab", "spgemm_kernel")
 
@@ -135,6 +136,10 @@ def lib():
                 fn = getattr(handle, name)       # AttributeError if a declared symbol is not exported
                 fn.restype = res
                 fn.argtypes = args
+            got = handle.sg_abi_version()
+            if got != ABI_VERSION:
+                raise ImportError(f"{LIB_PATH} has ABI version {got}, this binding was written for {ABI_VERSION} "
+                                  f"(include/sg_hip.h: SG_ABI_VERSION): rebuild the library (make -C string_grouper_amd/csrc)")
             _lib = handle
     return _lib
 

@@ -16,7 +16,7 @@ void sg_set_error(const char *fmt, ...) {
 }
 
 extern "C" const char *sg_last_error(void) { return g_err; }
-extern "C" int sg_abi_version(void) { return 1; }
+extern "C" int sg_abi_version(void) { return SG_ABI_VERSION; }
 
 extern "C" int sg_device_count(int *count) {
     SG_REQUIRE(count != nullptr, "count is null");

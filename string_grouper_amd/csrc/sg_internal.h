@@ -232,6 +232,8 @@ struct sg_topn {
     int64_t n_rows = 0, n_cols = 0;
     int32_t stride = 0;
     int32_t dtype = SG_F32;
+    int32_t top_n_asked = 0;             // a result over GROUPS of identical rows: the caller's top_n (the stride is cut at the
+                                         // number of groups, the expansion to member rows must not be -- sg_topn_expand_groups)
     int32_t *d_cols = nullptr;
     void *d_vals = nullptr;
     int32_t *d_counts = nullptr;

@@ -30,6 +30,7 @@
 // Roofline: HBM/cache bandwidth bound, no MFMA (0.25 flop per byte; scatter, not a dense contraction).
 // Algorithmic bytes per intermediate product ("MAC"): 4 + s (one (j, value) posting), plus
 // nnz(A)*(4+s) + out -- see DESIGN.md.
+#include <cstring>
 #include <math.h>
 
 #include "sg_internal.h"
@@ -942,7 +943,11 @@ extern "C" int sg_spgemm_topn(sg_ctx *ctx, const sg_csr *A, const sg_postings *B
         // there are any is read back (four bytes), because the index build leaves the exact kernel's postings out when
         // the pruned multiply is expected to take everything (sg_postings_ensure_full writes them on demand).
         bool need_exact = !prune && !sym_done;
-        if (prune && !sym_done && st == SG_OK) {
+        if (prune && !sym_done && st == SG_OK && (Bt->d_vals != nullptr || Bt->nnz <= 0)) {
+            // the exact kernel's postings exist: its launch over the handed rows goes out on the device-side count, as
+            // before the postings became lazy -- blocked and zipped multiplies enqueue without a host round trip per part
+            need_exact = true;
+        } else if (prune && !sym_done && st == SG_OK) {
             uint32_t *h_handed = (uint32_t *)(ctx->h_stat_words + 7);   // pinned
             *h_handed = 0;
             if (hipMemcpyAsync(h_handed, handed_count, 4, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
@@ -1044,8 +1049,10 @@ extern "C" int sg_selfjoin_range(sg_ctx *ctx, const sg_csr *A, const sg_postings
         sg_postings view = *Bt;           // shallow: the same index, seen without the groups
         view.collapse = nullptr;
         view.plain = nullptr;
-        return sg_selfjoin_range(ctx, c->unique, &view, top_n, threshold, row_lo, row_hi, out, d_pairs, n_pairs, pair_words, applicable,
-                                 row_step);
+        const int st_u = sg_selfjoin_range(ctx, c->unique, &view, top_n, threshold, row_lo, row_hi, out, d_pairs, n_pairs, pair_words,
+                                           applicable, row_step);
+        if (st_u == SG_OK && *out) (*out)->top_n_asked = top_n;      // (fewer groups than top_n: the rows over MEMBERS are wider)
+        return st_u;
     }
     if (!(threshold > 0.0)) threshold = 0.0;
     int64_t stride64 = top_n;
@@ -1113,8 +1120,16 @@ extern "C" int sg_topn_expand_groups(sg_ctx *ctx, const sg_postings *Bt, const s
     SG_REQUIRE(groups->dtype == Bt->dtype, "result and index differ in value type");
     if (!d_rows) n_rows = c->n_orig;
     SG_REQUIRE(n_rows >= 0 && n_rows <= c->n_orig, "more rows than the matrix has");
+    // a row over members holds up to min(top_n, rows) columns -- as spgemm_topn_collapsed sizes it --, not the groups' stride,
+    // which is cut at the number of GROUPS (eight distinct names in 200 k rows, top_n 20: 20 columns per row, not 8)
+    int64_t stride64 = groups->top_n_asked > groups->stride ? groups->top_n_asked : groups->stride;
+    if (stride64 > c->n_orig) stride64 = c->n_orig > 0 ? c->n_orig : 1;
+    if ((double)n_rows * (double)stride64 > 2.0e9) {
+        sg_set_error("result of %lld rows x top_n %lld does not fit the 32-bit result index", (long long)n_rows, (long long)stride64);
+        return SG_ERR_OVERFLOW;
+    }
     sg_topn *r = nullptr;
-    SG_TRY(topn_alloc(ctx, n_rows, c->n_orig, groups->stride, groups->dtype, &r));
+    SG_TRY(topn_alloc(ctx, n_rows, c->n_orig, (int32_t)stride64, groups->dtype, &r));
     int st = SG_OK;
     {
         SgTimer timer(ctx, SG_K_ZIP);
@@ -1404,14 +1419,29 @@ extern "C" int sg_sp_matmul_topn_host(sg_ctx *ctx, int64_t n_left, int64_t n_rig
     sg_csr *A = nullptr, *B = nullptr;
     sg_postings *P = nullptr;
     sg_topn *R = nullptr;
+    SG_REQUIRE(ctx && a_indptr && b_indptr && out_cols && out_vals && out_counts, "null argument");
+    SG_REQUIRE(n_left >= 0 && n_right >= 0 && n_cols >= 0, "negative size");
+    SG_REQUIRE(dtype == SG_F32 || dtype == SG_F64, "dtype must be SG_F32 or SG_F64");
+    // A self-join as the reference issues it -- sp_matmul_topn(M, M.transpose(), ...), string_grouper.py:725-729 -- reaches
+    // this function as the same matrix twice: the same buffers, or (a binding that converted the index arrays) equal ones.
+    // One upload then serves both sides, and the multiply sees that A IS the indexed matrix: the self-join form, every pair
+    // scored once.  (memcmp leaves at the first difference, so a real B costs nothing to tell apart.)
+    bool same = n_left == n_right && a_indptr[n_left] == b_indptr[n_right];
+    if (same && !(a_indptr == b_indptr && a_indices == b_indices && a_data == b_data)) {
+        const size_t nnz = (size_t)a_indptr[n_left];
+        same = std::memcmp(a_indptr, b_indptr, sizeof(int64_t) * (size_t)(n_left + 1)) == 0 &&
+               (nnz == 0 || (std::memcmp(a_indices, b_indices, sizeof(int32_t) * nnz) == 0 &&
+                             std::memcmp(a_data, b_data, (dtype == SG_F64 ? 8 : 4) * nnz) == 0));
+    }
     int st = sg_csr_from_host(ctx, n_left, n_cols, a_indptr, a_indices, a_data, dtype, &A);
-    if (st == SG_OK) st = sg_csr_from_host(ctx, n_right, n_cols, b_indptr, b_indices, b_data, dtype, &B);
+    if (same) B = A;
+    else if (st == SG_OK) st = sg_csr_from_host(ctx, n_right, n_cols, b_indptr, b_indices, b_data, dtype, &B);
     if (st == SG_OK) st = sg_postings_build(ctx, B, 0, &P);
     if (st == SG_OK) st = sg_spgemm_topn(ctx, A, P, top_n, threshold, sort, &R);
     if (st == SG_OK) st = sg_topn_to_host(ctx, R, out_cols, out_vals, out_counts);
     sg_topn_free(R);
     sg_postings_free(P);
-    sg_csr_free(B);
+    if (!same) sg_csr_free(B);
     sg_csr_free(A);
     return st;
 }

@@ -58,13 +58,49 @@ def weighted_row_blocks(row_cost: np.ndarray, world: int) -> np.ndarray:
 
 
 # ---------------------------------------------------------------------------------------------- collectives
+# Transport.  The product runs one process per GPU on RCCL (backend "nccl"), whose collectives take device tensors.  A group
+# on gloo -- several ranks on ONE device (RCCL refuses two ranks of a communicator on the same GPU), which is how the device
+# ops of the N > 1 path are tested and benchmarked on a one-GPU box -- has no device collectives here: the three wrappers
+# below run the collective on a host copy and put the result back.  Host tensors (the CPU tests) pass through untouched.
+def _host_staged(t, group) -> bool:
+    return bool(t.is_cuda) and dist.get_backend(group) == "gloo"
+
+
+def _all_gather_into(out, t, group=None) -> None:
+    if _host_staged(t, group):
+        h = torch.empty(out.shape, dtype=out.dtype)
+        dist.all_gather_into_tensor(h, t.cpu(), group=group)
+        out.copy_(h)
+        return
+    dist.all_gather_into_tensor(out, t, group=group)
+
+
+def _all_reduce(t, op=None, group=None) -> None:
+    op = dist.ReduceOp.SUM if op is None else op
+    if _host_staged(t, group):
+        h = t.cpu()
+        dist.all_reduce(h, op=op, group=group)
+        t.copy_(h)
+        return
+    dist.all_reduce(t, op=op, group=group)
+
+
+def _broadcast(t, src: int, group=None) -> None:
+    if _host_staged(t, group):
+        h = t.cpu()
+        dist.broadcast(h, src=src, group=group)
+        t.copy_(h)
+        return
+    dist.broadcast(t, src=src, group=group)
+
+
 def all_headers(values: Sequence[int], device, group=None) -> List[List[int]]:
     """Every rank's small vector of integers (sizes, flags), as a list in rank order: ONE collective and ONE
     device-to-host copy -- the only synchronisation a group of ragged gathers needs."""
     world = dist.get_world_size(group)
     mine = torch.tensor([int(v) for v in values], dtype=torch.int64, device=device)
     out = torch.empty(world * mine.numel(), dtype=torch.int64, device=device)
-    dist.all_gather_into_tensor(out, mine, group=group)
+    _all_gather_into(out, mine, group)
     return out.reshape(world, mine.numel()).tolist()
 
 
@@ -86,7 +122,7 @@ def all_gather_ragged(t, group=None, sizes: Optional[Sequence[int]] = None) -> l
         padded = torch.empty(longest, dtype=t.dtype, device=t.device)
         padded[: t.numel()] = t
     out = torch.empty(len(sizes) * longest, dtype=t.dtype, device=t.device)
-    dist.all_gather_into_tensor(out, padded, group=group)
+    _all_gather_into(out, padded, group)
     return [out[r * longest: r * longest + n] for r, n in enumerate(sizes)]
 
 
@@ -110,16 +146,16 @@ def broadcast_csr(indptr, indices, data, shape, src: int = 0, device=None, group
         header[0], header[1] = int(shape[0]), int(shape[1])
         header[2] = int(indices.numel())
         header[3] = 1 if data.dtype == torch.float64 else 0
-    dist.broadcast(header, src=src, group=group)
+    _broadcast(header, src, group)
     n_rows, n_cols, nnz, is_f64 = (int(x) for x in header.tolist())
     if rank != src:
         indptr = torch.empty(n_rows + 1, dtype=torch.int64, device=device)
         indices = torch.empty(max(nnz, 1), dtype=torch.int32, device=device)[:nnz]
         data = torch.empty(max(nnz, 1), dtype=torch.float64 if is_f64 else torch.float32, device=device)[:nnz]
-    dist.broadcast(indptr, src=src, group=group)
+    _broadcast(indptr, src, group)
     if nnz > 0:
-        dist.broadcast(indices, src=src, group=group)
-        dist.broadcast(data, src=src, group=group)
+        _broadcast(indices, src, group)
+        _broadcast(data, src, group)
     return indptr, indices, data, (n_rows, n_cols)
 
 
@@ -168,8 +204,8 @@ def sharded_tfidf(ops, local_sets: Sequence, group=None):
     df = ops.df_tensor(state)                                   # dense int32 table over the n-gram key space
     n_docs = torch.tensor([sum(ops.n_strings(s) for s in local_sets)], dtype=torch.int64, device=df.device)
     if world > 1:
-        dist.all_reduce(df, op=dist.ReduceOp.SUM, group=group)
-        dist.all_reduce(n_docs, op=dist.ReduceOp.SUM, group=group)
+        _all_reduce(df, dist.ReduceOp.SUM, group)
+        _all_reduce(n_docs, dist.ReduceOp.SUM, group)
     ops.fit_end(state, int(n_docs.item()))
     return state, [ops.transform(state, s) for s in local_sets]
 
@@ -598,13 +634,13 @@ def broadcast_strings(ctx, t_bytes, t_offs, src: int = 0, group=None):
     if rank == src:
         header[0] = t_offs.numel() - 1
         header[1] = t_offs[-1]
-    dist.broadcast(header, src=src, group=group)
+    _broadcast(header, src, group)
     n, total = (int(x) for x in header.tolist())
     if rank != src:
         t_bytes = torch.empty(max(total, 1), dtype=torch.uint8, device=dev)
         t_offs = torch.empty(n + 1, dtype=torch.int64, device=dev)
-    dist.broadcast(t_bytes, src=src, group=group)
-    dist.broadcast(t_offs, src=src, group=group)
+    _broadcast(t_bytes, src, group)
+    _broadcast(t_offs, src, group)
     torch.cuda.current_stream(dev).synchronize()
     return _wrap_device_strings(ctx, t_bytes, t_offs, n, total), t_bytes, t_offs
 
@@ -619,7 +655,7 @@ def pruned_multiply_expected(top_n: int, threshold: float, ctx=None) -> bool:
     opts = ctx.options() if ctx is not None else os.environ
     if opts.get("SG_PRUNE", "1").startswith("0"):
         return False
-    return top_n <= 64 and threshold >= float(opts.get("SG_PRUNE_MIN_THRESHOLD", "0.45"))
+    return top_n <= 128 and threshold >= float(opts.get("SG_PRUNE_MIN_THRESHOLD", "0.45"))   # (2 x SG_TOPN_LANES: pruned_applicable)
 
 
 def sharded_self_join_replicated(ctx, prepared_dev, vectorizer_factory, top_n: int, threshold: float,

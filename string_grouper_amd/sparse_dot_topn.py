@@ -24,6 +24,17 @@ def _right_as_csr(B) -> sp.csr_matrix:
     return sp.csr_matrix(B).T.tocsr()
 
 
+def _same_matrix(A: sp.csr_matrix, Bm: sp.csr_matrix) -> bool:
+    """A self-join as the reference issues it: ``sp_matmul_topn(master_matrix, master_matrix.transpose(), ...)``
+    (string_grouper.py:725-729) -- the transposed view shares the three arrays of the matrix.  The library then takes the
+    self-join form (every pair scored once) and indexes identical rows once."""
+    if Bm is A:
+        return True
+    return (A.shape == Bm.shape and A.dtype == Bm.dtype and A.indptr.dtype == Bm.indptr.dtype
+            and A.data.ctypes.data == Bm.data.ctypes.data and A.indices.ctypes.data == Bm.indices.ctypes.data
+            and A.indptr.ctypes.data == Bm.indptr.ctypes.data and A.data.shape == Bm.data.shape)
+
+
 def sp_matmul_topn(A, B, top_n: int, threshold: Optional[float] = None, sort: bool = False,
                    density: Optional[float] = None, n_threads: Optional[int] = None,
                    idx_dtype=None, ctx: Optional[N.Context] = None) -> sp.csr_matrix:
@@ -43,12 +54,12 @@ def sp_matmul_topn(A, B, top_n: int, threshold: Optional[float] = None, sort: bo
         A, Bm = A.astype(np.float64), Bm.astype(np.float64)
     thr = 0.0 if threshold is None else max(float(threshold), 0.0)
     dA = ctx.csr_from_scipy(A)
-    dB = dA if Bm is A else ctx.csr_from_scipy(Bm)
+    dB = dA if _same_matrix(A, Bm) else ctx.csr_from_scipy(Bm)
     post = ctx.postings_build(dB)
     res = ctx.spgemm_topn(dA, post, int(top_n), thr, bool(sort))
     C = res.to_scipy()
     for h in (res, post, dB, dA):
-        h.free()
+        h.free()                      # (dB may be dA: free() is idempotent)
     if idx_dtype is not None:
         C.indices = C.indices.astype(idx_dtype)
         C.indptr = C.indptr.astype(idx_dtype)

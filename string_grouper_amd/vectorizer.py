@@ -222,3 +222,31 @@ class HipTfidfVectorizer:
 
     def get_feature_names_out(self):
         return np.asarray(self._terms(), dtype=object)
+
+
+class TfidfVectorizer(HipTfidfVectorizer):
+    """Seam b1 BY NAME: the constructor call the reference makes, ``TfidfVectorizer(min_df=1, analyzer=self.n_grams,
+    dtype=self._config.tfidf_matrix_dtype)`` (string_grouper/string_grouper.py:306), served by the device vectoriser.  With
+
+        import string_grouper.string_grouper as ref
+        ref.TfidfVectorizer = string_grouper_amd.vectorizer.TfidfVectorizer
+
+    (or the one-line import patch of INTEGRATION.md) the unmodified reference vectorises on the GPU.  The analyzer is a
+    Python callable, which the device cannot run; what it computes is fully described by the options of the object it is
+    bound to -- ``StringGrouper.n_grams`` reads ``self._config.{ngram_size, regex, ignore_case, normalize_to_ascii}``
+    (:365-378) -- so those are taken from ``analyzer.__self__._config``.  Any other analyzer is refused: there is no CPU
+    tokeniser to fall back to."""
+
+    def __init__(self, *, min_df=1, analyzer=None, dtype=np.float64, ctx: Optional[N.Context] = None, **unsupported):
+        if unsupported:
+            raise TypeError(f"TfidfVectorizer options the device vectoriser does not implement: {sorted(unsupported)}")
+        if min_df != 1:
+            raise NotImplementedError("min_df != 1 (the reference always passes 1, string_grouper.py:306)")
+        owner = getattr(analyzer, "__self__", None)
+        cfg = getattr(owner, "_config", None)
+        if getattr(analyzer, "__name__", "") != "n_grams" or cfg is None:
+            raise TypeError("analyzer must be the bound n_grams method of a StringGrouper (string_grouper.py:365-378): its "
+                            "options, not its code, are what reaches the device")
+        super().__init__(ngram_size=cfg.ngram_size, regex=cfg.regex, ignore_case=cfg.ignore_case,
+                         normalize_to_ascii=cfg.normalize_to_ascii, dtype=dtype, ctx=ctx)
+        self.min_df, self.analyzer = min_df, analyzer

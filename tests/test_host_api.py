@@ -174,7 +174,8 @@ def test_assigning_the_match_list_drops_a_device_copy():
 def test_pruned_multiply_rule_used_for_the_row_split():
     from string_grouper_amd.distributed import pruned_multiply_expected
     assert pruned_multiply_expected(10, 0.8)
-    assert not pruned_multiply_expected(65, 0.8)
+    assert pruned_multiply_expected(128, 0.8)          # (65 .. 128: the pruned kernel + a hand-over of full rows)
+    assert not pruned_multiply_expected(129, 0.8)
     assert not pruned_multiply_expected(10, 0.3)
 
 
