@@ -186,6 +186,7 @@ extern "C" int sg_ctx_destroy(sg_ctx *ctx) {
         (void)hipEventDestroy(ctx->ev_stop[i]);
     }
     (void)hipFree(ctx->d_stat_words);
+    (void)hipFree(ctx->d_scan_desc);
     (void)hipHostFree(ctx->h_stat_words);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -474,16 +475,91 @@ extern "C" int sg_csr_free(sg_csr *m) {
     return SG_OK;
 }
 
+// ------------------------------------------------------------------------------------ zeroing several arrays at once
+// Counters and per-row count arrays are cleared in groups at the head of a call; every hipMemsetAsync is a launch of its
+// own (a fillBuffer kernel: 33 of the step's 135 launches at 663 k).  One kernel clears up to eight ranges (4-byte
+// granularity, 16-byte stores where the range is aligned).
+struct SgZeroJobs {
+    uint32_t *ptr[8];
+    uint64_t words[8];    // 4-byte words of range i
+    uint64_t first[8];    // words of the ranges before i (prefix sum); first[n] = all
+    int n;
+};
+__global__ void __launch_bounds__(256) zero_ranges_kernel(SgZeroJobs jobs) {
+    const uint64_t total = jobs.first[jobs.n < 8 ? jobs.n : 7] + (jobs.n == 8 ? jobs.words[7] : 0);
+    // a thread clears four consecutive words of one range (the ranges are padded to multiples of four in this numbering)
+    for (uint64_t q = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; q < total; q += (uint64_t)gridDim.x * blockDim.x * 4) {
+        int r = 0;
+#pragma unroll
+        for (int i = 1; i < 8; ++i)
+            if (i < jobs.n && q >= jobs.first[i]) r = i;
+        const uint64_t w = q - jobs.first[r];
+        uint32_t *p = jobs.ptr[r] + w;
+        const uint64_t left = jobs.words[r] - w;
+        if (left >= 4 && ((uintptr_t)p & 15u) == 0) {
+            *reinterpret_cast<uint4 *>(p) = make_uint4(0u, 0u, 0u, 0u);
+        } else {
+            for (uint64_t e = 0; e < 4 && e < left; ++e) p[e] = 0u;
+        }
+    }
+}
+
+int sg_zero_ranges(sg_ctx *ctx, int n, void *const *ptrs, const size_t *bytes) {
+    SgZeroJobs jobs;
+    jobs.n = 0;
+    uint64_t first = 0;
+    for (int i = 0; i < n; ++i) {
+        if (!ptrs[i] || bytes[i] == 0) continue;
+        if (jobs.n == 8 || (bytes[i] & 3u) || ((uintptr_t)ptrs[i] & 3u)) {   // (not expected: plain memsets serve)
+            SG_HIP_TRY(hipMemsetAsync(ptrs[i], 0, bytes[i], ctx->stream));
+            continue;
+        }
+        jobs.ptr[jobs.n] = (uint32_t *)ptrs[i];
+        jobs.words[jobs.n] = bytes[i] / 4;
+        jobs.first[jobs.n] = first;
+        first += (jobs.words[jobs.n] + 3) & ~(uint64_t)3;
+        ++jobs.n;
+    }
+    if (jobs.n == 0) return SG_OK;
+    for (int i = jobs.n; i < 8; ++i) {
+        jobs.ptr[i] = nullptr;
+        jobs.words[i] = 0;
+        jobs.first[i] = first;
+    }
+    uint64_t threads = first / 4;
+    unsigned grid = (unsigned)((threads + 255) / 256);
+    if (grid > (unsigned)ctx->num_cu * 16u) grid = (unsigned)ctx->num_cu * 16u;
+    if (grid < 1) grid = 1;
+    hipLaunchKernelGGL(zero_ranges_kernel, dim3(grid), dim3(256), 0, ctx->stream, jobs);
+    SG_HIP_TRY(hipGetLastError());
+    return SG_OK;
+}
+
 // ------------------------------------------------------------------------------------ prefix sums
-// Three-phase scan: per-block totals -> scan of the totals (recursive) -> per-block scan + offset.
-// 256 threads x 8 items per block; HBM-bound, two reads and one write per element.
-#define SCAN_THREADS 256
+// ONE launch per scan (round 4; rounds 1-3: per-block totals -> recursive scan of the totals -> per-block apply, three to
+// five launches and two extra passes over the totals -- a sixth of the step's 135 launches at 663 k were scans).
+// Single pass with decoupled look-back: a tile (1024 threads x 8 items) sums its items, publishes {aggregate}, looks back
+// over its predecessors' descriptors until it meets an inclusive prefix, publishes {inclusive prefix}, and writes its
+// items.  HBM-bound: one read and one write per element.
+//   * Tiles are numbered by a TICKET (atomic counter), not by blockIdx: a tile only ever waits for tiles with smaller
+//     tickets, which have started -- forward progress whatever order the hardware schedules workgroups in.  The counter is
+//     never reset: the host knows how many tickets every scan takes and passes the first one (`ticket_base`).
+//   * A descriptor is ONE 64-bit word {epoch:16 | state:2 | value:46}, written and read with relaxed device-scope
+//     atomics (the word carries everything: no ordering against other memory is needed).  The epoch names the scan, so the
+//     descriptor array of the context is never cleared between scans (a clear would be the launch this saves); when the
+//     16-bit epoch wraps -- every 65 535 scans -- it is cleared once.  Values are < 2^46 (7 * 10^13 entries).
+//   * In-place (d_out == d_in) is fine: a tile holds its items in registers before it writes them.
+#define SCAN_THREADS 1024      // (tiles of 8192 items: the look-back walks 64 predecessors per ~1.5 us round trip -- with
+                               //  tiles of 2048 a scan of 5 M bins spent 50 us waiting for its 2 440 tiles' chain)
 #define SCAN_ITEMS 8
 #define SCAN_BLOCK (SCAN_THREADS * SCAN_ITEMS)
+#define SCAN_VALUE_BITS 46
+#define SCAN_STATE_AGGREGATE 1ull
+#define SCAN_STATE_PREFIX 2ull
 
 template <typename TO>
 __device__ __forceinline__ TO block_exclusive_scan(TO v, TO *lds_wave_tot, TO *block_total) {
-    // inclusive scan inside the 64-wide wave by shuffles, then across the 4 waves through LDS
+    // inclusive scan inside the 64-wide wave by shuffles, then across the waves through LDS
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     TO incl = v;
 #pragma unroll
@@ -505,24 +581,21 @@ __device__ __forceinline__ TO block_exclusive_scan(TO v, TO *lds_wave_tot, TO *b
     return wave_off + incl - v;
 }
 
-template <typename TI, typename TO>
-__global__ void __launch_bounds__(SCAN_THREADS) scan_block_totals(const TI *in, TO *totals, int64_t n) {
-    __shared__ TO wt[SCAN_THREADS / 64];
-    const int64_t base = (int64_t)blockIdx.x * SCAN_BLOCK + (int64_t)threadIdx.x * SCAN_ITEMS;
-    TO s = 0;
-#pragma unroll
-    for (int i = 0; i < SCAN_ITEMS; ++i)
-        if (base + i < n) s += (TO)in[base + i];
-    TO tot;
-    (void)block_exclusive_scan<TO>(s, wt, &tot);
-    if (threadIdx.x == 0) totals[blockIdx.x] = tot;
+__device__ __forceinline__ unsigned long long scan_desc(uint32_t epoch, unsigned long long state, unsigned long long value) {
+    return ((unsigned long long)epoch << 48) | (state << SCAN_VALUE_BITS) | (value & ((1ull << SCAN_VALUE_BITS) - 1ull));
 }
 
 template <typename TI, typename TO>
-__global__ void __launch_bounds__(SCAN_THREADS) scan_block_apply(const TI *in, TO *out, const TO *block_offsets,
-                                                                 int64_t n, TO *d_total) {
+__global__ void __launch_bounds__(SCAN_THREADS) scan_lookback_kernel(const TI *in, TO *out, int64_t n, TO *d_total,
+                                                                     unsigned long long *desc, uint32_t *ticket,
+                                                                     uint32_t ticket_base, uint32_t epoch) {
     __shared__ TO wt[SCAN_THREADS / 64];
-    const int64_t base = (int64_t)blockIdx.x * SCAN_BLOCK + (int64_t)threadIdx.x * SCAN_ITEMS;
+    __shared__ uint32_t s_tile;
+    __shared__ unsigned long long s_excl;
+    if (threadIdx.x == 0) s_tile = atomicAdd(ticket, 1u) - ticket_base;
+    __syncthreads();
+    const uint32_t tile = s_tile;
+    const int64_t base = (int64_t)tile * SCAN_BLOCK + (int64_t)threadIdx.x * SCAN_ITEMS;
     TO v[SCAN_ITEMS];
     TO s = 0;
 #pragma unroll
@@ -531,14 +604,56 @@ __global__ void __launch_bounds__(SCAN_THREADS) scan_block_apply(const TI *in, T
         s += v[i];
     }
     TO tot;
-    TO run = block_exclusive_scan<TO>(s, wt, &tot) + (block_offsets ? block_offsets[blockIdx.x] : (TO)0);
+    TO run = block_exclusive_scan<TO>(s, wt, &tot);
+    if (threadIdx.x < 64) {   // the tile's first wave publishes and looks back, 64 predecessors at a time
+        const int lane = threadIdx.x;
+        if (lane == 0)
+            __hip_atomic_store(&desc[tile], scan_desc(epoch, tile == 0 ? SCAN_STATE_PREFIX : SCAN_STATE_AGGREGATE, (unsigned long long)tot),
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        unsigned long long excl = 0;
+        int64_t hi = (int64_t)tile;   // predecessors [.., hi) still to be added
+        while (hi > 0) {
+            const int64_t at = hi - 1 - lane;
+            unsigned long long d = 0;
+            bool ready = true;
+            if (at >= 0) {
+                d = __hip_atomic_load(&desc[at], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                ready = (uint32_t)(d >> 48) == epoch && ((d >> SCAN_VALUE_BITS) & 3ull) != 0ull;
+            }
+            // lanes are ordered nearest predecessor first: use the ready descriptors up to (and including) the first
+            // inclusive prefix, provided every one before it is ready; otherwise look again
+            const uint64_t not_ready = __ballot(!ready);
+            const uint64_t is_prefix = __ballot(at >= 0 && ready && ((d >> SCAN_VALUE_BITS) & 3ull) == SCAN_STATE_PREFIX);
+            const int first_gap = not_ready ? __builtin_ctzll(not_ready) : 64;
+            const int first_prefix = is_prefix ? __builtin_ctzll(is_prefix) : 64;
+            const int usable = first_prefix < first_gap ? first_prefix + 1 : first_gap;   // lanes [0, usable)
+            unsigned long long add = (lane < usable && at >= 0) ? (d & ((1ull << SCAN_VALUE_BITS) - 1ull)) : 0ull;
+#pragma unroll
+            for (int dd = 32; dd > 0; dd >>= 1) {
+                const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)add, dd, 64), hh = (uint32_t)__shfl_xor((int)(uint32_t)(add >> 32), dd, 64);
+                add += ((unsigned long long)hh << 32) | lo;
+            }
+            excl += add;
+            if (first_prefix < first_gap) break;      // met an inclusive prefix: done
+            hi -= usable;                               // (usable may be 0: spin on the same window)
+            if (usable == 0) __builtin_amdgcn_s_sleep(1);
+        }
+        if (lane == 0) {
+            if (tile != 0)
+                __hip_atomic_store(&desc[tile], scan_desc(epoch, SCAN_STATE_PREFIX, excl + (unsigned long long)tot), __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+            s_excl = excl;
+        }
+    }
+    __syncthreads();
+    run += (TO)s_excl;
 #pragma unroll
     for (int i = 0; i < SCAN_ITEMS; ++i) {
         if (base + i < n) out[base + i] = run;
         run += v[i];
     }
     // the element one past the end receives the grand total (row-pointer convention)
-    if (d_total && blockIdx.x == gridDim.x - 1 && threadIdx.x == SCAN_THREADS - 1) *d_total = run;
+    if (d_total && (int64_t)tile == (n - 1) / SCAN_BLOCK && threadIdx.x == SCAN_THREADS - 1) *d_total = run;
 }
 
 template <typename TI, typename TO>
@@ -548,24 +663,35 @@ static int scan_impl(sg_ctx *ctx, const TI *d_in, TO *d_out, int64_t n, TO *d_to
         return SG_OK;
     }
     const int64_t nblocks = (n + SCAN_BLOCK - 1) / SCAN_BLOCK;
-    if (nblocks == 1) {
-        hipLaunchKernelGGL((scan_block_apply<TI, TO>), dim3(1), dim3(SCAN_THREADS), 0, ctx->stream, d_in, d_out,
-                           (const TO *)nullptr, n, d_total);
-        SG_HIP_TRY(hipGetLastError());
-        return SG_OK;
+    SG_REQUIRE(nblocks < ((int64_t)1 << 31), "scan of more than 2^42 entries");
+    if ((size_t)nblocks > ctx->scan_desc_cap) {   // grow the descriptor array (+ the ticket word behind it)
+        size_t cap = ctx->scan_desc_cap ? ctx->scan_desc_cap : 4096;
+        while (cap < (size_t)nblocks) cap *= 2;
+        void *p = nullptr;
+        SG_HIP_TRY(hipMalloc(&p, (cap + 2) * sizeof(unsigned long long)));
+        if (hipMemsetAsync(p, 0, (cap + 2) * sizeof(unsigned long long), ctx->stream) != hipSuccess) {
+            (void)hipFree(p);
+            return SG_ERR_HIP;
+        }
+        if (ctx->d_scan_desc) {   // scans in flight on the stream still use the old array
+            SG_HIP_TRY(hipStreamSynchronize(ctx->stream));
+            (void)hipFree(ctx->d_scan_desc);
+        }
+        ctx->d_scan_desc = (unsigned long long *)p;
+        ctx->scan_desc_cap = cap;
+        ctx->scan_ticket_base = 0;
+        ctx->scan_epoch = 0;
     }
-    TO *d_tot = nullptr;
-    SG_TRY(sg_alloc(ctx, (size_t)nblocks, &d_tot));
-    hipLaunchKernelGGL((scan_block_totals<TI, TO>), dim3((unsigned)nblocks), dim3(SCAN_THREADS), 0, ctx->stream, d_in,
-                       d_tot, n);
-    int st = scan_impl<TO, TO>(ctx, d_tot, d_tot, nblocks, (TO *)nullptr);
-    if (st == SG_OK) {
-        hipLaunchKernelGGL((scan_block_apply<TI, TO>), dim3((unsigned)nblocks), dim3(SCAN_THREADS), 0, ctx->stream,
-                           d_in, d_out, (const TO *)d_tot, n, d_total);
-        if (hipGetLastError() != hipSuccess) st = SG_ERR_HIP;
+    if (++ctx->scan_epoch > 0xFFFFu) {            // the 16-bit epoch wraps: stale descriptors could pass for fresh ones
+        SG_HIP_TRY(hipMemsetAsync(ctx->d_scan_desc, 0, ctx->scan_desc_cap * sizeof(unsigned long long), ctx->stream));
+        ctx->scan_epoch = 1;
     }
-    ctx->release(d_tot);   // stream-ordered reuse: later users launch on the same stream
-    return st;
+    uint32_t *ticket = reinterpret_cast<uint32_t *>(ctx->d_scan_desc + ctx->scan_desc_cap);
+    hipLaunchKernelGGL((scan_lookback_kernel<TI, TO>), dim3((unsigned)nblocks), dim3(SCAN_THREADS), 0, ctx->stream, d_in, d_out, n,
+                       d_total, ctx->d_scan_desc, ticket, ctx->scan_ticket_base, ctx->scan_epoch);
+    ctx->scan_ticket_base += (uint32_t)nblocks;   // (mod 2^32, like the device counter)
+    SG_HIP_TRY(hipGetLastError());
+    return SG_OK;
 }
 
 int sg_exclusive_scan_u32(sg_ctx *ctx, const uint32_t *d_in, uint32_t *d_out, int64_t n, uint32_t *d_total) {

@@ -235,9 +235,7 @@ int sg_collapse_build(sg_ctx *ctx, const sg_csr *B, SgCollapse **out) {
     if (st == SG_OK) st = sg_alloc(ctx, (size_t)n_u + 2, &c->d_group_ptr);
     if (st == SG_OK) st = sg_alloc(ctx, (size_t)n + 1, &c->d_members);
     if (st == SG_OK) st = sg_alloc(ctx, (size_t)n_u + 1, &c->d_rep_rows);
-    if (st == SG_OK && (hipMemsetAsync(is_rep, 0, sizeof(uint32_t) * (size_t)(n + 1), ctx->stream) != hipSuccess ||
-                        hipMemsetAsync(size, 0, sizeof(uint32_t) * (size_t)(n_u + 1), ctx->stream) != hipSuccess))
-        st = SG_ERR_HIP;
+    if (st == SG_OK) st = SG_ZERO2(ctx, is_rep, sizeof(uint32_t) * (size_t)(n + 1), size, sizeof(uint32_t) * (size_t)(n_u + 1));
     if (st == SG_OK) {
         hipLaunchKernelGGL(head_pos_kernel, dim3(g1), dim3(256), 0, ctx->stream, (const uint32_t *)head, (const uint32_t *)run_excl, n,
                            head_pos);

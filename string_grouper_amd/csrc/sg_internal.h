@@ -78,6 +78,12 @@ struct sg_ctx {
     }
     bool poison = false;                         // SG_POISON_ALLOC=1 (copied out of opts: read under the pool's lock)
 
+    // single-pass prefix sums (sg_api.hip: scan_lookback_kernel): tile descriptors + the ticket counter behind them,
+    // owned by the context and reused by every scan (scans of one context run one after the other on its stream)
+    unsigned long long *d_scan_desc = nullptr;
+    size_t scan_desc_cap = 0;
+    uint32_t scan_ticket_base = 0, scan_epoch = 0;
+
     int alloc(size_t bytes, void **out);         // pooled hipMalloc
     void release(void *p);                       // back to the pool
     void trim();
@@ -172,6 +178,7 @@ struct sg_postings {
     const void *b_data = nullptr;
     uint32_t *d_seg = nullptr;           // n_terms * n_tiles + 1
     uint32_t *d_term_len = nullptr;      // n_terms: entries of term k's list (= seg[(k+1) * n_tiles] - seg[k * n_tiles])
+    uint32_t *d_term_start = nullptr;    // n_terms + 1: start of term k's list (LDS build path; sg_postings_ensure_full re-reads it)
     int32_t *d_rows = nullptr;           // nnz   (row j of B)                  } null until sg_postings_ensure_full when the
     void *d_vals = nullptr;              // nnz   (value B[j, k])               } build left the postings proper out
     sg_csr src;                          // the matrix the index was built over (rows in position order; not owned)
@@ -309,6 +316,11 @@ int sg_sort_pairs_u64_u32(sg_ctx *ctx, const uint64_t *d_keys, const uint32_t *d
 int sg_sort_unique_u64(sg_ctx *ctx, uint64_t *d_keys, int64_t n, uint64_t *d_unique, int32_t *d_counts, int64_t *n_unique);
 
 // exclusive prefix sum of n uint32 values (in place allowed); total written to *d_total if non-null
+// several arrays cleared by ONE launch (bytes and pointers multiples of four)
+int sg_zero_ranges(sg_ctx *ctx, int n, void *const *ptrs, const size_t *bytes);
+#define SG_ZERO2(ctx, p0, b0, p1, b1) [&]() { void *const pp_[] = {(void *)(p0), (void *)(p1)}; const size_t bb_[] = {(size_t)(b0), (size_t)(b1)}; return sg_zero_ranges(ctx, 2, pp_, bb_); }()
+#define SG_ZERO3(ctx, p0, b0, p1, b1, p2, b2) [&]() { void *const pp_[] = {(void *)(p0), (void *)(p1), (void *)(p2)}; const size_t bb_[] = {(size_t)(b0), (size_t)(b1), (size_t)(b2)}; return sg_zero_ranges(ctx, 3, pp_, bb_); }()
+#define SG_ZERO4(ctx, p0, b0, p1, b1, p2, b2, p3, b3) [&]() { void *const pp_[] = {(void *)(p0), (void *)(p1), (void *)(p2), (void *)(p3)}; const size_t bb_[] = {(size_t)(b0), (size_t)(b1), (size_t)(b2), (size_t)(b3)}; return sg_zero_ranges(ctx, 4, pp_, bb_); }()
 int sg_exclusive_scan_u32(sg_ctx *ctx, const uint32_t *d_in, uint32_t *d_out, int64_t n, uint32_t *d_total);
 // same for int64 outputs from int32 inputs (row pointers)
 int sg_exclusive_scan_i32_to_i64(sg_ctx *ctx, const int32_t *d_in, int64_t *d_out, int64_t n);

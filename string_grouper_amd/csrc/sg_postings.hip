@@ -125,11 +125,24 @@ __global__ void __launch_bounds__(256) postings_fill(const int64_t *__restrict__
 // 256 CUs; a segment (k, t) is then the parts' sub-segments back to back, which the multiply never notices since the
 // order inside a segment is free.  Sixteen lanes walk one row (the loads of a row are contiguous across lanes; a thread
 // per row steps 64 rows with one cache line each), LDS atomics take the place of 2 x nnz global ones.
-// Counter layout while building: bin (k, t, part) at (k * n_tiles + t) * split + part.
+//
+// Round 4: the counters live in a table that is WORKGROUP-major while the index is built -- cnt[w * n_terms + k], w =
+// tile * split + part -- so that a workgroup writes its histogram and reads its cursors as ONE contiguous run of
+// n_terms words.  (Rounds 2-3 kept it term-major, (k * n_tiles + t) * split + part: every workgroup then gathered its
+// 18 300 cursors from 18 300 different cache lines, and so did the histogram's write-back.)  The offsets come in two
+// steps: postings_colscan_kernel turns every term's column of counts into running sums over w (the term's entries in
+// earlier parts) and its total, one small scan over the totals gives the terms' starts, and a cursor is the sum of
+// the two.  postings_tables_kernel then writes what the multiply reads -- the term-major segment table and the two
+// padded tables of segment ends -- transposed through LDS.
+// Both passes walk FOUR rows per sixteen lanes and trip with all their loads issued before the first is used: a
+// workgroup's trips are serial (32 of them for a part of 2048 rows) and a trip is a chain of dependent round trips --
+// row pointers, entries, LDS, store -- so that the build ran at the latency of its loads, not at any bandwidth
+// (profiles/r04_s1_kernel_stats_baseline.csv: 0.31 ms for 100 MB).
+#define SG_POST_ROWS 4    // rows per sixteen lanes and trip
 __global__ void __launch_bounds__(1024) postings_count_lds(const int64_t *__restrict__ indptr,
                                                            const int32_t *__restrict__ indices, int64_t n_rows,
-                                                           int32_t tile_log2, int32_t n_tiles, int32_t n_terms, int32_t split,
-                                                           uint32_t *seg_counts) {
+                                                           int32_t tile_log2, int32_t n_terms, int32_t split,
+                                                           uint32_t *__restrict__ cnt /* [wgs][n_terms] */) {
     extern __shared__ uint32_t hist[];
     const int64_t t = blockIdx.x / split;
     const int32_t part = blockIdx.x % split;
@@ -140,36 +153,118 @@ __global__ void __launch_bounds__(1024) postings_count_lds(const int64_t *__rest
     int64_t j1 = j0 + part_rows;
     if (j1 > n_rows) j1 = n_rows;
     const int sub = threadIdx.x & 15;
-    for (int64_t j = j0 + (threadIdx.x >> 4); j < j1; j += blockDim.x >> 4)
-        for (int64_t p = indptr[j] + sub; p < indptr[j + 1]; p += 16) atomicAdd(&hist[indices[p]], 1u);
+    const int64_t groups = blockDim.x >> 4;
+    for (int64_t jb = j0 + (threadIdx.x >> 4) * SG_POST_ROWS; jb < j1; jb += groups * SG_POST_ROWS) {
+        int64_t lo[SG_POST_ROWS], hi[SG_POST_ROWS];
+#pragma unroll
+        for (int r = 0; r < SG_POST_ROWS; ++r) {
+            const bool valid = jb + r < j1;
+            lo[r] = valid ? indptr[jb + r] : 0;
+            hi[r] = valid ? indptr[jb + r + 1] : 0;
+        }
+        int32_t k0[SG_POST_ROWS];
+#pragma unroll
+        for (int r = 0; r < SG_POST_ROWS; ++r) k0[r] = lo[r] + sub < hi[r] ? indices[lo[r] + sub] : -1;
+#pragma unroll
+        for (int r = 0; r < SG_POST_ROWS; ++r) {
+            if (k0[r] >= 0) atomicAdd(&hist[k0[r]], 1u);
+            for (int64_t p = lo[r] + sub + 16; p < hi[r]; p += 16) atomicAdd(&hist[indices[p]], 1u);   // rows beyond 16 entries
+        }
+    }
     __syncthreads();
-    for (int k = threadIdx.x; k < n_terms; k += blockDim.x)
-        seg_counts[((int64_t)k * n_tiles + t) * split + part] = hist[k];
+    uint32_t *mine = cnt + (int64_t)blockIdx.x * n_terms;
+    for (int k = threadIdx.x; k < n_terms; k += blockDim.x) mine[k] = hist[k];
 }
 
-// is_frequent[k] = term k's list holds >= freq_min entries; seg[i] = start of bin i without the parts
-__global__ void __launch_bounds__(256) frequent_terms_kernel(const uint32_t *__restrict__ segp, int64_t n_terms, int64_t row_stride,
-                                                             uint32_t freq_min, uint8_t *__restrict__ is_frequent) {
-    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (k < n_terms) is_frequent[k] = segp[(k + 1) * row_stride] - segp[k * row_stride] >= freq_min ? 1 : 0;
+// Per term: counts of the workgroups -> entries of the term in EARLIER workgroups (in place), the term's total, and
+// whether it is frequent.  A workgroup takes 64 terms x all workgroups of the build: 16 threads per term, each a run of
+// consecutive w, the runs joined through LDS; loads and stores are contiguous across the 64 terms.
+__global__ void __launch_bounds__(1024) postings_colscan_kernel(uint32_t *__restrict__ cnt, int32_t n_wgs, int32_t n_terms,
+                                                                uint32_t freq_min, uint32_t *__restrict__ term_len,
+                                                                uint8_t *__restrict__ is_frequent) {
+    __shared__ uint32_t part_sum[16][64];
+    const int kk = threadIdx.x & 63, c = threadIdx.x >> 6;
+    const int64_t k = (int64_t)blockIdx.x * 64 + kk;
+    const int32_t run = (n_wgs + 15) / 16;
+    const int32_t w0 = c * run, w1 = min(w0 + run, n_wgs);
+    uint32_t s = 0;
+    if (k < n_terms)
+        for (int32_t w = w0; w < w1; ++w) s += cnt[(int64_t)w * n_terms + k];
+    part_sum[c][kk] = s;
+    __syncthreads();
+    uint32_t before = 0, total = 0;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const uint32_t v = part_sum[q][kk];
+        before += q < c ? v : 0u;
+        total += v;
+    }
+    if (k < n_terms) {
+        for (int32_t w = w0; w < w1; ++w) {
+            const uint32_t v = cnt[(int64_t)w * n_terms + k];
+            cnt[(int64_t)w * n_terms + k] = before;
+            before += v;
+        }
+        if (c == 0) {
+            term_len[k] = total;
+            if (is_frequent) is_frequent[k] = total >= freq_min ? 1 : 0;
+        }
+    }
 }
-__global__ void __launch_bounds__(256) term_len_kernel(const uint32_t *__restrict__ seg, int64_t n_terms, int32_t n_tiles,
-                                                       uint32_t *__restrict__ term_len) {
-    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (k < n_terms) term_len[k] = seg[(k + 1) * n_tiles] - seg[k * n_tiles];
-}
-__global__ void __launch_bounds__(256) unsplit_seg_kernel(const uint32_t *__restrict__ segp, int64_t n_bins, int32_t split,
-                                                          uint32_t *__restrict__ seg) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i <= n_bins) seg[i] = segp[i * split];
+
+// What the multiply reads, from the build's tables: S(k, t) = term_start[k] + cnt[(t * split) * n_terms + k] is the start
+// of term k's postings in tile t, S(k, n_tiles) = term_start[k + 1];
+//   seg[k * n_tiles + t] = S(k, t)                                   (+ seg[n_terms * n_tiles] = all postings)
+//   ends[k * nt_pad + t] = S(k, min(t, n_tiles - 1) + 1) << 2        byte offsets into the filter postings, rows padded to
+//                                                                    a multiple of four tiles; row n_terms: zeros (the
+//                                                                    segments of a lane without a term)
+//   ends8[k * nv_pad + v] = S(k, min((v + 1) << fold_log2, n_tiles)) << 2   the same for super-tiles (stream form)
+// A workgroup takes 64 terms and walks the tiles 64 at a time: read with the lanes along the terms (the table is
+// workgroup-major), written with the lanes along the tiles (the multiply's tables are term-major), through LDS.
+__global__ void __launch_bounds__(1024) postings_tables_kernel(const uint32_t *__restrict__ cnt, const uint32_t *__restrict__ term_start,
+                                                               int32_t n_terms, int32_t n_tiles, int32_t split,
+                                                               uint32_t *__restrict__ seg, uint32_t *__restrict__ ends, int32_t nt_pad,
+                                                               uint32_t *__restrict__ ends8, int32_t nv_pad, int32_t fold_log2) {
+    __shared__ uint32_t tile[64][66];
+    const int x = threadIdx.x & 63, y = threadIdx.x >> 6;   // y: 0 .. 15
+    const int64_t k0 = (int64_t)blockIdx.x * 64;
+    auto S = [&](int64_t k, int64_t t) -> uint32_t {        // k <= n_terms, t <= n_tiles
+        if (k >= n_terms) return term_start[n_terms];
+        return t >= n_tiles ? term_start[k + 1] : term_start[k] + cnt[(t * split) * (int64_t)n_terms + k];
+    };
+    const int64_t t_lim = nt_pad > n_tiles ? nt_pad : n_tiles;
+    for (int64_t tb = 0; tb < t_lim; tb += 64) {
+        // columns tb .. tb + 64 (one more than is written: an end is the next tile's start)
+        for (int tt = y; tt < 65; tt += 16) {
+            const int64_t k = k0 + x;
+            tile[x][tt] = k <= n_terms ? S(k, min(tb + tt, (int64_t)n_tiles)) : 0u;
+        }
+        __syncthreads();
+        for (int kq = y; kq < 64; kq += 16) {
+            const int64_t k = k0 + kq, t = tb + x;
+            if (k < n_terms && t < n_tiles) seg[k * n_tiles + t] = tile[kq][x];
+            if (k == n_terms && t == 0) seg[k * n_tiles] = tile[kq][0];                    // the table's last entry: all postings
+            if (ends && k <= n_terms && t < nt_pad)
+                ends[k * nt_pad + t] = k == n_terms ? 0u : tile[kq][min(t, (int64_t)n_tiles - 1) + 1 - tb] << 2;
+        }
+        __syncthreads();
+    }
+    if (ends8) {
+        for (int64_t i = threadIdx.x; i < (int64_t)64 * nv_pad; i += blockDim.x) {
+            const int64_t k = k0 + (i & 63), v = i >> 6;
+            if (k > n_terms) continue;
+            ends8[k * nv_pad + v] = k == n_terms ? 0u : S(k, min((v + 1) << fold_log2, (int64_t)n_tiles)) << 2;
+        }
+    }
 }
 
 template <typename T>
 __global__ void __launch_bounds__(1024) postings_fill_lds(const int64_t *__restrict__ indptr,
                                                           const int32_t *__restrict__ indices,
                                                           const T *__restrict__ data, int64_t n_rows, int32_t tile_log2,
-                                                          int32_t n_tiles, int32_t n_terms, int32_t split,
-                                                          const uint32_t *__restrict__ segp,
+                                                          int32_t n_terms, int32_t split,
+                                                          const uint32_t *__restrict__ cnt /* [wgs][n_terms]: entries in earlier workgroups */,
+                                                          const uint32_t *__restrict__ term_start,
                                                           const uint8_t *__restrict__ is_frequent, int32_t *out_rows,
                                                           T *out_vals, uint32_t *out_filt, float inv_norm_up, int32_t fold_log2) {
     extern __shared__ uint32_t cursor[];   // next free slot of (term k, this tile, this part); then the frequent-term bits
@@ -177,7 +272,8 @@ __global__ void __launch_bounds__(1024) postings_fill_lds(const int64_t *__restr
     const int64_t t = blockIdx.x / split;
     const int32_t part = blockIdx.x % split;
     for (int k = threadIdx.x; k < (n_terms + 31) / 32; k += blockDim.x) freq_bits[k] = 0;
-    for (int k = threadIdx.x; k < n_terms; k += blockDim.x) cursor[k] = segp[((int64_t)k * n_tiles + t) * split + part];
+    const uint32_t *mine = cnt + (int64_t)blockIdx.x * n_terms;
+    for (int k = threadIdx.x; k < n_terms; k += blockDim.x) cursor[k] = term_start[k] + mine[k];
     __syncthreads();
     if (out_filt)
         for (int k = threadIdx.x; k < n_terms; k += blockDim.x)
@@ -188,36 +284,71 @@ __global__ void __launch_bounds__(1024) postings_fill_lds(const int64_t *__restr
     int64_t j1 = j0 + part_rows;
     if (j1 > n_rows) j1 = n_rows;
     const int lane = threadIdx.x & 63, sub = lane & 15;
+    (void)lane;
+    const int64_t groups = blockDim.x >> 4;
     // every wave makes the same number of trips, so that the cross-lane sums below always run with all lanes
-    const int64_t trips = (j1 - j0 + (blockDim.x >> 4) - 1) / (blockDim.x >> 4);
+    const int64_t trips = (j1 - j0 + groups * SG_POST_ROWS - 1) / (groups * SG_POST_ROWS);
     for (int64_t it = 0; it < trips; ++it) {
-        const int64_t j = j0 + it * (blockDim.x >> 4) + (threadIdx.x >> 4);
-        const bool valid = j < j1;
-        const int64_t lo = valid ? indptr[j] : 0, hi = valid ? indptr[j + 1] : 0;
-        uint32_t fq = 0;
-        if (out_filt) {
-            // norm of the row's frequent part, quantised upwards to 8 bits relative to norm_up (the order of the additions
-            // is free: the result is rounded up with a margin far above the rounding of a double sum)
-            double f2 = 0.0;
-            for (int64_t p = lo + sub; p < hi; p += 16) {
-                const int32_t k = indices[p];
-                if ((freq_bits[k >> 5] >> (k & 31)) & 1u) f2 += (double)data[p] * (double)data[p];
-            }
+        const int64_t jb = j0 + (it * groups + (threadIdx.x >> 4)) * SG_POST_ROWS;
+        int64_t lo[SG_POST_ROWS], hi[SG_POST_ROWS];
 #pragma unroll
-            for (int d = 8; d > 0; d >>= 1) {
-                const uint64_t bits = (uint64_t)__double_as_longlong(f2);
-                const uint32_t l = (uint32_t)__shfl_xor((int)(uint32_t)bits, d, 64), h = (uint32_t)__shfl_xor((int)(uint32_t)(bits >> 32), d, 64);
-                f2 += __longlong_as_double((long long)(((uint64_t)h << 32) | l));
-            }
-            fq = (uint32_t)ceilf(__double2float_ru(sqrt(f2) * (1.0 + 1e-12)) * inv_norm_up * 255.0f * 1.000002f);
-            if (fq > 255u) fq = 255u;
+        for (int r = 0; r < SG_POST_ROWS; ++r) {
+            const bool valid = jb + r < j1;
+            lo[r] = valid ? indptr[jb + r] : 0;
+            hi[r] = valid ? indptr[jb + r + 1] : 0;
         }
-        const uint32_t col = (uint32_t)(j - (t << tile_log2));
-        for (int64_t p = lo + sub; p < hi; p += 16) {
-            const uint32_t pos = atomicAdd(&cursor[indices[p]], 1u);
-            emit_posting<T>(out_rows, out_vals, out_filt, pos, col, data[p], fq, tile_log2, inv_norm_up, (uint32_t)t, fold_log2);
+        // the lane's first entry of every row: all loads before the first use (rows of up to sixteen entries are through
+        // with these; the rest of a longer row goes entry by entry below)
+        int32_t k0[SG_POST_ROWS];
+        T v0[SG_POST_ROWS];
+#pragma unroll
+        for (int r = 0; r < SG_POST_ROWS; ++r) {
+            const bool have = lo[r] + sub < hi[r];
+            k0[r] = have ? indices[lo[r] + sub] : -1;
+            v0[r] = have ? data[lo[r] + sub] : (T)0;
+        }
+        uint32_t fq[SG_POST_ROWS];
+#pragma unroll
+        for (int r = 0; r < SG_POST_ROWS; ++r) {
+            fq[r] = 0;
+            if (out_filt) {
+                // norm of the row's frequent part, quantised upwards to 8 bits relative to norm_up (the order of the additions
+                // is free: the result is rounded up with a margin far above the rounding of a double sum)
+                double f2 = 0.0;
+                if (k0[r] >= 0 && ((freq_bits[k0[r] >> 5] >> (k0[r] & 31)) & 1u)) f2 = (double)v0[r] * (double)v0[r];
+                for (int64_t p = lo[r] + sub + 16; p < hi[r]; p += 16) {
+                    const int32_t k = indices[p];
+                    if ((freq_bits[k >> 5] >> (k & 31)) & 1u) f2 += (double)data[p] * (double)data[p];
+                }
+#pragma unroll
+                for (int d = 8; d > 0; d >>= 1) {
+                    const uint64_t bits = (uint64_t)__double_as_longlong(f2);
+                    const uint32_t l = (uint32_t)__shfl_xor((int)(uint32_t)bits, d, 64), h = (uint32_t)__shfl_xor((int)(uint32_t)(bits >> 32), d, 64);
+                    f2 += __longlong_as_double((long long)(((uint64_t)h << 32) | l));
+                }
+                fq[r] = (uint32_t)ceilf(__double2float_ru(sqrt(f2) * (1.0 + 1e-12)) * inv_norm_up * 255.0f * 1.000002f);
+                if (fq[r] > 255u) fq[r] = 255u;
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < SG_POST_ROWS; ++r) {
+            const uint32_t col = (uint32_t)(jb + r - (t << tile_log2));
+            if (k0[r] >= 0) {
+                const uint32_t pos = atomicAdd(&cursor[k0[r]], 1u);
+                emit_posting<T>(out_rows, out_vals, out_filt, pos, col, v0[r], fq[r], tile_log2, inv_norm_up, (uint32_t)t, fold_log2);
+            }
+            for (int64_t p = lo[r] + sub + 16; p < hi[r]; p += 16) {
+                const uint32_t pos = atomicAdd(&cursor[indices[p]], 1u);
+                emit_posting<T>(out_rows, out_vals, out_filt, pos, col, data[p], fq[r], tile_log2, inv_norm_up, (uint32_t)t, fold_log2);
+            }
         }
     }
+}
+
+__global__ void __launch_bounds__(256) term_len_kernel(const uint32_t *__restrict__ seg, int64_t n_terms, int32_t n_tiles,
+                                                       uint32_t *__restrict__ term_len) {
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < n_terms) term_len[k] = seg[(k + 1) * n_tiles] - seg[k * n_tiles];
 }
 
 // Packed copy of B's rows for the pruned multiply (one 16-byte load = two f32 entries or one f64 entry): a thread per
@@ -288,36 +419,21 @@ __global__ void __launch_bounds__(256) row_blocks_kernel(const int64_t *__restri
     reinterpret_cast<uint4 *>(reinterpret_cast<char *>(blk) + (size_t)p * blk_bytes)[c] = w;
 }
 
-// segment ends of every term as byte offsets into the filter postings, rows padded to a multiple of four tiles
-__global__ void __launch_bounds__(256) pack_ends_kernel(const uint32_t *__restrict__ seg, int64_t n_terms, int32_t n_tiles,
-                                                        int32_t nt_pad, uint32_t *__restrict__ ends) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (n_terms + 1) * nt_pad) return;
-    const int64_t k = i / nt_pad;
-    if (k == n_terms) {   // one more row, all zero: the segments of a lane without a term (always empty)
-        ends[i] = 0;
-        return;
-    }
-    int32_t t = (int32_t)(i - k * nt_pad);
-    if (t >= n_tiles) t = n_tiles - 1;
-    ends[i] = seg[k * n_tiles + t + 1] << 2;
-}
-
-// Stream form: the same for SUPER-TILES of 2^fold_log2 tiles (one visit of the stream form): ends8[k * nv_pad + v] = byte
-// offset of the end of term k's postings in tiles [0, (v + 1) << fold_log2); entries past the last super-tile repeat the
-// end of the list; one more all-zero row for lanes without a term.
-__global__ void __launch_bounds__(256) pack_super_ends_kernel(const uint32_t *__restrict__ seg, int64_t n_terms, int32_t n_tiles,
-                                                              int32_t fold_log2, int32_t nv_pad, uint32_t *__restrict__ ends8) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (n_terms + 1) * nv_pad) return;
-    const int64_t k = i / nv_pad;
-    if (k == n_terms) {
-        ends8[i] = 0;
-        return;
-    }
-    int64_t t = ((i - k * nv_pad + 1) << fold_log2);   // first tile past super-tile v
-    if (t > n_tiles) t = n_tiles;
-    ends8[i] = seg[k * n_tiles + t] << 2;
+// (path with global counters) the two padded tables of segment ends from the term-major segment table: a thread per term
+__global__ void __launch_bounds__(256) ends_from_seg_kernel(const uint32_t *__restrict__ seg, int64_t n_terms, int32_t n_tiles,
+                                                            uint32_t *__restrict__ ends, int32_t nt_pad, uint32_t *__restrict__ ends8,
+                                                            int32_t nv_pad, int32_t fold_log2) {
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k > n_terms) return;
+    if (ends)
+        for (int32_t t = 0; t < nt_pad; ++t)
+            ends[k * nt_pad + t] = k == n_terms ? 0u : seg[k * n_tiles + (t < n_tiles ? t : n_tiles - 1) + 1] << 2;
+    if (ends8)
+        for (int32_t v = 0; v < nv_pad; ++v) {
+            int64_t t = (int64_t)(v + 1) << fold_log2;   // first tile past super-tile v
+            if (t > n_tiles) t = n_tiles;
+            ends8[k * nv_pad + v] = k == n_terms ? 0u : seg[k * n_tiles + t] << 2;
+        }
 }
 
 __global__ void __launch_bounds__(256) null_postings_kernel(uint32_t *__restrict__ slack) {
@@ -623,6 +739,7 @@ extern "C" int sg_postings_build_flags(sg_ctx *ctx, const sg_csr *B_in, int32_t 
         bool in_lds = B->n_rows > 0 && lds <= 124 * 1024 && B->n_cols > 0;
         if (const char *e = ctx->opt("SG_POSTINGS_LDS")) in_lds = in_lds && e[0] != '0';
         const float inv_norm = p->d_filt ? 1.0f / p->norm_up : 0.f;
+        bool tables_done = false;
         if (in_lds) {
             static bool attr_done = false;
             if (!attr_done) {
@@ -641,37 +758,41 @@ extern "C" int sg_postings_build_flags(sg_ctx *ctx, const sg_csr *B_in, int32_t 
                 if ((o == 1 || o == 2 || o == 4) && tile_cols / o >= 64 && n_bins * o + 1 < ((int64_t)1 << 31)) split = o;
             }
             p->split = split;
-            uint32_t *segp = p->d_seg;          // counters with the parts; the table itself when split == 1
+            const int64_t wgs64 = (int64_t)p->n_tiles * split;
+            uint32_t *cnt = nullptr;            // [workgroup][term] (see postings_count_lds)
             uint8_t *is_frequent = nullptr;
-            if (split > 1) st = sg_alloc(ctx, (size_t)(n_bins * split) + 1, &segp);
-            if (st == SG_OK) st = sg_alloc(ctx, (size_t)B->n_cols + 1, &is_frequent);
+            st = sg_alloc(ctx, (size_t)(wgs64 * B->n_cols) + 1, &cnt);
+            if (st == SG_OK) st = sg_alloc(ctx, (size_t)B->n_cols + 4, &is_frequent);
+            if (st == SG_OK) st = sg_alloc(ctx, (size_t)B->n_cols + 2, &p->d_term_start);
             if (st == SG_OK) {
-                const unsigned wgs = (unsigned)(p->n_tiles * split);
+                const unsigned wgs = (unsigned)wgs64;
+                const unsigned strips = (unsigned)((B->n_cols + 63) / 64), strips1 = (unsigned)((B->n_cols + 64) / 64);
                 hipLaunchKernelGGL(postings_count_lds, dim3(wgs), dim3(1024), (size_t)B->n_cols * 4, ctx->stream, B->d_indptr,
-                                   B->d_indices, B->n_rows, tile_log2, p->n_tiles, (int32_t)B->n_cols, split, segp);
-                // counts -> offsets, in place; the last entry receives the total (= nnz)
-                st = sg_exclusive_scan_u32(ctx, segp, segp, n_bins * split, segp + n_bins * split);
+                                   B->d_indices, B->n_rows, tile_log2, (int32_t)B->n_cols, split, cnt);
+                hipLaunchKernelGGL(postings_colscan_kernel, dim3(strips), dim3(1024), 0, ctx->stream, cnt, (int32_t)wgs64,
+                                   (int32_t)B->n_cols, p->freq_min, p->d_term_len, is_frequent);
+                // the terms' lists back to back: starts of the lists, the last entry receives the total (= nnz)
+                st = sg_exclusive_scan_u32(ctx, p->d_term_len, p->d_term_start, B->n_cols, p->d_term_start + B->n_cols);
                 if (st == SG_OK) {
-                    hipLaunchKernelGGL(frequent_terms_kernel, dim3((unsigned)((B->n_cols + 255) / 256)), dim3(256), 0, ctx->stream,
-                                       (const uint32_t *)segp, B->n_cols, (int64_t)p->n_tiles * split, p->freq_min, is_frequent);
                     if (B->dtype == SG_F64)
                         hipLaunchKernelGGL(postings_fill_lds<double>, dim3(wgs), dim3(1024), lds, ctx->stream, B->d_indptr,
-                                           B->d_indices, (const double *)B->d_data, B->n_rows, tile_log2, p->n_tiles,
-                                           (int32_t)B->n_cols, split, (const uint32_t *)segp, (const uint8_t *)is_frequent,
+                                           B->d_indices, (const double *)B->d_data, B->n_rows, tile_log2, (int32_t)B->n_cols, split,
+                                           (const uint32_t *)cnt, (const uint32_t *)p->d_term_start, (const uint8_t *)is_frequent,
                                            p->d_rows, (double *)p->d_vals, p->d_filt, inv_norm, p->fold_log2);
                     else
                         hipLaunchKernelGGL(postings_fill_lds<float>, dim3(wgs), dim3(1024), lds, ctx->stream, B->d_indptr,
-                                           B->d_indices, (const float *)B->d_data, B->n_rows, tile_log2, p->n_tiles,
-                                           (int32_t)B->n_cols, split, (const uint32_t *)segp, (const uint8_t *)is_frequent,
+                                           B->d_indices, (const float *)B->d_data, B->n_rows, tile_log2, (int32_t)B->n_cols, split,
+                                           (const uint32_t *)cnt, (const uint32_t *)p->d_term_start, (const uint8_t *)is_frequent,
                                            p->d_rows, (float *)p->d_vals, p->d_filt, inv_norm, p->fold_log2);
-                    if (split > 1)
-                        hipLaunchKernelGGL(unsplit_seg_kernel, dim3((unsigned)((n_bins + 256) / 256)), dim3(256), 0, ctx->stream,
-                                           (const uint32_t *)segp, n_bins, split, p->d_seg);
+                    hipLaunchKernelGGL(postings_tables_kernel, dim3(strips1), dim3(1024), 0, ctx->stream, (const uint32_t *)cnt,
+                                       (const uint32_t *)p->d_term_start, (int32_t)B->n_cols, p->n_tiles, split, p->d_seg, p->d_ends,
+                                       p->nt_pad, p->d_ends8, p->nv_pad, p->fold_log2);
                     if (hipGetLastError() != hipSuccess) st = SG_ERR_HIP;
                 }
             }
-            if (split > 1) ctx->release(segp);
+            ctx->release(cnt);
             ctx->release(is_frequent);
+            tables_done = true;
         } else {
             uint32_t *cursor = nullptr;
             st = sg_alloc(ctx, (size_t)n_bins + 1, &cursor);
@@ -703,19 +824,14 @@ extern "C" int sg_postings_build_flags(sg_ctx *ctx, const sg_csr *B_in, int32_t 
             }
             ctx->release(cursor);
         }
-        if (st == SG_OK && B->n_cols > 0)
+        if (st == SG_OK && !tables_done && B->n_cols > 0) {
+            // (the path with global counters builds the term-major table itself; lists and ends are read off it)
             hipLaunchKernelGGL(term_len_kernel, dim3((unsigned)((B->n_cols + 255) / 256)), dim3(256), 0, ctx->stream,
                                (const uint32_t *)p->d_seg, B->n_cols, p->n_tiles, p->d_term_len);
-        if (st == SG_OK && p->d_ends && B->n_cols > 0) {
-            const int64_t cells = (B->n_cols + 1) * (int64_t)p->nt_pad;
-            hipLaunchKernelGGL(pack_ends_kernel, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, ctx->stream,
-                               (const uint32_t *)p->d_seg, B->n_cols, p->n_tiles, p->nt_pad, p->d_ends);
-            if (hipGetLastError() != hipSuccess) st = SG_ERR_HIP;
-        }
-        if (st == SG_OK && p->d_ends8 && B->n_cols > 0) {
-            const int64_t cells = (B->n_cols + 1) * (int64_t)p->nv_pad;
-            hipLaunchKernelGGL(pack_super_ends_kernel, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, ctx->stream,
-                               (const uint32_t *)p->d_seg, B->n_cols, p->n_tiles, p->fold_log2, p->nv_pad, p->d_ends8);
+            if (p->d_ends || p->d_ends8)
+                hipLaunchKernelGGL(ends_from_seg_kernel, dim3((unsigned)((B->n_cols + 256) / 256)), dim3(256), 0, ctx->stream,
+                                   (const uint32_t *)p->d_seg, B->n_cols, p->n_tiles, p->d_ends, p->nt_pad, p->d_ends8, p->nv_pad,
+                                   p->fold_log2);
             if (hipGetLastError() != hipSuccess) st = SG_ERR_HIP;
         }
         if (st == SG_OK && p->d_fwd) {   // (packed rows in use: no row blocks)
@@ -778,29 +894,36 @@ int sg_postings_ensure_full(sg_ctx *ctx, const sg_postings *cp) {
     int st = SG_OK;
     if (B->dtype == SG_F64) st = sg_alloc(ctx, (size_t)B->nnz + 64, &p->d_rows);
     if (st == SG_OK) st = ctx->alloc(((size_t)B->nnz + 64) * 8, &p->d_vals);
-    uint32_t *segp = nullptr;
-    if (st == SG_OK) st = sg_alloc(ctx, (size_t)(n_bins * split) + 1, &segp);
+    uint32_t *cnt = nullptr, *len_scratch = nullptr;
+    const int64_t wgs64 = (int64_t)p->n_tiles * split;
+    (void)n_bins;
+    if (st == SG_OK && !p->d_term_start) {
+        sg_set_error("postings were built without the LDS path: nothing is lazy there");
+        st = SG_ERR_BADARG;
+    }
+    if (st == SG_OK) st = sg_alloc(ctx, (size_t)(wgs64 * B->n_cols) + 1, &cnt);
+    if (st == SG_OK) st = sg_alloc(ctx, (size_t)B->n_cols + 2, &len_scratch);
     if (st == SG_OK) {
-        const unsigned wgs = (unsigned)(p->n_tiles * split);
+        const unsigned wgs = (unsigned)wgs64;
         const size_t lds = (size_t)B->n_cols * 4 + ((size_t)(B->n_cols + 31) / 32) * 4;
         hipLaunchKernelGGL(postings_count_lds, dim3(wgs), dim3(1024), (size_t)B->n_cols * 4, ctx->stream, B->d_indptr, B->d_indices,
-                           B->n_rows, p->tile_log2, p->n_tiles, (int32_t)B->n_cols, split, segp);
-        st = sg_exclusive_scan_u32(ctx, segp, segp, n_bins * split, segp + n_bins * split);
-        if (st == SG_OK) {
-            if (B->dtype == SG_F64)
-                hipLaunchKernelGGL(postings_fill_lds<double>, dim3(wgs), dim3(1024), lds, ctx->stream, B->d_indptr, B->d_indices,
-                                   (const double *)B->d_data, B->n_rows, p->tile_log2, p->n_tiles, (int32_t)B->n_cols, split,
-                                   (const uint32_t *)segp, (const uint8_t *)nullptr, p->d_rows, (double *)p->d_vals,
-                                   (uint32_t *)nullptr, 0.f, 0);
-            else
-                hipLaunchKernelGGL(postings_fill_lds<float>, dim3(wgs), dim3(1024), lds, ctx->stream, B->d_indptr, B->d_indices,
-                                   (const float *)B->d_data, B->n_rows, p->tile_log2, p->n_tiles, (int32_t)B->n_cols, split,
-                                   (const uint32_t *)segp, (const uint8_t *)nullptr, p->d_rows, (float *)p->d_vals,
-                                   (uint32_t *)nullptr, 0.f, 0);
-            if (hipGetLastError() != hipSuccess) st = SG_ERR_HIP;
-        }
+                           B->n_rows, p->tile_log2, (int32_t)B->n_cols, split, cnt);
+        hipLaunchKernelGGL(postings_colscan_kernel, dim3((unsigned)((B->n_cols + 63) / 64)), dim3(1024), 0, ctx->stream, cnt,
+                           (int32_t)wgs64, (int32_t)B->n_cols, 0u, len_scratch, (uint8_t *)nullptr);
+        if (B->dtype == SG_F64)
+            hipLaunchKernelGGL(postings_fill_lds<double>, dim3(wgs), dim3(1024), lds, ctx->stream, B->d_indptr, B->d_indices,
+                               (const double *)B->d_data, B->n_rows, p->tile_log2, (int32_t)B->n_cols, split, (const uint32_t *)cnt,
+                               (const uint32_t *)p->d_term_start, (const uint8_t *)nullptr, p->d_rows, (double *)p->d_vals,
+                               (uint32_t *)nullptr, 0.f, 0);
+        else
+            hipLaunchKernelGGL(postings_fill_lds<float>, dim3(wgs), dim3(1024), lds, ctx->stream, B->d_indptr, B->d_indices,
+                               (const float *)B->d_data, B->n_rows, p->tile_log2, (int32_t)B->n_cols, split, (const uint32_t *)cnt,
+                               (const uint32_t *)p->d_term_start, (const uint8_t *)nullptr, p->d_rows, (float *)p->d_vals,
+                               (uint32_t *)nullptr, 0.f, 0);
+        if (hipGetLastError() != hipSuccess) st = SG_ERR_HIP;
     }
-    ctx->release(segp);
+    ctx->release(cnt);
+    ctx->release(len_scratch);
     if (st != SG_OK) {
         ctx->release(p->d_vals);
         ctx->release(p->d_rows);
@@ -814,6 +937,7 @@ extern "C" int sg_postings_free(sg_postings *p) {
     if (!p) return SG_OK;
     p->ctx->release(p->d_seg);
     p->ctx->release(p->d_term_len);
+    p->ctx->release(p->d_term_start);
     p->ctx->release(p->d_rows);
     p->ctx->release(p->d_vals);
     p->ctx->release(p->d_fwd);

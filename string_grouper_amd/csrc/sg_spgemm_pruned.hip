@@ -1674,11 +1674,8 @@ int sg_spgemm_pruned_symmetric(sg_ctx *ctx, const sg_csr *A, const sg_postings *
     st = sg_alloc(ctx, (size_t)4, &d_stats3);
     hipError_t e = hipSuccess;
     if (st == SG_OK) {
-        e = hipMemsetAsync(words, 0, (128 + (size_t)pl.chunks) * sizeof(uint32_t), ctx->stream);
-        if (e == hipSuccess) e = hipMemsetAsync(d_stats3, 0, 4 * sizeof(unsigned long long), ctx->stream);
-        if (e == hipSuccess) e = hipMemsetAsync(cnt, 0, sizeof(uint32_t) * (size_t)(n + 2), ctx->stream);
-        if (e == hipSuccess) e = hipMemsetAsync(cursor, 0, sizeof(uint32_t) * (size_t)(n + 2), ctx->stream);
-        if (e != hipSuccess) st = SG_ERR_HIP;
+        st = SG_ZERO4(ctx, words, (128 + (size_t)pl.chunks) * sizeof(uint32_t), d_stats3, 4 * sizeof(unsigned long long), cnt,
+                      sizeof(uint32_t) * (size_t)(n + 2), cursor, sizeof(uint32_t) * (size_t)(n + 2));   // (one launch, not four)
     }
     const float s_budget = prune_budget(Bt, threshold, delta);
     SgPairSink sink;
@@ -1817,9 +1814,7 @@ int sg_selfjoin_merge_pairs(sg_ctx *ctx, sg_topn *r, const int32_t *d_pairs, int
     if (st == SG_OK) st = sg_alloc(ctx, (size_t)n_pairs + 64, &lcol);
     if (st == SG_OK) st = ctx->alloc(((size_t)n_pairs + 64) * vs, &lval);
     if (st == SG_OK) {
-        if (hipMemsetAsync(cnt, 0, sizeof(uint32_t) * (size_t)(n + 2), ctx->stream) != hipSuccess ||
-            hipMemsetAsync(cursor, 0, sizeof(uint32_t) * (size_t)(n + 2), ctx->stream) != hipSuccess)
-            st = SG_ERR_HIP;
+        st = SG_ZERO2(ctx, cnt, sizeof(uint32_t) * (size_t)(n + 2), cursor, sizeof(uint32_t) * (size_t)(n + 2));
     }
     if (st == SG_OK) {
         const unsigned pg = (unsigned)((n_pairs + 255) / 256);

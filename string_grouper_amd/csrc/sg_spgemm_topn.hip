@@ -919,10 +919,8 @@ extern "C" int sg_spgemm_topn(sg_ctx *ctx, const sg_csr *A, const sg_postings *B
     {
         SgTimer timer(ctx, SG_K_SPGEMM);
         st = SG_OK;
-        if (hipMemsetAsync(counters, 0, sizeof(uint32_t) * n_words, ctx->stream) != hipSuccess ||
-            hipMemsetAsync(r->d_counts, 0, sizeof(int32_t) * (size_t)A->n_rows, ctx->stream) != hipSuccess ||
-            hipMemsetAsync(ctx->d_stat_words + 2, 0, 4 * sizeof(int64_t), ctx->stream) != hipSuccess)
-            st = SG_ERR_HIP;
+        st = SG_ZERO3(ctx, counters, sizeof(uint32_t) * n_words, r->d_counts, sizeof(int32_t) * (size_t)A->n_rows,
+                      ctx->d_stat_words + 2, 4 * sizeof(int64_t));
         bool sym_done = false;
         if (symmetric && st == SG_OK)
             st = sg_spgemm_pruned_symmetric(ctx, A, Bt, stride, r, threshold, delta,
@@ -1071,9 +1069,7 @@ extern "C" int sg_selfjoin_range(sg_ctx *ctx, const sg_csr *A, const sg_postings
     bool done = false;
     {
         SgTimer timer(ctx, SG_K_SPGEMM);
-        if (hipMemsetAsync(r->d_counts, 0, sizeof(int32_t) * (size_t)A->n_rows, ctx->stream) != hipSuccess ||
-            hipMemsetAsync(ctx->d_stat_words, 0, 8 * sizeof(int64_t), ctx->stream) != hipSuccess)
-            st = SG_ERR_HIP;
+        st = SG_ZERO2(ctx, r->d_counts, sizeof(int32_t) * (size_t)A->n_rows, ctx->d_stat_words, 8 * sizeof(int64_t));
         if (st == SG_OK)
             st = sg_spgemm_pruned_symmetric(ctx, A, Bt, stride, r, threshold, delta, (unsigned long long *)(ctx->d_stat_words + 2),
                                             &done, row_lo, row_hi, d_pairs, n_pairs, row_step);

@@ -188,33 +188,90 @@ __global__ void __launch_bounds__(64 * TOK_SHORT_WAVES) tokenize_short_kernel(
     const uint64_t lt_mask = ((uint64_t)1 << lane) - 1;
     // keys that leave six spare bits are ranked with the lane number appended: one comparison per pair
     const bool tagged = sizeof(KeyT) == 4 && p.bits * p.ngram <= 25;
-    const int64_t stride = (int64_t)gridDim.x * TOK_SHORT_WAVES;
-    for (int64_t row = (int64_t)blockIdx.x * TOK_SHORT_WAVES + wv; row < n_rows; row += stride) {
-        const int64_t b0 = offsets[row];
-        const int64_t len = offsets[row + 1] - b0;
-        if (len > 64) {
-            if (lane == 0) {
-                mid_rows[atomicAdd(mid_count, 1u)] = (uint32_t)row;
-                out_cnt[row] = 0;
+    // A wave works off ~80 strings one after the other, and a string was a chain of dependent loads -- offsets, characters,
+    // the row's slot, the document-frequency mark -- each a round trip of a microsecond or two under load: the kernel ran
+    // at the latency of its loads (0.39 ms for 16 MB in, 130 MB out at 663 k).  Round 4: a software pipeline.
+    //   * A wave takes BLOCKS of sixteen consecutive strings: their offsets and slots are two coalesced loads, handed
+    //     to the strings lane to lane (v_readlane) -- no load per string for them.
+    //   * The characters of string i + 1 are loaded while string i is tokenised; the two live in registers of their
+    //     own (the trip is written twice, A and B): rotating ONE register would be a copy of a register whose load is
+    //     in flight, i.e. a wait.
+    //   * What a trip computes -- keys, counts, marks -- is stored at the head of the NEXT trip: the wait counter
+    //     covers stores as well as loads, in order, and the compiler waits for "everything" at a trip's first use of a
+    //     loaded value; that way everything is a whole trip old.
+    //   * Inside a trip nothing else loads from memory: the tables of the kernel's argument block, indexed per lane,
+    //     would be served with loads from the block's memory -- the deletion mask is selected from its four words, the
+    //     character ranks are read from a copy in LDS, and a key's mark is a plain store (count_document: racing
+    //     stores write the same 1).
+    __shared__ uint16_t s_rank[128];
+    if (threadIdx.x < 128) s_rank[threadIdx.x] = p.rank_of_byte[threadIdx.x];
+    __syncthreads();
+    // (two 64-bit words and one select: a four-way select on the words the compiler turns into a table in scratch memory)
+    const uint64_t dm_lo = (uint64_t)p.del_mask[0] | ((uint64_t)p.del_mask[1] << 32), dm_hi = (uint64_t)p.del_mask[2] | ((uint64_t)p.del_mask[3] << 32);
+    struct Pending {
+        bool head;        // this lane holds a distinct n-gram
+        bool mark;        // ... that is in the vocabulary's key space
+        int64_t at;       // its slot
+        KeyT key;
+        int32_t tf;
+        int64_t row;      // the row whose count goes out (-1: none)
+        int32_t cnt;
+    };
+    auto store_pending = [&](const Pending &q) {
+        if (q.head) {
+            out_keys[q.at] = q.key;
+            out_tf[q.at] = q.tf;
+            if (q.mark) {
+                if (df_replicas == 0) df_table[(int64_t)q.key] = 1;   // mark (see count_document): racing stores write the same 1
+                else count_document(df_table, df_replicas, df_stride, q.row, (int64_t)q.key);
             }
-            continue;
         }
-        uint32_t code = 0;
-        const bool keep = lane < len && char_code<SYMBOLS>(chars_in, b0 + lane, p, &code);
+        if (lane == 0 && q.row >= 0) out_cnt[q.row] = q.cnt;
+    };
+    auto read_lane_i64 = [&](int64_t v, int i) -> int64_t {
+        const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(uint64_t)v, i);
+        const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)((uint64_t)v >> 32), i);
+        return (int64_t)(((uint64_t)hi << 32) | lo);
+    };
+    auto load_raw = [&](int64_t b0, int64_t b1) -> uint32_t {   // the lane's character, untouched (0 past the end / for long rows)
+        const int64_t len = b1 - b0;
+        if (len > 64 || lane >= len) return 0u;
+        return SYMBOLS ? (uint32_t)reinterpret_cast<const uint16_t *>(chars_in)[b0 + lane]
+                       : (uint32_t)reinterpret_cast<const uint8_t *>(chars_in)[b0 + lane];
+    };
+    // the character code of the lane's character (filter, lower, delete, rank): false = dropped
+    auto code_of = [&](uint32_t raw, int64_t len, uint32_t &code) -> bool {
+        code = 0;
+        if (lane >= len) return false;
+        if (SYMBOLS) {
+            code = raw;
+            return true;
+        }
+        uint32_t c = raw;
+        if (p.lower && c >= 'A' && c <= 'Z') c += 32;
+        const uint64_t dm = c < 64 ? dm_lo : dm_hi;
+        if (c >= 0x80 || ((dm >> (c & 63)) & 1ull)) return false;
+        code = s_rank[c];
+        return true;
+    };
+    // one string, its characters coded: n-grams, ranks, run lengths -> what the next trip stores
+    auto tokenize_row = [&](int64_t row, int64_t len, int64_t ub, bool keep, uint32_t code) -> Pending {
+        Pending q{false, false, 0, 0, 0, row, 0};
+        if (len > 64) {
+            if (lane == 0) mid_rows[atomicAdd(mid_count, 1u)] = (uint32_t)row;   // (its count, 0, goes out with the next trip)
+            return q;
+        }
         const uint64_t km = __ballot(keep);
         const int g = __popcll(km) - p.ngram + 1;   // number of n-grams
-        if (g <= 0) {
-            if (lane == 0) out_cnt[row] = 0;
-            continue;
-        }
+        if (g <= 0) return q;
         if (keep) chars[__popcll(km & lt_mask)] = (uint16_t)code;
         wave_sync();
         KeyT key = KeyTraits<KeyT>::PAD;
         if (lane < g) {
             key = 0;
             bool absent = false;
-            for (int q = 0; q < p.ngram; ++q) {
-                const uint32_t ch = chars[lane + q];
+            for (int e = 0; e < p.ngram; ++e) {
+                const uint32_t ch = chars[lane + e];
                 absent |= ch == SG_CHAR_ABSENT;
                 key = (key << p.bits) | (KeyT)ch;
             }
@@ -243,14 +300,54 @@ __global__ void __launch_bounds__(64 * TOK_SHORT_WAVES) tokenize_short_kernel(
         if (head) {
             const uint64_t above = (hm >> lane) >> 1;   // the heads behind this one
             const int next = above ? lane + 1 + __builtin_ctzll(above) : g;
-            const int64_t o = ub_ptr[row] + __popcll(hm & lt_mask);
-            out_keys[o] = mine;
-            out_tf[o] = next - lane;
-            if (df_table && mine != KeyTraits<KeyT>::OOV) count_document(df_table, df_replicas, df_stride, row, (int64_t)mine);
+            q.head = true;
+            q.at = ub + __popcll(hm & lt_mask);
+            q.key = mine;
+            q.tf = next - lane;
+            q.mark = df_table != nullptr && mine != KeyTraits<KeyT>::OOV;
         }
-        if (lane == 0) out_cnt[row] = __popcll(hm);
+        q.cnt = __popcll(hm);
         wave_sync();   // the next string overwrites chars / keys
+        return q;
+    };
+    constexpr int BLK = 16;
+    const int64_t n_blocks = (n_rows + BLK - 1) / BLK;
+    const int64_t stride = (int64_t)gridDim.x * TOK_SHORT_WAVES;
+    Pending pend{false, false, 0, 0, 0, -1, 0};
+    for (int64_t blk = (int64_t)blockIdx.x * TOK_SHORT_WAVES + wv; blk < n_blocks; blk += stride) {
+        const int64_t r0 = blk * BLK;
+        const int nrow = (int)min((int64_t)BLK, n_rows - r0);
+        // lane l <= nrow: the l-th offset of the block; lane l < nrow: the slot of its l-th string
+        const int64_t m_off = lane <= nrow ? offsets[r0 + lane] : 0;
+        const int64_t m_ub = lane < nrow ? ub_ptr[r0 + lane] : 0;
+        int64_t b0A = read_lane_i64(m_off, 0), b1A = read_lane_i64(m_off, 1);
+        uint32_t rawA = load_raw(b0A, b1A), rawB = 0;
+        for (int i = 0; i < BLK; i += 2) {   // (BLK even; strings past the block's end have no characters and no row)
+            {   // trip A: string i
+                uint32_t code;
+                const int64_t len = i < nrow ? b1A - b0A : 0;
+                const bool keep = code_of(rawA, len, code);
+                const int64_t b0B = i + 1 < nrow ? read_lane_i64(m_off, i + 1) : 0, b1B = i + 1 < nrow ? read_lane_i64(m_off, i + 2) : 0;
+                rawB = load_raw(b0B, b1B);
+                store_pending(pend);
+                pend = i < nrow ? tokenize_row(r0 + i, len, read_lane_i64(m_ub, i), keep, code) : Pending{false, false, 0, 0, 0, -1, 0};
+                b0A = b0B;   // (scalars: no load is in flight into them)
+                b1A = b1B;
+            }
+            {   // trip B: string i + 1 (b0A, b1A are its offsets now)
+                uint32_t code;
+                const int64_t len = i + 1 < nrow ? b1A - b0A : 0;
+                const bool keep = code_of(rawB, len, code);
+                const int64_t b0N = i + 2 < nrow ? read_lane_i64(m_off, i + 2) : 0, b1N = i + 2 < nrow ? read_lane_i64(m_off, i + 3) : 0;
+                rawA = load_raw(b0N, b1N);
+                store_pending(pend);
+                pend = i + 1 < nrow ? tokenize_row(r0 + i + 1, len, read_lane_i64(m_ub, i + 1), keep, code) : Pending{false, false, 0, 0, 0, -1, 0};
+                b0A = b0N;
+                b1A = b1N;
+            }
+        }
     }
+    store_pending(pend);
 }
 
 template <typename KeyT, bool SYMBOLS>
@@ -803,8 +900,7 @@ static int tokenize_set_t(sg_ctx *ctx, const sg_strings *s, const TokParams &tp,
     if (st == SG_OK && s->n > 0) {
         // strings of up to 64 characters: tokenize_short_kernel; what it queues (mids): tokenize_kernel, launched on the
         // device-side count; what that one queues (longs, > TOK_CAP n-grams): tokenize_long_kernel after one host round trip
-        hipError_t e = hipMemsetAsync(longs, 0, 4, ctx->stream);
-        if (e == hipSuccess) e = hipMemsetAsync(mids, 0, 4, ctx->stream);
+        hipError_t e = SG_ZERO2(ctx, longs, 4, mids, 4) == SG_OK ? hipSuccess : hipErrorUnknown;
         unsigned grid = (unsigned)ctx->num_cu * 8u;
         const int64_t wgs = (s->n + TOK_SHORT_WAVES - 1) / TOK_SHORT_WAVES;
         if ((int64_t)grid > wgs) grid = (unsigned)wgs;
