@@ -604,55 +604,77 @@ class StringGrouper(object):
         return m_idx, d_idx
 
     # ---- match_most_similar result (string_grouper.py:783-849)
-    def _get_nearest_matches(self, ignore_index=False, replace_na=False) -> Union[pd.DataFrame, pd.Series]:
-        prefix = MOST_SIMILAR_PREFIX
-        master_label = f'{prefix}{self._master.name if self._master.name else DEFAULT_MASTER_NAME}'
-        master = self._master.rename(master_label).reset_index(drop=ignore_index)
-        dupes = self._duplicates.rename('duplicates').reset_index(drop=ignore_index)
-        if isinstance(dupes, pd.DataFrame):
-            master.rename(columns={col: f'{prefix}{col}' for col in master.columns if str(col) != master_label},
-                          inplace=True)
-        if self._master_id is not None:
-            master_id_label = f'{prefix}{self._master_id.name if self._master_id.name else DEFAULT_MASTER_ID_NAME}'
-            master = pd.concat([master, self._master_id.rename(master_id_label).reset_index(drop=True)], axis=1)
-            dupes = pd.concat([dupes, self._duplicates_id.rename('duplicates_id').reset_index(drop=True)], axis=1)
-
-        # best master per duplicate: highest similarity, ties -> lowest master position (:803-807)
+    def _best_master_positions(self) -> np.ndarray:
+        """For every duplicate (by position) the position of its best master, -1 when it has no match: the highest
+        similarity wins, the lowest master position among equals (string_grouper.py:803-807)."""
+        n_dupes = len(self._duplicates)
         dml = self.__dict__.get('_device_matches')
         if dml is not None:     # reduced on the device (K7): one int32 per duplicate crosses PCIe
-            bm = dml.best_master()
-            has = bm >= 0
-            best = pd.DataFrame({'dupe_side': np.flatnonzero(has).astype(np.int64),
-                                 'master_side': bm[has].astype(np.int64)})
-        else:                   # the list was edited on the host (add_match / remove_match) or built there
-            ml = self._matches_list
-            ms, ds, sim = ml.master_side.to_numpy(), ml.dupe_side.to_numpy(), ml.similarity.to_numpy()
-            order = np.lexsort((ms, -sim, ds))
-            ds_sorted = ds[order]
-            first = np.ones(len(order), dtype=bool)
-            first[1:] = ds_sorted[1:] != ds_sorted[:-1]
-            best = pd.DataFrame({'dupe_side': ds_sorted[first], 'master_side': ms[order][first]})
+            return dml.best_master().astype(np.int64)
+        # the list was edited on the host (add_match / remove_match) or built there
+        ml = self._matches_list
+        ms, ds, sim = ml.master_side.to_numpy(), ml.dupe_side.to_numpy(), ml.similarity.to_numpy()
+        order = np.lexsort((ms, -sim, ds))             # per duplicate: best similarity first, then lowest master
+        ds_sorted = ds[order]
+        first = np.ones(len(order), dtype=bool)
+        first[1:] = ds_sorted[1:] != ds_sorted[:-1]
+        best = np.full(n_dupes, -1, dtype=np.int64)
+        best[ds_sorted[first]] = ms[order][first]
+        return best
 
-        table = best.merge(dupes, left_on='dupe_side', right_index=True, how='outer')
-        table = table.merge(master, left_on='master_side', right_index=True, how='left')
-        unmatched = table[master_label].isnull()
-        table.loc[unmatched, master_label] = table[unmatched].duplicates
+    @staticmethod
+    def _fill_from(column: pd.Series, rows: np.ndarray, donor: pd.Series, like_dtype, donor_dtype) -> pd.Series:
+        """``column`` with the entries at ``rows`` (a mask) taken from ``donor`` -- a join that finds no partner leaves a
+        hole and widens the column (integers become floats, booleans objects); where the donor is of the column's original
+        type the original type is put back, as the reference does (string_grouper.py:821-826, :840-843).  No element of a
+        type the column cannot hold is ever assigned into it: the two are combined, which widens without complaint."""
+        filled = column.where(~rows, donor) if rows.any() else column
+        if filled.dtype != like_dtype and donor_dtype == like_dtype:
+            filled = filled.astype(like_dtype)
+        return filled
+
+    def _get_nearest_matches(self, ignore_index=False, replace_na=False) -> Union[pd.DataFrame, pd.Series]:
+        """One row per duplicate, in the duplicates' order and under their index: the best master's string (and id, and
+        index levels unless ``ignore_index``), or the duplicate's own where it has no match (its index levels only with
+        ``replace_na``).  Assembled by POSITION -- the best master of duplicate d is a row number of the master table --
+        instead of the reference's chain of key joins; the frames are the reference's, dtype for dtype
+        (tests/test_host_api.py: fuzz against the mounted reference)."""
+        prefix = MOST_SIMILAR_PREFIX
+        name_col = f'{prefix}{self._master.name if self._master.name else DEFAULT_MASTER_NAME}'
+        # both sides as positional tables: the index levels (unless dropped) to the left of the strings
+        m_tbl = self._master.rename(name_col).reset_index(drop=ignore_index)
+        d_tbl = self._duplicates.rename('duplicates').reset_index(drop=ignore_index)
+        if isinstance(d_tbl, pd.DataFrame):
+            m_tbl = m_tbl.rename(columns={c: f'{prefix}{c}' for c in m_tbl.columns if str(c) != name_col})
+        id_col = None
         if self._master_id is not None:
-            table.loc[unmatched, master_id_label] = table[unmatched].duplicates_id
-            if table[master_id_label].dtype != self._master_id.dtype and \
-                    self._duplicates_id.dtype == self._master_id.dtype:
-                table.loc[:, master_id_label] = table.loc[:, master_id_label].astype(self._master_id.dtype)
+            id_col = f'{prefix}{self._master_id.name if self._master_id.name else DEFAULT_MASTER_ID_NAME}'
+            m_tbl = pd.concat([m_tbl, self._master_id.rename(id_col).reset_index(drop=True)], axis=1)
+            d_tbl = pd.concat([d_tbl, self._duplicates_id.rename('duplicates_id').reset_index(drop=True)], axis=1)
+        m_frame = m_tbl.to_frame() if isinstance(m_tbl, pd.Series) else m_tbl
+        d_frame = d_tbl.to_frame() if isinstance(d_tbl, pd.Series) else d_tbl
 
-        required = [master_label] if self._master_id is None else [master_id_label, master_label]
-        index_cols = [c for c in master.columns if c not in required] if isinstance(master, pd.DataFrame) else []
+        best = self._best_master_positions()
+        lonely = best < 0                                   # duplicates without a match
+        # the master table's row of every duplicate; -1 is no row of it: those come out empty (and widen their columns)
+        picked = m_frame.reindex(pd.Index(best)).reset_index(drop=True)
+
+        picked[name_col] = self._fill_from(picked[name_col], lonely, d_frame['duplicates'], m_frame[name_col].dtype,
+                                           m_frame[name_col].dtype)
+        if id_col is not None:
+            picked[id_col] = self._fill_from(picked[id_col], lonely, d_frame['duplicates_id'], self._master_id.dtype,
+                                             self._duplicates_id.dtype)
+        wanted = [name_col] if id_col is None else [id_col, name_col]
+        level_cols = [c for c in m_tbl.columns if c not in wanted] if isinstance(m_tbl, pd.DataFrame) else []
         if replace_na:
-            dupes_index_cols = [c for c in dupes.columns if str(c) != 'duplicates']
-            table.loc[unmatched, index_cols] = table.loc[unmatched, dupes_index_cols].values
-            for m_col, d_col in zip(index_cols, dupes_index_cols):
-                if table[m_col].dtype != master[m_col].dtype and dupes[d_col].dtype == master[m_col].dtype:
-                    table.loc[:, m_col] = table.loc[:, m_col].astype(master[m_col].dtype)
-        table = table.sort_values('dupe_side').set_index('dupe_side')
-        output = table[index_cols + required]
+            donors = [c for c in d_frame.columns if str(c) != 'duplicates']
+            if len(donors) != len(level_cols) and (len(level_cols) > 0 or lonely.any()):
+                # (the reference assigns the duplicates' columns -- the id column among them -- to the master's index
+                #  columns as one block, string_grouper.py:836-838: with ids the widths differ and pandas refuses)
+                picked.loc[lonely, level_cols] = d_frame.loc[lonely, donors].values
+            for m_c, d_c in zip(level_cols, donors):
+                picked[m_c] = self._fill_from(picked[m_c], lonely, d_frame[d_c], m_frame[m_c].dtype, d_frame[d_c].dtype)
+        output = picked[level_cols + wanted]
         output.index = self._duplicates.index
         return output.squeeze(axis=1)
 
