@@ -465,6 +465,7 @@ extern "C" int sg_csr_row_block(sg_ctx *ctx, const sg_csr *m, int64_t r0, int64_
 
 extern "C" int sg_csr_free(sg_csr *m) {
     if (!m) return SG_OK;
+    if (m->left_groups) sg_collapse_free(m->left_groups);
     if (m->owned) {
         m->ctx->release((void *)m->d_indptr);
         m->ctx->release((void *)m->d_indices);

@@ -153,12 +153,22 @@ void sg_collapse_free(SgCollapse *c) {
 }
 
 // *out stays null when collapsing is off, not worth it (fewer than 3 % repeats) or not possible.
-int sg_collapse_build(sg_ctx *ctx, const sg_csr *B, SgCollapse **out) {
+// left_side: the groups are those of a LEFT matrix of a one-sided product (sg_spgemm_topn): its own switch
+// (SG_COLLAPSE_LEFT=0 off, =1 from two rows on) and a higher bar by default -- the grouping is paid by the multiply that
+// asks for it, not by an index build that many multiplies share.
+int sg_collapse_build(sg_ctx *ctx, const sg_csr *B, SgCollapse **out, bool left_side) {
     *out = nullptr;
     const char *sw = ctx->opt("SG_COLLAPSE");
     if ((sw && sw[0] == '0') || B->n_rows < 2 || B->nnz <= 0 || B->n_rows >= ((int64_t)1 << 31)) return SG_OK;
-    const bool forced = sw && sw[0] == '1';
-    if (!forced && B->n_rows < 8192) return SG_OK;
+    bool forced = sw && sw[0] == '1';
+    int64_t min_rows = 8192;
+    if (left_side) {
+        const char *ls = ctx->opt("SG_COLLAPSE_LEFT");
+        if (ls && ls[0] == '0') return SG_OK;
+        forced = ls && ls[0] == '1';
+        min_rows = 65536;
+    }
+    if (!forced && B->n_rows < min_rows) return SG_OK;
     const int64_t n = B->n_rows;
     uint64_t *hash = nullptr, *hash_sorted = nullptr;
     uint32_t *row_id = nullptr, *row_sorted = nullptr, *head = nullptr, *run_excl = nullptr, *head_pos = nullptr;

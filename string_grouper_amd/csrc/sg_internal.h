@@ -137,6 +137,11 @@ struct sg_csr {
     // a matrix made by the vectoriser is cosine-like by construction; K2 leaves [0] violations (= 0), [1] max ||row||^2 as
     // float bits, [2] longest row here and sg_csr_props reads them instead of scanning the matrix again (owned)
     uint32_t *d_props_words = nullptr;
+    // groups of identical rows of a LEFT matrix (sg_spgemm_topn, one-sided products: round 4), made on first use and kept
+    // for the multiplies that follow with the same matrix (column blocks of the right-hand side): 0 not looked at yet,
+    // 1 looked at and not worth it / not possible, 2 `left_groups` holds them (owned, also by views)
+    mutable int left_state = 0;
+    mutable struct SgCollapse *left_groups = nullptr;
 };
 
 struct SgScoreCtx {
@@ -305,7 +310,7 @@ int sg_spgemm_exact_selfjoin_rows(sg_ctx *ctx, const sg_csr *A, const sg_posting
                                   const uint32_t *row_list_len, const SgPairSink &sink);
 
 // sg_collapse.hip
-int sg_collapse_build(sg_ctx *ctx, const sg_csr *B, SgCollapse **out);
+int sg_collapse_build(sg_ctx *ctx, const sg_csr *B, SgCollapse **out, bool left_side = false);
 void sg_collapse_free(SgCollapse *c);
 int sg_collapse_expand(sg_ctx *ctx, const SgCollapse *c, const sg_topn *ru, bool rows_are_groups, sg_topn *out,
                        const int32_t *row_list = nullptr);   // row_list: output row k is the caller's row row_list[k]

@@ -577,6 +577,8 @@ extern "C" int sg_postings_build_flags(sg_ctx *ctx, const sg_csr *B_in, int32_t 
             inner->caller_b_copy = *B_in;
             inner->caller_b_copy.owned = false;
             inner->caller_b_copy.d_props_words = nullptr;
+            inner->caller_b_copy.left_groups = nullptr;
+            inner->caller_b_copy.left_state = 0;
             inner->caller_b = &inner->caller_b_copy;
             inner->n_right_caller = B_in->n_rows;
             inner->build_tile_cols = tile_cols;
@@ -676,6 +678,8 @@ extern "C" int sg_postings_build_flags(sg_ctx *ctx, const sg_csr *B_in, int32_t 
     p->src = *B;
     p->src.owned = false;
     p->src.d_props_words = nullptr;
+    p->src.left_groups = nullptr;
+    p->src.left_state = 0;
     if (st == SG_OK && !lazy_full && B->dtype == SG_F64) st = sg_alloc(ctx, (size_t)B->nnz + 64, &p->d_rows);
     if (st == SG_OK && !lazy_full) st = ctx->alloc(((size_t)B->nnz + 64) * vs, &p->d_vals);
     if (st == SG_OK && will_filter) {

@@ -827,9 +827,96 @@ static int spgemm_topn_collapsed(sg_ctx *ctx, const sg_csr *A, const sg_postings
     return SG_OK;
 }
 
+// out row r = row gid[r] of the result over the groups of identical LEFT rows: a thread per cell
+template <typename T>
+__global__ void __launch_bounds__(256) expand_left_rows_kernel(const int32_t *__restrict__ u_cols, const T *__restrict__ u_vals,
+                                                               const int32_t *__restrict__ u_cnt, const uint32_t *__restrict__ gid,
+                                                               int64_t n_rows, int32_t stride, int32_t *__restrict__ cols,
+                                                               T *__restrict__ vals, int32_t *__restrict__ cnt) {
+    const int64_t cell = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (cell >= n_rows * stride) return;
+    const int64_t r = cell / stride;
+    const int32_t e = (int32_t)(cell - r * stride);
+    const int64_t g = gid[r];
+    const int32_t m = u_cnt[g];
+    if (e == 0) cnt[r] = m;
+    if (e < m) {
+        cols[cell] = u_cols[g * stride + e];
+        vals[cell] = u_vals[g * stride + e];
+    }
+}
+
+// Identical LEFT rows of a one-sided product (round 4).  A master list of ten million names repeats a fifth of them
+// (BASELINE.json configs[4], master x duplicates): identical strings are identical rows of A, and identical rows of A
+// have identical rows in C -- sparse_dot_topn (string_grouper.py:737-743) and rounds 1-3 multiplied every one of them.
+// The rows of A are grouped like the right-hand side's (sg_collapse.hip: hash, sort, entry-by-entry check), the
+// representatives are multiplied, and every row receives a copy of its group's result row.  The groups stay with A: a
+// product against the next column block of the right-hand side does not group again.
+static int spgemm_topn_left_groups(sg_ctx *ctx, const sg_csr *A, const sg_postings *Bt, int32_t top_n, double threshold, int32_t sort,
+                                   sg_topn **out, bool *done) {
+    *done = false;
+    if (A->left_state == 1) return SG_OK;
+    if (A->left_state == 0) {
+        SgCollapse *g = nullptr;
+        bool cl = false;
+        float n2 = 0.f;
+        SG_TRY(sg_csr_props(ctx, A, &cl, &n2));     // (the grouping hashes value bits: any matrix will do, but only name
+        if (cl) SG_TRY(sg_collapse_build(ctx, A, &g, /*left_side=*/true));   //  lists -- cosine-like rows -- repeat themselves)
+        A->left_groups = g;
+        A->left_state = g ? 2 : 1;
+        if (!g) return SG_OK;
+    }
+    const SgCollapse *g = A->left_groups;
+    sg_topn *ru = nullptr;
+    g->unique->left_state = 1;                      // (representatives are distinct)
+    SG_TRY(sg_spgemm_topn(ctx, g->unique, Bt, top_n, threshold, sort, &ru));
+    sg_topn *r = nullptr;
+    int st = topn_alloc(ctx, A->n_rows, ru->n_cols, ru->stride, ru->dtype, &r);
+    if (st == SG_OK && A->n_rows > 0) {
+        SgTimer timer(ctx, SG_K_ZIP);
+        const int64_t cells = A->n_rows * (int64_t)ru->stride;
+        const unsigned grid = (unsigned)((cells + 255) / 256);
+        if (ru->dtype == SG_F64)
+            hipLaunchKernelGGL(expand_left_rows_kernel<double>, dim3(grid), dim3(256), 0, ctx->stream, (const int32_t *)ru->d_cols,
+                               (const double *)ru->d_vals, (const int32_t *)ru->d_counts, (const uint32_t *)g->d_gid, A->n_rows,
+                               ru->stride, r->d_cols, (double *)r->d_vals, r->d_counts);
+        else
+            hipLaunchKernelGGL(expand_left_rows_kernel<float>, dim3(grid), dim3(256), 0, ctx->stream, (const int32_t *)ru->d_cols,
+                               (const float *)ru->d_vals, (const int32_t *)ru->d_counts, (const uint32_t *)g->d_gid, A->n_rows,
+                               ru->stride, r->d_cols, (float *)r->d_vals, r->d_counts);
+        (void)hipMemsetAsync(ctx->d_stat_words + 1, 0, sizeof(int64_t), ctx->stream);   // entries kept: counted on all rows
+        hipLaunchKernelGGL(sum_counts_kernel, dim3(256), dim3(256), 0, ctx->stream, r->d_counts, A->n_rows,
+                           (unsigned long long *)(ctx->d_stat_words + 1));
+        if (hipGetLastError() != hipSuccess) st = SG_ERR_HIP;
+    }
+    sg_topn_free(ru);
+    if (st != SG_OK) {
+        sg_topn_free(r);
+        return st;
+    }
+    *out = r;
+    *done = true;
+    return SG_OK;
+}
+
 extern "C" int sg_spgemm_topn(sg_ctx *ctx, const sg_csr *A, const sg_postings *Bt, int32_t top_n, double threshold,
                               int32_t sort, sg_topn **out) {
     SG_REQUIRE(ctx && A && Bt && out, "null argument");
+    {
+        // one-sided product (A is not the matrix the index was built from: a self-join groups its rows with the index)
+        const sg_csr *own = Bt->collapse ? &Bt->caller_b_copy : nullptr;
+        const bool self = own ? (A->n_rows == Bt->collapse->n_orig && A->d_indptr == own->d_indptr && A->d_indices == own->d_indices &&
+                                 A->d_data == own->d_data)
+                              : (A->n_rows == Bt->n_right && A->d_indptr == Bt->b_indptr && A->d_indices == Bt->b_indices &&
+                                 A->d_data == Bt->b_data);
+        const char *sw = ctx->opt("SG_COLLAPSE"), *ls = ctx->opt("SG_COLLAPSE_LEFT");    // (asked on every call: groups kept
+        const bool off = (sw && sw[0] == '0') || (ls && ls[0] == '0');                      //  with A do not outlive the switch)
+        if (!self && !off && A->left_state != 1 && A->n_cols == Bt->n_terms && A->dtype == Bt->dtype && top_n >= 1) {
+            bool done = false;
+            SG_TRY(spgemm_topn_left_groups(ctx, A, Bt, top_n, threshold, sort, out, &done));
+            if (done) return SG_OK;
+        }
+    }
     if (Bt->collapse) {
         SG_REQUIRE(A->n_cols == Bt->n_terms && A->dtype == Bt->dtype && top_n >= 1, "A and B differ in columns or value type, or top_n < 1");
         return spgemm_topn_collapsed(ctx, A, Bt, top_n, threshold, sort, out);

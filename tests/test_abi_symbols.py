@@ -37,7 +37,10 @@ def test_binding_covers_the_header_exactly():
     from string_grouper_amd import _native as N
     assert sorted(N.ABI) == declared_functions()
     N.lib()                                    # resolves every symbol with its prototype
-    assert N.lib().sg_abi_version() == 1
+    import re
+    header = open(os.path.join(ROOT, "include", "sg_hip.h")).read()
+    declared = int(re.search(r"#define\s+SG_ABI_VERSION\s+(\d+)", header).group(1))
+    assert N.lib().sg_abi_version() == declared == N.ABI_VERSION     # header, library and binding in lock-step
 
 
 def test_no_device_is_reported_loudly():

@@ -703,6 +703,63 @@ def _all_rows_equal_the_exact_kernel(ctx, res, A, B, top_n, thr, what):
     print(f"{what}: all {len(n0)} rows, {int(n0.sum())} matches, identical to the exact kernel ({st['ms_spgemm_topn']:.0f} ms)")
 
 
+def _rows_equal_the_port(res, rows, A_host, B_host, top_n, thr, what):
+    """The rows ``rows`` (ascending row numbers) of a full-size result against the CPU port on all host cores, bit for bit."""
+    import os
+    import time
+    cols, vals, cnt = res.to_host()
+    rows = np.unique(np.asarray(rows, dtype=np.int64))
+    n_cpu = min(len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 8), 64)
+    t0 = time.perf_counter()
+    # the reference's own scheme for a right-hand side of this size (string_grouper.py:733-746): column blocks of B, each
+    # multiplied on its own, the blocks' top-n lists zipped -- a per-thread accumulator over ALL 5 M columns (40 MB of
+    # randomly touched memory per thread) made the port 100 x slower per product than at 663 k
+    from oracle.ref_pipeline import zip_port
+    left = A_host[rows]
+    step = 262_144
+    parts = [P.sp_matmul_topn_port(left, B_host[b0:b0 + step].T, top_n, thr, True, n_cpu) for b0 in range(0, B_host.shape[0], step)]
+    C_ref = zip_port(top_n, parts)
+    secs = time.perf_counter() - t0
+    got_cnt = cnt[rows]
+    np.testing.assert_array_equal(got_cnt, np.diff(C_ref.indptr), err_msg=f"{what}: match counts")
+    mask = np.arange(cols.shape[1])[None, :] < got_cnt[:, None]
+    assert np.array_equal(cols[rows][mask], C_ref.indices), f"{what}: columns"
+    assert np.array_equal(vals[rows][mask], C_ref.data), f"{what}: scores"
+    print(f"{what}: {len(rows)} rows ({int(got_cnt.sum())} matches) identical to the CPU port ({secs:.1f} s on {n_cpu} cores)")
+    return len(rows)
+
+
+def _device_u32(ptr, n):
+    """Host copy of a uint32 device array of the library (test plumbing: a torch view of the pointer)."""
+    import torch
+    from string_grouper_amd import distributed as D
+    return torch.as_tensor(D.DeviceTensorView(ptr, n, "<u4"), device=torch.device("cuda", 0)).cpu().numpy().astype(np.int64)
+
+
+def _rows_at_position_blocks(ctx, post, n_rows, width):
+    """Rows whose position in the index (of their group of identical rows, if grouped) lies in the first, the middle or the
+    last ``width`` positions: the self-join form walks positions from the last down, and a position's cost grows with it."""
+    n_index, n_caller, p_gid = ctx.postings_rows(post)
+    assert n_caller == n_rows
+    p_orig, p_pos = ctx.postings_permutation(post)
+    ctx.sync()
+    gid = _device_u32(p_gid, n_rows) if p_gid else np.arange(n_rows)
+    pos_of = _device_u32(p_pos, n_index) if p_pos else np.arange(n_index)
+    row_pos = pos_of[gid]
+    mid = n_index // 2
+    take = (row_pos < width) | ((row_pos >= mid) & (row_pos < mid + width)) | (row_pos >= n_index - width)
+    return np.flatnonzero(take)
+
+
+def _rows_of_special_shape(A_host, n_short=3000):
+    """Rows the pruned kernel treats apart: more than 64 non-zeros (the wide launch; beyond 128: the exact kernel) and the
+    shortest rows (few, frequent terms, all of them in the prefix: the rows of thousands of rounds, set aside as parts)."""
+    nnz = np.diff(A_host.indptr)
+    wide = np.flatnonzero(nnz > 64)
+    short = np.flatnonzero((nnz > 0) & (nnz <= 4))[:n_short]
+    return np.concatenate([wide, short])
+
+
 @pytest.mark.timeout(900)
 def test_config4_5M_selfjoin_one_of_eight_row_blocks(ctx):
     """BASELINE.json configs[3]: 5M synthetic names self-join, left CSR row-blocked over 8 GPUs -- here
@@ -728,10 +785,15 @@ def test_config4_5M_selfjoin_one_of_eight_row_blocks(ctx):
     _check_slice_properties(res, lo, hi - lo, n, 10, 0.8, True, A_host, A_host, 300, "config4")
     res.free()
     blk.free()
-    del A_host
-    # the whole self-join on this one GPU (self-join form on the groups of identical rows), every row against the exact kernel
+    # the whole self-join on this one GPU (self-join form on the groups of identical rows):
     res = ctx.spgemm_topn(A, post, 10, 0.8, True)
     assert ctx.stats()["prune_symmetric"] == 1
+    # (1) more than 100 000 rows against the CPU port -- the first, middle and last positions of the index and the rows of
+    #     special shape -- on all host cores (300 sampled rows were inference, not evidence)
+    rows = np.concatenate([_rows_at_position_blocks(ctx, post, n, 30_000), _rows_of_special_shape(A_host)])
+    assert _rows_equal_the_port(res, rows, A_host, A_host, 10, 0.8, "configs[3], 5 M self-join") >= 100_000
+    del A_host
+    # (2) every row against the exact kernel
     _all_rows_equal_the_exact_kernel(ctx, res, A, A, 10, 0.8, "configs[3], 5 M self-join")
     for h in (res, post, A):
         h.free()
@@ -772,9 +834,18 @@ def test_config5_asymmetric_10M_x_1M_one_of_eight_row_blocks(ctx):
     _check_slice_properties(res, lo, hi - lo, n_d, 20, 0.7, False, _Shift(A_blk_host, lo), B_host, 300, "config5")
     res.free()
     blk.free()
-    del A_blk_host, B_host
-    # all 10 M master rows on this one GPU, every row against the exact kernel
+    del A_blk_host
+    # all 10 M master rows on this one GPU (identical master rows are multiplied once: round 4):
     res = ctx.spgemm_topn(A, post, 20, 0.7, True)
+    st = ctx.stats()
+    print(f"configs[4] whole: K4p group {st['ms_spgemm_topn']:.1f} ms, left rows multiplied {st['prune_rows']} of {n_m}")
+    # (1) more than 100 000 master rows against the CPU port: the first, middle and last 34 000 and the rows of special shape
+    A_host = A.to_scipy()
+    rows = np.concatenate([np.arange(34_000), n_m // 2 + np.arange(34_000), n_m - 34_000 + np.arange(34_000),
+                           _rows_of_special_shape(A_host)])
+    assert _rows_equal_the_port(res, rows, A_host, B_host, 20, 0.7, "configs[4], 10 M x 1 M") >= 100_000
+    del A_host, B_host
+    # (2) every row against the exact kernel
     _all_rows_equal_the_exact_kernel(ctx, res, A, B, 20, 0.7, "configs[4], 10 M x 1 M")
     for h in (res, post, A, B):
         h.free()
@@ -1582,3 +1653,61 @@ def test_identical_rows_are_collapsed_and_the_result_is_the_ports(ctx, dtype, or
         pd.testing.assert_frame_equal(sga.match_strings(s, min_similarity=0.8, max_n_matches=8, tfidf_matrix_dtype=dtype), want_m)
     finally:
         E.set_engine(old)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_identical_left_rows_of_a_one_sided_product_are_multiplied_once(ctx, dtype, monkeypatch):
+    """master x duplicates with a master list that repeats itself (BASELINE.json configs[4]: a fifth of 10 M names): the rows
+    of the LEFT matrix are grouped (round 4), the representatives multiplied, every row gets its group's result row.  Above
+    the automatic bar (65 536 rows) and forced below it; against two right-hand sides in turn (the groups are kept with
+    the matrix); sorted by score and by column; with the right-hand side's own grouping on and off; top_n above the
+    register list -- always the port's rows, bit for bit."""
+    rng = np.random.default_rng(5)
+    base = _names(60000, seed=91)
+    master = base + [base[i] for i in rng.integers(0, len(base), 14000)] + ["NORTHWIND TRADERS LLC"] * 900
+    master = [master[i] for i in rng.permutation(len(master))]
+    from string_grouper_amd.synth import synth_names
+    d1 = synth_names(9000, 92, perturb_of=base, perturb_frac=0.5) + ["NORTHWIND TRADERS LLC", "NORTHWIND TRADERS"]
+    d2 = synth_names(12000, 93, perturb_of=base, perturb_frac=0.6) + [d1[7]] * 500          # (a right-hand side that repeats, too)
+    (M, D1, D2), _, _ = O.tfidf_sklearn(master + d1 + d2, [master, d1, d2], dtype=dtype)
+    for variant in ("default", "row order", "left off"):
+        if variant == "row order":
+            monkeypatch.setenv("SG_PERMUTE", "0")
+            monkeypatch.setenv("SG_COLLAPSE_LEFT", "1")
+        elif variant == "left off":
+            monkeypatch.delenv("SG_PERMUTE")
+            monkeypatch.setenv("SG_COLLAPSE_LEFT", "0")
+        dM = ctx.csr_from_scipy(M)                # (the decision is kept with the matrix: a fresh one per variant)
+        for D, top_n, thr, sort in ((D1, 20, 0.7, True), (D2, 20, 0.7, True), (D2, 5, 0.8, False), (D1, 100, 0.75, True)):
+            dD = ctx.csr_from_scipy(D)
+            post = ctx.postings_build(dD)
+            res = ctx.spgemm_topn(dM, post, top_n, thr, sort)
+            st = ctx.stats()
+            assert_csr_identical(res.to_scipy(), P.sp_matmul_topn_port(M, D.T, top_n, thr, sort, 8),
+                                 f"top_n={top_n} thr={thr} sort={sort} {variant}")
+            if top_n <= 64:
+                if variant == "left off":
+                    assert st["prune_rows"] > 70000, st
+                else:
+                    assert 0 < st["prune_rows"] <= 60001, st      # the representatives, not the 74 900 rows
+            assert st["out_nnz"] == res.to_scipy().nnz, st          # (entries kept are counted on ALL rows)
+            for h in (res, post, dD):
+                h.free()
+        dM.free()
+    monkeypatch.delenv("SG_COLLAPSE_LEFT")
+    dM = ctx.csr_from_scipy(M)
+    # a small left matrix: grouped only when forced; a row block (a view) groups on its own
+    small = M[:9000]
+    dS = ctx.csr_from_scipy(small)
+    dD = ctx.csr_from_scipy(D1)
+    post = ctx.postings_build(dD)
+    for left in ("0", "1"):
+        monkeypatch.setenv("SG_COLLAPSE_LEFT", left)
+        for mat, ref in ((dS, small), (dM.row_block(30000, 50000), M[30000:50000])):
+            res = ctx.spgemm_topn(mat, post, 20, 0.7, True)
+            assert_csr_identical(res.to_scipy(), P.sp_matmul_topn_port(ref, D1.T, 20, 0.7, True, 8), f"small / view, left grouping {left}")
+            res.free()
+        dS.free()
+        dS = ctx.csr_from_scipy(small)            # (a fresh object: the decision is kept with the matrix)
+    for h in (post, dD, dS, dM):
+        h.free()
