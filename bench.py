@@ -358,6 +358,22 @@ def run(args):
     except Exception:
         pass
 
+    # VALU issue fraction of the same kernel (the kernel is instruction bound, the HBM fraction is the wrong
+    # yardstick for it): wave-level VALU instructions per launch from the committed PMC pass x 4 cycles / 1024 SIMDs / 2.4 GHz,
+    # over this run's kernel time
+    try:
+        with open(os.path.join(ROOT, "profiles", "k4_counters.json")) as f:
+            kc = json.load(f)
+        if (kc.get("workload_rows") == args.rows and kc.get("dtype") == args.dtype and world == 1
+                and kc.get("kernel", "K4") == (("K4p-sym" if symmetric else "K4p") if pruned else "K4")):
+            valu = float(kc["per_launch"]["SQ_INSTS_VALU"])
+            result["roofline"]["valu_issue_frac"] = valu * 4.0 / 1024.0 / 2.4e9 / (k4_avg_ms * 1e-3)
+            result["roofline"]["valu_insts_per_launch"] = valu
+            result["roofline"]["valu_source"] = ("committed PMC pass (profiles/k4_counters.json, written by scripts/pmc_counters.py); "
+                                                 "instruction counts do not depend on the run, the kernel time is this run's")
+    except Exception:
+        pass
+
     if world == 1 and not args.no_side_runs:
         # the step WITHOUT the collapse of identical rows (every one of the 663 000 rows indexed and multiplied: 16.5 % of
         # SynthNames-v1's names repeat, a property of the generator, not of sec__edgar) ...

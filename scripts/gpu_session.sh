@@ -76,6 +76,7 @@ for step in "$@"; do
         ( cd /tmp && export TMPDIR=/tmp && timeout 600 rocprofv3 --pmc $ctrs --output-format csv -d $OLDPWD/gpurun_out/${name}_pmcsq$i -o k -- python $OLDPWD/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-exact-kernel --no-end-to-end --no-side-runs $arg > /dev/null 2> $OLDPWD/gpurun_out/${name}_pmcsq$i.err )
         echo "-- pmc pass $i rc=$?: $ctrs" >> $LOG
         python scripts/pmc_summary.py gpurun_out/${name}_pmcsq$i 2>&1 | grep -A14 "spgemm_topn_pruned" | head -16 >> $LOG
+        [ $i -eq 1 ] && python scripts/pmc_counters.py gpurun_out/${name}_pmcsq$i gpurun_out/${name}_k4_counters.json >> $LOG 2>&1
         rm -rf gpurun_out/${name}_pmcsq$i
       done ;;
     py)
