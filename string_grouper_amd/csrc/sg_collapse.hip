@@ -26,9 +26,14 @@
 template <typename T>
 __global__ void __launch_bounds__(256) row_hash_kernel(const int64_t *__restrict__ indptr, const int32_t *__restrict__ indices,
                                                        const T *__restrict__ data, int64_t n_rows, uint64_t *__restrict__ hash,
-                                                       uint32_t *__restrict__ row_id) {
+                                                       uint32_t *__restrict__ row_id /* null: not wanted */,
+                                                       uint32_t *__restrict__ table /* null, or the slots to mark empty */,
+                                                       uint64_t table_size) {
     const int64_t r = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
     const int sub = threadIdx.x & 15;
+    if (table)   // (the table of the grouping below: cleared here instead of by a launch of its own)
+        for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < table_size; i += (uint64_t)gridDim.x * blockDim.x)
+            table[i] = 0xFFFFFFFFu;
     uint64_t h = 0;
     if (r < n_rows) {
         const int64_t lo = indptr[r], hi = indptr[r + 1];
@@ -53,7 +58,141 @@ __global__ void __launch_bounds__(256) row_hash_kernel(const int64_t *__restrict
     if (r < n_rows && sub == 0) {
         const int64_t len = indptr[r + 1] - indptr[r];
         hash[r] = h ^ ((uint64_t)len * 0xD6E8FEB86659FD93ull);
-        row_id[r] = (uint32_t)r;
+        if (row_id) row_id[r] = (uint32_t)r;
+    }
+}
+
+// ---- grouping through a hash table (round 4; the sort-based path below stays for lists with very large groups).
+// The stable sort of (hash, row) was 21 launches and 0.17 ms of the 0.42 ms the grouping cost at 663 k.  An open-addressing
+// table keyed by the 64-bit row hash does the same job: a slot belongs to ONE hash value (that of the row it names) and
+// ends up naming the LOWEST row with that hash (atomicMin) -- the group's representative, as before; every row then
+// checks itself against that row entry by entry (a row whose hash collides with different content becomes a group of its
+// own: nothing is ever merged on the hash alone).  Groups are numbered by ascending representative and list their
+// members ascending as before: members are scattered in arrival order and every group of several members is sorted
+// (two members: a swap; up to 32: by its thread; up to 8192: by a workgroup in LDS; a list with a larger group takes
+// the sort-based path).
+#define SG_GROUP_EMPTY 0xFFFFFFFFu
+#define SG_GROUP_SORT_LDS 8192
+__global__ void __launch_bounds__(256) group_insert_kernel(const uint64_t *__restrict__ hash, int64_t n_rows, uint32_t *table,
+                                                           uint32_t mask, uint32_t *__restrict__ slot_of_row) {
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_rows) return;
+    const uint64_t h = hash[r];
+    uint32_t s = (uint32_t)(h ^ (h >> 29)) & mask;
+    for (;;) {
+        uint32_t cur = __hip_atomic_load(&table[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (cur == SG_GROUP_EMPTY) {
+            cur = atomicCAS(&table[s], SG_GROUP_EMPTY, (uint32_t)r);
+            if (cur == SG_GROUP_EMPTY) break;                 // the slot is this hash's now
+        }
+        if (hash[cur] == h) {                                 // (whoever holds the slot has the slot's hash)
+            atomicMin(&table[s], (uint32_t)r);
+            break;
+        }
+        s = (s + 1u) & mask;
+    }
+    slot_of_row[r] = s;
+}
+
+// rep_of_row[r] = the lowest row with r's content (r itself when it is that row, or when its hash's slot names a row of
+// other content); is_rep[r] = 1 for representatives.  Sixteen lanes per row.
+template <typename T>
+__global__ void __launch_bounds__(256) group_verify_kernel(const int64_t *__restrict__ indptr, const int32_t *__restrict__ indices,
+                                                           const T *__restrict__ data, int64_t n_rows,
+                                                           const uint32_t *__restrict__ table, const uint32_t *__restrict__ slot_of_row,
+                                                           uint32_t *__restrict__ rep_of_row, uint32_t *__restrict__ is_rep) {
+    const int64_t r = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+    const int sub = threadIdx.x & 15;
+    if (r >= n_rows) return;
+    const int64_t rep = table[slot_of_row[r]];
+    bool same = true;
+    if (rep != r) {
+        const int64_t la = indptr[r], lb = indptr[rep];
+        const int64_t n = indptr[r + 1] - la;
+        same = n == indptr[rep + 1] - lb;
+        if (same)
+            for (int64_t e = sub; e < n; e += 16) same = same && indices[la + e] == indices[lb + e] && data[la + e] == data[lb + e];
+#pragma unroll
+        for (int d = 8; d > 0; d >>= 1) same = same && (__shfl_xor((int)same, d, 64) != 0);
+    }
+    if (sub == 0) {
+        const bool own = rep == r || !same;
+        rep_of_row[r] = own ? (uint32_t)r : (uint32_t)rep;
+        is_rep[r] = own ? 1u : 0u;
+    }
+}
+
+// members in arrival order (a group of one needs no ticket)
+__global__ void __launch_bounds__(256) group_scatter_kernel(const uint32_t *__restrict__ gid, const uint32_t *__restrict__ group_ptr,
+                                                            int64_t n_rows, uint32_t *cursor, uint32_t *__restrict__ members) {
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_rows) return;
+    const uint32_t g = gid[r];
+    const uint32_t lo = group_ptr[g], m = group_ptr[g + 1] - lo;
+    members[lo + (m == 1u ? 0u : atomicAdd(&cursor[g], 1u))] = (uint32_t)r;
+}
+
+// a thread per group: members ascending.  Groups of more than 32 are queued for the workgroup sort; words[0] = queue
+// length, words[1] = largest group.
+__global__ void __launch_bounds__(256) group_sort_small_kernel(const uint32_t *__restrict__ group_ptr, int64_t n_u, uint32_t *members,
+                                                               uint32_t *words, uint32_t *__restrict__ queue) {
+    const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= n_u) return;
+    const uint32_t lo = group_ptr[g], m = group_ptr[g + 1] - lo;
+    if (m < 2u) return;
+    if (m == 2u) {
+        const uint32_t a = members[lo], b = members[lo + 1];
+        if (a > b) {
+            members[lo] = b;
+            members[lo + 1] = a;
+        }
+        return;
+    }
+    if (m > 32u) {
+        atomicMax(&words[1], m);
+        if (m <= (uint32_t)SG_GROUP_SORT_LDS) queue[atomicAdd(&words[0], 1u)] = (uint32_t)g;
+        return;
+    }
+    for (uint32_t i = 1; i < m; ++i) {           // insertion sort in place (the segment is this thread's alone)
+        const uint32_t v = members[lo + i];
+        uint32_t j = i;
+        while (j > 0 && members[lo + j - 1] > v) {
+            members[lo + j] = members[lo + j - 1];
+            --j;
+        }
+        members[lo + j] = v;
+    }
+}
+
+// a workgroup per queued group: bitonic sort in LDS
+__global__ void __launch_bounds__(256) group_sort_lds_kernel(const uint32_t *__restrict__ group_ptr, uint32_t *members,
+                                                             const uint32_t *__restrict__ words, const uint32_t *__restrict__ queue) {
+    __shared__ uint32_t buf[SG_GROUP_SORT_LDS];
+    const uint32_t n_q = words[0];
+    for (uint32_t q = blockIdx.x; q < n_q; q += gridDim.x) {
+        const uint32_t g = queue[q];
+        const uint32_t lo = group_ptr[g], m = group_ptr[g + 1] - lo;
+        uint32_t P = 64;
+        while (P < m) P <<= 1;
+        for (uint32_t i = threadIdx.x; i < P; i += blockDim.x) buf[i] = i < m ? members[lo + i] : 0xFFFFFFFFu;
+        __syncthreads();
+        for (uint32_t k = 2; k <= P; k <<= 1)
+            for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+                for (uint32_t i = threadIdx.x; i < P; i += blockDim.x) {
+                    const uint32_t x = i ^ j;
+                    if (x > i) {
+                        const uint32_t a = buf[i], b = buf[x];
+                        const bool up = (i & k) == 0;
+                        if ((a > b) == up) {
+                            buf[i] = b;
+                            buf[x] = a;
+                        }
+                    }
+                }
+                __syncthreads();
+            }
+        for (uint32_t i = threadIdx.x; i < m; i += blockDim.x) members[lo + i] = buf[i];
+        __syncthreads();
     }
 }
 
@@ -152,6 +291,8 @@ void sg_collapse_free(SgCollapse *c) {
     delete c;
 }
 
+static int collapse_groups(sg_ctx *ctx, const sg_csr *B, bool forced, bool by_table, SgCollapse **out);
+
 // *out stays null when collapsing is off, not worth it (fewer than 3 % repeats) or not possible.
 // left_side: the groups are those of a LEFT matrix of a one-sided product (sg_spgemm_topn): its own switch
 // (SG_COLLAPSE_LEFT=0 off, =1 from two rows on) and a higher bar by default -- the grouping is paid by the multiply that
@@ -169,19 +310,45 @@ int sg_collapse_build(sg_ctx *ctx, const sg_csr *B, SgCollapse **out, bool left_
         min_rows = 65536;
     }
     if (!forced && B->n_rows < min_rows) return SG_OK;
+    const bool want_table = !(ctx->opt("SG_GROUP_SORT") && ctx->opt("SG_GROUP_SORT")[0] == '1');   // (=1: the sort-based path)
+    int st = collapse_groups(ctx, B, forced, want_table, out);
+    if (st == SG_OK && *out == nullptr && want_table && ctx->group_table_overflow) {
+        // a group of more than SG_GROUP_SORT_LDS members (a hub of identical names): the sort-based path lists any group
+        ctx->group_table_overflow = false;
+        st = collapse_groups(ctx, B, forced, false, out);
+    }
+    return st;
+}
+
+// One of the two ways to the groups; *out stays null when grouping is not worth it (or, table path, when a group is too
+// large for it: ctx->group_table_overflow says so).
+static int collapse_groups(sg_ctx *ctx, const sg_csr *B, bool forced, bool by_table, SgCollapse **out) {
+    *out = nullptr;
+    ctx->group_table_overflow = false;
     const int64_t n = B->n_rows;
     uint64_t *hash = nullptr, *hash_sorted = nullptr;
     uint32_t *row_id = nullptr, *row_sorted = nullptr, *head = nullptr, *run_excl = nullptr, *head_pos = nullptr;
     uint32_t *rep_of_row = nullptr, *rank_of_row = nullptr, *is_rep = nullptr, *rep_excl = nullptr, *size = nullptr;
-    uint32_t *totals = nullptr;
+    uint32_t *totals = nullptr, *table = nullptr, *slot_of_row = nullptr, *cursor = nullptr, *queue = nullptr;
     SgCollapse *c = nullptr;
+    uint64_t table_size = 0;
     int st = sg_alloc(ctx, (size_t)n + 1, &hash);
-    if (st == SG_OK) st = sg_alloc(ctx, (size_t)n + 1, &hash_sorted);
-    if (st == SG_OK) st = sg_alloc(ctx, (size_t)n + 1, &row_id);
-    if (st == SG_OK) st = sg_alloc(ctx, (size_t)n + 1, &row_sorted);
-    if (st == SG_OK) st = sg_alloc(ctx, (size_t)n + 1, &head);
-    if (st == SG_OK) st = sg_alloc(ctx, (size_t)n + 1, &run_excl);
-    if (st == SG_OK) st = sg_alloc(ctx, (size_t)4, &totals);
+    if (st == SG_OK) st = sg_alloc(ctx, (size_t)8, &totals);
+    if (by_table) {
+        table_size = 1024;
+        while (table_size < 2 * (uint64_t)n) table_size <<= 1;
+        if (st == SG_OK) st = sg_alloc(ctx, (size_t)table_size, &table);
+        if (st == SG_OK) st = sg_alloc(ctx, (size_t)n + 1, &slot_of_row);
+        if (st == SG_OK) st = sg_alloc(ctx, (size_t)n + 1, &rep_of_row);
+        if (st == SG_OK) st = sg_alloc(ctx, (size_t)n + 1, &is_rep);
+        if (st == SG_OK) st = sg_alloc(ctx, (size_t)n + 1, &rep_excl);
+    } else {
+        if (st == SG_OK) st = sg_alloc(ctx, (size_t)n + 1, &hash_sorted);
+        if (st == SG_OK) st = sg_alloc(ctx, (size_t)n + 1, &row_id);
+        if (st == SG_OK) st = sg_alloc(ctx, (size_t)n + 1, &row_sorted);
+        if (st == SG_OK) st = sg_alloc(ctx, (size_t)n + 1, &head);
+        if (st == SG_OK) st = sg_alloc(ctx, (size_t)n + 1, &run_excl);
+    }
     auto cleanup = [&]() {
         ctx->release(hash);
         ctx->release(hash_sorted);
@@ -196,25 +363,41 @@ int sg_collapse_build(sg_ctx *ctx, const sg_csr *B, SgCollapse **out, bool left_
         ctx->release(rep_excl);
         ctx->release(size);
         ctx->release(totals);
+        ctx->release(table);
+        ctx->release(slot_of_row);
+        ctx->release(cursor);
+        ctx->release(queue);
     };
     const unsigned g1 = (unsigned)((n + 255) / 256), g16 = (unsigned)((n * 16 + 255) / 256);
     if (st == SG_OK) {
         if (B->dtype == SG_F64)
             hipLaunchKernelGGL(row_hash_kernel<double>, dim3(g16), dim3(256), 0, ctx->stream, B->d_indptr, B->d_indices,
-                               (const double *)B->d_data, n, hash, row_id);
+                               (const double *)B->d_data, n, hash, row_id, table, table_size);
         else
             hipLaunchKernelGGL(row_hash_kernel<float>, dim3(g16), dim3(256), 0, ctx->stream, B->d_indptr, B->d_indices,
-                               (const float *)B->d_data, n, hash, row_id);
-        st = sg_sort_pairs_u64_u32(ctx, hash, row_id, n, hash_sorted, row_sorted);
+                               (const float *)B->d_data, n, hash, row_id, table, table_size);
     }
-    if (st == SG_OK) {
+    if (st == SG_OK && by_table) {
+        hipLaunchKernelGGL(group_insert_kernel, dim3(g1), dim3(256), 0, ctx->stream, (const uint64_t *)hash, n, table,
+                           (uint32_t)(table_size - 1), slot_of_row);
         if (B->dtype == SG_F64)
-            hipLaunchKernelGGL(group_heads_kernel<double>, dim3(g1), dim3(256), 0, ctx->stream, B->d_indptr, B->d_indices,
-                               (const double *)B->d_data, n, (const uint64_t *)hash_sorted, (const uint32_t *)row_sorted, head);
+            hipLaunchKernelGGL(group_verify_kernel<double>, dim3(g16), dim3(256), 0, ctx->stream, B->d_indptr, B->d_indices,
+                               (const double *)B->d_data, n, (const uint32_t *)table, (const uint32_t *)slot_of_row, rep_of_row, is_rep);
         else
-            hipLaunchKernelGGL(group_heads_kernel<float>, dim3(g1), dim3(256), 0, ctx->stream, B->d_indptr, B->d_indices,
-                               (const float *)B->d_data, n, (const uint64_t *)hash_sorted, (const uint32_t *)row_sorted, head);
-        st = sg_exclusive_scan_u32(ctx, head, run_excl, n, totals);   // totals[0] = number of groups
+            hipLaunchKernelGGL(group_verify_kernel<float>, dim3(g16), dim3(256), 0, ctx->stream, B->d_indptr, B->d_indices,
+                               (const float *)B->d_data, n, (const uint32_t *)table, (const uint32_t *)slot_of_row, rep_of_row, is_rep);
+        st = sg_exclusive_scan_u32(ctx, is_rep, rep_excl, n, totals);   // totals[0] = number of groups
+    } else if (st == SG_OK) {
+        st = sg_sort_pairs_u64_u32(ctx, hash, row_id, n, hash_sorted, row_sorted);
+        if (st == SG_OK) {
+            if (B->dtype == SG_F64)
+                hipLaunchKernelGGL(group_heads_kernel<double>, dim3(g1), dim3(256), 0, ctx->stream, B->d_indptr, B->d_indices,
+                                   (const double *)B->d_data, n, (const uint64_t *)hash_sorted, (const uint32_t *)row_sorted, head);
+            else
+                hipLaunchKernelGGL(group_heads_kernel<float>, dim3(g1), dim3(256), 0, ctx->stream, B->d_indptr, B->d_indices,
+                                   (const float *)B->d_data, n, (const uint64_t *)hash_sorted, (const uint32_t *)row_sorted, head);
+            st = sg_exclusive_scan_u32(ctx, head, run_excl, n, totals);   // totals[0] = number of groups
+        }
     }
     uint32_t n_groups = 0;
     if (st == SG_OK) {
@@ -235,31 +418,48 @@ int sg_collapse_build(sg_ctx *ctx, const sg_csr *B, SgCollapse **out, bool left_
     c->ctx = ctx;
     c->n_orig = n;
     c->n_u = n_u;
-    st = sg_alloc(ctx, (size_t)n_u + 1, &head_pos);
-    if (st == SG_OK) st = sg_alloc(ctx, (size_t)n + 1, &rep_of_row);
-    if (st == SG_OK) st = sg_alloc(ctx, (size_t)n + 1, &rank_of_row);
-    if (st == SG_OK) st = sg_alloc(ctx, (size_t)n + 1, &is_rep);
-    if (st == SG_OK) st = sg_alloc(ctx, (size_t)n + 1, &rep_excl);
-    if (st == SG_OK) st = sg_alloc(ctx, (size_t)n_u + 1, &size);
+    st = sg_alloc(ctx, (size_t)n_u + 1, &size);
     if (st == SG_OK) st = sg_alloc(ctx, (size_t)n + 1, &c->d_gid);
     if (st == SG_OK) st = sg_alloc(ctx, (size_t)n_u + 2, &c->d_group_ptr);
     if (st == SG_OK) st = sg_alloc(ctx, (size_t)n + 1, &c->d_members);
     if (st == SG_OK) st = sg_alloc(ctx, (size_t)n_u + 1, &c->d_rep_rows);
-    if (st == SG_OK) st = SG_ZERO2(ctx, is_rep, sizeof(uint32_t) * (size_t)(n + 1), size, sizeof(uint32_t) * (size_t)(n_u + 1));
-    if (st == SG_OK) {
-        hipLaunchKernelGGL(head_pos_kernel, dim3(g1), dim3(256), 0, ctx->stream, (const uint32_t *)head, (const uint32_t *)run_excl, n,
-                           head_pos);
-        hipLaunchKernelGGL(group_members_kernel, dim3(g1), dim3(256), 0, ctx->stream, (const uint32_t *)head,
-                           (const uint32_t *)run_excl, (const uint32_t *)head_pos, (const uint32_t *)row_sorted, n, rep_of_row,
-                           rank_of_row, is_rep);
-        st = sg_exclusive_scan_u32(ctx, is_rep, rep_excl, n, nullptr);
+    if (by_table) {
+        if (st == SG_OK) st = sg_alloc(ctx, (size_t)n_u + 1, &cursor);
+        if (st == SG_OK) st = sg_alloc(ctx, (size_t)n_u + 1, &queue);
+        if (st == SG_OK)
+            st = SG_ZERO3(ctx, size, sizeof(uint32_t) * (size_t)(n_u + 1), cursor, sizeof(uint32_t) * (size_t)(n_u + 1), totals + 4,
+                          4 * sizeof(uint32_t));
+    } else {
+        if (st == SG_OK) st = sg_alloc(ctx, (size_t)n_u + 1, &head_pos);
+        if (st == SG_OK) st = sg_alloc(ctx, (size_t)n + 1, &rep_of_row);
+        if (st == SG_OK) st = sg_alloc(ctx, (size_t)n + 1, &rank_of_row);
+        if (st == SG_OK) st = sg_alloc(ctx, (size_t)n + 1, &is_rep);
+        if (st == SG_OK) st = sg_alloc(ctx, (size_t)n + 1, &rep_excl);
+        if (st == SG_OK) st = SG_ZERO2(ctx, is_rep, sizeof(uint32_t) * (size_t)(n + 1), size, sizeof(uint32_t) * (size_t)(n_u + 1));
+        if (st == SG_OK) {
+            hipLaunchKernelGGL(head_pos_kernel, dim3(g1), dim3(256), 0, ctx->stream, (const uint32_t *)head, (const uint32_t *)run_excl, n,
+                               head_pos);
+            hipLaunchKernelGGL(group_members_kernel, dim3(g1), dim3(256), 0, ctx->stream, (const uint32_t *)head,
+                               (const uint32_t *)run_excl, (const uint32_t *)head_pos, (const uint32_t *)row_sorted, n, rep_of_row,
+                               rank_of_row, is_rep);
+            st = sg_exclusive_scan_u32(ctx, is_rep, rep_excl, n, nullptr);
+        }
     }
     if (st == SG_OK) {
         hipLaunchKernelGGL(group_ids_kernel, dim3(g1), dim3(256), 0, ctx->stream, (const uint32_t *)rep_of_row,
                            (const uint32_t *)rep_excl, (const uint32_t *)is_rep, n, c->d_gid, size, c->d_rep_rows);
         st = sg_exclusive_scan_u32(ctx, size, c->d_group_ptr, n_u, c->d_group_ptr + n_u);
     }
-    if (st == SG_OK) {
+    if (st == SG_OK && by_table) {
+        const unsigned gu1 = (unsigned)((n_u + 255) / 256);
+        hipLaunchKernelGGL(group_scatter_kernel, dim3(g1), dim3(256), 0, ctx->stream, (const uint32_t *)c->d_gid,
+                           (const uint32_t *)c->d_group_ptr, n, cursor, c->d_members);
+        hipLaunchKernelGGL(group_sort_small_kernel, dim3(gu1), dim3(256), 0, ctx->stream, (const uint32_t *)c->d_group_ptr, n_u,
+                           c->d_members, totals + 4, queue);
+        hipLaunchKernelGGL(group_sort_lds_kernel, dim3(512), dim3(256), 0, ctx->stream, (const uint32_t *)c->d_group_ptr, c->d_members,
+                           (const uint32_t *)(totals + 4), (const uint32_t *)queue);
+        if (hipGetLastError() != hipSuccess) st = SG_ERR_HIP;
+    } else if (st == SG_OK) {
         hipLaunchKernelGGL(group_fill_kernel, dim3(g1), dim3(256), 0, ctx->stream, (const uint32_t *)c->d_gid,
                            (const uint32_t *)rank_of_row, (const uint32_t *)c->d_group_ptr, n, c->d_members);
         if (hipGetLastError() != hipSuccess) st = SG_ERR_HIP;
@@ -289,9 +489,22 @@ int sg_collapse_build(sg_ctx *ctx, const sg_csr *B, SgCollapse **out, bool left_
         else
             hipLaunchKernelGGL(unique_rows_kernel<float>, dim3(gu), dim3(256), 0, ctx->stream, B->d_indptr, B->d_indices,
                                (const float *)B->d_data, (const uint32_t *)c->d_rep_rows, n_u, (const int64_t *)ptr, idx, (float *)val);
+        uint32_t h_words[4] = {0, 0, 0, 0};      // table path: [0] groups queued for the LDS sort, [1] the largest group
         if (hipMemcpyAsync(&nnz_u, ptr + n_u, 8, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+            (by_table && hipMemcpyAsync(h_words, totals + 4, 16, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) ||
             hipStreamSynchronize(ctx->stream) != hipSuccess)
             st = SG_ERR_HIP;
+        if (st == SG_OK && by_table && h_words[1] > (uint32_t)SG_GROUP_SORT_LDS) {
+            // a group too large for the workgroup sort: its members are not in order -- the caller takes the sort-based path
+            ctx->group_table_overflow = true;
+            ctx->release(len);
+            ctx->release(ptr);
+            ctx->release(idx);
+            ctx->release(val);
+            cleanup();
+            sg_collapse_free(c);
+            return SG_OK;
+        }
     }
     ctx->release(len);
     cleanup();

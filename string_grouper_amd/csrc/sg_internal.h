@@ -83,6 +83,7 @@ struct sg_ctx {
     unsigned long long *d_scan_desc = nullptr;
     size_t scan_desc_cap = 0;
     uint32_t scan_ticket_base = 0, scan_epoch = 0;
+    bool group_table_overflow = false;           // sg_collapse.hip: the table path met a group too large for it
 
     int alloc(size_t bytes, void **out);         // pooled hipMalloc
     void release(void *p);                       // back to the pool
