@@ -132,6 +132,14 @@ int sg_vocab_byte_alphabet(const sg_vocab *v, uint8_t *byte_of_code /* 128 */, i
 /* idf is computed by the caller from df (numpy, sklearn's exact op sequence text.py:1664-1679,
  * so that log() is bit-identical) and installed here; dtype must match params.dtype. */
 int sg_vocab_set_idf(sg_ctx *ctx, sg_vocab *v, const void *idf, int32_t dtype);
+/* The same without the round trip (round 4).  idf of a term depends on its document count and the number of documents
+ * only -- idf = f(df; n_docs) -- so the caller hands the library, ONCE per (n_docs, dtype), the table f(0 .. n_docs) made
+ * with its own numpy (n_docs + 1 values; sg_ctx_put_idf_table, kept by the context, a handful of them), and every later fit
+ * over as many documents weights its terms on the device: idf[column] = table[df[column]] (sg_vocab_apply_idf_table;
+ * *applied == 0: the context has no table for this vocabulary's n_docs and dtype -- put one, or use sg_vocab_set_idf).
+ * A fit() then needs neither sg_vocab_to_host nor an upload; keys and counts still come to the host when asked for. */
+int sg_ctx_put_idf_table(sg_ctx *ctx, int64_t n_docs, int32_t dtype, const void *table);
+int sg_vocab_apply_idf_table(sg_ctx *ctx, sg_vocab *v, int32_t *applied);
 int sg_vocab_free(sg_vocab *v);
 /* TfidfVectorizer.transform(strings): counts -> *idf -> row L2 normalise, CSR with sorted indices. */
 int sg_vec_transform(sg_ctx *ctx, const sg_vocab *v, const sg_strings *strings, sg_csr **out);

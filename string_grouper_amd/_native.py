@@ -63,6 +63,8 @@ ABI = {
     "sg_vocab_to_host": (C.c_int, [_P, _P, _P, _P]),
     "sg_vocab_byte_alphabet": (C.c_int, [_P, _P, C.POINTER(C.c_int32)]),
     "sg_vocab_set_idf": (C.c_int, [_P, _P, _P, C.c_int32]),
+    "sg_ctx_put_idf_table": (C.c_int, [_P, C.c_int64, C.c_int32, _P]),
+    "sg_vocab_apply_idf_table": (C.c_int, [_P, _P, C.POINTER(C.c_int32)]),
     "sg_vocab_free": (C.c_int, [_P]),
     "sg_vec_transform": (C.c_int, [_P, _P, _P, _PP]),
     "sg_csr_from_host": (C.c_int, [_P, C.c_int64, C.c_int64, _P, _P, _P, C.c_int32, _PP]),
@@ -442,6 +444,19 @@ class Context:
     def vocab_set_idf(self, v: Vocab, idf: np.ndarray):
         idf = np.ascontiguousarray(idf)
         check(lib().sg_vocab_set_idf(self.h, v.h, _ptr(idf), np_dtype_code(idf.dtype)))
+
+    def put_idf_table(self, n_docs: int, table: np.ndarray) -> None:
+        """idf as a function of the document count, table[df] for df = 0 .. n_docs, made by the caller's numpy; the context
+        keeps it for the fits over n_docs documents that follow (sg_ctx_put_idf_table)."""
+        table = np.ascontiguousarray(table)
+        assert table.shape == (n_docs + 1,)
+        check(lib().sg_ctx_put_idf_table(self.h, int(n_docs), np_dtype_code(table.dtype), _ptr(table)))
+
+    def vocab_apply_idf_table(self, v: Vocab) -> bool:
+        """idf[column] = table[df[column]] on the device; False: no table for this vocabulary's size and dtype yet."""
+        ok = C.c_int32()
+        check(lib().sg_vocab_apply_idf_table(self.h, v.h, C.byref(ok)))
+        return bool(ok.value)
 
     def vec_transform(self, v: Vocab, s: Strings) -> Csr:
         out = C.c_void_p()

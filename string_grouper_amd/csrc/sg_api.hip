@@ -187,6 +187,7 @@ extern "C" int sg_ctx_destroy(sg_ctx *ctx) {
     }
     (void)hipFree(ctx->d_stat_words);
     (void)hipFree(ctx->d_scan_desc);
+    for (auto &t : ctx->idf_tables) (void)hipFree(t.d);
     (void)hipHostFree(ctx->h_stat_words);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;

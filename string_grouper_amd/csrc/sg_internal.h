@@ -83,6 +83,12 @@ struct sg_ctx {
     unsigned long long *d_scan_desc = nullptr;
     size_t scan_desc_cap = 0;
     uint32_t scan_ticket_base = 0, scan_epoch = 0;
+    struct IdfTable {                            // sg_ctx_put_idf_table: idf as a function of the document count
+        int64_t n_docs;
+        int32_t dtype;
+        void *d;
+    };
+    std::vector<IdfTable> idf_tables;
     bool group_table_overflow = false;           // sg_collapse.hip: the table path met a group too large for it
 
     int alloc(size_t bytes, void **out);         // pooled hipMalloc
@@ -135,6 +141,7 @@ struct sg_csr {
     mutable int props_state = 0;
     mutable float props_max_norm2 = 0.f;
     mutable uint32_t props_max_nnz = 0;  // longest row
+    mutable bool props_by_construction = false;   // the two above are the vectoriser's guarantees, not measurements
     // a matrix made by the vectoriser is cosine-like by construction; K2 leaves [0] violations (= 0), [1] max ||row||^2 as
     // float bits, [2] longest row here and sg_csr_props reads them instead of scanning the matrix again (owned)
     uint32_t *d_props_words = nullptr;

@@ -688,14 +688,19 @@ extern "C" int sg_postings_build_flags(sg_ctx *ctx, const sg_csr *B_in, int32_t 
             uint32_t max_nnz = 0;
             bool cl = false;
             float n2 = 0.f;
-            st = sg_csr_props(ctx, B, &cl, &n2, &max_nnz);
+            const bool want_blk = ctx->opt("SG_ROW_BLOCKS") && ctx->opt("SG_ROW_BLOCKS")[0] == '1';
+            if (want_blk) {
+                // the longest row is measured only for this (a vectoriser-made matrix, and what is derived from it, is known
+                // to be cosine-like without a look: sg_csr_props)
+                if (B->props_max_nnz == 0 && !B->d_props_words) B->props_state = 0;
+                st = sg_csr_props(ctx, B, &cl, &n2, &max_nnz);
+            }
             const size_t es = B->dtype == SG_F64 ? 16 : 8;
             const size_t need = (((size_t)max_nnz + 1) * es + 127) / 128 * 128;
             // Opt-in (SG_ROW_BLOCKS=1): the blocks cut the memory-side traffic of the multiply by a fifth (57.9 -> 43 GB per
             // launch at 663 k) but not its time -- the kernel is not bound by bytes -- and their scorer's extra loop
             // trips cost 0.3 - 0.7 ms (9.76 ms packed / 10.08 ms with 64-byte units / 10.50 ms with 32-byte units:
             // profiles/r03_row_blocks_ab.log); the index build pays 0.11 ms for them.
-            const bool want_blk = ctx->opt("SG_ROW_BLOCKS") && ctx->opt("SG_ROW_BLOCKS")[0] == '1';
             if (st == SG_OK && want_blk && need <= 1024 && (double)need * (double)B->n_rows < 3.5e9 &&
                 (ctx->total_mem == 0 || need * (size_t)B->n_rows < ctx->total_mem / 8)) {
                 p->blk_bytes = (uint32_t)need;

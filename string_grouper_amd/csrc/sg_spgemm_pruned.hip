@@ -1387,7 +1387,18 @@ __global__ void __launch_bounds__(256) csr_props_kernel(const int64_t *__restric
 }
 
 int sg_csr_props(sg_ctx *ctx, const sg_csr *m, bool *cosine_like, float *max_norm2, uint32_t *max_nnz) {
-    if (m->props_state == 0) {
+    // A matrix made by the vectoriser (K2) is cosine-like BY CONSTRUCTION -- counts times positive weights, columns in key
+    // order, every row divided by its norm -- and its largest squared row norm is 1 up to the rounding of the division
+    // (two roundings per entry: <= 1 + 3 * 2^-24 in fp32): nothing has to come back from the device for that (round 4:
+    // the read-back was one of the step's ten synchronisations).  Only the longest row is not known this way; the one
+    // caller that wants it (the opt-in row blocks, SG_ROW_BLOCKS=1) still reads the words K2 leaves.
+    if (m->props_state == 0 && m->d_props_words && max_nnz == nullptr) {
+        m->props_max_norm2 = 1.000001f;
+        m->props_max_nnz = 0;
+        m->props_state = 1;
+        m->props_by_construction = true;
+    }
+    if (m->props_state == 0 || (max_nnz != nullptr && m->props_by_construction && m->props_max_nnz == 0 && m->d_props_words)) {
         uint32_t *d = nullptr;
         SG_TRY(sg_alloc(ctx, (size_t)4, &d));
         uint32_t h[4] = {0, 0, 0, 0};
@@ -1413,7 +1424,7 @@ int sg_csr_props(sg_ctx *ctx, const sg_csr *m, bool *cosine_like, float *max_nor
         }
         float n2;
         memcpy(&n2, &h[1], 4);
-        m->props_max_norm2 = n2;
+        if (!m->props_by_construction) m->props_max_norm2 = n2;     // (a bound already in use stays: the index may be built on it)
         m->props_max_nnz = h[2];
         m->props_state = (h[0] == 0 && n2 <= 1.0001f) ? 1 : 2;
     }

@@ -758,8 +758,7 @@ static bool pruned_applicable(sg_ctx *ctx, const sg_csr *A, const sg_postings *B
     if (*delta < 0.02) *delta = 0.02;
     bool a_ok = false;
     float a_n2 = 0.f;
-    uint32_t a_max_nnz = 0;
-    *status = sg_csr_props(ctx, A, &a_ok, &a_n2, &a_max_nnz);
+    *status = sg_csr_props(ctx, A, &a_ok, &a_n2, nullptr);     // (the longest row is not asked for: it alone needs a look)
     if (*status != SG_OK || !a_ok) return false;
     // self-join (A is the matrix the postings were built from): score every pair once, from the row with the larger
     // index (sg_spgemm_pruned.hip, symmetric mode; rows the pruned kernel cannot take go through the exact kernel's

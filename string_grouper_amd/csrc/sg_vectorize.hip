@@ -62,7 +62,9 @@ struct TokenCache {             // tokenised strings in the padded layout
     const sg_strings *src = nullptr;
     int64_t n = 0;
     int64_t cap_total = 0;
-    int64_t *d_ub_ptr = nullptr;   // n + 1: start of row i's slots
+    const int64_t *d_ub_ptr = nullptr;   // n + 1: row i's slots start at d_ub_ptr[i] - d_ub_ptr[0] -- round 4: the strings' own offsets
+                                         // (borrowed): a row of L characters holds at most L n-grams, and the arrays below are
+                                         // sized by the characters anyway; rounds 1-3 counted L - n + 1 per row and scanned
     int32_t *d_cnt = nullptr;      // n: distinct n-grams of row i
     void *d_keys = nullptr;        // cap_total keys (uint32 in dense mode, uint64 in sorted mode)
     int32_t *d_tf = nullptr;       // cap_total
@@ -319,7 +321,7 @@ __global__ void __launch_bounds__(64 * TOK_SHORT_WAVES) tokenize_short_kernel(
         const int nrow = (int)min((int64_t)BLK, n_rows - r0);
         // lane l <= nrow: the l-th offset of the block; lane l < nrow: the slot of its l-th string
         const int64_t m_off = lane <= nrow ? offsets[r0 + lane] : 0;
-        const int64_t m_ub = lane < nrow ? ub_ptr[r0 + lane] : 0;
+        const int64_t m_ub = lane < nrow ? ub_ptr[r0 + lane] - ub_ptr[0] : 0;
         int64_t b0A = read_lane_i64(m_off, 0), b1A = read_lane_i64(m_off, 1);
         uint32_t rawA = load_raw(b0A, b1A), rawB = 0;
         for (int i = 0; i < BLK; i += 2) {   // (BLK even; strings past the block's end have no characters and no row)
@@ -447,7 +449,7 @@ __global__ void __launch_bounds__(64) tokenize_kernel(const void *__restrict__ c
         }
         if (lane == 0) starts[uniq] = (uint16_t)g;
         wave_sync();
-        const int64_t obase = ub_ptr[row];
+        const int64_t obase = ub_ptr[row] - ub_ptr[0];
         for (int u = lane; u < uniq; u += 64) {
             const int s0 = starts[u];
             const KeyT key = keys[s0];
@@ -534,7 +536,7 @@ __global__ void __launch_bounds__(256) tokenize_long_kernel(const void *__restri
         }
     }
     // ---- run-length encode into the string's slots (block-wide, 256 keys per step)
-    const int64_t obase = ub_ptr[row];
+    const int64_t obase = ub_ptr[row] - ub_ptr[0];
     __syncthreads();
     if (tid == 0) carry = 0;   // distinct keys so far
     __syncthreads();
@@ -616,7 +618,7 @@ __global__ void __launch_bounds__(1024) df_count_lds_kernel(const int64_t *__res
     if (r1 > n_rows) r1 = n_rows;
     const int sub = threadIdx.x & 15;
     for (int64_t row = r0 + (threadIdx.x >> 4); row < r1; row += blockDim.x >> 4) {
-        const int64_t b = ub_ptr[row];
+        const int64_t b = ub_ptr[row] - ub_ptr[0];
         const int c = cnt[row];
         for (int q = sub; q < c; q += 16) {
             const uint32_t key = keys[b + q];
@@ -667,7 +669,7 @@ __global__ void __launch_bounds__(256) kept_count_kernel(const int64_t *__restri
                                                          int32_t *kept) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const int64_t b = ub_ptr[i];
+    const int64_t b = ub_ptr[i] - ub_ptr[0];
     const int c = cnt[i];
     int k = 0;
     for (int q = 0; q < c; ++q) k += lookup(keys[b + q]) >= 0;
@@ -680,7 +682,7 @@ __global__ void __launch_bounds__(256) gather_keys_kernel(const int64_t *__restr
                                                           int64_t n, uint64_t *__restrict__ dst) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const int64_t b = ub_ptr[i], d = dst_ptr[i];
+    const int64_t b = ub_ptr[i] - ub_ptr[0], d = dst_ptr[i];
     const int c = cnt[i];
     for (int q = 0; q < c; ++q) dst[d + q] = keys[b + q];
 }
@@ -705,7 +707,7 @@ __global__ void __launch_bounds__(256) weight_normalize_kernel(const int64_t *__
     float n2 = 0.f;
     uint32_t len = 0;
     if (i < n) {
-        const int64_t b = ub_ptr[i];
+        const int64_t b = ub_ptr[i] - ub_ptr[0];
         const int c = cnt[i];
         int64_t o = indptr[i];
         const int64_t o0 = o;
@@ -779,7 +781,7 @@ __global__ void __launch_bounds__(256) weight_normalize_rows16_kernel(const int6
     const int lane = threadIdx.x & 63, sub = lane & 15, grp_shift = lane & 48;
     const int64_t row = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
     const bool valid = row < n;
-    const int64_t b = valid ? ub_ptr[row] : 0;
+    const int64_t b = valid ? ub_ptr[row] - ub_ptr[0] : 0;
     const int c = valid ? cnt[row] : 0;
     const int64_t o0 = valid ? indptr[row] : 0;
     int cmax = c;   // the wave walks its four rows together
@@ -847,7 +849,6 @@ __global__ void __launch_bounds__(256) weight_normalize_rows16_kernel(const int6
 
 // -------------------------------------------------------------------------------------------------
 static void free_cache(sg_ctx *ctx, TokenCache &c) {
-    ctx->release(c.d_ub_ptr);
     ctx->release(c.d_cnt);
     ctx->release(c.d_keys);
     ctx->release(c.d_tf);
@@ -874,22 +875,12 @@ static int tokenize_set_t(sg_ctx *ctx, const sg_strings *s, const TokParams &tp,
     TokenCache c;
     c.src = s;
     c.n = s->n;
-    int32_t *ub = nullptr;
     uint32_t *longs = nullptr;   // [0] count, then the rows
     uint32_t *mids = nullptr;    // the same for the rows of more than 64 characters
-    int st = sg_alloc(ctx, (size_t)s->n + 1, &ub);
-    if (st == SG_OK) st = sg_alloc(ctx, (size_t)s->n + 1, &c.d_ub_ptr);
-    if (st == SG_OK) st = sg_alloc(ctx, (size_t)s->n + 1, &c.d_cnt);
+    int st = sg_alloc(ctx, (size_t)s->n + 1, &c.d_cnt);
     if (st == SG_OK) st = sg_alloc(ctx, (size_t)s->n + 2, &longs);
     if (st == SG_OK) st = sg_alloc(ctx, (size_t)s->n + 2, &mids);
-    if (st == SG_OK && s->n > 0) {
-        hipLaunchKernelGGL(ub_count_kernel, dim3((unsigned)((s->n + 255) / 256)), dim3(256), 0, ctx->stream,
-                           s->d_offsets, s->n, tp.ngram, ub);
-        st = sg_exclusive_scan_i32_to_i64(ctx, ub, c.d_ub_ptr, s->n);
-    } else if (st == SG_OK) {
-        if (hipMemsetAsync(c.d_ub_ptr, 0, sizeof(int64_t), ctx->stream) != hipSuccess) st = SG_ERR_HIP;
-    }
-    ctx->release(ub);
+    c.d_ub_ptr = s->d_offsets;   // (no count, no scan: see TokenCache)
     // every row of L characters has at most L - n + 1 n-grams, so the total length bounds the padded size
     c.cap_total = s->total_bytes + 1;
     KeyT *keys = nullptr;
@@ -1354,6 +1345,67 @@ extern "C" int sg_vocab_set_idf(sg_ctx *ctx, sg_vocab *v, const void *idf, int32
     if (!v->d_idf) SG_TRY(ctx->alloc(((size_t)v->n_terms + 1) * s, &v->d_idf));
     SG_HIP_TRY(hipMemcpyAsync(v->d_idf, idf, s * (size_t)v->n_terms, hipMemcpyHostToDevice, ctx->stream));
     SG_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return SG_OK;
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) idf_from_table_kernel(const int32_t *__restrict__ df, int64_t n_terms, const T *__restrict__ table,
+                                                             int64_t n_docs, T *__restrict__ idf) {
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n_terms) return;
+    int64_t d = df[k];
+    if (d < 0) d = 0;
+    if (d > n_docs) d = n_docs;
+    idf[k] = table[d];
+}
+
+extern "C" int sg_ctx_put_idf_table(sg_ctx *ctx, int64_t n_docs, int32_t dtype, const void *table) {
+    SG_REQUIRE(ctx && table && n_docs >= 0, "null argument");
+    SG_REQUIRE(dtype == SG_F32 || dtype == SG_F64, "dtype must be SG_F32 or SG_F64");
+    const size_t bytes = ((size_t)n_docs + 1) * (dtype == SG_F64 ? 8 : 4);
+    void *d = nullptr;
+    SG_HIP_TRY(hipMalloc(&d, bytes));
+    if (hipMemcpyAsync(d, table, bytes, hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
+        hipStreamSynchronize(ctx->stream) != hipSuccess) {
+        (void)hipFree(d);
+        sg_set_error("upload of the idf table failed");
+        return SG_ERR_HIP;
+    }
+    for (auto &t : ctx->idf_tables)
+        if (t.n_docs == n_docs && t.dtype == dtype) {      // replaced (scans in flight are behind the synchronisation above)
+            (void)hipFree(t.d);
+            t.d = d;
+            return SG_OK;
+        }
+    if (ctx->idf_tables.size() >= 4) {                      // the oldest goes
+        (void)hipFree(ctx->idf_tables.front().d);
+        ctx->idf_tables.erase(ctx->idf_tables.begin());
+    }
+    ctx->idf_tables.push_back({n_docs, dtype, d});
+    return SG_OK;
+}
+
+extern "C" int sg_vocab_apply_idf_table(sg_ctx *ctx, sg_vocab *v, int32_t *applied) {
+    SG_REQUIRE(ctx && v && applied, "null argument");
+    *applied = 0;
+    SG_REQUIRE(v->d_df != nullptr || v->n_terms == 0, "the vocabulary has no document counts (fit first)");
+    const void *table = nullptr;
+    for (const auto &t : ctx->idf_tables)
+        if (t.n_docs == v->n_docs && t.dtype == v->params.dtype) table = t.d;
+    if (!table) return SG_OK;
+    const size_t s = v->params.dtype == SG_F64 ? 8 : 4;
+    if (!v->d_idf) SG_TRY(ctx->alloc(((size_t)v->n_terms + 1) * s, &v->d_idf));
+    if (v->n_terms > 0) {
+        const unsigned grid = (unsigned)((v->n_terms + 255) / 256);
+        if (v->params.dtype == SG_F64)
+            hipLaunchKernelGGL(idf_from_table_kernel<double>, dim3(grid), dim3(256), 0, ctx->stream, (const int32_t *)v->d_df, v->n_terms,
+                               (const double *)table, v->n_docs, (double *)v->d_idf);
+        else
+            hipLaunchKernelGGL(idf_from_table_kernel<float>, dim3(grid), dim3(256), 0, ctx->stream, (const int32_t *)v->d_df, v->n_terms,
+                               (const float *)table, v->n_docs, (float *)v->d_idf);
+        SG_HIP_TRY(hipGetLastError());
+    }
+    *applied = 1;
     return SG_OK;
 }
 

@@ -72,7 +72,8 @@ class HipTfidfVectorizer:
         self._fit_sets: List[StringColumn] = []
         self._keys = None
         self._df = None
-        self.idf_ = None
+        self._idf = None
+        self._n_docs = 0
         self._vocabulary: Optional[Dict[str, int]] = None
         self._alphabet: Optional[np.ndarray] = None        # symbol fits: sorted code points, rank = symbol
         # a regex that is not a character class is applied on the host (strprep): nothing left for the device to delete
@@ -151,13 +152,43 @@ class HipTfidfVectorizer:
         self._fit_originals = list(sets)
         self._dev_of = {id(s): d for s, d in zip(sets, dev_sets)}
 
+    # the idf of a term is a function of its document count and the number of documents only: for fits of up to this many
+    # documents the function is tabulated once per (documents, dtype) -- with numpy, so that log() stays sklearn's --, kept
+    # on the device, and a fit() weights its terms there: no download of the counts, no upload of the weights, no
+    # synchronisation (include/sg_hip.h: sg_ctx_put_idf_table).  Larger fits take the round trip (the table would be
+    # as large as the strings).
+    IDF_TABLE_MAX_DOCS = 4_000_000
+
     def _finish_fit(self) -> "HipTfidfVectorizer":
         n_terms, n_docs = self.ctx.vocab_size(self._vocab)
-        self._keys, self._df = self.ctx.vocab_to_host(self._vocab)
-        self.idf_ = idf_from_df(self._df, n_docs, self.dtype)
-        self.ctx.vocab_set_idf(self._vocab, self.idf_)
+        self._n_docs = n_docs
+        self._keys = self._df = self._idf = None
         self._vocabulary = None
+        if n_docs <= self.IDF_TABLE_MAX_DOCS:
+            if not self.ctx.vocab_apply_idf_table(self._vocab):
+                self.ctx.put_idf_table(n_docs, idf_from_df(np.arange(n_docs + 1, dtype=np.int64), n_docs, self.dtype))
+                if not self.ctx.vocab_apply_idf_table(self._vocab):
+                    raise RuntimeError("the idf table that was just installed is not there")
+            return self
+        self._fetch_vocabulary()
+        self._idf = idf_from_df(self._df, n_docs, self.dtype)
+        self.ctx.vocab_set_idf(self._vocab, self._idf)
         return self
+
+    def _fetch_vocabulary(self) -> None:
+        """Keys and document counts of the fitted vocabulary on the host (downloaded when first asked for)."""
+        if self._keys is None:
+            if self._vocab is None:
+                raise AttributeError("available after fit()")
+            self._keys, self._df = self.ctx.vocab_to_host(self._vocab)
+
+    @property
+    def idf_(self) -> np.ndarray:
+        """sklearn's attribute: the inverse document frequency of every column (computed as sklearn computes it)."""
+        if getattr(self, "_idf", None) is None:
+            self._fetch_vocabulary()
+            self._idf = idf_from_df(self._df, self._n_docs, self.dtype)
+        return self._idf
 
     # ---- the two halves of fit for a caller that shards the strings over several GPUs (distributed.py)
     def fit_begin_prepared(self, sets: Sequence[StringColumn]) -> "HipTfidfVectorizer":
@@ -208,6 +239,7 @@ class HipTfidfVectorizer:
         return self.fit_prepared([p]).transform_prepared(p).to_scipy()      # one tokenisation pass
 
     def _terms(self) -> List[str]:
+        self._fetch_vocabulary()
         bits, symbols, _ = self.ctx.vocab_coding(self._vocab)
         alphabet = self._alphabet if symbols else self.ctx.vocab_byte_alphabet(self._vocab)
         return keys_to_terms(self._keys, self.ngram_size, bits, alphabet)
@@ -215,7 +247,7 @@ class HipTfidfVectorizer:
     @property
     def vocabulary_(self) -> Dict[str, int]:
         if self._vocabulary is None:
-            if self._keys is None:
+            if self._vocab is None:
                 raise AttributeError("vocabulary_ is available after fit()")
             self._vocabulary = {t: i for i, t in enumerate(self._terms())}
         return self._vocabulary
