@@ -669,7 +669,8 @@ int sg_collapse_expand(sg_ctx *ctx, const SgCollapse *c, const sg_topn *ru, bool
     if (n_out <= 0) return SG_OK;
     uint32_t *slow = nullptr;
     SG_TRY(sg_alloc(ctx, (size_t)n_out + 4, &slow));
-    int st = hipMemsetAsync(slow, 0, 16, ctx->stream) == hipSuccess ? SG_OK : SG_ERR_HIP;
+    // (the output's counts and the slow-row queue's head in one launch; the callers do not clear the counts themselves)
+    int st = SG_ZERO2(ctx, out->d_counts, sizeof(int32_t) * (size_t)(n_out + 1), slow, 16);
     if (st == SG_OK) {
         const unsigned g1 = (unsigned)((n_out + 255) / 256);
         const uint32_t *gid = rows_are_groups ? c->d_gid : nullptr;

@@ -141,6 +141,7 @@ struct sg_csr {
     mutable int props_state = 0;
     mutable float props_max_norm2 = 0.f;
     mutable uint32_t props_max_nnz = 0;  // longest row
+    bool from_vectoriser = false;        // made by sg_vec_transform (K2): cosine-like by construction (sg_csr_props)
     mutable bool props_by_construction = false;   // the two above are the vectoriser's guarantees, not measurements
     // a matrix made by the vectoriser is cosine-like by construction; K2 leaves [0] violations (= 0), [1] max ||row||^2 as
     // float bits, [2] longest row here and sg_csr_props reads them instead of scanning the matrix again (owned)

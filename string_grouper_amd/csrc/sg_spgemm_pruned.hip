@@ -1197,6 +1197,18 @@ spgemm_topn_pruned_kernel(const int64_t *__restrict__ a_indptr, const int32_t *_
 // Symmetric mode, second pass: the pair list (i, j < i, s) -> for every row j the list of the rows i > j that match it
 // -> merged with the row's own top list (its matches <= j, written by pass 1) -> top-n.
 // (one workgroup per chunk of the pair list, one thread per entry)
+// The statistics of the pass that counted ([0..2] rows / postings / pairs of pass 1, [3] rows that went through the exact
+// kernel) copied into the context's words by the FIRST thread of a kernel of the second pass (two device-to-device
+// copies of a few bytes were two launches of their own).
+__device__ __forceinline__ void publish_pass_stats(const unsigned long long *src, const uint32_t *word, unsigned long long *dst) {
+    if (dst != nullptr && blockIdx.x == 0 && threadIdx.x == 0) {
+        dst[0] = src[0];
+        dst[1] = src[1];
+        dst[2] = src[2];
+        reinterpret_cast<uint32_t *>(dst + 3)[0] = *word;
+    }
+}
+
 template <typename T>
 __global__ void __launch_bounds__(SG_PAIR_CHUNK) pairs_fill_kernel(const uint32_t *__restrict__ pi, const uint32_t *__restrict__ pj,
                                                                    const T *__restrict__ ps, const uint32_t *__restrict__ chunk_count,
@@ -1216,8 +1228,11 @@ __global__ void __launch_bounds__(SG_PAIR_CHUNK) pairs_fill_kernel(const uint32_
 template <typename T>
 __global__ void __launch_bounds__(SG_PAIR_CHUNK) pairs_export_kernel(const uint32_t *__restrict__ pi, const uint32_t *__restrict__ pj,
                                                                      const T *__restrict__ ps, const uint32_t *__restrict__ chunk_count,
-                                                                     const uint32_t *__restrict__ chunk_start, int32_t *__restrict__ out) {
+                                                                     const uint32_t *__restrict__ chunk_start, int32_t *__restrict__ out,
+                                                                     const unsigned long long *st_src, const uint32_t *st_word,
+                                                                     unsigned long long *st_dst) {
     constexpr int W = sizeof(T) == 8 ? 4 : 3;
+    publish_pass_stats(st_src, st_word, st_dst);
     if (threadIdx.x >= chunk_count[blockIdx.x]) return;
     const size_t p = (size_t)blockIdx.x * SG_PAIR_CHUNK + threadIdx.x;
     int32_t *o = out + ((size_t)chunk_start[blockIdx.x] + threadIdx.x) * W;
@@ -1269,8 +1284,11 @@ template <typename T>
 __global__ void __launch_bounds__(64) pairs_select_kernel(const uint32_t *__restrict__ ptr, const int32_t *__restrict__ lcol,
                                                           const T *__restrict__ lval, uint32_t n_rows, int32_t keep,
                                                           int32_t out_stride, int32_t *__restrict__ out_cols,
-                                                          T *__restrict__ out_vals, int32_t *__restrict__ out_cnt) {
+                                                          T *__restrict__ out_vals, int32_t *__restrict__ out_cnt,
+                                                          const unsigned long long *st_src, const uint32_t *st_word,
+                                                          unsigned long long *st_dst) {
     const int lane = threadIdx.x;
+    publish_pass_stats(st_src, st_word, st_dst);
     // The 64 rows a wave looks at are n_groups apart, not neighbours: on a sorted list the rows with long mirrored lists
     // (hubs of near-identical names) ARE neighbours, and a wave that owned 64 of them in a row worked through them one
     // after the other while the others idled (4.9 ms instead of 0.25 at 663 k sorted names).
@@ -1392,13 +1410,13 @@ int sg_csr_props(sg_ctx *ctx, const sg_csr *m, bool *cosine_like, float *max_nor
     // (two roundings per entry: <= 1 + 3 * 2^-24 in fp32): nothing has to come back from the device for that (round 4:
     // the read-back was one of the step's ten synchronisations).  Only the longest row is not known this way; the one
     // caller that wants it (the opt-in row blocks, SG_ROW_BLOCKS=1) still reads the words K2 leaves.
-    if (m->props_state == 0 && m->d_props_words && max_nnz == nullptr) {
+    if (m->props_state == 0 && m->from_vectoriser && max_nnz == nullptr) {
         m->props_max_norm2 = 1.000001f;
         m->props_max_nnz = 0;
         m->props_state = 1;
         m->props_by_construction = true;
     }
-    if (m->props_state == 0 || (max_nnz != nullptr && m->props_by_construction && m->props_max_nnz == 0 && m->d_props_words)) {
+    if (m->props_state == 0 || (max_nnz != nullptr && m->props_by_construction && m->props_max_nnz == 0)) {
         uint32_t *d = nullptr;
         SG_TRY(sg_alloc(ctx, (size_t)4, &d));
         uint32_t h[4] = {0, 0, 0, 0};
@@ -1755,16 +1773,17 @@ int sg_spgemm_pruned_symmetric(sg_ctx *ctx, const sg_csr *A, const sg_postings *
         if (st == SG_OK && chunks_used > 0) {
             if (A->dtype == SG_F64)
                 hipLaunchKernelGGL(pairs_export_kernel<double>, pgrid, dim3(SG_PAIR_CHUNK), 0, ctx->stream, pl.d_i, pl.d_j,
-                                   (const double *)pl.d_s, pl.d_chunk_count, chunk_start, flat);
+                                   (const double *)pl.d_s, pl.d_chunk_count, chunk_start, flat,
+                                   (const unsigned long long *)d_stats3, (const uint32_t *)(words + 1), stats);
             else
                 hipLaunchKernelGGL(pairs_export_kernel<float>, pgrid, dim3(SG_PAIR_CHUNK), 0, ctx->stream, pl.d_i, pl.d_j,
-                                   (const float *)pl.d_s, pl.d_chunk_count, chunk_start, flat);
+                                   (const float *)pl.d_s, pl.d_chunk_count, chunk_start, flat,
+                                   (const unsigned long long *)d_stats3, (const uint32_t *)(words + 1), stats);
             if (hipGetLastError() != hipSuccess) st = SG_ERR_HIP;
-        }
-        if (st == SG_OK && (hipMemcpyAsync(stats, d_stats3, 3 * sizeof(unsigned long long), hipMemcpyDeviceToDevice,
-                                           ctx->stream) != hipSuccess ||
-                            hipMemcpyAsync(stats + 3, words + 1, 4, hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess))
-            st = SG_ERR_HIP;
+        } else if (st == SG_OK && (hipMemcpyAsync(stats, d_stats3, 3 * sizeof(unsigned long long), hipMemcpyDeviceToDevice,
+                                                  ctx->stream) != hipSuccess ||
+                                   hipMemcpyAsync(stats + 3, words + 1, 4, hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess))
+            st = SG_ERR_HIP;   // (no pairs, no export kernel: the statistics go by copy)
         ctx->release(chunk_start);
         ctx->release(d_stats3);
         cleanup();
@@ -1788,19 +1807,16 @@ int sg_spgemm_pruned_symmetric(sg_ctx *ctx, const sg_csr *A, const sg_postings *
             hipLaunchKernelGGL(pairs_fill_kernel<double>, pgrid, dim3(SG_PAIR_CHUNK), 0, ctx->stream, pl.d_i, pl.d_j,
                                (const double *)pl.d_s, pl.d_chunk_count, cnt, cursor, lcol, (double *)lval);
             hipLaunchKernelGGL(pairs_select_kernel<double>, dim3(sgrid), dim3(64), 0, ctx->stream, cnt, lcol, (const double *)lval,
-                               (uint32_t)n, keep, r->stride, r->d_cols, (double *)r->d_vals, r->d_counts);
+                               (uint32_t)n, keep, r->stride, r->d_cols, (double *)r->d_vals, r->d_counts,
+                               (const unsigned long long *)d_stats3, (const uint32_t *)(words + 1), stats);
         } else {
             hipLaunchKernelGGL(pairs_fill_kernel<float>, pgrid, dim3(SG_PAIR_CHUNK), 0, ctx->stream, pl.d_i, pl.d_j,
                                (const float *)pl.d_s, pl.d_chunk_count, cnt, cursor, lcol, (float *)lval);
             hipLaunchKernelGGL(pairs_select_kernel<float>, dim3(sgrid), dim3(64), 0, ctx->stream, cnt, lcol, (const float *)lval,
-                               (uint32_t)n, keep, r->stride, r->d_cols, (float *)r->d_vals, r->d_counts);
+                               (uint32_t)n, keep, r->stride, r->d_cols, (float *)r->d_vals, r->d_counts,
+                               (const unsigned long long *)d_stats3, (const uint32_t *)(words + 1), stats);
         }
-        if (hipGetLastError() != hipSuccess) st = SG_ERR_HIP;
-        // the statistics of the pass that counted ([3]: rows that went through the exact kernel)
-        if (st == SG_OK && (hipMemcpyAsync(stats, d_stats3, 3 * sizeof(unsigned long long), hipMemcpyDeviceToDevice,
-                                           ctx->stream) != hipSuccess ||
-                            hipMemcpyAsync(stats + 3, words + 1, 4, hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess))
-            st = SG_ERR_HIP;
+        if (hipGetLastError() != hipSuccess) st = SG_ERR_HIP;   // (pairs_select also publishes the pass's statistics)
     }
     ctx->release(d_stats3);
     cleanup();
@@ -1843,13 +1859,15 @@ int sg_selfjoin_merge_pairs(sg_ctx *ctx, sg_topn *r, const int32_t *d_pairs, int
                                    (uint32_t)row_lo, (uint32_t)row_hi, step, pos_of, cnt, cursor, lcol, (double *)lval);
                 hipLaunchKernelGGL(pairs_select_kernel<double>, dim3(sgrid), dim3(64), 0, ctx->stream, cnt, lcol,
                                    (const double *)lval, (uint32_t)n, r->stride, r->stride, r->d_cols, (double *)r->d_vals,
-                                   r->d_counts);
+                                   r->d_counts, (const unsigned long long *)nullptr, (const uint32_t *)nullptr,
+                                   (unsigned long long *)nullptr);
             } else {
                 hipLaunchKernelGGL(pairs_flat_fill_kernel<float>, dim3(pg), dim3(256), 0, ctx->stream, d_pairs, n_pairs,
                                    (uint32_t)row_lo, (uint32_t)row_hi, step, pos_of, cnt, cursor, lcol, (float *)lval);
                 hipLaunchKernelGGL(pairs_select_kernel<float>, dim3(sgrid), dim3(64), 0, ctx->stream, cnt, lcol,
                                    (const float *)lval, (uint32_t)n, r->stride, r->stride, r->d_cols, (float *)r->d_vals,
-                                   r->d_counts);
+                                   r->d_counts, (const unsigned long long *)nullptr, (const uint32_t *)nullptr,
+                                   (unsigned long long *)nullptr);
             }
             if (hipGetLastError() != hipSuccess) st = SG_ERR_HIP;
         }

@@ -798,8 +798,7 @@ static int spgemm_topn_collapsed(sg_ctx *ctx, const sg_csr *A, const sg_postings
     int st = topn_alloc(ctx, A->n_rows, c->n_orig, (int32_t)stride64, A->dtype, &r);
     if (st == SG_OK) {
         SgTimer timer(ctx, SG_K_ZIP);    // the expansion is a merge by column, like the zip of column blocks
-        if (hipMemsetAsync(r->d_counts, 0, sizeof(int32_t) * (size_t)(A->n_rows + 1), ctx->stream) != hipSuccess) st = SG_ERR_HIP;
-        if (st == SG_OK) st = sg_collapse_expand(ctx, c, ru, self, r);
+        st = sg_collapse_expand(ctx, c, ru, self, r);   // (clears r's counts itself)
         if (st == SG_OK && !sort && A->n_rows > 0) {
             const unsigned g2 = (unsigned)(A->n_rows < 65535 * 16 ? A->n_rows : 65535 * 16);
             const size_t l2 = (size_t)r->stride * (4 + (A->dtype == SG_F64 ? 8 : 4));
@@ -1006,7 +1005,7 @@ extern "C" int sg_spgemm_topn(sg_ctx *ctx, const sg_csr *A, const sg_postings *B
         SgTimer timer(ctx, SG_K_SPGEMM);
         st = SG_OK;
         st = SG_ZERO3(ctx, counters, sizeof(uint32_t) * n_words, r->d_counts, sizeof(int32_t) * (size_t)A->n_rows,
-                      ctx->d_stat_words + 2, 4 * sizeof(int64_t));
+                      ctx->d_stat_words, 6 * sizeof(int64_t));   // ([0], [1]: written by the counting kernels at the end)
         bool sym_done = false;
         if (symmetric && st == SG_OK)
             st = sg_spgemm_pruned_symmetric(ctx, A, Bt, stride, r, threshold, delta,
@@ -1076,7 +1075,6 @@ extern "C" int sg_spgemm_topn(sg_ctx *ctx, const sg_csr *A, const sg_postings *B
     }
     // measurement words: MACs and kept entries of this multiply
     if (st == SG_OK) {
-        (void)hipMemsetAsync(ctx->d_stat_words, 0, 2 * sizeof(int64_t), ctx->stream);
         const bool own = A->n_rows == Bt->n_right && A->d_indptr == Bt->b_indptr && A->d_indices == Bt->b_indices &&
                          A->d_data == Bt->b_data;
         if (A->nnz > 0 && own)      // (10 M gathers less per multiply: 54 -> 3 us at 663 k)
@@ -1215,8 +1213,7 @@ extern "C" int sg_topn_expand_groups(sg_ctx *ctx, const sg_postings *Bt, const s
     int st = SG_OK;
     {
         SgTimer timer(ctx, SG_K_ZIP);
-        if (hipMemsetAsync(r->d_counts, 0, sizeof(int32_t) * (size_t)(n_rows + 1), ctx->stream) != hipSuccess) st = SG_ERR_HIP;
-        if (st == SG_OK) st = sg_collapse_expand(ctx, c, groups, true, r, d_rows);
+        st = sg_collapse_expand(ctx, c, groups, true, r, d_rows);   // (clears r's counts itself)
     }
     if (st != SG_OK) {
         sg_topn_free(r);

@@ -68,6 +68,8 @@ struct TokenCache {             // tokenised strings in the padded layout
     int32_t *d_cnt = nullptr;      // n: distinct n-grams of row i
     void *d_keys = nullptr;        // cap_total keys (uint32 in dense mode, uint64 in sorted mode)
     int32_t *d_tf = nullptr;       // cap_total
+    uint32_t *d_longs = nullptr;   // [0] how many strings are still to be tokenised by the workgroup-per-string kernel, then
+                                   // their rows: kept while that question is open (tokenize_set_t, defer_longs)
 };
 
 struct VocabImpl {
@@ -76,6 +78,7 @@ struct VocabImpl {
     uint8_t byte_of_rank[128];
     int32_t *d_df_table = nullptr; // dense mode: key_space counters, or marks (df_marks)
     bool df_marks = false;         // the table only marks the keys that occur; df is counted per column at fit_end
+    int64_t df_stride = 0;         // entries of one copy of the table
     bool local_alphabet = false;   // byte columns coded by rank among the bytes seen at fit() (7 * ngram_size > 24)
     bool symbols = false;          // the fit's columns are symbol columns (sg_strings_from_host_symbols)
     int32_t alphabet = 0;          // their alphabet size
@@ -849,6 +852,8 @@ __global__ void __launch_bounds__(256) weight_normalize_rows16_kernel(const int6
 
 // -------------------------------------------------------------------------------------------------
 static void free_cache(sg_ctx *ctx, TokenCache &c) {
+    ctx->release(c.d_longs);
+    c.d_longs = nullptr;
     ctx->release(c.d_cnt);
     ctx->release(c.d_keys);
     ctx->release(c.d_tf);
@@ -867,18 +872,79 @@ static TokParams make_tok_params(const sg_vocab *v, const VocabImpl *im, const s
     return tp;
 }
 
+// The strings of more than TOK_CAP n-grams that the wave-per-string kernels queued (c.d_longs): a workgroup per string, after
+// one host round trip for their sizes.
+template <typename KeyT, bool SYMBOLS>
+static int tokenize_longs_t(sg_ctx *ctx, const sg_strings *s, const TokParams &tp, int32_t *df_table, int32_t df_replicas,
+                            int64_t df_stride, TokenCache &c, uint32_t n_long) {
+    if (n_long == 0) return SG_OK;
+    uint32_t *longs = c.d_longs;
+    KeyT *keys = (KeyT *)c.d_keys;
+    // sizes of the long strings -> scratch offsets (characters: the length; keys: the next power of two)
+    int64_t *d_sizes = nullptr, *d_coff = nullptr, *d_koff = nullptr;
+    std::vector<int64_t> sizes(n_long), coff(n_long + 1, 0), koff(n_long + 1, 0);
+    int st = sg_alloc(ctx, (size_t)n_long, &d_sizes);
+    if (st == SG_OK) st = sg_alloc(ctx, (size_t)n_long + 1, &d_coff);
+    if (st == SG_OK) st = sg_alloc(ctx, (size_t)n_long + 1, &d_koff);
+    hipError_t e = hipSuccess;
+    if (st == SG_OK) {
+        hipLaunchKernelGGL(long_sizes_kernel, dim3((n_long + 255) / 256), dim3(256), 0, ctx->stream, s->d_offsets,
+                           (const uint32_t *)(longs + 1), n_long, d_sizes);
+        e = hipMemcpyAsync(sizes.data(), d_sizes, sizeof(int64_t) * n_long, hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    }
+    uint16_t *lchars = nullptr;
+    KeyT *lkeys = nullptr;
+    if (st == SG_OK && e == hipSuccess) {
+        for (uint32_t i = 0; i < n_long; ++i) {
+            int64_t p2 = 64;
+            while (p2 < sizes[i]) p2 <<= 1;
+            coff[i + 1] = coff[i] + sizes[i] + 8;
+            koff[i + 1] = koff[i] + p2;
+        }
+        st = sg_alloc(ctx, (size_t)coff[n_long] + 8, &lchars);
+        if (st == SG_OK) st = sg_alloc(ctx, (size_t)koff[n_long] + 8, &lkeys);
+        if (st == SG_OK) {
+            e = hipMemcpyAsync(d_coff, coff.data(), sizeof(int64_t) * (n_long + 1), hipMemcpyHostToDevice, ctx->stream);
+            if (e == hipSuccess)
+                e = hipMemcpyAsync(d_koff, koff.data(), sizeof(int64_t) * (n_long + 1), hipMemcpyHostToDevice, ctx->stream);
+            if (e == hipSuccess) {
+                hipLaunchKernelGGL((tokenize_long_kernel<KeyT, SYMBOLS>), dim3(n_long), dim3(256), 0, ctx->stream,
+                                   (const void *)s->d_bytes, s->d_offsets, tp, (const uint32_t *)(longs + 1),
+                                   (const int64_t *)d_coff, (const int64_t *)d_koff, lchars, lkeys,
+                                   (const int64_t *)c.d_ub_ptr, c.d_cnt, keys, c.d_tf, df_table, df_replicas, df_stride);
+                e = hipGetLastError();
+            }
+            if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);   // coff / koff are locals
+        }
+    }
+    ctx->release(d_sizes);
+    ctx->release(d_coff);
+    ctx->release(d_koff);
+    ctx->release(lchars);
+    ctx->release(lkeys);
+    if (st == SG_OK && e != hipSuccess) {
+        sg_set_error("tokenize_long_kernel: %s", hipGetErrorString(e));
+        st = SG_ERR_HIP;
+    }
+    return st;
+}
+
 // K1 over one string column: the one-wave-per-string kernel, then the workgroup-per-string kernel for the strings it
 // handed over (one small host round trip: how many there are and how long they are).
+// defer_longs (round 4): do NOT ask how many strings the last stage has to take -- the answer is "none" for any list of
+// names, and asking is a synchronisation per column and fit.  The caller asks together with its own next question
+// (sg_vec_fit_end: the size of the vocabulary) and tokenises the long strings then (resolve_longs), before anything
+// that depends on them is final.
 template <typename KeyT, bool SYMBOLS>
 static int tokenize_set_t(sg_ctx *ctx, const sg_strings *s, const TokParams &tp, int32_t *df_table, int32_t df_replicas,
-                          int64_t df_stride, TokenCache *out) {
+                          int64_t df_stride, TokenCache *out, bool defer_longs) {
     TokenCache c;
     c.src = s;
     c.n = s->n;
-    uint32_t *longs = nullptr;   // [0] count, then the rows
-    uint32_t *mids = nullptr;    // the same for the rows of more than 64 characters
+    uint32_t *mids = nullptr;    // [0] count, then the rows of more than 64 characters
     int st = sg_alloc(ctx, (size_t)s->n + 1, &c.d_cnt);
-    if (st == SG_OK) st = sg_alloc(ctx, (size_t)s->n + 2, &longs);
+    if (st == SG_OK) st = sg_alloc(ctx, (size_t)s->n + 2, &c.d_longs);
     if (st == SG_OK) st = sg_alloc(ctx, (size_t)s->n + 2, &mids);
     c.d_ub_ptr = s->d_offsets;   // (no count, no scan: see TokenCache)
     // every row of L characters has at most L - n + 1 n-grams, so the total length bounds the padded size
@@ -891,6 +957,7 @@ static int tokenize_set_t(sg_ctx *ctx, const sg_strings *s, const TokParams &tp,
     if (st == SG_OK && s->n > 0) {
         // strings of up to 64 characters: tokenize_short_kernel; what it queues (mids): tokenize_kernel, launched on the
         // device-side count; what that one queues (longs, > TOK_CAP n-grams): tokenize_long_kernel after one host round trip
+        uint32_t *longs = c.d_longs;
         hipError_t e = SG_ZERO2(ctx, longs, 4, mids, 4) == SG_OK ? hipSuccess : hipErrorUnknown;
         unsigned grid = (unsigned)ctx->num_cu * 8u;
         const int64_t wgs = (s->n + TOK_SHORT_WAVES - 1) / TOK_SHORT_WAVES;
@@ -904,63 +971,20 @@ static int tokenize_set_t(sg_ctx *ctx, const sg_strings *s, const TokParams &tp,
                            s->d_offsets, s->n, tp, (const int64_t *)c.d_ub_ptr, c.d_cnt, keys, c.d_tf, df_table, df_replicas,
                            df_stride, longs, longs + 1, (const uint32_t *)(mids + 1), (const uint32_t *)mids);
         if (e == hipSuccess) e = hipGetLastError();
-        if (e == hipSuccess) e = hipMemcpyAsync(&n_long, longs, 4, hipMemcpyDeviceToHost, ctx->stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e == hipSuccess && !defer_longs) {
+            e = hipMemcpyAsync(&n_long, longs, 4, hipMemcpyDeviceToHost, ctx->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        }
         if (e != hipSuccess) {
             sg_set_error("tokenize_kernel: %s", hipGetErrorString(e));
             st = SG_ERR_HIP;
         }
     }
-    if (st == SG_OK && n_long > 0) {
-        // sizes of the long strings -> scratch offsets (characters: the length; keys: the next power of two)
-        int64_t *d_sizes = nullptr, *d_coff = nullptr, *d_koff = nullptr;
-        std::vector<int64_t> sizes(n_long), coff(n_long + 1, 0), koff(n_long + 1, 0);
-        st = sg_alloc(ctx, (size_t)n_long, &d_sizes);
-        if (st == SG_OK) st = sg_alloc(ctx, (size_t)n_long + 1, &d_coff);
-        if (st == SG_OK) st = sg_alloc(ctx, (size_t)n_long + 1, &d_koff);
-        hipError_t e = hipSuccess;
-        if (st == SG_OK) {
-            hipLaunchKernelGGL(long_sizes_kernel, dim3((n_long + 255) / 256), dim3(256), 0, ctx->stream, s->d_offsets,
-                               (const uint32_t *)(longs + 1), n_long, d_sizes);
-            e = hipMemcpyAsync(sizes.data(), d_sizes, sizeof(int64_t) * n_long, hipMemcpyDeviceToHost, ctx->stream);
-            if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-        }
-        uint16_t *lchars = nullptr;
-        KeyT *lkeys = nullptr;
-        if (st == SG_OK && e == hipSuccess) {
-            for (uint32_t i = 0; i < n_long; ++i) {
-                int64_t p2 = 64;
-                while (p2 < sizes[i]) p2 <<= 1;
-                coff[i + 1] = coff[i] + sizes[i] + 8;
-                koff[i + 1] = koff[i] + p2;
-            }
-            st = sg_alloc(ctx, (size_t)coff[n_long] + 8, &lchars);
-            if (st == SG_OK) st = sg_alloc(ctx, (size_t)koff[n_long] + 8, &lkeys);
-            if (st == SG_OK) {
-                e = hipMemcpyAsync(d_coff, coff.data(), sizeof(int64_t) * (n_long + 1), hipMemcpyHostToDevice, ctx->stream);
-                if (e == hipSuccess)
-                    e = hipMemcpyAsync(d_koff, koff.data(), sizeof(int64_t) * (n_long + 1), hipMemcpyHostToDevice, ctx->stream);
-                if (e == hipSuccess) {
-                    hipLaunchKernelGGL((tokenize_long_kernel<KeyT, SYMBOLS>), dim3(n_long), dim3(256), 0, ctx->stream,
-                                       (const void *)s->d_bytes, s->d_offsets, tp, (const uint32_t *)(longs + 1),
-                                       (const int64_t *)d_coff, (const int64_t *)d_koff, lchars, lkeys,
-                                       (const int64_t *)c.d_ub_ptr, c.d_cnt, keys, c.d_tf, df_table, df_replicas, df_stride);
-                    e = hipGetLastError();
-                }
-                if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);   // coff / koff are locals
-            }
-        }
-        ctx->release(d_sizes);
-        ctx->release(d_coff);
-        ctx->release(d_koff);
-        ctx->release(lchars);
-        ctx->release(lkeys);
-        if (st == SG_OK && e != hipSuccess) {
-            sg_set_error("tokenize_long_kernel: %s", hipGetErrorString(e));
-            st = SG_ERR_HIP;
-        }
+    if (st == SG_OK && !defer_longs) {
+        st = tokenize_longs_t<KeyT, SYMBOLS>(ctx, s, tp, df_table, df_replicas, df_stride, c, n_long);
+        ctx->release(c.d_longs);
+        c.d_longs = nullptr;
     }
-    ctx->release(longs);
     ctx->release(mids);
     if (st != SG_OK) {
         free_cache(ctx, c);
@@ -971,14 +995,32 @@ static int tokenize_set_t(sg_ctx *ctx, const sg_strings *s, const TokParams &tp,
 }
 
 static int tokenize_set(sg_ctx *ctx, const sg_vocab *v, const sg_strings *s, int32_t *df_table, int32_t df_replicas,
-                        int64_t df_stride, TokenCache *out) {
+                        int64_t df_stride, TokenCache *out, bool defer_longs = false) {
     const TokParams tp = make_tok_params(v, v->impl, s);
     const bool sym = s->sym_width == 2;
     if (v->sorted_mode)
-        return sym ? tokenize_set_t<uint64_t, true>(ctx, s, tp, df_table, df_replicas, df_stride, out)
-                   : tokenize_set_t<uint64_t, false>(ctx, s, tp, df_table, df_replicas, df_stride, out);
-    return sym ? tokenize_set_t<uint32_t, true>(ctx, s, tp, df_table, df_replicas, df_stride, out)
-               : tokenize_set_t<uint32_t, false>(ctx, s, tp, df_table, df_replicas, df_stride, out);
+        return sym ? tokenize_set_t<uint64_t, true>(ctx, s, tp, df_table, df_replicas, df_stride, out, defer_longs)
+                   : tokenize_set_t<uint64_t, false>(ctx, s, tp, df_table, df_replicas, df_stride, out, defer_longs);
+    return sym ? tokenize_set_t<uint32_t, true>(ctx, s, tp, df_table, df_replicas, df_stride, out, defer_longs)
+               : tokenize_set_t<uint32_t, false>(ctx, s, tp, df_table, df_replicas, df_stride, out, defer_longs);
+}
+
+// the question tokenize_set_t(defer_longs) left open, answered: n_long strings of cache c go through the last stage
+static int resolve_longs(sg_ctx *ctx, const sg_vocab *v, TokenCache &c, int32_t *df_table, int32_t df_replicas, int64_t df_stride,
+                         uint32_t n_long) {
+    const sg_strings *s = c.src;
+    const TokParams tp = make_tok_params(v, v->impl, s);
+    const bool sym = s->sym_width == 2;
+    int st;
+    if (v->sorted_mode)
+        st = sym ? tokenize_longs_t<uint64_t, true>(ctx, s, tp, df_table, df_replicas, df_stride, c, n_long)
+                 : tokenize_longs_t<uint64_t, false>(ctx, s, tp, df_table, df_replicas, df_stride, c, n_long);
+    else
+        st = sym ? tokenize_longs_t<uint32_t, true>(ctx, s, tp, df_table, df_replicas, df_stride, c, n_long)
+                 : tokenize_longs_t<uint32_t, false>(ctx, s, tp, df_table, df_replicas, df_stride, c, n_long);
+    ctx->release(c.d_longs);
+    c.d_longs = nullptr;
+    return st;
 }
 
 // fit = begin (tokenise, count document frequencies) + end (vocabulary).  The two halves are separate entry points so
@@ -1097,7 +1139,9 @@ static int fit_begin(sg_ctx *ctx, const sg_strings *const *sets, int32_t n_sets,
         }
         for (int i = 0; i < n_sets && st == SG_OK; ++i) {
             TokenCache c;
-            st = tokenize_set(ctx, v, sets[i], im->d_df_table, replicas, df_stride, &c);
+            // (marks, dense table: the single-GPU fit, whose end asks for the long strings together with the vocabulary's size)
+            st = tokenize_set(ctx, v, sets[i], im->d_df_table, replicas, df_stride, &c, !v->sorted_mode && df_marks);
+            im->df_stride = df_stride;
             if (st == SG_OK) {
                 im->caches.push_back(c);
                 v->n_docs += sets[i]->n;
@@ -1257,12 +1301,31 @@ extern "C" int sg_vec_fit_end(sg_ctx *ctx, sg_vocab *v, int64_t n_docs_total) {
                                            v->key_space, d_total);
             }
             uint32_t n_terms = 0;
-            if (st == SG_OK) {
-                if (hipMemcpyAsync(&n_terms, d_total, 4, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
-                    hipStreamSynchronize(ctx->stream) != hipSuccess) {
-                    sg_set_error("reading the vocabulary size failed: %s", hipGetErrorString(hipGetLastError()));
+            for (int attempt = 0; attempt < 2 && st == SG_OK; ++attempt) {
+                // the size of the vocabulary and -- the question fit_begin left open -- whether any column holds strings for the
+                // last tokeniser stage: ONE synchronisation
+                std::vector<uint32_t> n_long(im->caches.size(), 0u);
+                hipError_t e = hipMemcpyAsync(&n_terms, d_total, 4, hipMemcpyDeviceToHost, ctx->stream);
+                for (size_t q = 0; q < im->caches.size() && e == hipSuccess; ++q)
+                    if (im->caches[q].d_longs) e = hipMemcpyAsync(&n_long[q], im->caches[q].d_longs, 4, hipMemcpyDeviceToHost, ctx->stream);
+                if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+                if (e != hipSuccess) {
+                    sg_set_error("reading the vocabulary size failed: %s", hipGetErrorString(e));
                     st = SG_ERR_HIP;
+                    break;
                 }
+                bool any_long = false;
+                for (size_t q = 0; q < im->caches.size() && st == SG_OK; ++q) {
+                    if (!im->caches[q].d_longs) continue;
+                    any_long = any_long || n_long[q] > 0;
+                    st = resolve_longs(ctx, v, im->caches[q], im->d_df_table, 0, im->df_stride, n_long[q]);   // (marks: replicas 0)
+                }
+                if (!any_long || st != SG_OK) break;
+                // long strings have marked keys of their own: the vocabulary is taken again
+                const unsigned grid = (unsigned)((v->key_space + 255) / 256);
+                hipLaunchKernelGGL(presence_kernel, dim3(grid), dim3(256), 0, ctx->stream, im->d_df_table, v->key_space,
+                                   (uint32_t *)v->d_key_to_col);
+                st = sg_exclusive_scan_u32(ctx, (const uint32_t *)v->d_key_to_col, (uint32_t *)v->d_key_to_col, v->key_space, d_total);
             }
             ctx->release(d_total);
             if (st == SG_OK) {
@@ -1510,8 +1573,13 @@ extern "C" int sg_vec_transform(sg_ctx *ctx, const sg_vocab *v, const sg_strings
         m->d_indices = idx;
         m->d_data = val;
         m->nnz = nnz;
-        if (st == SG_OK) st = sg_alloc(ctx, (size_t)4, &m->d_props_words);
-        if (st == SG_OK && hipMemsetAsync(m->d_props_words, 0, 16, ctx->stream) != hipSuccess) st = SG_ERR_HIP;
+        m->from_vectoriser = true;
+        // (K2 can leave the largest row norm and the longest row behind; nothing reads them unless the opt-in row blocks
+        //  are built -- the matrix is cosine-like by construction, sg_csr_props)
+        if (st == SG_OK && ctx->opt("SG_ROW_BLOCKS") && ctx->opt("SG_ROW_BLOCKS")[0] == '1') {
+            st = sg_alloc(ctx, (size_t)4, &m->d_props_words);
+            if (st == SG_OK && hipMemsetAsync(m->d_props_words, 0, 16, ctx->stream) != hipSuccess) st = SG_ERR_HIP;
+        }
         if (st == SG_OK && n > 0) {
             uint32_t *props = m->d_props_words;
             if (v->sorted_mode) {
