@@ -249,6 +249,8 @@ def run(args):
             one = float(tt.item())
         args.steps = int(max(5, min(2000, np.ceil(2.0 / max(one, 1e-4)))))
     barrier()
+    if distributed:
+        D.reset_collective_tally()
     t0 = time.perf_counter()
     k4_ms = []
     stats = None
@@ -262,6 +264,7 @@ def run(args):
         out_nnz = stats["out_nnz"]
     barrier()
     elapsed = time.perf_counter() - t0
+    coll_tally = {k: list(v) for k, v in D.COLLECTIVE_TALLY.items()} if distributed else None   # (the timed steps' own)
     index_rows = None
     if not distributed:
         index_rows = int(ctx.postings_rows(last._keep[1])[0])    # < rows: identical rows indexed once (include/sg_hip.h)
@@ -310,6 +313,9 @@ def run(args):
         "vs_baseline": None,
         "dtype": args.dtype,
         "backend": (backend if distributed else None),
+        # what rank 0's collectives moved per step: {kind: [calls, bytes received]} (string_grouper_amd/distributed.py)
+        "collectives_per_step": ({k: [v[0] / args.steps, v[1] / args.steps] for k, v in coll_tally.items()}
+                                 if distributed else None),
         "data": "synthetic (SynthNames-v1 seed 1234; sec__edgar names are not distributable)",
         "config": {"workload": f"{args.rows}-name self-join (BASELINE.json configs[2] on the synthetic stand-in)",
                    "ngram_size": 3, "max_n_matches": args.top_n, "min_similarity": args.min_similarity,

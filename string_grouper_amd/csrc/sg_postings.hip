@@ -311,7 +311,11 @@ __global__ void __launch_bounds__(1024) postings_fill_lds(const int64_t *__restr
 #pragma unroll
         for (int r = 0; r < SG_POST_ROWS; ++r) {
             fq[r] = 0;
+#if defined(SG_K3_PROBE_NO_FQ)
+            if (out_filt && n_rows < 0) {
+#else
             if (out_filt) {
+#endif
                 // norm of the row's frequent part, quantised upwards to 8 bits relative to norm_up (the order of the additions
                 // is free: the result is rounded up with a margin far above the rounding of a double sum)
                 double f2 = 0.0;
@@ -334,7 +338,14 @@ __global__ void __launch_bounds__(1024) postings_fill_lds(const int64_t *__restr
         for (int r = 0; r < SG_POST_ROWS; ++r) {
             const uint32_t col = (uint32_t)(jb + r - (t << tile_log2));
             if (k0[r] >= 0) {
+#if defined(SG_K3_PROBE_NO_ATOMIC)   // timing probes (wrong results): a build of the library per probe, A/B through SG_HIP_LIB
+                const uint32_t pos = cursor[k0[r]] + (uint32_t)(threadIdx.x & 3);
+#else
                 const uint32_t pos = atomicAdd(&cursor[k0[r]], 1u);
+#endif
+#if defined(SG_K3_PROBE_NO_STORE)
+                if (pos == 0xFFFFFFF0u)
+#endif
                 emit_posting<T>(out_rows, out_vals, out_filt, pos, col, v0[r], fq[r], tile_log2, inv_norm_up, (uint32_t)t, fold_log2);
             }
             for (int64_t p = lo[r] + sub + 16; p < hi[r]; p += 16) {

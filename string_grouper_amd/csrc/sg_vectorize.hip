@@ -68,6 +68,7 @@ struct TokenCache {             // tokenised strings in the padded layout
     int32_t *d_cnt = nullptr;      // n: distinct n-grams of row i
     void *d_keys = nullptr;        // cap_total keys (uint32 in dense mode, uint64 in sorted mode)
     int32_t *d_tf = nullptr;       // cap_total
+    bool keys_are_columns = false; // d_keys holds column ids instead of n-gram keys (dense mode, after the fit's df pass)
     uint32_t *d_longs = nullptr;   // [0] how many strings are still to be tokenised by the workgroup-per-string kernel, then
                                    // their rows: kept while that question is open (tokenize_set_t, defer_longs)
 };
@@ -608,10 +609,14 @@ __global__ void __launch_bounds__(256) vocab_finalize_kernel(const int32_t *__re
 // contiguous), counts the columns of its tokens in an LDS histogram over [col0, col0 + n_cols) and stores the histogram
 // as one row of `partial`; df_sum_kernel adds the rows up.
 __global__ void __launch_bounds__(1024) df_count_lds_kernel(const int64_t *__restrict__ ub_ptr, const int32_t *__restrict__ cnt,
-                                                            const uint32_t *__restrict__ keys,
+                                                            uint32_t *keys /* read; with cols_out also written */,
                                                             const int32_t *__restrict__ key_to_col, int64_t n_rows,
                                                             int32_t col0, int32_t n_cols, int64_t n_terms,
-                                                            uint32_t *__restrict__ partial) {
+                                                            uint32_t *__restrict__ partial,
+                                                            int32_t cols_out /* != 0: every key is REPLACED by its column (the pass
+                                                                                over all columns of a fit's own tokens): the weighting
+                                                                                kernel then has no table to gather from -- 12.5 M reads
+                                                                                scattered over an 8 MB table at 663 k were its cost */) {
     extern __shared__ uint32_t df_hist[];
     for (int k = threadIdx.x; k < n_cols; k += blockDim.x) df_hist[k] = 0;
     __syncthreads();
@@ -620,14 +625,38 @@ __global__ void __launch_bounds__(1024) df_count_lds_kernel(const int64_t *__res
     int64_t r1 = r0 + per_wg;
     if (r1 > n_rows) r1 = n_rows;
     const int sub = threadIdx.x & 15;
-    for (int64_t row = r0 + (threadIdx.x >> 4); row < r1; row += blockDim.x >> 4) {
-        const int64_t b = ub_ptr[row] - ub_ptr[0];
-        const int c = cnt[row];
-        for (int q = sub; q < c; q += 16) {
-            const uint32_t key = keys[b + q];
-            if (key == SG_KEY_OOV32) continue;
-            const int32_t col = key_to_col[key] - col0;
-            if (col >= 0 && col < n_cols) atomicAdd(&df_hist[col], 1u);
+    const int64_t groups = blockDim.x >> 4;
+    // four rows per sixteen lanes and trip, every load of a stage issued before the first is used (a workgroup's trips
+    // are serial: the kernel ran at the latency of its three dependent loads per trip)
+    for (int64_t rb = r0 + (threadIdx.x >> 4) * 4; rb < r1; rb += groups * 4) {
+        int64_t b[4];
+        int c[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const bool valid = rb + r < r1;
+            b[r] = valid ? ub_ptr[rb + r] - ub_ptr[0] : 0;
+            c[r] = valid ? cnt[rb + r] : 0;
+        }
+        uint32_t key[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) key[r] = sub < c[r] ? keys[b[r] + sub] : SG_KEY_OOV32;
+        int32_t col[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) col[r] = key[r] != SG_KEY_OOV32 ? key_to_col[key[r]] : -1;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            if (sub < c[r]) {
+                if (cols_out) keys[b[r] + sub] = (uint32_t)col[r];
+                const int32_t cc = col[r] - col0;
+                if (col[r] >= 0 && cc >= 0 && cc < n_cols) atomicAdd(&df_hist[cc], 1u);
+            }
+            for (int q = sub + 16; q < c[r]; q += 16) {          // rows of more than sixteen distinct n-grams
+                const uint32_t k2 = keys[b[r] + q];
+                const int32_t c2 = k2 != SG_KEY_OOV32 ? key_to_col[k2] : -1;
+                if (cols_out) keys[b[r] + q] = (uint32_t)c2;
+                const int32_t cc = c2 - col0;
+                if (c2 >= 0 && cc >= 0 && cc < n_cols) atomicAdd(&df_hist[cc], 1u);
+            }
         }
     }
     __syncthreads();
@@ -650,6 +679,10 @@ __global__ void __launch_bounds__(256) df_sum_kernel(const uint32_t *__restrict_
 struct DenseLookup {
     const int32_t *key_to_col;
     __device__ __forceinline__ int32_t operator()(uint32_t key) const { return key == SG_KEY_OOV32 ? -1 : key_to_col[key]; }
+};
+// the keys of the cache ARE columns already (df_count_lds_kernel, cols_out; -1 = out of vocabulary)
+struct ColumnsLookup {
+    __device__ __forceinline__ int32_t operator()(uint32_t key) const { return (int32_t)key; }
 };
 struct SortedLookup {
     const uint64_t *vocab;
@@ -1256,16 +1289,18 @@ static int count_df_by_column(sg_ctx *ctx, sg_vocab *v) {
     int st = sg_alloc(ctx, (size_t)((int64_t)(n_partial > 0 ? n_partial : 1) * v->n_terms), &partial);
     if (st != SG_OK) return st;
     int32_t at = 0;
+    const bool one_pass = v->n_terms <= max_cols && !(ctx->opt("SG_K2_COLUMNS") && ctx->opt("SG_K2_COLUMNS")[0] == '0');
     for (size_t i = 0; i < im->caches.size(); ++i) {
-        const TokenCache &c = im->caches[i];
+        TokenCache &c = im->caches[i];
         if (wgs[i] == 0) continue;
         for (int64_t col0 = 0; col0 < v->n_terms; col0 += max_cols) {
             const int32_t n_cols = (int32_t)(v->n_terms - col0 < max_cols ? v->n_terms - col0 : max_cols);
             hipLaunchKernelGGL(df_count_lds_kernel, dim3((unsigned)wgs[i]), dim3(1024), (size_t)n_cols * 4, ctx->stream,
-                               (const int64_t *)c.d_ub_ptr, (const int32_t *)c.d_cnt, (const uint32_t *)c.d_keys,
+                               (const int64_t *)c.d_ub_ptr, (const int32_t *)c.d_cnt, (uint32_t *)c.d_keys,
                                (const int32_t *)v->d_key_to_col, c.n, (int32_t)col0, n_cols, v->n_terms,
-                               partial + (int64_t)at * v->n_terms);
+                               partial + (int64_t)at * v->n_terms, one_pass ? 1 : 0);
         }
+        if (one_pass) c.keys_are_columns = true;   // (one pass saw every token: its keys are columns now)
         at += wgs[i];
     }
     (void)hipMemsetAsync(v->d_df, 0, sizeof(int32_t) * (size_t)v->n_terms, ctx->stream);
@@ -1585,6 +1620,10 @@ extern "C" int sg_vec_transform(sg_ctx *ctx, const sg_vocab *v, const sg_strings
             if (v->sorted_mode) {
                 if (m->dtype == SG_F64) launch_weight<double, uint64_t>(ctx, tc, sorted, v, n, indptr, idx, val, props);
                 else launch_weight<float, uint64_t>(ctx, tc, sorted, v, n, indptr, idx, val, props);
+            } else if (tc->keys_are_columns) {   // (the fit's df pass left the columns in place of the keys)
+                const ColumnsLookup cols{};
+                if (m->dtype == SG_F64) launch_weight<double, uint32_t>(ctx, tc, cols, v, n, indptr, idx, val, props);
+                else launch_weight<float, uint32_t>(ctx, tc, cols, v, n, indptr, idx, val, props);
             } else {
                 if (m->dtype == SG_F64) launch_weight<double, uint32_t>(ctx, tc, dense, v, n, indptr, idx, val, props);
                 else launch_weight<float, uint32_t>(ctx, tc, dense, v, n, indptr, idx, val, props);

@@ -66,7 +66,23 @@ def _host_staged(t, group) -> bool:
     return bool(t.is_cuda) and dist.get_backend(group) == "gloo"
 
 
+# What the collectives of this module moved, per kind: calls and bytes this rank RECEIVED (bench.py prints them for N > 1;
+# scripts/sim_scaling.py prices its model of the collectives with them).  reset_collective_tally() before a region.
+COLLECTIVE_TALLY = {"all_gather": [0, 0], "all_reduce": [0, 0], "broadcast": [0, 0]}
+
+
+def reset_collective_tally() -> None:
+    for v in COLLECTIVE_TALLY.values():
+        v[0] = v[1] = 0
+
+
+def _tally(kind: str, n_bytes: int) -> None:
+    COLLECTIVE_TALLY[kind][0] += 1
+    COLLECTIVE_TALLY[kind][1] += int(n_bytes)
+
+
 def _all_gather_into(out, t, group=None) -> None:
+    _tally("all_gather", out.numel() * out.element_size() - t.numel() * t.element_size())
     if _host_staged(t, group):
         h = torch.empty(out.shape, dtype=out.dtype)
         dist.all_gather_into_tensor(h, t.cpu(), group=group)
@@ -77,6 +93,7 @@ def _all_gather_into(out, t, group=None) -> None:
 
 def _all_reduce(t, op=None, group=None) -> None:
     op = dist.ReduceOp.SUM if op is None else op
+    _tally("all_reduce", t.numel() * t.element_size())
     if _host_staged(t, group):
         h = t.cpu()
         dist.all_reduce(h, op=op, group=group)
@@ -86,6 +103,7 @@ def _all_reduce(t, op=None, group=None) -> None:
 
 
 def _broadcast(t, src: int, group=None) -> None:
+    _tally("broadcast", t.numel() * t.element_size())
     if _host_staged(t, group):
         h = t.cpu()
         dist.broadcast(h, src=src, group=group)
