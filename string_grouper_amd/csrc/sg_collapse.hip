@@ -280,6 +280,24 @@ __global__ void __launch_bounds__(256) unique_rows_kernel(const int64_t *__restr
     }
 }
 
+int sg_collapse_materialize(sg_ctx *ctx, SgCollapse *c) {
+    if (!c || !c->pending_src) return SG_OK;
+    const sg_csr *B = c->pending_src;
+    sg_csr *m = c->unique;
+    const unsigned gu = (unsigned)((c->n_u * 16 + 255) / 256);
+    if (B->dtype == SG_F64)
+        hipLaunchKernelGGL(unique_rows_kernel<double>, dim3(gu), dim3(256), 0, ctx->stream, B->d_indptr, B->d_indices,
+                           (const double *)B->d_data, (const uint32_t *)c->d_rep_rows, c->n_u, m->d_indptr, (int32_t *)m->d_indices,
+                           (double *)m->d_data);
+    else
+        hipLaunchKernelGGL(unique_rows_kernel<float>, dim3(gu), dim3(256), 0, ctx->stream, B->d_indptr, B->d_indices,
+                           (const float *)B->d_data, (const uint32_t *)c->d_rep_rows, c->n_u, m->d_indptr, (int32_t *)m->d_indices,
+                           (float *)m->d_data);
+    SG_HIP_TRY(hipGetLastError());
+    c->pending_src = nullptr;
+    return SG_OK;
+}
+
 void sg_collapse_free(SgCollapse *c) {
     if (!c) return;
     sg_ctx *ctx = c->ctx;
@@ -291,13 +309,13 @@ void sg_collapse_free(SgCollapse *c) {
     delete c;
 }
 
-static int collapse_groups(sg_ctx *ctx, const sg_csr *B, bool forced, bool by_table, SgCollapse **out);
+static int collapse_groups(sg_ctx *ctx, const sg_csr *B, bool forced, bool by_table, bool defer_rows, SgCollapse **out);
 
 // *out stays null when collapsing is off, not worth it (fewer than 3 % repeats) or not possible.
 // left_side: the groups are those of a LEFT matrix of a one-sided product (sg_spgemm_topn): its own switch
 // (SG_COLLAPSE_LEFT=0 off, =1 from two rows on) and a higher bar by default -- the grouping is paid by the multiply that
 // asks for it, not by an index build that many multiplies share.
-int sg_collapse_build(sg_ctx *ctx, const sg_csr *B, SgCollapse **out, bool left_side) {
+int sg_collapse_build(sg_ctx *ctx, const sg_csr *B, SgCollapse **out, bool left_side, bool defer_rows) {
     *out = nullptr;
     const char *sw = ctx->opt("SG_COLLAPSE");
     if ((sw && sw[0] == '0') || B->n_rows < 2 || B->nnz <= 0 || B->n_rows >= ((int64_t)1 << 31)) return SG_OK;
@@ -311,18 +329,18 @@ int sg_collapse_build(sg_ctx *ctx, const sg_csr *B, SgCollapse **out, bool left_
     }
     if (!forced && B->n_rows < min_rows) return SG_OK;
     const bool want_table = !(ctx->opt("SG_GROUP_SORT") && ctx->opt("SG_GROUP_SORT")[0] == '1');   // (=1: the sort-based path)
-    int st = collapse_groups(ctx, B, forced, want_table, out);
+    int st = collapse_groups(ctx, B, forced, want_table, defer_rows, out);
     if (st == SG_OK && *out == nullptr && want_table && ctx->group_table_overflow) {
         // a group of more than SG_GROUP_SORT_LDS members (a hub of identical names): the sort-based path lists any group
         ctx->group_table_overflow = false;
-        st = collapse_groups(ctx, B, forced, false, out);
+        st = collapse_groups(ctx, B, forced, false, defer_rows, out);
     }
     return st;
 }
 
 // One of the two ways to the groups; *out stays null when grouping is not worth it (or, table path, when a group is too
 // large for it: ctx->group_table_overflow says so).
-static int collapse_groups(sg_ctx *ctx, const sg_csr *B, bool forced, bool by_table, SgCollapse **out) {
+static int collapse_groups(sg_ctx *ctx, const sg_csr *B, bool forced, bool by_table, bool defer_rows, SgCollapse **out) {
     *out = nullptr;
     ctx->group_table_overflow = false;
     const int64_t n = B->n_rows;
@@ -482,7 +500,9 @@ static int collapse_groups(sg_ctx *ctx, const sg_csr *B, bool forced, bool by_ta
     }
     if (st == SG_OK) {
         const unsigned gu = (unsigned)((n_u * 16 + 255) / 256);
-        if (B->dtype == SG_F64)
+        if (defer_rows)
+            c->pending_src = B;       // (written by the index build, or by sg_collapse_materialize)
+        else if (B->dtype == SG_F64)
             hipLaunchKernelGGL(unique_rows_kernel<double>, dim3(gu), dim3(256), 0, ctx->stream, B->d_indptr, B->d_indices,
                                (const double *)B->d_data, (const uint32_t *)c->d_rep_rows, n_u, (const int64_t *)ptr, idx,
                                (double *)val);

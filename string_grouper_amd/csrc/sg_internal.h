@@ -176,6 +176,10 @@ struct SgCollapse {
     uint32_t *d_members = nullptr;       // n_orig: rows of group g = members[group_ptr[g] .. group_ptr[g + 1]), ascending
     uint32_t *d_rep_rows = nullptr;      // n_u: lowest row of every group
     struct sg_csr *unique = nullptr;     // the representatives' rows (owned)
+    // round 4: the rows of `unique` may not have been WRITTEN yet (row pointers and sizes are final): they are the rows
+    // d_rep_rows of pending_src, and the index build writes them together with its own copies of them (one read of the
+    // source instead of three passes: sg_postings.hip, gather_rows_kernel); sg_collapse_materialize writes them alone
+    const struct sg_csr *pending_src = nullptr;
 };
 
 struct sg_postings {
@@ -319,7 +323,8 @@ int sg_spgemm_exact_selfjoin_rows(sg_ctx *ctx, const sg_csr *A, const sg_posting
                                   const uint32_t *row_list_len, const SgPairSink &sink);
 
 // sg_collapse.hip
-int sg_collapse_build(sg_ctx *ctx, const sg_csr *B, SgCollapse **out, bool left_side = false);
+int sg_collapse_build(sg_ctx *ctx, const sg_csr *B, SgCollapse **out, bool left_side = false, bool defer_rows = false);
+int sg_collapse_materialize(sg_ctx *ctx, SgCollapse *c);
 void sg_collapse_free(SgCollapse *c);
 int sg_collapse_expand(sg_ctx *ctx, const SgCollapse *c, const sg_topn *ru, bool rows_are_groups, sg_topn *out,
                        const int32_t *row_list = nullptr);   // row_list: output row k is the caller's row row_list[k]

@@ -463,7 +463,7 @@ __global__ void __launch_bounds__(256) permutation_kernel(uint32_t n, uint64_t m
     const uint32_t p = (uint32_t)(((uint64_t)j * mult) % (uint64_t)n);
     pos_of[j] = p;
     orig_of[p] = j;
-    len_by_pos[p] = (uint32_t)(indptr[j + 1] - indptr[j]);
+    len_by_pos[p] = (uint32_t)(indptr[j + 1] - indptr[j]);   // (the matrix's own row pointers: final also while its rows are pending)
 }
 
 // rows of B copied into position order: sixteen lanes per row
@@ -483,6 +483,55 @@ __global__ void __launch_bounds__(256) permute_rows_kernel(const int64_t *__rest
     }
 }
 
+// Round 4: ONE read of the source rows for every copy of them the index keeps.  Position p of the index holds row
+// g = orig_of[p] of the matrix it is built over; with groups of identical rows that matrix is the representatives' --
+// row g = row rep_rows[g] of the caller's matrix, not written anywhere yet (SgCollapse::pending_src) -- and the copies are
+//   * the representatives' matrix itself (rows in group order; the left side of a one-sided fallback, the exact kernel),
+//   * the matrix in position order (what the index and the self-join form read),
+//   * its packed rows {term, value} + {pointer, row} per position (the exact scoring of the pruned multiply).
+// Rounds 2-3 made them one after the other: unique_rows, permute_rows, fwd_pack -- 530 MB moved for 350.
+template <typename T>
+__global__ void __launch_bounds__(256) gather_rows_kernel(const int64_t *__restrict__ indptr, const int32_t *__restrict__ indices,
+                                                          const T *__restrict__ data, int64_t n_rows,
+                                                          const uint32_t *__restrict__ orig_of,
+                                                          const uint32_t *__restrict__ rep_rows /* null: the source IS the matrix */,
+                                                          const int64_t *__restrict__ perm_ptr, int32_t *__restrict__ perm_indices,
+                                                          T *__restrict__ perm_data,
+                                                          const int64_t *__restrict__ uniq_ptr /* null: no copy in row order */,
+                                                          int32_t *__restrict__ uniq_indices, T *__restrict__ uniq_data,
+                                                          uint32_t *__restrict__ fwd_ptr /* null: no packed rows */, void *__restrict__ fwd) {
+    const int64_t p = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+    const int sub = threadIdx.x & 15;
+    if (p > n_rows) return;
+    if (p == n_rows) {
+        if (fwd_ptr && sub == 0) reinterpret_cast<uint2 *>(fwd_ptr)[p] = make_uint2((uint32_t)perm_ptr[n_rows], 0u);
+        return;
+    }
+    const int64_t g = orig_of[p];
+    const int64_t j = rep_rows ? (int64_t)rep_rows[g] : g;
+    const int64_t src = indptr[j], n = indptr[j + 1] - src, dst = perm_ptr[p];
+    const int64_t udst = uniq_ptr ? uniq_ptr[g] : 0;
+    if (fwd_ptr && sub == 0) reinterpret_cast<uint2 *>(fwd_ptr)[p] = make_uint2((uint32_t)dst, (uint32_t)g);
+    for (int64_t e = sub; e < n; e += 16) {
+        const int32_t k = indices[src + e];
+        const T v = data[src + e];
+        perm_indices[dst + e] = k;
+        perm_data[dst + e] = v;
+        if (uniq_ptr) {
+            uniq_indices[udst + e] = k;
+            uniq_data[udst + e] = v;
+        }
+        if (fwd) {
+            if (sizeof(T) == 4) {
+                reinterpret_cast<int2 *>(fwd)[dst + e] = make_int2(k, __float_as_int((float)v));
+            } else {
+                const long long bits = __double_as_longlong((double)v);
+                reinterpret_cast<int4 *>(fwd)[dst + e] = make_int4(k, 0, (int)(bits & 0xffffffffll), (int)(bits >> 32));
+            }
+        }
+    }
+}
+
 __global__ void score_ctx_kernel(SgScoreCtx v, SgScoreCtx *out) { *out = v; }
 
 static uint64_t gcd_u64(uint64_t a, uint64_t b) {
@@ -496,7 +545,9 @@ static uint64_t gcd_u64(uint64_t a, uint64_t b) {
 
 // B with its rows in position order + the two tables; *out_perm stays null when the permutation is off or pointless
 static int build_permuted(sg_ctx *ctx, const sg_csr *B, int64_t tile_cols, sg_csr **out_perm, uint32_t **out_orig_of,
-                          uint32_t **out_pos_of) {
+                          uint32_t **out_pos_of, SgCollapse *pending /* B = pending->unique, its rows not written yet; or null */,
+                          uint32_t *fwd_ptr, void *fwd /* packed rows to write along (null: none) */, bool *fwd_done) {
+    *fwd_done = false;
     *out_perm = nullptr;
     *out_orig_of = *out_pos_of = nullptr;
     const char *e = ctx->opt("SG_PERMUTE");
@@ -521,14 +572,23 @@ static int build_permuted(sg_ctx *ctx, const sg_csr *B, int64_t tile_cols, sg_cs
         st = sg_exclusive_scan_i32_to_i64(ctx, (const int32_t *)len_by_pos, ptr, (int64_t)n);
     }
     if (st == SG_OK) {
-        const unsigned grid = (unsigned)((n * 16 + 255) / 256);
+        const unsigned grid = (unsigned)(((n + 1) * 16 + 255) / 256);
+        const sg_csr *src = pending && pending->pending_src ? pending->pending_src : B;
+        const uint32_t *rep_rows = pending && pending->pending_src ? pending->d_rep_rows : nullptr;
+        const int64_t *uniq_ptr = rep_rows ? B->d_indptr : nullptr;
         if (B->dtype == SG_F64)
-            hipLaunchKernelGGL(permute_rows_kernel<double>, dim3(grid), dim3(256), 0, ctx->stream, B->d_indptr, B->d_indices,
-                               (const double *)B->d_data, B->n_rows, (const uint32_t *)orig_of, (const int64_t *)ptr, idx, (double *)val);
+            hipLaunchKernelGGL(gather_rows_kernel<double>, dim3(grid), dim3(256), 0, ctx->stream, src->d_indptr, src->d_indices,
+                               (const double *)src->d_data, B->n_rows, (const uint32_t *)orig_of, rep_rows, (const int64_t *)ptr, idx,
+                               (double *)val, uniq_ptr, (int32_t *)B->d_indices, (double *)B->d_data, fwd_ptr, fwd);
         else
-            hipLaunchKernelGGL(permute_rows_kernel<float>, dim3(grid), dim3(256), 0, ctx->stream, B->d_indptr, B->d_indices,
-                               (const float *)B->d_data, B->n_rows, (const uint32_t *)orig_of, (const int64_t *)ptr, idx, (float *)val);
+            hipLaunchKernelGGL(gather_rows_kernel<float>, dim3(grid), dim3(256), 0, ctx->stream, src->d_indptr, src->d_indices,
+                               (const float *)src->d_data, B->n_rows, (const uint32_t *)orig_of, rep_rows, (const int64_t *)ptr, idx,
+                               (float *)val, uniq_ptr, (int32_t *)B->d_indices, (float *)B->d_data, fwd_ptr, fwd);
         if (hipGetLastError() != hipSuccess) st = SG_ERR_HIP;
+        if (st == SG_OK) {
+            if (pending) pending->pending_src = nullptr;     // (the representatives' rows are written now)
+            *fwd_done = fwd_ptr != nullptr;
+        }
     }
     ctx->release(len_by_pos);
     sg_csr *m = st == SG_OK ? new (std::nothrow) sg_csr() : nullptr;
@@ -567,8 +627,14 @@ extern "C" int sg_postings_build(sg_ctx *ctx, const sg_csr *B, int32_t tile_cols
 #define SG_POSTINGS_NO_COLLAPSE (1 << 8)   // index every row (the collapse wrapper's own inner call; the on-demand plain index)
 #define SG_POSTINGS_INNER (1 << 9)         // called by the collapse wrapper: the wrapper's timer covers the build
 
+// the groups whose representatives' rows the inner build of sg_postings_build_flags is to write (handed from the outer call
+// to the inner one of the same thread)
+static thread_local SgCollapse *tl_pending_groups = nullptr;
+
 extern "C" int sg_postings_build_flags(sg_ctx *ctx, const sg_csr *B_in, int32_t tile_cols, int32_t flags, sg_postings **out) {
     SG_REQUIRE(ctx && B_in && out, "null argument");
+    SgCollapse *pending = tl_pending_groups;
+    tl_pending_groups = nullptr;
     if (!(flags & SG_POSTINGS_NO_COLLAPSE)) {
         // identical rows (identical strings): one representative per group is indexed (sg_collapse.hip)
         bool cl = false;
@@ -576,10 +642,12 @@ extern "C" int sg_postings_build_flags(sg_ctx *ctx, const sg_csr *B_in, int32_t 
         SG_TRY(sg_csr_props(ctx, B_in, &cl, &n2));
         SgCollapse *col = nullptr;
         SgTimer timer(ctx, SG_K_POSTINGS);   // grouping + the index over the representatives
-        if (cl) SG_TRY(sg_collapse_build(ctx, B_in, &col));
+        if (cl) SG_TRY(sg_collapse_build(ctx, B_in, &col, /*left_side=*/false, /*defer_rows=*/true));
         if (col) {
             sg_postings *inner = nullptr;
+            tl_pending_groups = col;      // (the inner build writes the representatives' rows with its own copies of them)
             const int st = sg_postings_build_flags(ctx, col->unique, tile_cols, flags | SG_POSTINGS_NO_COLLAPSE | SG_POSTINGS_INNER, &inner);
+            tl_pending_groups = nullptr;
             if (st != SG_OK) {
                 sg_collapse_free(col);
                 return st;
@@ -649,7 +717,46 @@ extern "C" int sg_postings_build_flags(sg_ctx *ctx, const sg_csr *B_in, int32_t 
         SgTimer *t;
         ~TimerGuard() { delete t; }
     } timer_guard{timer};
-    if (!(flags & SG_POSTINGS_NO_PERMUTATION)) SG_TRY(build_permuted(ctx, B_in, tile_cols, &permuted, &orig_of, &pos_of));
+    // the packed rows of the pruned multiply are written by the same pass that copies the rows into position order
+    void *early_fwd = nullptr;
+    uint32_t *early_fwd_ptr = nullptr;
+    bool fwd_done = false;
+    {
+        const bool filt = want_pruned && sg_pruned_supports_tile(tile_log2) &&
+                          (B->n_cols + 1) * ((n_tiles64 + 3) & ~(int64_t)3) < ((int64_t)1 << 30);
+        const bool blk = ctx->opt("SG_ROW_BLOCKS") && ctx->opt("SG_ROW_BLOCKS")[0] == '1';
+        if (filt && !blk && !(flags & SG_POSTINGS_NO_PERMUTATION) && B_in->n_rows > 0) {
+            int st0 = ctx->alloc(((size_t)B_in->nnz + 8) * (B_in->dtype == SG_F64 ? 16 : 8), &early_fwd);
+            if (st0 == SG_OK) st0 = sg_alloc(ctx, 2 * ((size_t)B_in->n_rows + 2), &early_fwd_ptr);
+            if (st0 != SG_OK) {
+                ctx->release(early_fwd);
+                return st0;
+            }
+        }
+    }
+    if (!(flags & SG_POSTINGS_NO_PERMUTATION)) {
+        const int stp = build_permuted(ctx, B_in, tile_cols, &permuted, &orig_of, &pos_of, pending, early_fwd_ptr, early_fwd, &fwd_done);
+        if (stp != SG_OK) {
+            ctx->release(early_fwd);
+            ctx->release(early_fwd_ptr);
+            return stp;
+        }
+    }
+    if (!fwd_done) {
+        ctx->release(early_fwd);
+        ctx->release(early_fwd_ptr);
+        early_fwd = nullptr;
+        early_fwd_ptr = nullptr;
+    }
+    if (pending && pending->pending_src) {      // no copy in position order was made: the representatives' rows by themselves
+        const int stm = sg_collapse_materialize(ctx, pending);
+        if (stm != SG_OK) {
+            sg_csr_free(permuted);
+            ctx->release(orig_of);
+            ctx->release(pos_of);
+            return stm;
+        }
+    }
     if (permuted) B = permuted;   // everything below indexes right-hand rows by POSITION
     sg_postings *p = new (std::nothrow) sg_postings();
     if (!p) {
@@ -718,8 +825,16 @@ extern "C" int sg_postings_build_flags(sg_ctx *ctx, const sg_csr *B_in, int32_t 
                 st = ctx->alloc(need * ((size_t)B->n_rows + 1), &p->d_blk);
             }
         }
-        if (st == SG_OK && !p->d_blk) st = ctx->alloc(((size_t)B->nnz + 8) * (B->dtype == SG_F64 ? 16 : 8), &p->d_fwd);
-        if (st == SG_OK) st = sg_alloc(ctx, 2 * ((size_t)B->n_rows + 2), &p->d_fwd_ptr);   // uint2 per row
+        if (early_fwd && !p->d_blk) {          // written along with the rows' copy in position order (build_permuted)
+            p->d_fwd = early_fwd;
+            p->d_fwd_ptr = early_fwd_ptr;
+            early_fwd = nullptr;
+            early_fwd_ptr = nullptr;
+        } else {
+            if (st == SG_OK && !p->d_blk) st = ctx->alloc(((size_t)B->nnz + 8) * (B->dtype == SG_F64 ? 16 : 8), &p->d_fwd);
+            if (st == SG_OK) st = sg_alloc(ctx, 2 * ((size_t)B->n_rows + 2), &p->d_fwd_ptr);   // uint2 per row
+            fwd_done = false;
+        }
         // slack: the pruned multiply loads a lane's four slots of a segment unconditionally (<= 4 * 63 entries past it)
         if (st == SG_OK) st = sg_alloc(ctx, (size_t)B->nnz + 512, &p->d_filt);
         // the stream form points lanes without a posting at the slack behind the array: entries that add 0 (bq = 0), each to
@@ -871,7 +986,7 @@ extern "C" int sg_postings_build_flags(sg_ctx *ctx, const sg_csr *B_in, int32_t 
                                    (const float *)B->d_data, B->n_rows, (const uint32_t *)p->d_orig_of, p->blk_bytes, p->d_blk);
             if (hipGetLastError() != hipSuccess) st = SG_ERR_HIP;
         }
-        if (st == SG_OK && p->d_fwd_ptr) {
+        if (st == SG_OK && p->d_fwd_ptr && !fwd_done) {
             const int64_t work = B->nnz > B->n_rows + 1 ? B->nnz : B->n_rows + 1;
             const unsigned g2 = (unsigned)((work + 255) / 256);
             if (B->dtype == SG_F64)

@@ -910,6 +910,14 @@ extern "C" int sg_spgemm_topn(sg_ctx *ctx, const sg_csr *A, const sg_postings *B
         const char *sw = ctx->opt("SG_COLLAPSE"), *ls = ctx->opt("SG_COLLAPSE_LEFT");    // (asked on every call: groups kept
         const bool off = (sw && sw[0] == '0') || (ls && ls[0] == '0');                      //  with A do not outlive the switch)
         if (!self && !off && A->left_state != 1 && A->n_cols == Bt->n_terms && A->dtype == Bt->dtype && top_n >= 1) {
+            // (the result is one row per row of A whatever the number of groups: the 32-bit result index must hold it)
+            const int64_t n_right = Bt->collapse ? Bt->collapse->n_orig : Bt->n_right;
+            const int64_t stride64 = top_n < n_right ? top_n : (n_right > 0 ? n_right : 1);
+            if ((double)A->n_rows * (double)stride64 > 2.0e9) {
+                sg_set_error("result of %lld rows x top_n %lld does not fit the 32-bit result index; split the left matrix",
+                             (long long)A->n_rows, (long long)stride64);
+                return SG_ERR_OVERFLOW;
+            }
             bool done = false;
             SG_TRY(spgemm_topn_left_groups(ctx, A, Bt, top_n, threshold, sort, out, &done));
             if (done) return SG_OK;

@@ -287,7 +287,12 @@ __global__ void __launch_bounds__(64 * TOK_SHORT_WAVES) tokenize_short_kernel(
         if (tagged) {
             const uint32_t body = key == KeyTraits<KeyT>::OOV ? 0x3FFFFFFu : (uint32_t)key;   // real keys are < 2^25
             const uint32_t kt = lane < g ? (body << 6) | (uint32_t)lane : 0xFFFFFFFFu;
-            for (int i = 0; i < g; ++i) rank += (uint32_t)__builtin_amdgcn_readlane((int)kt, i) < kt;
+            // four comparisons per trip of the loop (a lane past the last n-gram holds the largest value: it counts for
+            // nobody): the loop's own scalar instructions were as many as its vector ones, and the kernel is bound by the
+            // instructions it issues since its loads are pipelined
+            const int g4 = (g + 3) & ~3;
+#pragma unroll 4
+            for (int i = 0; i < g4; ++i) rank += (uint32_t)__builtin_amdgcn_readlane((int)kt, i) < kt;
         } else {
             for (int i = 0; i < g; ++i) {
                 const KeyT o = read_lane_key<KeyT>(key, i);
