@@ -466,23 +466,6 @@ __global__ void __launch_bounds__(256) permutation_kernel(uint32_t n, uint64_t m
     len_by_pos[p] = (uint32_t)(indptr[j + 1] - indptr[j]);   // (the matrix's own row pointers: final also while its rows are pending)
 }
 
-// rows of B copied into position order: sixteen lanes per row
-template <typename T>
-__global__ void __launch_bounds__(256) permute_rows_kernel(const int64_t *__restrict__ indptr, const int32_t *__restrict__ indices,
-                                                           const T *__restrict__ data, int64_t n_rows,
-                                                           const uint32_t *__restrict__ orig_of, const int64_t *__restrict__ out_ptr,
-                                                           int32_t *__restrict__ out_indices, T *__restrict__ out_data) {
-    const int64_t p = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
-    const int sub = threadIdx.x & 15;
-    if (p >= n_rows) return;
-    const int64_t j = orig_of[p];
-    const int64_t src = indptr[j], n = indptr[j + 1] - src, dst = out_ptr[p];
-    for (int64_t e = sub; e < n; e += 16) {
-        out_indices[dst + e] = indices[src + e];
-        out_data[dst + e] = data[src + e];
-    }
-}
-
 // Round 4: ONE read of the source rows for every copy of them the index keeps.  Position p of the index holds row
 // g = orig_of[p] of the matrix it is built over; with groups of identical rows that matrix is the representatives' --
 // row g = row rep_rows[g] of the caller's matrix, not written anywhere yet (SgCollapse::pending_src) -- and the copies are

@@ -96,16 +96,6 @@ struct TokParams {
 };
 
 // -------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) ub_count_kernel(const int64_t *__restrict__ offsets, int64_t n, int32_t ngram,
-                                                       int32_t *ub) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const int64_t len = offsets[i + 1] - offsets[i];      // bytes or symbols: an upper bound of the characters kept
-    int64_t g = len - ngram + 1;
-    if (g < 0) g = 0;
-    ub[i] = (int32_t)g;
-}
-
 // alphabet presence: which filtered byte values occur at all (only needed when 7*n bits is too wide)
 __global__ void __launch_bounds__(256) alphabet_kernel(const uint8_t *__restrict__ bytes, int64_t total, TokParams p,
                                                        uint32_t *present /*[4]*/) {

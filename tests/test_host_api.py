@@ -508,3 +508,35 @@ print(json.dumps({k: [ask(R._is_series_of_strings, v), ask(M._is_series_of_strin
             assert ref == mine, (k, ref, mine)
             compared += 1
     assert compared > 15
+
+
+# ------------------------------------------------------------------------------------------------
+# Seam b1 by name (round 4): the constructor call the reference makes, served by the device vectoriser's front end
+def test_tfidf_vectorizer_by_name_takes_its_options_from_the_bound_analyzer():
+    import pandas as pd
+    import string_grouper_amd as sga
+    from string_grouper_amd.vectorizer import TfidfVectorizer
+    sg = sga.StringGrouper(pd.Series(["Acme Inc", "Ácme Corp"]), ngram_size=4, regex=r"[ie]", ignore_case=False,
+                           normalize_to_ascii=False, tfidf_matrix_dtype=np.float32)
+    vec = TfidfVectorizer(min_df=1, analyzer=sg.n_grams, dtype=np.float32)       # string_grouper.py:306, verbatim
+    assert (vec.ngram_size, vec.regex, vec.ignore_case, vec.normalize_to_ascii, vec.dtype) == (4, r"[ie]", False, False, np.float32)
+    with pytest.raises(TypeError):
+        TfidfVectorizer(min_df=1, analyzer=lambda s: list(s), dtype=np.float32)      # code the device cannot run
+    with pytest.raises(TypeError):
+        TfidfVectorizer(min_df=1, analyzer=sg.n_grams, dtype=np.float32, sublinear_tf=True)
+    with pytest.raises(NotImplementedError):
+        TfidfVectorizer(min_df=2, analyzer=sg.n_grams, dtype=np.float32)
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/string_grouper"), reason="reference tree not mounted")
+def test_reference_package_is_packed_for_the_gpu_box():
+    """oracle/mount_reference.py: the archive the GPU suite runs the unmodified reference from (a build output, git-ignored)."""
+    import subprocess
+    import zipfile
+    from oracle import mount_reference
+    path = mount_reference.mount()
+    assert path and os.path.exists(path)
+    names = zipfile.ZipFile(path).namelist()
+    assert "string_grouper/string_grouper.py" in names and "string_grouper/test/test_string_grouper.py" in names
+    tracked = subprocess.run(["git", "ls-files", "oracle/_ref"], cwd=ROOT, capture_output=True, text=True).stdout.strip()
+    assert tracked == "", "nothing under oracle/_ref may enter the history"
