@@ -69,10 +69,11 @@ __global__ void __launch_bounds__(256) row_hash_kernel(const int64_t *__restrict
 // checks itself against that row entry by entry (a row whose hash collides with different content becomes a group of its
 // own: nothing is ever merged on the hash alone).  Groups are numbered by ascending representative and list their
 // members ascending as before: members are scattered in arrival order and every group of several members is sorted
-// (two members: a swap; up to 32: by its thread; up to 8192: by a workgroup in LDS; a list with a larger group takes
-// the sort-based path).
+// (two members: a swap; up to 32: by its thread; up to 8192: by a workgroup in LDS; a larger one -- a hub -- by a
+// flag / prefix-sum / scatter pass of its own; a list with dozens of such hubs takes the sort-based path).
 #define SG_GROUP_EMPTY 0xFFFFFFFFu
 #define SG_GROUP_SORT_LDS 8192
+#define SG_GROUP_LARGE_MAX 28u      // very large groups listed per call (more: the sort-based path)
 __global__ void __launch_bounds__(256) group_insert_kernel(const uint64_t *__restrict__ hash, int64_t n_rows, uint32_t *table,
                                                            uint32_t mask, uint32_t *__restrict__ slot_of_row) {
     const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -86,7 +87,9 @@ __global__ void __launch_bounds__(256) group_insert_kernel(const uint64_t *__res
             if (cur == SG_GROUP_EMPTY) break;                 // the slot is this hash's now
         }
         if (hash[cur] == h) {                                 // (whoever holds the slot has the slot's hash)
-            atomicMin(&table[s], (uint32_t)r);
+            // (a hub of 66 000 identical names is 66 000 rows at ONE slot: only a row below what the slot shows sends an
+            //  atomic -- the value only ever falls, so a stale reading only costs an atomic that changes nothing)
+            if ((uint32_t)r < cur) atomicMin(&table[s], (uint32_t)r);
             break;
         }
         s = (s + 1u) & mask;
@@ -129,7 +132,23 @@ __global__ void __launch_bounds__(256) group_scatter_kernel(const uint32_t *__re
     if (r >= n_rows) return;
     const uint32_t g = gid[r];
     const uint32_t lo = group_ptr[g], m = group_ptr[g + 1] - lo;
+    if (m > (uint32_t)SG_GROUP_SORT_LDS) return;        // a very large group: listed by a compaction of its own (large_group_*)
     members[lo + (m == 1u ? 0u : atomicAdd(&cursor[g], 1u))] = (uint32_t)r;
+}
+
+// A group too large for the workgroup sort (a hub of thousands of identical names): its members in ascending order are the
+// rows r with gid[r] == g in row order -- a flag per row, a prefix sum, a scatter (tickets on one counter would be tens of
+// thousands of returning atomics on one address, and the list would still have to be sorted).
+__global__ void __launch_bounds__(256) large_group_flag_kernel(const uint32_t *__restrict__ gid, int64_t n_rows, uint32_t g,
+                                                               uint32_t *__restrict__ flag) {
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < n_rows) flag[r] = gid[r] == g ? 1u : 0u;
+}
+__global__ void __launch_bounds__(256) large_group_fill_kernel(const uint32_t *__restrict__ gid, const uint32_t *__restrict__ at,
+                                                               int64_t n_rows, uint32_t g, const uint32_t *__restrict__ group_ptr,
+                                                               uint32_t *__restrict__ members) {
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < n_rows && gid[r] == g) members[group_ptr[g] + at[r]] = (uint32_t)r;
 }
 
 // a thread per group: members ascending.  Groups of more than 32 are queued for the workgroup sort; words[0] = queue
@@ -151,6 +170,10 @@ __global__ void __launch_bounds__(256) group_sort_small_kernel(const uint32_t *_
     if (m > 32u) {
         atomicMax(&words[1], m);
         if (m <= (uint32_t)SG_GROUP_SORT_LDS) queue[atomicAdd(&words[0], 1u)] = (uint32_t)g;
+        else {                                               // words[2] = how many, words[3 ..] the first of them
+            const uint32_t q = atomicAdd(&words[2], 1u);
+            if (q < SG_GROUP_LARGE_MAX) words[3 + q] = (uint32_t)g;
+        }
         return;
     }
     for (uint32_t i = 1; i < m; ++i) {           // insertion sort in place (the segment is this thread's alone)
@@ -245,11 +268,28 @@ __global__ void __launch_bounds__(256) group_ids_kernel(const uint32_t *__restri
                                                         uint32_t *__restrict__ gid, uint32_t *__restrict__ size,
                                                         uint32_t *__restrict__ rep_rows) {
     const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= n_rows) return;
-    const uint32_t g = rep_excl[rep_of_row[r]];
-    gid[r] = g;
-    atomicAdd(&size[g], 1u);
-    if (is_rep[r]) rep_rows[g] = (uint32_t)r;
+    const bool valid = r < n_rows;
+    uint32_t g = 0xFFFFFFFFu;
+    bool rep = false;
+    if (valid) {
+        g = rep_excl[rep_of_row[r]];
+        gid[r] = g;
+        rep = is_rep[r] != 0u;
+        if (rep) {
+            rep_rows[g] = (uint32_t)r;
+            atomicAdd(&size[g], 1u);          // (one representative per group: an address of its own)
+        }
+    }
+    // the other members: the lanes of a wave that belong to one group send ONE atomic between them -- a hub of 66 000
+    // identical names was 66 000 atomics on one word, which are served one at a time (~12 ns each: 0.8 ms of a 2 ms build)
+    uint64_t todo = __ballot(valid && !rep);
+    while (todo) {
+        const int lead = __builtin_ctzll(todo);
+        const uint32_t lg = (uint32_t)__builtin_amdgcn_readlane((int)g, lead);
+        const uint64_t same = __ballot(valid && !rep && g == lg) & todo;
+        if ((int)(threadIdx.x & 63) == lead) atomicAdd(&size[lg], (uint32_t)__popcll(same));
+        todo &= ~same;
+    }
 }
 
 __global__ void __launch_bounds__(256) group_fill_kernel(const uint32_t *__restrict__ gid, const uint32_t *__restrict__ rank_of_row,
@@ -351,7 +391,7 @@ static int collapse_groups(sg_ctx *ctx, const sg_csr *B, bool forced, bool by_ta
     SgCollapse *c = nullptr;
     uint64_t table_size = 0;
     int st = sg_alloc(ctx, (size_t)n + 1, &hash);
-    if (st == SG_OK) st = sg_alloc(ctx, (size_t)8, &totals);
+    if (st == SG_OK) st = sg_alloc(ctx, (size_t)40, &totals);
     if (by_table) {
         table_size = 1024;
         while (table_size < 2 * (uint64_t)n) table_size <<= 1;
@@ -446,7 +486,7 @@ static int collapse_groups(sg_ctx *ctx, const sg_csr *B, bool forced, bool by_ta
         if (st == SG_OK) st = sg_alloc(ctx, (size_t)n_u + 1, &queue);
         if (st == SG_OK)
             st = SG_ZERO3(ctx, size, sizeof(uint32_t) * (size_t)(n_u + 1), cursor, sizeof(uint32_t) * (size_t)(n_u + 1), totals + 4,
-                          4 * sizeof(uint32_t));
+                          32 * sizeof(uint32_t));
     } else {
         if (st == SG_OK) st = sg_alloc(ctx, (size_t)n_u + 1, &head_pos);
         if (st == SG_OK) st = sg_alloc(ctx, (size_t)n + 1, &rep_of_row);
@@ -509,13 +549,14 @@ static int collapse_groups(sg_ctx *ctx, const sg_csr *B, bool forced, bool by_ta
         else
             hipLaunchKernelGGL(unique_rows_kernel<float>, dim3(gu), dim3(256), 0, ctx->stream, B->d_indptr, B->d_indices,
                                (const float *)B->d_data, (const uint32_t *)c->d_rep_rows, n_u, (const int64_t *)ptr, idx, (float *)val);
-        uint32_t h_words[4] = {0, 0, 0, 0};      // table path: [0] groups queued for the LDS sort, [1] the largest group
+        uint32_t h_words[32];      // table path: [0] groups queued for the LDS sort, [1] the largest group, [2] very large groups, [3 ..] which
+        for (auto &w : h_words) w = 0;
         if (hipMemcpyAsync(&nnz_u, ptr + n_u, 8, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
-            (by_table && hipMemcpyAsync(h_words, totals + 4, 16, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) ||
+            (by_table && hipMemcpyAsync(h_words, totals + 4, sizeof(h_words), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) ||
             hipStreamSynchronize(ctx->stream) != hipSuccess)
             st = SG_ERR_HIP;
-        if (st == SG_OK && by_table && h_words[1] > (uint32_t)SG_GROUP_SORT_LDS) {
-            // a group too large for the workgroup sort: its members are not in order -- the caller takes the sort-based path
+        if (st == SG_OK && by_table && h_words[2] > SG_GROUP_LARGE_MAX) {
+            // dozens of very large groups: the sort-based path lists any number of them in one go -- the caller takes it
             ctx->group_table_overflow = true;
             ctx->release(len);
             ctx->release(ptr);
@@ -524,6 +565,17 @@ static int collapse_groups(sg_ctx *ctx, const sg_csr *B, bool forced, bool by_ta
             cleanup();
             sg_collapse_free(c);
             return SG_OK;
+        }
+        for (uint32_t q = 0; q < h_words[2] && st == SG_OK && by_table; ++q) {
+            // (is_rep / rep_excl have served: flag and positions of the group's rows)
+            const uint32_t g = h_words[3 + q];
+            hipLaunchKernelGGL(large_group_flag_kernel, dim3(g1), dim3(256), 0, ctx->stream, (const uint32_t *)c->d_gid, n, g, is_rep);
+            st = sg_exclusive_scan_u32(ctx, is_rep, rep_excl, n, nullptr);
+            if (st == SG_OK) {
+                hipLaunchKernelGGL(large_group_fill_kernel, dim3(g1), dim3(256), 0, ctx->stream, (const uint32_t *)c->d_gid,
+                                   (const uint32_t *)rep_excl, n, g, (const uint32_t *)c->d_group_ptr, c->d_members);
+                if (hipGetLastError() != hipSuccess) st = SG_ERR_HIP;
+            }
         }
     }
     ctx->release(len);
