@@ -117,10 +117,26 @@ def main():
             t_p1, k_p1, got = best
             res, ptr, n_pairs, words = got
             pair_counts.append(n_pairs)
+            # the OTHER form of the step (distributed.sharded_topn without the self-join form): the rank's block of rows
+            # against all columns, one-sided -- twice the pairs of the self-join form in all, but no pair exchange, no
+            # merge, no expansion of groups, no launch over parts
+
+            def row_block_form():
+                blk = A.row_block(lo, hi)
+                out = ctx.spgemm_topn(blk, post, 10, 0.8, True)
+                out.free()
+                blk.free()
+                return None
+            if world > 1:
+                row_block_form()
+                t_rb, k_rb, _ = ms(row_block_form)
+            else:
+                t_rb, k_rb = float("nan"), {}
             per_rank.append({"rank": r, "rows": hi - lo, "range": [plo, phi, pstep], "vectorise_ms_wall": t_vec,
                              "vectorise_ms_kernels": k_vec.get("tokenize", 0) + k_vec.get("vocab", 0) + k_vec.get("weight", 0),
                              "pass1_ms_wall": t_p1, "pass1_ms_kernel": k_p1.get("spgemm_topn", 0.0),
                              "pass1_ms_kernel_alone": k_p1.get("spgemm_kernel", 0.0), "pairs": int(n_pairs),
+                             "row_block_form_ms_wall": t_rb,
                              "_res": res, "_ptr": ptr, "_words": words})
         # the merge needs ALL ranks' pairs: concatenate them on the device (what the all-gather delivers)
         import torch
@@ -156,18 +172,25 @@ def main():
         crit = max(p["vectorise_ms_wall"] + t_post + p["pass1_ms_wall"] + p["merge_ms_wall"] for p in per_rank) + coll_ms
         crit_kernels = max(p["vectorise_ms_kernels"] + k_post.get("postings", 0) + p["pass1_ms_kernel"] + p["merge_ms_wall"]
                            for p in per_rank) + coll_ms
+        # ... and the critical path of the row-block form: no pairs to exchange, nothing to merge
+        coll_rb = 0.0 if world == 1 else (2 * table * frac + csr_bytes * frac) / (LINK_GBPS * 1e6) + 2 * COLLECTIVE_LATENCY_MS
+        crit_rb = (max(p["vectorise_ms_wall"] + t_post + p["row_block_form_ms_wall"] for p in per_rank) + coll_rb) if world > 1 else float("nan")
         if world == 1:
             one_gpu = crit
         slow = max(per_rank, key=lambda p: p["pass1_ms_wall"])
         report["ranks"][str(world)] = {"critical_path_ms": crit, "critical_path_ms_kernels_only": crit_kernels,
                                        "speedup_vs_1": one_gpu / crit, "collectives_ms_model": coll_ms,
                                        "slowest_pass1_ms": slow["pass1_ms_wall"], "fixed_ms": max(p["vectorise_ms_wall"] for p in per_rank) + t_post,
-                                       "merge_ms": max(p["merge_ms_wall"] for p in per_rank), "per_rank": per_rank}
+                                       "merge_ms": max(p["merge_ms_wall"] for p in per_rank),
+                                       "row_block_form_critical_path_ms": crit_rb, "per_rank": per_rank}
         print(f"N={world}: critical path {crit:7.3f} ms (kernels only {crit_kernels:7.3f})  = vectorise "
               f"{max(p['vectorise_ms_wall'] for p in per_rank):.3f} + index {t_post:.3f} + slowest range {slow['pass1_ms_wall']:.3f} "
               f"+ merge {max(p['merge_ms_wall'] for p in per_rank):.3f} + collectives (model) {coll_ms:.3f}   "
               f"speed-up {one_gpu / crit:.2f}x;  ranges' pass 1: {[round(p['pass1_ms_wall'], 2) for p in per_rank]}"
               f" (kernel alone: {[round(p['pass1_ms_kernel_alone'], 2) for p in per_rank]})")
+        if world > 1:
+            print(f"      row-block form instead: critical path {crit_rb:7.3f} ms ({one_gpu / crit_rb:.2f}x); the ranks' one-sided multiplies "
+                  f"{[round(p['row_block_form_ms_wall'], 2) for p in per_rank]}")
     print("JSON " + json.dumps(report))
 
 
