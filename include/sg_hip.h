@@ -167,8 +167,9 @@ int sg_csr_rowwise_dot(sg_ctx *ctx, const sg_csr *A, const sg_csr *B, void *out_
 /* ------------------------------------------------------------------ seam b2: sparse top-n multiply */
 /* Inverted index of B (n_right x V): for every term k the (row j, value) pairs, grouped by column
  * tile j / tile_cols.  tile_cols must be a power of two supported by the multiply (0 = default).
- * The postings keep a reference to B's arrays (the multiply re-scores candidates against B's rows):
- * B must stay alive until the postings are freed. */
+ * The postings keep a reference to B's arrays (the multiply re-scores candidates against B's rows, and an index over
+ * all rows is built from them on demand when a multiply asks for more than 64 columns per row of an index over groups of
+ * identical rows): B MUST stay alive -- and unchanged -- until the postings are freed. */
 int sg_postings_build(sg_ctx *ctx, const sg_csr *B, int32_t tile_cols, sg_postings **out);
 /* The same with options.  SG_POSTINGS_NO_PERMUTATION: by default the index is built over a fixed permutation of B's rows
  * (a sorted name list has its similar names side by side, which piles a row's candidates into a few column tiles: the

@@ -782,8 +782,14 @@ static int spgemm_topn_collapsed(sg_ctx *ctx, const sg_csr *A, const sg_postings
     if (stride64 > c->n_orig) stride64 = c->n_orig > 0 ? c->n_orig : 1;
     if (stride64 > SG_TOPN_LANES) {
         // more columns per row than one register list: an index over all rows, built once, serves these calls
-        if (!Bt->plain)
-            SG_TRY(sg_postings_build_flags(ctx, &Bt->caller_b_copy, Bt->build_tile_cols, (Bt->build_flags & 0xff) | (1 << 8), &Bt->plain));
+        {
+            // (made on first use; two threads sharing the index must not both make it -- ADVICE r03.  It is built from the
+            //  caller's matrix, which has to be alive as long as the index is: include/sg_hip.h, sg_postings_build)
+            static std::mutex plain_mu;
+            std::lock_guard<std::mutex> lock(plain_mu);
+            if (!Bt->plain)
+                SG_TRY(sg_postings_build_flags(ctx, &Bt->caller_b_copy, Bt->build_tile_cols, (Bt->build_flags & 0xff) | (1 << 8), &Bt->plain));
+        }
         return sg_spgemm_topn(ctx, A, Bt->plain, top_n, threshold, sort, out);
     }
     const sg_csr *cb = &Bt->caller_b_copy;
