@@ -587,7 +587,8 @@ __device__ __forceinline__ unsigned long long scan_desc(uint32_t epoch, unsigned
     return ((unsigned long long)epoch << 48) | (state << SCAN_VALUE_BITS) | (value & ((1ull << SCAN_VALUE_BITS) - 1ull));
 }
 
-template <typename TI, typename TO>
+// NONZERO: the scan counts the entries that are > 0 (the vocabulary: keys that occur -- a pass of its own wrote 0 / 1 first)
+template <typename TI, typename TO, bool NONZERO>
 __global__ void __launch_bounds__(SCAN_THREADS) scan_lookback_kernel(const TI *in, TO *out, int64_t n, TO *d_total,
                                                                      unsigned long long *desc, uint32_t *ticket,
                                                                      uint32_t ticket_base, uint32_t epoch) {
@@ -602,7 +603,7 @@ __global__ void __launch_bounds__(SCAN_THREADS) scan_lookback_kernel(const TI *i
     TO s = 0;
 #pragma unroll
     for (int i = 0; i < SCAN_ITEMS; ++i) {
-        v[i] = (base + i < n) ? (TO)in[base + i] : (TO)0;
+        v[i] = (base + i < n) ? (NONZERO ? (TO)(in[base + i] > 0 ? 1 : 0) : (TO)in[base + i]) : (TO)0;
         s += v[i];
     }
     TO tot;
@@ -658,7 +659,7 @@ __global__ void __launch_bounds__(SCAN_THREADS) scan_lookback_kernel(const TI *i
     if (d_total && (int64_t)tile == (n - 1) / SCAN_BLOCK && threadIdx.x == SCAN_THREADS - 1) *d_total = run;
 }
 
-template <typename TI, typename TO>
+template <typename TI, typename TO, bool NONZERO = false>
 static int scan_impl(sg_ctx *ctx, const TI *d_in, TO *d_out, int64_t n, TO *d_total) {
     if (n <= 0) {
         if (d_total) SG_HIP_TRY(hipMemsetAsync(d_total, 0, sizeof(TO), ctx->stream));
@@ -689,7 +690,7 @@ static int scan_impl(sg_ctx *ctx, const TI *d_in, TO *d_out, int64_t n, TO *d_to
         ctx->scan_epoch = 1;
     }
     uint32_t *ticket = reinterpret_cast<uint32_t *>(ctx->d_scan_desc + ctx->scan_desc_cap);
-    hipLaunchKernelGGL((scan_lookback_kernel<TI, TO>), dim3((unsigned)nblocks), dim3(SCAN_THREADS), 0, ctx->stream, d_in, d_out, n,
+    hipLaunchKernelGGL((scan_lookback_kernel<TI, TO, NONZERO>), dim3((unsigned)nblocks), dim3(SCAN_THREADS), 0, ctx->stream, d_in, d_out, n,
                        d_total, ctx->d_scan_desc, ticket, ctx->scan_ticket_base, ctx->scan_epoch);
     ctx->scan_ticket_base += (uint32_t)nblocks;   // (mod 2^32, like the device counter)
     SG_HIP_TRY(hipGetLastError());
@@ -698,6 +699,10 @@ static int scan_impl(sg_ctx *ctx, const TI *d_in, TO *d_out, int64_t n, TO *d_to
 
 int sg_exclusive_scan_u32(sg_ctx *ctx, const uint32_t *d_in, uint32_t *d_out, int64_t n, uint32_t *d_total) {
     return scan_impl<uint32_t, uint32_t>(ctx, d_in, d_out, n, d_total);
+}
+
+int sg_exclusive_scan_positive_i32(sg_ctx *ctx, const int32_t *d_in, uint32_t *d_out, int64_t n, uint32_t *d_total) {
+    return scan_impl<int32_t, uint32_t, true>(ctx, d_in, d_out, n, d_total);
 }
 
 int sg_exclusive_scan_i32_to_i64(sg_ctx *ctx, const int32_t *d_in, int64_t *d_out, int64_t n) {

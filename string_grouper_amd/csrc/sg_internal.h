@@ -89,6 +89,7 @@ struct sg_ctx {
         void *d;
     };
     std::vector<IdfTable> idf_tables;
+    int inner_multiply_depth = 0;                // > 0: sg_spgemm_topn runs for a wrapper (groups of identical rows) that counts the kept entries itself
     bool group_table_overflow = false;           // sg_collapse.hip: the table path met a group too large for it
 
     int alloc(size_t bytes, void **out);         // pooled hipMalloc
@@ -340,6 +341,8 @@ int sg_zero_ranges(sg_ctx *ctx, int n, void *const *ptrs, const size_t *bytes);
 #define SG_ZERO2(ctx, p0, b0, p1, b1) [&]() { void *const pp_[] = {(void *)(p0), (void *)(p1)}; const size_t bb_[] = {(size_t)(b0), (size_t)(b1)}; return sg_zero_ranges(ctx, 2, pp_, bb_); }()
 #define SG_ZERO3(ctx, p0, b0, p1, b1, p2, b2) [&]() { void *const pp_[] = {(void *)(p0), (void *)(p1), (void *)(p2)}; const size_t bb_[] = {(size_t)(b0), (size_t)(b1), (size_t)(b2)}; return sg_zero_ranges(ctx, 3, pp_, bb_); }()
 #define SG_ZERO4(ctx, p0, b0, p1, b1, p2, b2, p3, b3) [&]() { void *const pp_[] = {(void *)(p0), (void *)(p1), (void *)(p2), (void *)(p3)}; const size_t bb_[] = {(size_t)(b0), (size_t)(b1), (size_t)(b2), (size_t)(b3)}; return sg_zero_ranges(ctx, 4, pp_, bb_); }()
+// d_out[i] = number of entries > 0 before i (d_out may not alias d_in: the types differ in meaning, not in size)
+int sg_exclusive_scan_positive_i32(sg_ctx *ctx, const int32_t *d_in, uint32_t *d_out, int64_t n, uint32_t *d_total);
 int sg_exclusive_scan_u32(sg_ctx *ctx, const uint32_t *d_in, uint32_t *d_out, int64_t n, uint32_t *d_total);
 // same for int64 outputs from int32 inputs (row pointers)
 int sg_exclusive_scan_i32_to_i64(sg_ctx *ctx, const int32_t *d_in, int64_t *d_out, int64_t n);

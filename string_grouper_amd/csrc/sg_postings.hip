@@ -224,8 +224,14 @@ __global__ void __launch_bounds__(1024) postings_colscan_kernel(uint32_t *__rest
 __global__ void __launch_bounds__(1024) postings_tables_kernel(const uint32_t *__restrict__ cnt, const uint32_t *__restrict__ term_start,
                                                                int32_t n_terms, int32_t n_tiles, int32_t split,
                                                                uint32_t *__restrict__ seg, uint32_t *__restrict__ ends, int32_t nt_pad,
-                                                               uint32_t *__restrict__ ends8, int32_t nv_pad, int32_t fold_log2) {
+                                                               uint32_t *__restrict__ ends8, int32_t nv_pad, int32_t fold_log2,
+                                                               SgScoreCtx sc, SgScoreCtx *__restrict__ sc_out /* null: none */,
+                                                               uint32_t *__restrict__ null_slack /* null: none */) {
     __shared__ uint32_t tile[64][66];
+    if (blockIdx.x == 0) {   // two one-line kernels of the build ride along: the scoring context as a struct in device memory
+        if (sc_out && threadIdx.x == 0) *sc_out = sc;                       // (score_ctx_kernel)
+        if (null_slack && threadIdx.x < 512) null_slack[threadIdx.x] = threadIdx.x << 2;   // (null_postings_kernel)
+    }
     const int x = threadIdx.x & 63, y = threadIdx.x >> 6;   // y: 0 .. 15
     const int64_t k0 = (int64_t)blockIdx.x * 64;
     auto S = [&](int64_t k, int64_t t) -> uint32_t {        // k <= n_terms, t <= n_tiles
@@ -488,6 +494,13 @@ __global__ void __launch_bounds__(256) gather_rows_kernel(const int64_t *__restr
     if (p > n_rows) return;
     if (p == n_rows) {
         if (fwd_ptr && sub == 0) reinterpret_cast<uint2 *>(fwd_ptr)[p] = make_uint2((uint32_t)perm_ptr[n_rows], 0u);
+        // the exact scoring reads packed rows in rounds of eight entries and multiplies what lies past a row's end by a = 0:
+        // the pad behind the LAST row must hold finite values (0 * NaN would poison that row's score)
+        if (fwd && sub < 8) {
+            const int64_t at = perm_ptr[n_rows] + sub;
+            if (sizeof(T) == 4) reinterpret_cast<int2 *>(fwd)[at] = make_int2(0, 0);
+            else reinterpret_cast<int4 *>(fwd)[at] = make_int4(0, 0, 0, 0);
+        }
         return;
     }
     const int64_t g = orig_of[p];
@@ -704,6 +717,7 @@ extern "C" int sg_postings_build_flags(sg_ctx *ctx, const sg_csr *B_in, int32_t 
     void *early_fwd = nullptr;
     uint32_t *early_fwd_ptr = nullptr;
     bool fwd_done = false;
+    bool aux_written = false;   // the scoring context and the null postings were written by the tables kernel
     {
         const bool filt = want_pruned && sg_pruned_supports_tile(tile_log2) &&
                           (B->n_cols + 1) * ((n_tiles64 + 3) & ~(int64_t)3) < ((int64_t)1 << 30);
@@ -822,10 +836,7 @@ extern "C" int sg_postings_build_flags(sg_ctx *ctx, const sg_csr *B_in, int32_t 
         if (st == SG_OK) st = sg_alloc(ctx, (size_t)B->nnz + 512, &p->d_filt);
         // the stream form points lanes without a posting at the slack behind the array: entries that add 0 (bq = 0), each to
         // an accumulator of its own (64 lanes adding to ONE LDS word are serialised: 3 ms at 663 k)
-        if (st == SG_OK) {
-            hipLaunchKernelGGL(null_postings_kernel, dim3(2), dim3(256), 0, ctx->stream, p->d_filt + B->nnz);
-            if (hipGetLastError() != hipSuccess) st = SG_ERR_HIP;
-        }
+        // (written by postings_tables_kernel on the LDS build path, by a launch of its own otherwise: below)
         p->nt_pad = (int32_t)((n_tiles64 + 3) & ~(int64_t)3);
         if (st == SG_OK) st = sg_alloc(ctx, (size_t)(B->n_cols + 1) * (size_t)p->nt_pad + 4, &p->d_ends);
         // stream form of the pruned multiply (sg_spgemm_pruned.hip): eight tiles share one accumulator tile
@@ -902,10 +913,23 @@ extern "C" int sg_postings_build_flags(sg_ctx *ctx, const sg_csr *B_in, int32_t 
                                            B->d_indices, (const float *)B->d_data, B->n_rows, tile_log2, (int32_t)B->n_cols, split,
                                            (const uint32_t *)cnt, (const uint32_t *)p->d_term_start, (const uint8_t *)is_frequent,
                                            p->d_rows, (float *)p->d_vals, p->d_filt, inv_norm, p->fold_log2);
-                    hipLaunchKernelGGL(postings_tables_kernel, dim3(strips1), dim3(1024), 0, ctx->stream, (const uint32_t *)cnt,
-                                       (const uint32_t *)p->d_term_start, (int32_t)B->n_cols, p->n_tiles, split, p->d_seg, p->d_ends,
-                                       p->nt_pad, p->d_ends8, p->nv_pad, p->fold_log2);
-                    if (hipGetLastError() != hipSuccess) st = SG_ERR_HIP;
+                    SgScoreCtx sc;
+                    if (p->d_fwd_ptr) {
+                        st = ctx->alloc(256, (void **)&p->d_score_ctx);
+                        sc.fwd_ptr = p->d_fwd_ptr;
+                        sc.fwd = p->d_fwd;
+                        sc.blk = p->d_blk;
+                        sc.blk_bytes = p->blk_bytes;
+                        sc.orig_of = p->d_orig_of;
+                    }
+                    if (st == SG_OK) {
+                        hipLaunchKernelGGL(postings_tables_kernel, dim3(strips1), dim3(1024), 0, ctx->stream, (const uint32_t *)cnt,
+                                           (const uint32_t *)p->d_term_start, (int32_t)B->n_cols, p->n_tiles, split, p->d_seg, p->d_ends,
+                                           p->nt_pad, p->d_ends8, p->nv_pad, p->fold_log2, sc, p->d_score_ctx,
+                                           p->d_filt ? p->d_filt + B->nnz : (uint32_t *)nullptr);
+                        if (hipGetLastError() != hipSuccess) st = SG_ERR_HIP;
+                        aux_written = st == SG_OK;
+                    }
                 }
             }
             ctx->release(cnt);
@@ -952,7 +976,7 @@ extern "C" int sg_postings_build_flags(sg_ctx *ctx, const sg_csr *B_in, int32_t 
                                    p->fold_log2);
             if (hipGetLastError() != hipSuccess) st = SG_ERR_HIP;
         }
-        if (st == SG_OK && p->d_fwd) {   // (packed rows in use: no row blocks)
+        if (st == SG_OK && p->d_fwd && !fwd_done) {   // (packed rows in use: no row blocks; the fused pass writes the pad itself)
             // the exact scoring reads packed rows in rounds of eight entries and multiplies the slots past a row's end by
             // a = 0: the pad behind the LAST row must hold finite values (0 * NaN would poison that row's score)
             const size_t es = B->dtype == SG_F64 ? 16 : 8;
@@ -981,7 +1005,11 @@ extern "C" int sg_postings_build_flags(sg_ctx *ctx, const sg_csr *B_in, int32_t 
             if (hipGetLastError() != hipSuccess) st = SG_ERR_HIP;
         }
     }
-    if (st == SG_OK && p->d_fwd_ptr) {
+    if (st == SG_OK && p->d_filt && !aux_written) {
+        hipLaunchKernelGGL(null_postings_kernel, dim3(2), dim3(256), 0, ctx->stream, p->d_filt + B->nnz);
+        if (hipGetLastError() != hipSuccess) st = SG_ERR_HIP;
+    }
+    if (st == SG_OK && p->d_fwd_ptr && !aux_written) {
         st = ctx->alloc(256, (void **)&p->d_score_ctx);
         if (st == SG_OK) {
             SgScoreCtx sc;

@@ -799,7 +799,10 @@ static int spgemm_topn_collapsed(sg_ctx *ctx, const sg_csr *A, const sg_postings
     view.collapse = nullptr;
     view.plain = nullptr;
     sg_topn *ru = nullptr;
-    SG_TRY(sg_spgemm_topn(ctx, self ? c->unique : A, &view, top_n, threshold, 1, &ru));
+    ++ctx->inner_multiply_depth;
+    const int st_inner = sg_spgemm_topn(ctx, self ? c->unique : A, &view, top_n, threshold, 1, &ru);
+    --ctx->inner_multiply_depth;
+    SG_TRY(st_inner);
     sg_topn *r = nullptr;
     int st = topn_alloc(ctx, A->n_rows, c->n_orig, (int32_t)stride64, A->dtype, &r);
     if (st == SG_OK) {
@@ -815,8 +818,8 @@ static int spgemm_topn_collapsed(sg_ctx *ctx, const sg_csr *A, const sg_postings
                 hipLaunchKernelGGL(topn_sort_by_col_kernel<float>, dim3(g2), dim3(64), l2, ctx->stream, r->d_cols, (float *)r->d_vals,
                                    r->d_counts, A->n_rows, r->stride);
         }
-        if (st == SG_OK && A->n_rows > 0) {   // entries kept, counted on the expanded result
-            (void)hipMemsetAsync(ctx->d_stat_words + 1, 0, sizeof(int64_t), ctx->stream);
+        if (st == SG_OK && A->n_rows > 0 && ctx->inner_multiply_depth == 0) {   // entries kept, counted on the expanded result
+            // (word [1] is still zero: the multiply on the groups cleared it and, being an inner one, did not count)
             hipLaunchKernelGGL(sum_counts_kernel, dim3(256), dim3(256), 0, ctx->stream, r->d_counts, A->n_rows,
                                (unsigned long long *)(ctx->d_stat_words + 1));
             if (hipGetLastError() != hipSuccess) st = SG_ERR_HIP;
@@ -873,7 +876,10 @@ static int spgemm_topn_left_groups(sg_ctx *ctx, const sg_csr *A, const sg_postin
     const SgCollapse *g = A->left_groups;
     sg_topn *ru = nullptr;
     g->unique->left_state = 1;                      // (representatives are distinct)
-    SG_TRY(sg_spgemm_topn(ctx, g->unique, Bt, top_n, threshold, sort, &ru));
+    ++ctx->inner_multiply_depth;
+    const int st_inner = sg_spgemm_topn(ctx, g->unique, Bt, top_n, threshold, sort, &ru);
+    --ctx->inner_multiply_depth;
+    SG_TRY(st_inner);
     sg_topn *r = nullptr;
     int st = topn_alloc(ctx, A->n_rows, ru->n_cols, ru->stride, ru->dtype, &r);
     if (st == SG_OK && A->n_rows > 0) {
@@ -888,7 +894,7 @@ static int spgemm_topn_left_groups(sg_ctx *ctx, const sg_csr *A, const sg_postin
             hipLaunchKernelGGL(expand_left_rows_kernel<float>, dim3(grid), dim3(256), 0, ctx->stream, (const int32_t *)ru->d_cols,
                                (const float *)ru->d_vals, (const int32_t *)ru->d_counts, (const uint32_t *)g->d_gid, A->n_rows,
                                ru->stride, r->d_cols, (float *)r->d_vals, r->d_counts);
-        (void)hipMemsetAsync(ctx->d_stat_words + 1, 0, sizeof(int64_t), ctx->stream);   // entries kept: counted on all rows
+        // entries kept: counted on all rows (word [1] is still zero: the inner multiplies clear it and do not count)
         hipLaunchKernelGGL(sum_counts_kernel, dim3(256), dim3(256), 0, ctx->stream, r->d_counts, A->n_rows,
                            (unsigned long long *)(ctx->d_stat_words + 1));
         if (hipGetLastError() != hipSuccess) st = SG_ERR_HIP;
@@ -1097,7 +1103,7 @@ extern "C" int sg_spgemm_topn(sg_ctx *ctx, const sg_csr *A, const sg_postings *B
         else if (A->nnz > 0)
             hipLaunchKernelGGL(count_macs_kernel, dim3(512), dim3(256), 0, ctx->stream, A->d_indptr, A->d_indices,
                                A->n_rows, (const uint32_t *)Bt->d_term_len, (unsigned long long *)ctx->d_stat_words);
-        if (A->n_rows > 0)
+        if (A->n_rows > 0 && ctx->inner_multiply_depth == 0)   // (an inner multiply's rows are not the caller's: its wrapper counts)
             hipLaunchKernelGGL(sum_counts_kernel, dim3(256), dim3(256), 0, ctx->stream, r->d_counts, A->n_rows,
                                (unsigned long long *)(ctx->d_stat_words + 1));
         // algorithmic bytes (stream model): macs*(4+s) + nnz(A)*(4+s) + (nL+V+2)*4 + out*(4+s);

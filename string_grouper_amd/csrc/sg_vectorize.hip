@@ -577,12 +577,6 @@ __global__ void __launch_bounds__(256) df_reduce_kernel(int32_t *df_table, int64
     df_table[i] = s;
 }
 
-__global__ void __launch_bounds__(256) presence_kernel(const int32_t *__restrict__ df_table, int64_t key_space,
-                                                       uint32_t *present) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < key_space) present[i] = df_table[i] > 0 ? 1u : 0u;
-}
-
 // rank[key] = column id (exclusive scan of presence) or -1; also the column -> key / df arrays
 __global__ void __launch_bounds__(256) vocab_finalize_kernel(const int32_t *__restrict__ df_table, int64_t key_space,
                                                              int32_t *rank_io /* in: exclusive scan, out: col or -1 */,
@@ -659,15 +653,21 @@ __global__ void __launch_bounds__(1024) df_count_lds_kernel(const int64_t *__res
 }
 
 __global__ void __launch_bounds__(256) df_sum_kernel(const uint32_t *__restrict__ partial, int32_t n_partial, int64_t n_terms,
-                                                     int32_t *__restrict__ df /* zeroed */) {
-    // blockIdx.y picks 16 of the partial histograms: enough workgroups to fill the chip, distinct addresses per atomic
-    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= n_terms) return;
-    const int r0 = blockIdx.y * 16;
-    const int r1 = r0 + 16 < n_partial ? r0 + 16 : n_partial;
+                                                     int32_t *__restrict__ df) {
+    // 64 columns per workgroup, four threads per column (each a quarter of the workgroups' histograms, joined through LDS);
+    // loads are contiguous across the 64 columns.  The sum is WRITTEN: no clear of df first (round 3: atomics into a
+    // cleared array).
+    __shared__ uint32_t part[4][64];
+    const int kk = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const int64_t k = (int64_t)blockIdx.x * 64 + kk;
+    const int per = (n_partial + 3) / 4;
+    const int r0 = q * per, r1 = r0 + per < n_partial ? r0 + per : n_partial;
     uint32_t s = 0;
-    for (int r = r0; r < r1; ++r) s += partial[(int64_t)r * n_terms + k];
-    if (s) atomicAdd(&df[k], (int32_t)s);
+    if (k < n_terms)
+        for (int r = r0; r < r1; ++r) s += partial[(int64_t)r * n_terms + k];
+    part[q][kk] = s;
+    __syncthreads();
+    if (q == 0 && k < n_terms) df[k] = (int32_t)(part[0][kk] + part[1][kk] + part[2][kk] + part[3][kk]);
 }
 
 // column of a key: dense mode = table lookup, sorted mode = binary search in the ascending vocabulary
@@ -1298,9 +1298,8 @@ static int count_df_by_column(sg_ctx *ctx, sg_vocab *v) {
         if (one_pass) c.keys_are_columns = true;   // (one pass saw every token: its keys are columns now)
         at += wgs[i];
     }
-    (void)hipMemsetAsync(v->d_df, 0, sizeof(int32_t) * (size_t)v->n_terms, ctx->stream);
-    hipLaunchKernelGGL(df_sum_kernel, dim3((unsigned)((v->n_terms + 255) / 256), (unsigned)((n_partial + 15) / 16 > 0 ? (n_partial + 15) / 16 : 1)),
-                       dim3(256), 0, ctx->stream, (const uint32_t *)partial, n_partial, v->n_terms, v->d_df);
+    hipLaunchKernelGGL(df_sum_kernel, dim3((unsigned)((v->n_terms + 63) / 64)), dim3(256), 0, ctx->stream, (const uint32_t *)partial,
+                       n_partial, v->n_terms, v->d_df);
     if (hipGetLastError() != hipSuccess) {
         sg_set_error("df_count_lds_kernel: %s", hipGetErrorString(hipGetLastError()));
         st = SG_ERR_HIP;
@@ -1325,10 +1324,8 @@ extern "C" int sg_vec_fit_end(sg_ctx *ctx, sg_vocab *v, int64_t n_docs_total) {
             st = sg_alloc(ctx, 4, &d_total);
             if (st == SG_OK) {
                 const unsigned grid = (unsigned)((v->key_space + 255) / 256);
-                hipLaunchKernelGGL(presence_kernel, dim3(grid), dim3(256), 0, ctx->stream, im->d_df_table, v->key_space,
-                                   (uint32_t *)v->d_key_to_col);
-                st = sg_exclusive_scan_u32(ctx, (const uint32_t *)v->d_key_to_col, (uint32_t *)v->d_key_to_col,
-                                           v->key_space, d_total);
+                (void)grid;   // (the scan itself asks "does the key occur": no pass that writes 0 / 1 first)
+                st = sg_exclusive_scan_positive_i32(ctx, im->d_df_table, (uint32_t *)v->d_key_to_col, v->key_space, d_total);
             }
             uint32_t n_terms = 0;
             for (int attempt = 0; attempt < 2 && st == SG_OK; ++attempt) {
@@ -1353,9 +1350,8 @@ extern "C" int sg_vec_fit_end(sg_ctx *ctx, sg_vocab *v, int64_t n_docs_total) {
                 if (!any_long || st != SG_OK) break;
                 // long strings have marked keys of their own: the vocabulary is taken again
                 const unsigned grid = (unsigned)((v->key_space + 255) / 256);
-                hipLaunchKernelGGL(presence_kernel, dim3(grid), dim3(256), 0, ctx->stream, im->d_df_table, v->key_space,
-                                   (uint32_t *)v->d_key_to_col);
-                st = sg_exclusive_scan_u32(ctx, (const uint32_t *)v->d_key_to_col, (uint32_t *)v->d_key_to_col, v->key_space, d_total);
+                (void)grid;
+                st = sg_exclusive_scan_positive_i32(ctx, im->d_df_table, (uint32_t *)v->d_key_to_col, v->key_space, d_total);
             }
             ctx->release(d_total);
             if (st == SG_OK) {
