@@ -58,10 +58,13 @@ __device__ __forceinline__ void store_posting<double>(int32_t *rows, double *val
     vals[pos] = v;
 }
 
-// norm of a row's frequent part (terms whose list holds >= freq_min entries), quantised upwards to 8 bits
-// relative to norm_up
+// norm of a row's frequent part (terms whose list holds >= freq_min entries) relative to norm_up, rounded up
+// (emit_posting quantises it upwards once more, to the bits the form of the posting has for it)
+__device__ __forceinline__ float frequent_norm_ratio_of(double f2, float inv_norm_up) {
+    return __double2float_ru(sqrt(f2) * (1.0 + 1e-12)) * inv_norm_up;
+}
 template <typename T>
-__device__ __forceinline__ uint32_t frequent_norm_q8(const int32_t *__restrict__ indices, const T *__restrict__ data,
+__device__ __forceinline__ float frequent_norm_ratio(const int32_t *__restrict__ indices, const T *__restrict__ data,
                                                      int64_t lo, int64_t hi, const uint32_t *__restrict__ seg, int32_t n_tiles,
                                                      uint32_t freq_min, float inv_norm_up) {
     double f2 = 0.0;
@@ -69,33 +72,64 @@ __device__ __forceinline__ uint32_t frequent_norm_q8(const int32_t *__restrict__
         const int64_t k = indices[p];
         if (seg[(k + 1) * n_tiles] - seg[k * n_tiles] >= freq_min) f2 += (double)data[p] * (double)data[p];
     }
-    uint32_t fq = (uint32_t)ceilf(__double2float_ru(sqrt(f2)) * inv_norm_up * 255.0f * 1.000002f);
-    return fq > 255u ? 255u : fq;
+    return frequent_norm_ratio_of(f2, inv_norm_up);
 }
 
+// Entry i of the 512 "null postings" behind the filter postings (stream form: a lane that is through with its segment
+// reads entries 4 * lane .. 4 * lane + 3): bq = fq = 0 and ALL FOUR entries of a lane name accumulator word `lane` -- one
+// LDS instruction of the wave then touches 64 different words, and the low 24 bits of the entry, which the multiply
+// takes for the value, stay below 256: (CA * 252) >> 32 == 0 for every CA < 2^24, the entry adds nothing.
+__device__ __forceinline__ uint32_t sg_null_posting(uint32_t i) { return ((i >> 2) << 2) | 0x80000000u; }
+
 // one posting (+ its filter posting) of column `col` of the tile at position `pos`.
-// Filter posting (read by K4p, sg_spgemm_pruned.hip), 32 bits, AB = tile_log2 + 1:
+// Filter posting (read by K4p, sg_spgemm_pruned.hip), 32 bits, AB = tile_log2 + 1.  `fr` = the norm of the row's frequent
+// part relative to norm_up, rounded up (frequent_norm_ratio).
+// Tile-by-tile form (fold_log2 == 0):
 //   [0]        h     which 16-bit half of the accumulator word the column owns (col & 1)
 //   [1]        0
 //   [2, AB)    word  (col >> 1): bits [0, AB) masked with ~3 ARE the byte address of the accumulator word in LDS
 //   [AB, 24)   bq    value quantised upwards relative to norm_up
-//   [24, 32)   fq    norm of the row's frequent part, quantised upwards relative to norm_up
-// Stream form (fold_log2 > 0; sg_spgemm_pruned.hip, "stream form"): 2^fold_log2 consecutive tiles share ONE accumulator
-// tile, and the posting says which of them its column lies in:
-//   [AB, AB + fold_log2)   fold   tile index mod 2^fold_log2
-//   [AB + fold_log2, 24)   bq     (8 bits at the default geometry: tile 4096, fold 8)
+//   [24, 32)   fq    fr quantised upwards to 8 bits
+// Stream form (fold_log2 == 3, tile_log2 == 12; sg_spgemm_pruned.hip, "stream form"): 2^fold_log2 consecutive tiles share
+// ONE accumulator tile, the posting says which of them its column lies in, and the fields are cut for the multiply's
+// instructions (round 4: 11 -> 8 VALU per posting):
+//   [0]        0
+//   [1]        h     (<< 3 it is the shift of the half: 0 or 16; bits [1, 16) >> 1 ARE the column inside the super-tile)
+//   [2, 13)    word
+//   [13, 16)   fold  tile index mod 8
+//   [16, 24)   bq    chosen so that the low 24 bits AS ONE NUMBER are >= v / norm_up * 255 * 2^16: the multiply feeds the
+//                    posting to v_mul_hi_u32_u24 as it is -- the bits below bq then count as part of the value, and K3,
+//                    which knows them, rounds bq down by what they are worth (the bound is as tight as rounding bq up
+//                    by itself was, and the multiply saves the mask)
+//   [24, 32)   fq    chosen the same way: bits [16, 32) as one number F >= fr * 255 * 2^8 (bq counts as its low byte), stored
+//                    with its top bit flipped (F - 32768 as int16) for v_mad_i32_i16, which then gives the column's whole
+//                    survivor threshold in ONE instruction (the 8-bit form: byte select + multiply, subtract, shift)
+#define SG_FILT_F16_MAX 65280u   // 255 * 256
 template <typename T>
 __device__ __forceinline__ void emit_posting(int32_t *out_rows, T *out_vals, uint32_t *out_filt, uint32_t pos, uint32_t col,
-                                             T v, uint32_t fq, int32_t tile_log2, float inv_norm_up, uint32_t tile,
+                                             T v, float fr, int32_t tile_log2, float inv_norm_up, uint32_t tile,
                                              int32_t fold_log2) {
     // the multiply wants the byte offset of the accumulator inside its LDS tile, not j itself
     if (out_vals) store_posting<T>(out_rows, out_vals, pos, (int32_t)(col * (uint32_t)sizeof(T)), v);   // (null: filter postings only)
     if (out_filt) {
         const int32_t ab = tile_log2 + 1, fb = ab + fold_log2;
-        const uint32_t bq_max = (1u << (24 - fb)) - 1u;   // the bits the address, the fold and fq leave
+        if (fold_log2 > 0) {   // stream form (fb == 16: sg_postings_build only folds tiles of 4096 columns by 8)
+            const uint32_t low = ((col >> 1) << 2) | ((col & 1u) << 1) | ((tile & ((1u << fold_log2) - 1u)) << ab);
+            uint32_t b24 = (uint32_t)ceilf((float)v * inv_norm_up * (255.0f * 65536.0f) * 1.000002f);
+            if (b24 > 0xFFFFFFu) b24 = 0xFFFFFFu;
+            const uint32_t bq = b24 > low ? (b24 - low + 65535u) >> 16 : 0u;                   // <= 255
+            uint32_t f16 = (uint32_t)ceilf(fr * (float)SG_FILT_F16_MAX * 1.000002f);
+            if (f16 > SG_FILT_F16_MAX) f16 = SG_FILT_F16_MAX;
+            const uint32_t fq = f16 > bq ? (f16 - bq + 255u) >> 8 : 0u;                        // <= 255
+            out_filt[pos] = low | (bq << 16) | ((fq ^ 0x80u) << 24);
+            return;
+        }
+        const uint32_t bq_max = (1u << (24 - fb)) - 1u;   // the bits the address and fq leave
         uint32_t bq = (uint32_t)ceilf((float)v * inv_norm_up * (float)bq_max * 1.000002f);
         if (bq > bq_max) bq = bq_max;
-        out_filt[pos] = ((col >> 1) << 2) | (col & 1u) | ((tile & ((1u << fold_log2) - 1u)) << ab) | (bq << fb) | (fq << 24);
+        uint32_t fq = (uint32_t)ceilf(fr * 255.0f * 1.000002f);
+        if (fq > 255u) fq = 255u;
+        out_filt[pos] = ((col >> 1) << 2) | (col & 1u) | (bq << fb) | (fq << 24);
     }
 }
 
@@ -112,7 +146,7 @@ __global__ void __launch_bounds__(256) postings_fill(const int64_t *__restrict__
     const int64_t lo = indptr[j], hi = indptr[j + 1];
     const uint32_t t = (uint32_t)(j >> tile_log2);
     const uint32_t col = (uint32_t)(j & (((int64_t)1 << tile_log2) - 1));
-    const uint32_t fq = out_filt ? frequent_norm_q8<T>(indices, data, lo, hi, seg, n_tiles, freq_min, inv_norm_up) : 0u;
+    const float fq = out_filt ? frequent_norm_ratio<T>(indices, data, lo, hi, seg, n_tiles, freq_min, inv_norm_up) : 0.f;
     for (int64_t p = lo; p < hi; ++p) {
         const int64_t bin = (int64_t)indices[p] * n_tiles + t;
         const uint32_t pos = seg[bin] + atomicAdd(&cursor[bin], 1u);
@@ -230,7 +264,7 @@ __global__ void __launch_bounds__(1024) postings_tables_kernel(const uint32_t *_
     __shared__ uint32_t tile[64][66];
     if (blockIdx.x == 0) {   // two one-line kernels of the build ride along: the scoring context as a struct in device memory
         if (sc_out && threadIdx.x == 0) *sc_out = sc;                       // (score_ctx_kernel)
-        if (null_slack && threadIdx.x < 512) null_slack[threadIdx.x] = threadIdx.x << 2;   // (null_postings_kernel)
+        if (null_slack && threadIdx.x < 512) null_slack[threadIdx.x] = sg_null_posting(threadIdx.x);   // (null_postings_kernel)
     }
     const int x = threadIdx.x & 63, y = threadIdx.x >> 6;   // y: 0 .. 15
     const int64_t k0 = (int64_t)blockIdx.x * 64;
@@ -313,17 +347,17 @@ __global__ void __launch_bounds__(1024) postings_fill_lds(const int64_t *__restr
             k0[r] = have ? indices[lo[r] + sub] : -1;
             v0[r] = have ? data[lo[r] + sub] : (T)0;
         }
-        uint32_t fq[SG_POST_ROWS];
+        float fq[SG_POST_ROWS];
 #pragma unroll
         for (int r = 0; r < SG_POST_ROWS; ++r) {
-            fq[r] = 0;
+            fq[r] = 0.f;
 #if defined(SG_K3_PROBE_NO_FQ)
             if (out_filt && n_rows < 0) {
 #else
             if (out_filt) {
 #endif
-                // norm of the row's frequent part, quantised upwards to 8 bits relative to norm_up (the order of the additions
-                // is free: the result is rounded up with a margin far above the rounding of a double sum)
+                // norm of the row's frequent part relative to norm_up, rounded up (the order of the additions is free: the
+                // result is rounded up with a margin far above the rounding of a double sum)
                 double f2 = 0.0;
                 if (k0[r] >= 0 && ((freq_bits[k0[r] >> 5] >> (k0[r] & 31)) & 1u)) f2 = (double)v0[r] * (double)v0[r];
                 for (int64_t p = lo[r] + sub + 16; p < hi[r]; p += 16) {
@@ -336,8 +370,7 @@ __global__ void __launch_bounds__(1024) postings_fill_lds(const int64_t *__restr
                     const uint32_t l = (uint32_t)__shfl_xor((int)(uint32_t)bits, d, 64), h = (uint32_t)__shfl_xor((int)(uint32_t)(bits >> 32), d, 64);
                     f2 += __longlong_as_double((long long)(((uint64_t)h << 32) | l));
                 }
-                fq[r] = (uint32_t)ceilf(__double2float_ru(sqrt(f2) * (1.0 + 1e-12)) * inv_norm_up * 255.0f * 1.000002f);
-                if (fq[r] > 255u) fq[r] = 255u;
+                fq[r] = frequent_norm_ratio_of(f2, inv_norm_up);
             }
         }
 #pragma unroll
@@ -454,8 +487,8 @@ __global__ void __launch_bounds__(256) ends_from_seg_kernel(const uint32_t *__re
 }
 
 __global__ void __launch_bounds__(256) null_postings_kernel(uint32_t *__restrict__ slack) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;   // 512 entries: word i of the accumulator tile, bq = fq = 0
-    slack[i] = i << 2;
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;   // 512 entries
+    slack[i] = sg_null_posting(i);
 }
 
 // ---- position space: a fixed permutation of the right-hand rows (see sg_postings in sg_internal.h)

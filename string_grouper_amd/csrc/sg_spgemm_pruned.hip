@@ -591,7 +591,14 @@ spgemm_topn_pruned_kernel(const int64_t *__restrict__ a_indptr, const int32_t *_
         const float c1 = b_s * norm_b * (SCALE / 255.0f) * 1.000002f;
         const int32_t T0 = (int32_t)floorf(t0 * 256.0f) - 256 * np;   // every add may fall short by < 1, |P| adds at most
         const int32_t C1 = (int32_t)(c1 * 256.0f) + 1;
-        if (!(T0 - C1 * 255 >= 256)) {   // delta too small for the fixed-point resolution: exact kernel
+        // Stream form: the posting's bits [16, 32) AS ONE NUMBER F (fq with bq as its low byte, stored as F - 32768: K3 rounds
+        // fq so that F is an upper bound of f_j / norm_up * 255 * 256) give the threshold in sixteen more bits,
+        //      d_j = T16 - C16 * F  <=  tq_j * 2^16,      survive when (q_ij << 16) >= d_j,
+        // in ONE instruction: v_mad_i32_i16 on the posting's upper half, d_j = T0s + C1n * int16(F - 32768).
+        const int32_t C16 = (int32_t)(b_s * norm_b * (SCALE * 65536.0f / 65280.0f) * 1.000002f) + 1;   // < 2^13
+        const int32_t T16 = T0 << 8;                                                                     // < 2^29
+        const int32_t T0s = T16 - 32768 * C16, C1n = -C16;
+        if (FOLD_LOG2 > 0 ? !(T16 - C16 * 65535 >= 65536) : !(T0 - C1 * 255 >= 256)) {   // delta too small for the fixed-point resolution: exact kernel
             if (lane == 0) flagged_rows[atomicAdd(flagged_count, 1u)] = row;
             continue;
         }
@@ -903,7 +910,7 @@ spgemm_topn_pruned_kernel(const int64_t *__restrict__ a_indptr, const int32_t *_
             // Accumulators are cleared once per visit (8 KiB, eight ds_write_b128 per lane) instead of per posting: with
             // more than one round the re-zeroing stores of a round would wipe sums that later rounds add to.
             constexpr int FOLD = 1 << FOLD_LOG2;
-            constexpr uint32_t COL_MASK = ((1u << (TILE_LOG2 + FOLD_LOG2)) - 1u) & ~1u;
+            constexpr uint32_t COL_MASK = (1u << (TILE_LOG2 + FOLD_LOG2)) - 1u;
             uint32_t *dt = reinterpret_cast<uint32_t *>(smem + TILE * 2 + 512 + (sizeof(T) == 4 ? 512 : 1024 + SG_SURV_CAP * 4));
             dt[lane] = 0xFFFFFFFFu;
             dt[lane + 64] = 0xFFFFFFFFu;
@@ -917,10 +924,6 @@ spgemm_topn_pruned_kernel(const int64_t *__restrict__ a_indptr, const int32_t *_
             // end of a super-tile
             const uint32_t hi_end = ends[(size_t)erow + t_end - 1u];
             typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-            // Ends of the visits, four per 16-byte load, the next four prefetched.  These loads are ordinary ones: the
-            // compiler waits for them with vmcnt(0) -- it does not know of the rounds in flight -- so every fourth visit the
-            // prefetched rounds are drained.  (Loading them by hand as well was tried: the value then flows through the
-            // phi of `if (c == 0)`, which the compiler lowers with copies of registers whose load is still in flight.)
             uint32_t v_lo = 0, v_end = n_visits;              // the visits this item covers
             uint32_t hi_stop = hi_end;                        // where the lane's stream ends
             uint32_t cur = (g ? my_lo << 2 : 0u) + u16;       // the lane's next four entries
@@ -942,16 +945,57 @@ spgemm_topn_pruned_kernel(const int64_t *__restrict__ a_indptr, const int32_t *_
                     }
                 }
             }
-            uint4 Ec = ends8_at(v_lo >> 2);
-            uint4 En = ends8_at(min((v_lo >> 2) + 1u, last_group8));
+            // Segment ends of the visits, four per 16-byte load: EA holds an even group of four visits, EB an odd one -- the
+            // group in use and the next one, which is loaded BY HAND into the other buffer when the lane's stream enters a
+            // group (load_ends below).  Two buffers that are never copied, because every way of writing "current = next;
+            // next = load" ends in the compiler loading into a temporary and copying it into place behind a vmcnt(0)
+            // right where the load is issued -- a full memory round trip AND the rounds in flight drained, every fourth
+            // visit (round 3 lived with that: 1.2 M such stalls per launch at 663 k).
+            u32x4 EA, EB;
+            {
+                const uint32_t g0 = v_lo >> 2;
+                const uint4 a = ends8_at(g0), b = ends8_at(min(g0 + 1u, last_group8));
+                const u32x4 av = u32x4{a.x, a.y, a.z, a.w}, bv = u32x4{b.x, b.y, b.z, b.w};
+                EA = (g0 & 1u) ? bv : av;
+                EB = (g0 & 1u) ? av : bv;
+            }
+            auto end_of_visit = [&](uint32_t v) {   // v is wave-uniform: a choice of register, not a computation
+                const uint32_t c = v & 3u;
+                const uint32_t ea = c == 0 ? EA.x : (c == 1 ? EA.y : (c == 2 ? EA.z : EA.w));
+                const uint32_t eb = c == 0 ? EB.x : (c == 1 ? EB.y : (c == 2 ? EB.z : EB.w));
+                return (v & 4u) ? eb : ea;
+            };
+            const uint32_t erow8_b = erow8 << 2;
+            // sel: 0 = load group `grp` into EA, 1 = into EB, 2 = nothing to load (most rounds).  ONE asm statement that
+            // the compiler sees on every path, with EA and EB as read-write operands: no branch of its own around it, so no
+            // copy of a register that is still in flight.  Nobody waits for this load by name: loads return in order, it
+            // is older than every round issued behind it, and it is first read four visits -- at least four rounds and
+            // their waits -- later.
+            auto load_ends = [&](uint32_t sel, uint32_t grp) {
+                uint32_t e_off;
+                asm volatile(
+                    "s_cmp_gt_u32 %[sel], 1\n\t"
+                    "s_cbranch_scc1 .Lends_done%=\n\t"
+                    "v_lshl_add_u32 %[off], %[grp], 4, %[erow]\n\t"
+                    "s_cmp_eq_u32 %[sel], 0\n\t"
+                    "s_cbranch_scc0 .Lends_b%=\n\t"
+                    "global_load_dwordx4 %[EA], %[off], %[base]\n\t"
+                    "s_branch .Lends_done%=\n"
+                    ".Lends_b%=:\n\t"
+                    "global_load_dwordx4 %[EB], %[off], %[base]\n"
+                    ".Lends_done%=:"
+                    : [EA] "+v"(EA), [EB] "+v"(EB), [off] "=&v"(e_off)
+                    : [sel] "s"(sel), [grp] "s"(grp), [erow] "v"(erow8_b), [base] "s"(ends8)
+                    : "scc", "memory");
+            };
             uint32_t gv = v_lo;                               // the visit whose loads are being issued (wave-uniform)
-            const uint32_t c_lo = v_lo & 3u;
-            uint32_t hi = min(c_lo == 0 ? Ec.x : (c_lo == 1 ? Ec.y : (c_lo == 2 ? Ec.z : Ec.w)), hi_stop);   // end of the lane's segment in visit gv
+            uint32_t hi = min(end_of_visit(v_lo), hi_stop);   // end of the lane's segment in visit gv
 
             struct SBatch {
                 u32x4 q;       // the lane's four entries of the round
             };
             const uint32_t null_at = null_off + ((uint32_t)lane << 4);   // this lane's four postings that add nothing
+            bool live = hi > cur;                             // the lane's segment in visit gv holds entries at and behind `cur`
             // One round's load for every lane.  tv = the visit it belongs to (>= n_visits: past the end), last = the
             // visit ends with this round.
             auto issue_s = [&](SBatch &bt, uint32_t &tv, bool &last) {
@@ -973,7 +1017,7 @@ spgemm_topn_pruned_kernel(const int64_t *__restrict__ a_indptr, const int32_t *_
                 // the wait stricter, never too lax (loads return in order).  tests/test_kernel_isa.py checks that nothing
                 // reads a round's registers between its load and its wait.
                 {
-                    const uint32_t at = (int32_t)(hi - cur) > 0 ? cur : null_at;
+                    const uint32_t at = live ? cur : null_at;
 #if defined(SG_STREAM_PROBE_NO_LOADS)   // timing probes (wrong results): scripts/gpu_session.sh ab:SG_HIP_LIB=...
                     bt.q = u32x4{at & 0x1ffcu, (at * 5u) & 0x1ffcu, (at * 9u) & 0x1ffcu, (at * 13u) & 0x1ffcu};
 #elif defined(SG_STREAM_PLAIN_LOADS)   // (A/B: the compiler's own loads and wait counts)
@@ -983,18 +1027,20 @@ spgemm_topn_pruned_kernel(const int64_t *__restrict__ a_indptr, const int32_t *_
 #endif
                 }
                 cur += G16;
-                last = ballot64((int32_t)(hi - cur) > 0) == 0;
+                live = hi > cur;   // (one compare per round: the next round's choice of address is this one's "more to come")
+                last = ballot64(live) == 0;
+                uint32_t sel = 2u, grp = 0u;
                 if (last) {   // next visit
                     ++gv;
-                    const uint32_t c = gv & 3u;
-                    if (c == 0) {
-                        Ec = En;
-                        En = ends8_at(min((gv >> 2) + 1u, last_group8));
+                    if ((gv & 3u) == 0u) {   // a new group of four: the one behind it goes into the buffer that has just been left
+                        grp = min((gv >> 2) + 1u, last_group8);
+                        sel = ((gv >> 2) + 1u) & 1u;
                     }
-                    const uint32_t e = c == 0 ? Ec.x : (c == 1 ? Ec.y : (c == 2 ? Ec.z : Ec.w));
                     cur = hi + u16;              // the next segment starts where this one ends
-                    hi = min(e, hi_stop);
+                    hi = min(end_of_visit(gv), hi_stop);
+                    live = hi > cur;
                 }
+                load_ends(sel, grp);
             };
             SBatch sb0, sb1, sb2, sb3;
             sb0.q = sb1.q = sb2.q = sb3.q = u32x4{0u, 0u, 0u, 0u};   // (the loads name their registers as read-write operands)
@@ -1006,8 +1052,11 @@ spgemm_topn_pruned_kernel(const int64_t *__restrict__ a_indptr, const int32_t *_
             uint32_t n_clean = 0;   // survivors at the front of the buffer that the repeat filter has seen already
             // (the rounds in flight land before the call: callees save and restore the registers they are loaded into, and
             //  the compiler does not know that they are in flight)
-            auto flush_s = [&]() {
-                asm volatile("s_waitcnt vmcnt(0) ; rounds %0 %1 %2 %3" : "+v"(sb0.q), "+v"(sb1.q), "+v"(sb2.q), "+v"(sb3.q)::"memory");
+            // (oa, ob, oc: the three rounds in flight.  The round being applied has landed and is NOT named: naming it would
+            //  make it a new value next to the copy the slots behind the call still read -- eight register moves per round
+            //  that records anything, i.e. most rounds)
+            auto flush_s = [&](SBatch &oa, SBatch &ob, SBatch &oc) {
+                asm volatile("s_waitcnt vmcnt(0) ; rounds %0 %1 %2 ends %3 %4" : "+v"(oa.q), "+v"(ob.q), "+v"(oc.q), "+v"(EA), "+v"(EB)::"memory");
                 const FlushOut<T> fo = flush_survivors<T, SYM, TILE_LOG2, WIDE>(nnz, thr, row, sc, pairs, top, n_surv, n_clean);
                 top = fo.top;
 #ifndef SG_STREAM_PROBE_COUNT_ROUNDS
@@ -1020,37 +1069,43 @@ spgemm_topn_pruned_kernel(const int64_t *__restrict__ a_indptr, const int32_t *_
             // COMBINED predicate is rebuilt through a select and a compare), a lane's slot in the buffer comes from mbcnt,
             // and the store runs under the two compares' masks.  16 -> 9 VALU per call, two to three calls per round
             // (profiles/r03_final_sq_counters.log: 128 VALU per round, 50 of them the round's own).
-            auto collect_s = [&](bool fired, uint64_t cm, uint32_t r, uint32_t tv) {
-                const uint32_t col = (tv << (TILE_LOG2 + FOLD_LOG2)) | ((r >> 1) & COL_MASK) | (r & 1u);
+            auto collect_s = [&](bool fired, uint64_t cm, uint32_t r, uint32_t tv, SBatch &oa, SBatch &ob, SBatch &oc) {
+                const uint32_t col = (tv << (TILE_LOG2 + FOLD_LOG2)) | ((r >> 1) & COL_MASK);   // bits [1, 16): fold, word, half
                 // SYM: the pair (i, j > i) is row j's to score.  One-sided: entries read past the end of a segment (see
                 // issue_s) may name columns of the last super-tile that do not exist.
                 const bool mine = SYM ? col <= row : col < n_right;
                 cm &= ballot64(mine);
                 const uint32_t n_new = (uint32_t)__popcll(cm);
-                if (n_surv + n_new > (uint32_t)SG_SURV_CAP - 1u) flush_s();   // (leaves fewer than 64)
+                if (n_surv + n_new > (uint32_t)SG_SURV_CAP - 1u) flush_s(oa, ob, oc);   // (leaves fewer than 64)
                 const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(cm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)cm, 0u));
                 if (fired && mine) surv[n_surv + below] = (int)col;
                 n_surv += n_new;
             };
             struct SSlot {
                 uint32_t z, sh, xs, x;
-                int32_t d;
+                uint32_t d;
             };
-            // what the LDS add needs (address, amount) ...
+            // what the LDS add needs (address, amount): 4 VALU.  The posting goes into the 24-bit multiply AS IT IS -- its
+            // bits below bq count as part of the value, which K3 has allowed for when it chose bq (emit_posting) ...
             auto prep_s = [&](uint32_t r) {
                 SSlot q;
                 q.z = r & ADDR_MASK;
-                q.sh = r << 4;   // bit 4 = the half
-                q.x = (uint32_t)(((uint64_t)(r & (BQ_MAX << FB)) * (uint64_t)(CA & 0xffffffu)) >> 32);
+                q.sh = r << 3;   // bit 4 = the half (bit 1 of the posting; bit 0 is 0)
+                q.x = (uint32_t)(((uint64_t)(r & 0xffffffu) * (uint64_t)(CA & 0xffffffu)) >> 32);
                 asm("v_lshlrev_b32 %0, %1, %2" : "=v"(q.xs) : "v"(q.sh), "v"(q.x));
                 q.d = 0;
                 return q;
             };
-            // ... and what only the test of its result needs: the accumulator must reach tq = (T0 - C1 fq) >> 8; with this
-            // posting's x added: old >= tq - x.  Computed while the adds are on their way (SG_STREAM_TEST_EARLY: before).
-            auto bar_s = [&](uint32_t r, uint32_t x) { return ((T0 - __mul24(C1, (int32_t)(r >> 24))) >> 8) - (int32_t)x; };
+            // ... and what only the test of its result needs: the accumulator, with this posting's x added, must reach the
+            // column's threshold -- ((old + x) << 16) >= d, d = T0s + C1n * int16(r >> 16): 1 VALU while the adds are on
+            // their way, 3 behind them (bit field, add + shift, compare).
+            auto bar_s = [&](uint32_t r) {
+                uint32_t d;
+                asm("v_mad_i32_i16 %0, %1, %2, %3 op_sel:[1,0,0,0]" : "=v"(d) : "v"(r), "v"(C1n), "v"(T0s));
+                return d;
+            };
             bool dirty = false;   // accumulators of the current visit hold sums
-            auto apply_s = [&](SBatch &bt, uint32_t tv, bool last) {
+            auto apply_s = [&](SBatch &bt, SBatch &oa, SBatch &ob, SBatch &oc, uint32_t tv, bool last) {
                 // the round's load is waited for HERE, on every path (also when no lane has a posting)
 #if defined(SG_STREAM_PLAIN_LOADS) || defined(SG_STREAM_PROBE_NO_LOADS)
                 asm volatile("" : "+v"(bt.q)::"memory");
@@ -1084,27 +1139,29 @@ spgemm_topn_pruned_kernel(const int64_t *__restrict__ a_indptr, const int32_t *_
                     uint32_t o3 = __hip_atomic_fetch_add(tab_at(s3.z), s3.xs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     SG_SCHED_FENCE();
 #endif
-                    s0.d = bar_s(q.x, s0.x);
-                    s1.d = bar_s(q.y, s1.x);
-                    s2.d = bar_s(q.z, s2.x);
-                    s3.d = bar_s(q.w, s3.x);
+                    s0.d = bar_s(q.x);
+                    s1.d = bar_s(q.y);
+                    s2.d = bar_s(q.z);
+                    s3.d = bar_s(q.w);
                     asm volatile("" : "+v"(s0.d), "+v"(s1.d), "+v"(s2.d), "+v"(s3.d));   // (before the wait, not behind it)
                     asm volatile("" : "+v"(o0), "+v"(o1), "+v"(o2), "+v"(o3));   // the one wait
-                    const bool f0 = (int32_t)__builtin_amdgcn_ubfe(o0, s0.sh, 16u) >= s0.d;
-                    const bool f1 = (int32_t)__builtin_amdgcn_ubfe(o1, s1.sh, 16u) >= s1.d;
-                    const bool f2 = (int32_t)__builtin_amdgcn_ubfe(o2, s2.sh, 16u) >= s2.d;
-                    const bool f3 = (int32_t)__builtin_amdgcn_ubfe(o3, s3.sh, 16u) >= s3.d;
+                    // (old + x never leaves sixteen bits -- the accumulators are laid out for that -- and d >= 2^16: unsigned)
+                    const bool f0 = ((__builtin_amdgcn_ubfe(o0, s0.sh, 16u) + s0.x) << 16) >= s0.d;
+                    const bool f1 = ((__builtin_amdgcn_ubfe(o1, s1.sh, 16u) + s1.x) << 16) >= s1.d;
+                    const bool f2 = ((__builtin_amdgcn_ubfe(o2, s2.sh, 16u) + s2.x) << 16) >= s2.d;
+                    const bool f3 = ((__builtin_amdgcn_ubfe(o3, s3.sh, 16u) + s3.x) << 16) >= s3.d;
                     const uint64_t c0 = ballot64(f0), c1m = ballot64(f1), c2 = ballot64(f2), c3 = ballot64(f3);
                     if (c0 | c1m | c2 | c3) {
-                        if (c0) collect_s(f0, c0, q.x, tv);
-                        if (c1m) collect_s(f1, c1m, q.y, tv);
-                        if (c2) collect_s(f2, c2, q.z, tv);
-                        if (c3) collect_s(f3, c3, q.w, tv);
+                        if (c0) collect_s(f0, c0, q.x, tv, oa, ob, oc);
+                        if (c1m) collect_s(f1, c1m, q.y, tv, oa, ob, oc);
+                        if (c2) collect_s(f2, c2, q.z, tv, oa, ob, oc);
+                        if (c3) collect_s(f3, c3, q.w, tv, oa, ob, oc);
                     }
                 }
 #ifndef SG_STREAM_PROBE_NO_CLEAR
-                if (last && dirty) {   // the visit is through: its accumulators back to zero
-                    for (int x = lane; x < TILE * 2 / 16; x += 64) tab_v[x] = make_uint4(0, 0, 0, 0);
+                if (last && dirty) {   // the visit is through: its accumulators back to zero (eight stores at constant offsets)
+#pragma unroll
+                    for (int x = 0; x < TILE * 2 / 16; x += 64) tab_v[x + lane] = make_uint4(0, 0, 0, 0);
                     dirty = false;
                 }
 #endif
@@ -1119,21 +1176,21 @@ spgemm_topn_pruned_kernel(const int64_t *__restrict__ a_indptr, const int32_t *_
             for (;;) {   // trips of four rounds; every round is re-issued right behind its use
                 SG_WD(wd_s, 1 << 26, 17)
                 if (tv0 >= v_end) break;
-                apply_s(sb0, tv0, la0);
+                apply_s(sb0, sb1, sb2, sb3, tv0, la0);
                 issue_s(sb0, tv0, la0);
                 if (tv1 >= v_end) break;
-                apply_s(sb1, tv1, la1);
+                apply_s(sb1, sb2, sb3, sb0, tv1, la1);
                 issue_s(sb1, tv1, la1);
                 if (tv2 >= v_end) break;
-                apply_s(sb2, tv2, la2);
+                apply_s(sb2, sb3, sb0, sb1, tv2, la2);
                 issue_s(sb2, tv2, la2);
                 if (tv3 >= v_end) break;
-                apply_s(sb3, tv3, la3);
+                apply_s(sb3, sb0, sb1, sb2, tv3, la3);
                 issue_s(sb3, tv3, la3);
             }
             // rounds issued past the end of the stream are still in flight: they must land before their registers are reused
-            asm volatile("s_waitcnt vmcnt(0) ; rounds %0 %1 %2 %3" : "+v"(sb0.q), "+v"(sb1.q), "+v"(sb2.q), "+v"(sb3.q)::"memory");
-            if (n_surv > n_clean) flush_s();   // repeats out of what is left (scored below)
+            asm volatile("s_waitcnt vmcnt(0) ; rounds %0 %1 %2 %3 ends %4 %5" : "+v"(sb0.q), "+v"(sb1.q), "+v"(sb2.q), "+v"(sb3.q), "+v"(EA), "+v"(EB)::"memory");
+            if (n_surv > n_clean) flush_s(sb1, sb2, sb3);   // repeats out of what is left (scored below; everything has landed)
         }
         {   // postings streamed = entries of P's lists in the tiles visited
             uint32_t mine = 0;

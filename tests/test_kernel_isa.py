@@ -81,7 +81,7 @@ def blocks_of(body):
     for line in body.split("\n"):
         m = re.match(r"^(\.LBB\S+):(.*)$", line)
         if m:
-            cur = {"label": m.group(1), "ins": [], "note": m.group(2)}
+            cur = {"label": m.group(1), "ins": [], "raw": [], "note": m.group(2)}
             out.append(cur)
             continue
         s = line.strip()
@@ -90,6 +90,7 @@ def blocks_of(body):
                 cur["note"] = s
             continue
         cur["ins"].append(s.split(";")[0].strip())
+        cur["raw"].append(s)
         if ";" in s and "Loop" in s and not cur["note"]:
             cur["note"] = s
     return out
@@ -161,6 +162,12 @@ def test_round_loop_of_the_stream_form_keeps_its_shape(asm, which):
     i0, i1 = blocks.index(rounds[0]), blocks.index(rounds[-1])
     for b in blocks[i0:i1 + 1]:
         assert not any(x.startswith("scratch_") for x in b["ins"]), (which, b["label"], "scratch access inside the trip")
+        # ... and no wait of the compiler's own for ALL loads: the only vmcnt(0) inside the trip are the hand-written ones in
+        # front of the calls that score survivors (round 3 had one behind every load of the next visits' segment ends --
+        # a full memory round trip with the rounds in flight drained, every fourth visit; round 4 loads the ends by hand)
+        for x in b["raw"]:
+            if x.startswith("s_waitcnt") and "vmcnt(0)" in x:
+                assert "; rounds" in x, (which, b["label"], x)
 
 
 def _regs_of(text):

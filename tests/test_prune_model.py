@@ -102,25 +102,49 @@ def test_survivors_cover_every_oracle_match(thr, delta, freq):
 # bq has 8 bits, the fixed point is 2^12, and a posting records its column when `old + x >= tq_j` -- whatever the
 # other columns folded onto the accumulator have added before.  The model runs the accumulation in a RANDOM order of
 # the postings (the kernel's order depends on how the lanes are dealt) and must still record every oracle match.
+#
+# Round 4: the posting's fields are cut for the multiply's instructions (sg_postings.hip, emit_posting).  Its low 24
+# bits go into v_mul_hi_u32_u24 AS ONE NUMBER (K3 rounds bq so that {bq, fold, word, half} >= v / norm_up * 255 * 2^16),
+# its upper 16 bits into v_mad_i32_i16 as F - 32768 (K3 rounds fq so that F = {fq, bq} >= f / norm_up * 255 * 256), and the
+# test is ((old + x) << 16) >= T16 - C16 * F.  `eight_bit=True` is round 3's arithmetic (masked bq, 8-bit fq), kept to
+# check that the new bounds are as tight.
 FOLD_LOG2 = 3
 FB = AB + FOLD_LOG2
 BQ_MAX_S = (1 << (24 - FB)) - 1
 SCALE_S = 32768 >> FOLD_LOG2
+F16_MAX = 255 * 256
 
 
-def quantise_right_stream(m, mt, freq_min, norm_up):
+def quantise_right_stream(m, mt, freq_min, norm_up, tile=4096):
+    """-> (fq8 per right row, bq8 per posting) of round 3, and the 32-bit filter postings of round 4 (mt's order)."""
     df = np.diff(mt.indptr)
     inv = f32(1.0) / f32(norm_up)
     frequent = df[m.indices] >= freq_min
     f2 = np.zeros(m.shape[0])
     np.add.at(f2, np.repeat(np.arange(m.shape[0]), np.diff(m.indptr))[frequent],
               m.data[frequent].astype(np.float64) ** 2)
-    fq = np.minimum(255, np.ceil(np.nextafter(np.sqrt(f2).astype(f32), f32(2)) * inv * f32(255.0) * f32(1.000002)))
-    bq_t = np.minimum(BQ_MAX_S, np.ceil(mt.data.astype(f32) * inv * f32(BQ_MAX_S) * f32(1.000002)))
-    return fq.astype(np.int64), bq_t.astype(np.int64)
+    fr = (np.nextafter(np.sqrt(f2).astype(f32), f32(2)) * inv).astype(f32)       # frequent_norm_ratio
+    fq8 = np.minimum(255, np.ceil(fr * f32(255.0) * f32(1.000002))).astype(np.int64)
+    v = mt.data.astype(f32)
+    bq8 = np.minimum(BQ_MAX_S, np.ceil(v * inv * f32(BQ_MAX_S) * f32(1.000002))).astype(np.int64)
+    j = mt.indices.astype(np.int64)
+    c, fold = j % tile, (j // tile) % (1 << FOLD_LOG2)
+    low = ((c >> 1) << 2) | ((c & 1) << 1) | (fold << AB)
+    b24 = np.minimum(0xFFFFFF, np.ceil(f32(v * inv) * f32(255.0 * 65536.0) * f32(1.000002))).astype(np.int64)
+    bq = np.where(b24 > low, (b24 - low + 65535) >> 16, 0)
+    f16 = np.minimum(F16_MAX, np.ceil(fr[j] * f32(F16_MAX) * f32(1.000002))).astype(np.int64)
+    fq = np.where(f16 > bq, (f16 - bq + 255) >> 8, 0)
+    assert bq.max() <= 255 and fq.max() <= 255
+    postings = low | (bq << 16) | ((fq ^ 0x80) << 24)
+    # what the bounds must hold (the kernel's two numbers are upper bounds of the exact ratios)
+    assert ((postings & 0xFFFFFF) >= np.ceil(v.astype(np.float64) / float(norm_up) * 255 * 65536 - 1e-3)).all()
+    F = ((postings >> 16) ^ 0x8000)
+    assert (F >= np.minimum(F16_MAX, np.ceil(np.sqrt(f2)[j] / float(norm_up) * F16_MAX - 1e-3))).all()
+    return fq8, bq8, postings
 
 
-def records_of_row_stream(a_idx, a_val, Bt_indptr, Bt_rows, bq_t, fq, thr, delta, norm_up, freq_min, rng, tile=4096):
+def records_of_row_stream(a_idx, a_val, Bt_indptr, Bt_rows, bq_t, fq, postings, thr, delta, norm_up, freq_min, rng, tile=4096,
+                          eight_bit=False):
     """Columns the stream form records for one left row, repeats and false positives included."""
     nnz = len(a_idx)
     df = (Bt_indptr[a_idx + 1] - Bt_indptr[a_idx]).astype(np.int64)
@@ -145,33 +169,51 @@ def records_of_row_stream(a_idx, a_val, Bt_indptr, Bt_rows, bq_t, fq, thr, delta
     n_p = int(in_p.sum())
     T0 = int(np.floor(f32(t0 * f32(256.0)))) - 256 * n_p
     C1 = int(f32(c1 * f32(256.0))) + 1
-    if T0 - C1 * 255 < 256:
+    C16 = int(f32(f32(f32(b_s * f32(norm_up)) * f32(f32(SCALE_S) * f32(65536.0) / f32(65280.0))) * f32(1.000002))) + 1
+    T16 = T0 << 8
+    if (T0 - C1 * 255 < 256) if eight_bit else (T16 - C16 * 65535 < 65536):
         return None, 0          # the kernel hands such a row to the exact kernel
-    cols, xs = [], []
+    assert C16 < (1 << 15) and T16 < (1 << 31)
+    T0s, C1n = T16 - 32768 * C16, -C16
+    cols, xs, rs = [], [], []
     for t in np.nonzero(in_p)[0]:
         lo, hi = Bt_indptr[a_idx[t]], Bt_indptr[a_idx[t] + 1]
         c_a = f32(f32(f32(f32(a_val[t]) * f32(norm_up)) * f32(SCALE_S / BQ_MAX_S)) * f32(1.000002))
         CA = int(f32(c_a * f32(1 << (32 - FB)))) + 1
         assert CA < (1 << 24)
-        xs.append((CA * (bq_t[lo:hi].astype(np.int64) << FB)) >> 32)      # v_mul_hi_u32_u24
+        if eight_bit:
+            xs.append((CA * (bq_t[lo:hi].astype(np.int64) << FB)) >> 32)      # v_mul_hi_u32_u24 of the masked field
+        else:
+            xs.append((CA * (postings[lo:hi] & 0xFFFFFF)) >> 32)              # v_mul_hi_u32_u24 of the posting as it is
         cols.append(Bt_rows[lo:hi])
+        rs.append(postings[lo:hi])
     cols = np.concatenate(cols)
     xs = np.concatenate(xs)
+    rs = np.concatenate(rs)
     order = rng.permutation(len(cols))
     acc = {}
     rec = []
-    for j, x in zip(cols[order], xs[order]):
+    for j, x, r in zip(cols[order], xs[order], rs[order]):
         key = (int(j) // (tile << FOLD_LOG2), int(j) % tile)     # (visit, accumulator)
         old = acc.get(key, 0)
         acc[key] = old + int(x)
         assert acc[key] < 65536                                  # sixteen bits hold the sums of all folded columns
-        if old + int(x) >= ((T0 - C1 * int(fq[j])) >> 8):
+        if eight_bit:
+            fired = old + int(x) >= ((T0 - C1 * int(fq[j])) >> 8)
+        else:
+            hi16 = int(r) >> 16
+            d = T0s + C1n * (hi16 - 65536 if hi16 >= 32768 else hi16)   # v_mad_i32_i16 on the posting's upper half
+            assert d >= 65536
+            fired = ((old + int(x)) << 16) >= d
+            col_bits = (int(r) >> 1) & 0x7FFF                           # v_bfe_u32 r, 1, 15: the column inside its super-tile
+            assert col_bits == ((int(j) // tile) % (1 << FOLD_LOG2)) * 4096 + int(j) % tile
+        if fired:
             rec.append(int(j))
     return np.array(rec, dtype=np.int64), len(cols)
 
 
 @pytest.mark.parametrize("thr,delta,freq,tile", [(0.8, 0.05, 0.0045, 4096), (0.8, 0.05, 0.0045, 16), (0.5, 0.2, 0.01, 16),
-                                                 (0.95, 0.3, 0.05, 64), (0.6, 0.02, 0.0, 16)])
+                                                 (0.95, 0.3, 0.05, 64), (0.6, 0.02, 0.0, 16), (0.8, 0.03, 0.0045, 4096)])
 def test_stream_form_records_cover_every_oracle_match(thr, delta, freq, tile):
     """`tile` much smaller than the kernel's 4096 folds 3000 columns as heavily as 663 k columns fold in the kernel."""
     names = synth_names(3000, 78)
@@ -183,17 +225,21 @@ def test_stream_form_records_cover_every_oracle_match(thr, delta, freq, tile):
     C = O.sp_matmul_topn(m, m.T.tocsr(), 10_000, thr, sort=True)
     norm_up = np.nextafter(f32(np.sqrt(f32(np.asarray(m.multiply(m).sum(axis=1)).max())) * f32(1.000001)), f32(2))
     freq_min = max(1, int(freq * m.shape[0]))
-    fq, bq_t = quantise_right_stream(m, mt, freq_min, norm_up)
-    rng = np.random.default_rng(5)
-    n_rec = n_true = 0
-    for i in range(0, m.shape[0], 7):
-        lo, hi = m.indptr[i], m.indptr[i + 1]
-        rec, _ = records_of_row_stream(m.indices[lo:hi], m.data[lo:hi], mt.indptr, mt.indices, bq_t, fq, thr, delta,
-                                       norm_up, freq_min, rng, tile=tile)
-        if rec is None:
-            continue
-        want = C.indices[C.indptr[i]:C.indptr[i + 1]]
-        assert set(want) <= set(rec.tolist()), (i, sorted(set(want) - set(rec.tolist())))
-        n_rec += len(set(rec.tolist()))
-        n_true += len(want)
-    assert n_true > 0 and n_rec >= n_true
+    fq, bq_t, postings = quantise_right_stream(m, mt, freq_min, norm_up, tile=tile)
+    n_true = 0
+    n_rec = {False: 0, True: 0}
+    for eight_bit in (False, True):
+        rng = np.random.default_rng(5)
+        for i in range(0, m.shape[0], 7):
+            lo, hi = m.indptr[i], m.indptr[i + 1]
+            rec, _ = records_of_row_stream(m.indices[lo:hi], m.data[lo:hi], mt.indptr, mt.indices, bq_t, fq, postings, thr,
+                                           delta, norm_up, freq_min, rng, tile=tile, eight_bit=eight_bit)
+            if rec is None:
+                continue
+            want = C.indices[C.indptr[i]:C.indptr[i + 1]]
+            assert set(want) <= set(rec.tolist()), (eight_bit, i, sorted(set(want) - set(rec.tolist())))
+            n_rec[eight_bit] += len(set(rec.tolist()))
+            n_true += len(want) if not eight_bit else 0
+    assert n_true > 0 and n_rec[False] >= n_true
+    # as tight as round 3's bounds (the sixteen-bit F is tighter than an 8-bit fq; the value pays for the address bits)
+    assert n_rec[False] <= 1.03 * n_rec[True] + 5, n_rec
