@@ -67,6 +67,20 @@
 #define SG_WATCH_NAME sg_debug_watch_pruned
 #include "sg_k4_device.h"
 
+#ifdef SG_DEBUG_WAVE_TIMES   // (scripts/build_variant.sh times -DSG_DEBUG_WAVE_TIMES; scripts/wave_times_probe.py)
+// per wave of the last launch over rows ([0, 8192)) and over parts ([8192, 16384)): {start, end} on the 100 MHz clock,
+// the wave's slowest row: its duration, row | pairs scored << 32
+__device__ unsigned long long sg_debug_wave_times[4 * 16384];
+extern "C" int sg_debug_read_wave_times(unsigned long long *out, int clear) {
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(sg_debug_wave_times), sizeof(sg_debug_wave_times)) != hipSuccess) return 1;
+    if (clear) {
+        static unsigned long long zero[4 * 16384];
+        if (hipMemcpyToSymbol(HIP_SYMBOL(sg_debug_wave_times), zero, sizeof(zero)) != hipSuccess) return 1;
+    }
+    return 0;
+}
+#endif
+
 // (SG_PAIR_CHUNK, the entries of a chunk of the symmetric mode's pair list: sg_internal.h)
 #ifdef SG_STREAM_NO_SCHED_FENCE   // (A/B: the compiler's own order of a round's four slots)
 #define SG_SCHED_FENCE()
@@ -90,6 +104,39 @@ __device__ __forceinline__ T wave_shfl(T v, int src) {
 // step -- and look every term up in one or two LDS reads.
 #define SG_HASH_SLOTS 128
 __device__ __forceinline__ uint32_t term_hash(int k) { return ((uint32_t)k * 2654435761u) >> 25; }
+
+// An object of the wave's LDS by its byte address.  The kernel's dynamic LDS is its only LDS and starts at address 0
+// (the accumulator tile first: a posting's address field IS an LDS address).  In the kernel `smem + x` is as good; in the
+// routines the kernel CALLS it is not: there the compiler finds the array through a table in memory
+// (llvm.amdgcn.dynlds.offset.table) with a scalar load and a wait in front of EVERY access -- eight per round of
+// entries in the exact scoring.
+template <typename P>
+__device__ __forceinline__ P *lds_object(uint32_t byte_addr) {
+    typedef __attribute__((address_space(3))) P lds_t;
+    return (P *)(lds_t *)(uintptr_t)byte_addr;
+}
+
+// A small struct of launch constants (SgScoreCtx, SgPairSink) read through the SCALAR cache.  The routines below are real
+// calls and get the struct's address in a vector register: every field was a vector load of its own with a full wait
+// behind it -- ten dependent round trips per call of drain_survivors before the first entry of a candidate was
+// requested.  The address is the same in every lane and nothing writes the struct while the kernel runs: constant
+// address space, s_load.
+template <typename S>
+__device__ __forceinline__ S load_launch_constants(const S *p) {
+    static_assert(sizeof(S) % 4 == 0, "dwords");
+    const uint64_t a = (uint64_t)(uintptr_t)p;
+    const uint64_t u = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(a >> 32)) << 32) |
+                       (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)a);
+    typedef const __attribute__((address_space(4))) uint32_t *const_words;
+    const const_words w = (const_words)(uintptr_t)u;
+    union {
+        S s;
+        uint32_t d[sizeof(S) / 4];
+    } out = {};
+#pragma unroll
+    for (unsigned i = 0; i < sizeof(S) / 4; ++i) out.d[i] = w[i];
+    return out.s;
+}
 
 // Packed rows of B (sg_postings.hip, fwd_pack): eight entries per round, as 16-byte loads.
 template <typename T>
@@ -165,8 +212,20 @@ __device__ __forceinline__ T exact_score(int j, const int *hk, const T *ha, int 
         const uint32_t pb = m0.x;
         const uint32_t pe = m1.x;
         row_of_j = (int)m0.y;
+        // A call is a chain of dependent misses -- the row's pointer, then its entries eight at a time: four in a row for
+        // a row of 19 entries (the mean of a name list), ~10 us per call of 64 candidates, a fifth of the kernel.  The
+        // rounds behind the first are therefore TOUCHED (one dword each, three registers) together with the first round's
+        // loads: when their turn comes they arrive from the cache.  (Two rounds in flight by name instead -- 32 registers
+        // -- spilled in every kernel of the file.)
+        constexpr uint32_t DW = sizeof(T) == 4 ? 2u : 4u;   // dwords per entry
+        const uint32_t *fw = reinterpret_cast<const uint32_t *>(fwd);
+        const uint32_t q0 = pb & ~1u;
+        uint32_t t1 = 0, t2 = 0, t3 = 0;
+        if (q0 + 8u < pe) t1 = fw[(q0 + 8u) * DW];
+        if (q0 + 16u < pe) t2 = fw[(q0 + 16u) * DW];
+        if (q0 + 24u < pe) t3 = fw[(q0 + 24u) * DW];
         SG_WD_DECL(wd_v);
-        for (uint32_t q = pb & ~1u; q < pe; q += 8) {
+        for (uint32_t q = q0; q < pe; q += 8) {
             SG_WD(wd_v, 1 << 20, 21)
             FwdRound<T> r;
             r.load(fwd, q, pe - 1u);
@@ -177,6 +236,7 @@ __device__ __forceinline__ T exact_score(int j, const int *hk, const T *ha, int 
                 sum = add_rn<T>(sum, mul_rn<T>(a, r.v[e]));
             }
         }
+        asm volatile("" ::"v"(t1), "v"(t2), "v"(t3));
     }
     return sum;
 }
@@ -250,17 +310,17 @@ __device__ __noinline__ TopList<T> drain_survivors(int nnz, T thr, uint32_t row,
                                                    const SgScoreCtx *__restrict__ sc /* packed rows of B, position -> row */,
                                                    const SgPairSink *__restrict__ pairs /* SYM: the pair list */,
                                                    TopList<T> top, uint32_t n_surv) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int TILE = 1 << TILE_LOG2;
-    const int *hk = reinterpret_cast<const int *>(smem + TILE * 2);
-    const T *ha = reinterpret_cast<const T *>(smem + TILE * 2 + 512);
-    int *surv = reinterpret_cast<int *>(smem + TILE * 2 + 512 + 1024);
+    const int *hk = lds_object<int>(TILE * 2);
+    const T *ha = lds_object<T>(TILE * 2 + 512);
+    int *surv = lds_object<int>(TILE * 2 + 512 + 1024);
     const int lane = threadIdx.x;
     const int j = (uint32_t)lane < n_surv ? surv[lane] : -1;   // a POSITION: the index is built over a permutation of B's rows
+    const SgScoreCtx scv = load_launch_constants(sc);
     // what leaves the kernel is the row itself: the top list orders equal scores by the ORIGINAL column, the pairs name rows
     int jo;
-    const T sum = sc->blk ? exact_score_blocks<T, WIDE>(j, hk, ha, nnz, sc, jo)
-                          : exact_score<T, WIDE>(j, hk, ha, nnz, sc->fwd_ptr, sc->fwd, jo);
+    const T sum = scv.blk ? exact_score_blocks<T, WIDE>(j, hk, ha, nnz, &scv, jo)
+                          : exact_score<T, WIDE>(j, hk, ha, nnz, scv.fwd_ptr, scv.fwd, jo);
     uint64_t hm = __ballot(j >= 0 && sum > thr);
     if (SYM) {
         // row i keeps its own matches j <= i in its top list like the one-sided form; what row j < i has to learn -- that
@@ -273,23 +333,26 @@ __device__ __noinline__ TopList<T> drain_survivors(int nnz, T thr, uint32_t row,
             // of the survivor buffer (which holds at most 127 columns).
             uint32_t pos = (uint32_t)surv[SG_SURV_CAP - 1];
             const uint32_t n_hit = (uint32_t)__popcll(mm);
-            uint32_t *const pair_i = pairs->d_i, *const pair_j = pairs->d_j, *const pair_row_count = pairs->d_row_count;
-            T *const pair_s = reinterpret_cast<T *>(pairs->d_s);
-            const uint32_t pair_chunks = pairs->chunks;
+            const SgPairSink pv = load_launch_constants(pairs);
+            uint32_t *const pair_i = pv.d_i, *const pair_j = pv.d_j, *const pair_row_count = pv.d_row_count;
+            T *const pair_s = reinterpret_cast<T *>(pv.d_s);
+            const uint32_t pair_chunks = pv.chunks;
+            // the left row's own name (self-join: A is B), the same for every lane
+            const uint32_t row_name = (uint32_t)__builtin_amdgcn_readfirstlane((int)reinterpret_cast<const uint2 *>(scv.fwd_ptr)[row].y);
             if (pos == SG_PAIR_NO_CHUNK || (pos & 511u) + n_hit > SG_PAIR_CHUNK) {
                 uint32_t c = 0;
                 if (lane == 0) {
                     if (pos != SG_PAIR_NO_CHUNK && (pos >> 9) < pair_chunks) {
-                        pairs->d_chunk_count[pos >> 9] = pos & 511u;
-                        atomicAdd(pairs->d_totals, (unsigned long long)(pos & 511u));
+                        pv.d_chunk_count[pos >> 9] = pos & 511u;
+                        atomicAdd(pv.d_totals, (unsigned long long)(pos & 511u));
                     }
-                    c = atomicAdd(pairs->d_chunks_used, 1u);
+                    c = atomicAdd(pv.d_chunks_used, 1u);
                 }
                 pos = (uint32_t)__builtin_amdgcn_readfirstlane((int)c) << 9;
             }
             if (((mm >> lane) & 1ull) && (pos >> 9) < pair_chunks) {   // past the capacity nothing is written: the caller falls back
                 const size_t o = (size_t)(pos >> 9) * SG_PAIR_CHUNK + (pos & 511u) + (uint32_t)__popcll(mm & ((1ull << lane) - 1ull));
-                pair_i[o] = reinterpret_cast<const uint2 *>(sc->fwd_ptr)[row].y;   // the left row's own name (self-join: A is B)
+                pair_i[o] = row_name;
                 pair_j[o] = (uint32_t)jo;
                 pair_s[o] = sum;
                 atomicAdd(&pair_row_count[jo], 1u);   // how many mirrored matches row j will receive (pass 2 scans these)
@@ -332,10 +395,9 @@ template <typename T, bool SYM, int TILE_LOG2, bool WIDE>
 __device__ __noinline__ FlushOut<T> flush_survivors(int nnz, T thr, uint32_t row, const SgScoreCtx *__restrict__ sc,
                                                     const SgPairSink *__restrict__ pairs, TopList<T> top, uint32_t n_surv,
                                                     uint32_t n_clean) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int TILE = 1 << TILE_LOG2;
-    int *surv = reinterpret_cast<int *>(smem + TILE * 2 + 512 + 1024);
-    uint32_t *dt = reinterpret_cast<uint32_t *>(smem + TILE * 2 + 512 + (sizeof(T) == 4 ? 512 : 1024 + SG_SURV_CAP * 4));
+    int *surv = lds_object<int>(TILE * 2 + 512 + 1024);
+    uint32_t *dt = lds_object<uint32_t>(TILE * 2 + 512 + (sizeof(T) == 4 ? 512 : 1024 + SG_SURV_CAP * 4));
     const int lane = threadIdx.x;
     const uint64_t lanes_below = (1ull << lane) - 1ull;
     int c0 = 0, c1 = 0;
@@ -374,32 +436,32 @@ __device__ __noinline__ FlushOut<T> flush_survivors(int nnz, T thr, uint32_t row
 // {column, row, score} -- "row receives column" -- through the wave's chunk like the mirrored pairs of drain_survivors.
 template <typename T, int TILE_LOG2>
 __device__ __noinline__ void emit_part_matches(const SgPairSink *__restrict__ pairs, T s, int c, int cnt, uint32_t row_out) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int TILE = 1 << TILE_LOG2;
-    int *surv = reinterpret_cast<int *>(smem + TILE * 2 + 512 + 1024);
+    int *surv = lds_object<int>(TILE * 2 + 512 + 1024);
     const int lane = threadIdx.x;
     if (cnt <= 0) return;
     uint32_t pos = (uint32_t)surv[SG_SURV_CAP - 1];
-    const uint32_t pair_chunks = pairs->chunks;
+    const SgPairSink pv = load_launch_constants(pairs);
+    const uint32_t pair_chunks = pv.chunks;
     if (pos == SG_PAIR_NO_CHUNK || (pos & 511u) + (uint32_t)cnt > SG_PAIR_CHUNK) {
         uint32_t ch = 0;
         if (lane == 0) {
             if (pos != SG_PAIR_NO_CHUNK && (pos >> 9) < pair_chunks) {
-                pairs->d_chunk_count[pos >> 9] = pos & 511u;
-                atomicAdd(pairs->d_totals, (unsigned long long)(pos & 511u));
+                pv.d_chunk_count[pos >> 9] = pos & 511u;
+                atomicAdd(pv.d_totals, (unsigned long long)(pos & 511u));
             }
-            ch = atomicAdd(pairs->d_chunks_used, 1u);
+            ch = atomicAdd(pv.d_chunks_used, 1u);
         }
         pos = (uint32_t)__builtin_amdgcn_readfirstlane((int)ch) << 9;
     }
     if ((pos >> 9) < pair_chunks) {   // past the capacity nothing is written: the caller falls back
         if (lane < cnt) {
             const size_t o = (size_t)(pos >> 9) * SG_PAIR_CHUNK + (pos & 511u) + (uint32_t)lane;
-            pairs->d_i[o] = (uint32_t)c;
-            pairs->d_j[o] = row_out;
-            reinterpret_cast<T *>(pairs->d_s)[o] = s;
+            pv.d_i[o] = (uint32_t)c;
+            pv.d_j[o] = row_out;
+            reinterpret_cast<T *>(pv.d_s)[o] = s;
         }
-        if (lane == 0) atomicAdd(&pairs->d_row_count[row_out], (uint32_t)cnt);
+        if (lane == 0) atomicAdd(&pv.d_row_count[row_out], (uint32_t)cnt);
     }
     __builtin_amdgcn_wave_barrier();
     if (lane == 0) surv[SG_SURV_CAP - 1] = (int)(pos + (uint32_t)cnt);
@@ -474,6 +536,10 @@ spgemm_topn_pruned_kernel(const int64_t *__restrict__ a_indptr, const int32_t *_
     // addressed to its own row; the second pass merges the parts' lists like mirrored matches.
     constexpr bool CAN_SPLIT = SYM && !WIDE && FOLD_LOG2 > 0;
     const bool part_mode = CAN_SPLIT && (part_cfg >> 31) != 0u;
+#ifdef SG_DEBUG_WAVE_TIMES
+    const unsigned long long dbg_t0 = __builtin_amdgcn_s_memrealtime();
+    unsigned long long dbg_worst = 0, dbg_worst_row = 0;
+#endif
     const uint32_t n_here = (WIDE || part_mode) ? (uint32_t)__builtin_amdgcn_readfirstlane((int)*row_list_len) << (part_mode ? SG_ROW_PARTS_LOG2 : 0)
                                                 : (SYM ? (sym_hi - sym_lo + sym_step - 1u) / sym_step : n_left);
     // rows are handed out four at a time: one global atomic per row capped the kernel at ~88 rows/us (larger first
@@ -573,6 +639,10 @@ spgemm_topn_pruned_kernel(const int64_t *__restrict__ a_indptr, const int32_t *_
             continue;
         }
         if (!part_mode) ++st_rows;
+#ifdef SG_DEBUG_WAVE_TIMES
+        const unsigned long long dbg_r0 = __builtin_amdgcn_s_memrealtime();
+        const unsigned long long dbg_surv0 = st_surv;
+#endif
 #pragma unroll
         for (int d = 32; d > 0; d >>= 1) {
             bs2 = fmaxf(bs2, __shfl_xor(bs2, d, 64));
@@ -1234,6 +1304,15 @@ spgemm_topn_pruned_kernel(const int64_t *__restrict__ a_indptr, const int32_t *_
             const uint32_t pos = (uint32_t)__builtin_amdgcn_readfirstlane(surv[SG_SURV_CAP - 1]);
             if (pos != SG_PAIR_NO_CHUNK && (pos >> 9) >= pair_chunks && lane == 0) atomicMax(row_counter, 0x20000000u);
         }
+#ifdef SG_DEBUG_WAVE_TIMES
+        {   // the wave's slowest row: {duration, row | pairs scored << 32}
+            const unsigned long long dt = __builtin_amdgcn_s_memrealtime() - dbg_r0;
+            if (dt > dbg_worst) {
+                dbg_worst = dt;
+                dbg_worst_row = (unsigned long long)row | ((st_surv - dbg_surv0) << 32);
+            }
+        }
+#endif
     }
     }
     if (SYM && lane == 0) {   // close the wave's last chunk
@@ -1248,6 +1327,15 @@ spgemm_topn_pruned_kernel(const int64_t *__restrict__ a_indptr, const int32_t *_
         if (st_post) atomicAdd(stats + 1, st_post);
         if (st_surv) atomicAdd(stats + 2, st_surv);
     }
+#ifdef SG_DEBUG_WAVE_TIMES
+    if (SYM && !WIDE && FOLD_LOG2 > 0 && sizeof(T) == 4 && lane == 0 && blockIdx.x < 8192u) {
+        unsigned long long *w = sg_debug_wave_times + 4u * (blockIdx.x + (part_mode ? 8192u : 0u));
+        w[0] = dbg_t0;
+        w[1] = __builtin_amdgcn_s_memrealtime();
+        w[2] = dbg_worst;
+        w[3] = dbg_worst_row;
+    }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------
