@@ -82,6 +82,13 @@ extern "C" int sg_debug_read_wave_times(unsigned long long *out, int clear) {
 #endif
 
 // (SG_PAIR_CHUNK, the entries of a chunk of the symmetric mode's pair list: sg_internal.h)
+// Waves per SIMD the f64 stream kernels are built for (A/B knob of the build: scripts/build_variant.sh).  Round 3 built
+// them for three (at 128 registers the visit ends were spilled inside the round loop); with round 4's loop they fit 128
+// registers with five spilled around the row's set-up and none in the loop, and LDS (10.5 KiB) allows 15 waves per CU:
+// 7.0 -> 6.5 ms at 663 k.
+#ifndef SG_F64_STREAM_WAVES
+#define SG_F64_STREAM_WAVES 4
+#endif
 #ifdef SG_STREAM_NO_SCHED_FENCE   // (A/B: the compiler's own order of a round's four slots)
 #define SG_SCHED_FENCE()
 #else
@@ -472,8 +479,12 @@ __device__ __noinline__ void emit_part_matches(const SgPairSink *__restrict__ pa
 // 16 single-wave workgroups per CU (the LDS limit) = 4 waves per SIMD: <= 128 VGPRs.  The f64 stream form has 10.5 KiB of LDS
 // per wave (15 per CU) and, at 128 registers, spills the visit ends inside its round loop -- scratch reloads that the
 // compiler waits for with vmcnt(0), i.e. the rounds in flight drained every round: it is built for 3 waves per SIMD.
-template <typename T, int TILE_LOG2, bool SYM, bool WIDE, int FOLD_LOG2>
-__global__ void __launch_bounds__(64, (sizeof(T) == 8 && FOLD_LOG2 > 0) ? 3 : 4)
+// SHARE: a launch over a rank's share of the rows, or over the parts of the rows such a launch has set aside (stream +
+// self-join form only).  The whole-matrix pass is an instantiation of its own: what the parts need alive across the round
+// loop -- the list of rows set aside, the end of the visits as a variable -- costs it scalar registers it does not have
+// (49 instead of 20 spilled, + 0.8 % at 663 k).
+template <typename T, int TILE_LOG2, bool SYM, bool WIDE, int FOLD_LOG2, bool SHARE = false>
+__global__ void __launch_bounds__(64, (sizeof(T) == 8 && FOLD_LOG2 > 0) ? SG_F64_STREAM_WAVES : 4)
 spgemm_topn_pruned_kernel(const int64_t *__restrict__ a_indptr, const int32_t *__restrict__ a_indices,
                           const T *__restrict__ a_data, uint32_t n_left, const uint32_t *__restrict__ seg,
                           const uint32_t *__restrict__ ends, int32_t nt_pad, uint32_t n_terms,
@@ -534,7 +545,7 @@ spgemm_topn_pruned_kernel(const int64_t *__restrict__ a_indptr, const int32_t *_
     // slowest row of the 663 k job when the whole pass takes 6), which is what a rank's range of the multi-GPU form ends
     // with (scripts/range_probe.py).  A part keeps its matches in its list like a row and hands them to the pair list,
     // addressed to its own row; the second pass merges the parts' lists like mirrored matches.
-    constexpr bool CAN_SPLIT = SYM && !WIDE && FOLD_LOG2 > 0;
+    constexpr bool CAN_SPLIT = SYM && !WIDE && FOLD_LOG2 > 0 && SHARE;
     const bool part_mode = CAN_SPLIT && (part_cfg >> 31) != 0u;
 #ifdef SG_DEBUG_WAVE_TIMES
     const unsigned long long dbg_t0 = __builtin_amdgcn_s_memrealtime();
@@ -561,10 +572,12 @@ spgemm_topn_pruned_kernel(const int64_t *__restrict__ a_indptr, const int32_t *_
                                               : (SYM ? sym_hi - 1u - rr * sym_step : rr);
         uint32_t part_lo = 0, part_hi = 0;   // part mode: the visits [part_lo, part_hi) of the row
         if (CAN_SPLIT && part_mode) {
-            const uint32_t nv = ((row >> TILE_LOG2) + (1u << FOLD_LOG2)) >> FOLD_LOG2;   // visits of the row (self-join form)
+            // (the visits in front of `from` the row has done itself, in the launch over rows: see `deferred` below)
+            const uint32_t from = (uint32_t)__builtin_amdgcn_readfirstlane((int)row_list[n_left + (rr >> SG_ROW_PARTS_LOG2)]);
+            const uint32_t nv = (((row >> TILE_LOG2) + (1u << FOLD_LOG2)) >> FOLD_LOG2) - from;   // visits of the row (self-join form) left
             const uint32_t part = rr & (SG_ROW_PARTS - 1u);
-            part_lo = (part * nv) >> SG_ROW_PARTS_LOG2;
-            part_hi = ((part + 1u) * nv) >> SG_ROW_PARTS_LOG2;
+            part_lo = from + ((part * nv) >> SG_ROW_PARTS_LOG2);
+            part_hi = from + (((part + 1u) * nv) >> SG_ROW_PARTS_LOG2);
             if (part_lo == part_hi) continue;
         }
         // self-join form: the left matrix IS the permuted one, `row` a position; its result row and its name in the pairs
@@ -1010,11 +1023,23 @@ spgemm_topn_pruned_kernel(const int64_t *__restrict__ a_indptr, const int32_t *_
 #pragma unroll
                     for (int d = 32; d > 0; d >>= 1) rl = fmaxf(rl, __shfl_xor(rl, d, 64));
                     if (wave_read<float>(rl, 0) >= (float)part_cfg) {
-                        if (lane == 0) heavy_rows[atomicAdd(heavy_count, 1u)] = row;
+                        if (lane == 0) {
+                            const uint32_t at = atomicAdd(heavy_count, 1u);
+                            heavy_rows[at] = row;
+                            heavy_rows[n_left + at] = 0u;   // from its first visit
+                        }
                         continue;
                     }
                 }
             }
+            // ... and a row that turns out to have MANY CANDIDATES hands the visits it has left to the launch over parts as
+            // well: a call of the exact scoring is ~10 us per 64 candidates, a hub of a few thousand near-identical names is
+            // 0.5 - 0.7 ms in one wave -- at 663 k the launch over an eighth's rows ended 0.4 ms after its median wave, on
+            // such rows (scripts/wave_times_probe.py).  Known only while it happens, hence decided at the end of a visit:
+            // the row keeps what it has found (its result row is written as usual, pass 2 merges the parts' matches into
+            // it like mirrored ones) and the parts start at visit `v_end`.
+            uint32_t row_scored = 0;      // pairs of this row scored so far (flush_s; kept in a vector register: the scalar ones are short)
+            asm volatile("" : "+v"(row_scored));
             // Segment ends of the visits, four per 16-byte load: EA holds an even group of four visits, EB an odd one -- the
             // group in use and the next one, which is loaded BY HAND into the other buffer when the lane's stream enters a
             // group (load_ends below).  Two buffers that are never copied, because every way of writing "current = next;
@@ -1125,13 +1150,20 @@ spgemm_topn_pruned_kernel(const int64_t *__restrict__ a_indptr, const int32_t *_
             // (oa, ob, oc: the three rounds in flight.  The round being applied has landed and is NOT named: naming it would
             //  make it a new value next to the copy the slots behind the call still read -- eight register moves per round
             //  that records anything, i.e. most rounds)
-            auto flush_s = [&](SBatch &oa, SBatch &ob, SBatch &oc) {
+            auto flush_s = [&](SBatch &oa, SBatch &ob, SBatch &oc, uint32_t tv) {
                 asm volatile("s_waitcnt vmcnt(0) ; rounds %0 %1 %2 ends %3 %4" : "+v"(oa.q), "+v"(ob.q), "+v"(oc.q), "+v"(EA), "+v"(EB)::"memory");
                 const FlushOut<T> fo = flush_survivors<T, SYM, TILE_LOG2, WIDE>(nnz, thr, row, sc, pairs, top, n_surv, n_clean);
                 top = fo.top;
 #ifndef SG_STREAM_PROBE_COUNT_ROUNDS
                 st_surv += (n_surv - fo.n_surv) & ~63u;   // 64 if a wave was scored (the rest were repeats)
 #endif
+                if (CAN_SPLIT) {
+                    // enough candidates for a row (pairs scored ~ the rounds' bar in time): the visit being applied is its
+                    // last, the parts take over behind it (the rounds in flight of later visits are dropped by the loop's
+                    // own end; once: tv + 3 > v_end from here on)
+                    row_scored += (n_surv - fo.n_surv) & ~63u;
+                    if (!part_mode && part_cfg != 0u && tv + 3u <= v_end && ballot64(row_scored >= (part_cfg << 3)) != 0) v_end = tv + 1u;
+                }
                 n_surv = n_clean = (uint32_t)__builtin_amdgcn_readfirstlane((int)fo.n_surv);
             };
             // `fired`: the lane's own test, `cm` its wave mask.  Written so that nothing of the bookkeeping goes through the
@@ -1146,7 +1178,7 @@ spgemm_topn_pruned_kernel(const int64_t *__restrict__ a_indptr, const int32_t *_
                 const bool mine = SYM ? col <= row : col < n_right;
                 cm &= ballot64(mine);
                 const uint32_t n_new = (uint32_t)__popcll(cm);
-                if (n_surv + n_new > (uint32_t)SG_SURV_CAP - 1u) flush_s(oa, ob, oc);   // (leaves fewer than 64)
+                if (n_surv + n_new > (uint32_t)SG_SURV_CAP - 1u) flush_s(oa, ob, oc, tv);   // (leaves fewer than 64)
                 const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(cm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)cm, 0u));
                 if (fired && mine) surv[n_surv + below] = (int)col;
                 n_surv += n_new;
@@ -1260,7 +1292,12 @@ spgemm_topn_pruned_kernel(const int64_t *__restrict__ a_indptr, const int32_t *_
             }
             // rounds issued past the end of the stream are still in flight: they must land before their registers are reused
             asm volatile("s_waitcnt vmcnt(0) ; rounds %0 %1 %2 %3 ends %4 %5" : "+v"(sb0.q), "+v"(sb1.q), "+v"(sb2.q), "+v"(sb3.q), "+v"(EA), "+v"(EB)::"memory");
-            if (n_surv > n_clean) flush_s(sb1, sb2, sb3);   // repeats out of what is left (scored below; everything has landed)
+            if (n_surv > n_clean) flush_s(sb1, sb2, sb3, v_end);   // repeats out of what is left (scored below; everything has landed)
+            if (CAN_SPLIT && !part_mode && v_end != n_visits && lane == 0) {   // handed on
+                const uint32_t at = atomicAdd(heavy_count, 1u);
+                heavy_rows[at] = row;
+                heavy_rows[n_left + at] = v_end;
+            }
         }
         {   // postings streamed = entries of P's lists in the tiles visited
             uint32_t mine = 0;
@@ -1641,7 +1678,12 @@ static int launch_pruned(sg_ctx *ctx, const sg_csr *A, const sg_postings *Bt, in
     const size_t lds = pruned_lds(TILE_LOG2, FOLD_LOG2, A->dtype);
     unsigned grid = pruned_grid(ctx, TILE_LOG2, SYM ? (int64_t)pl.rows() : A->n_rows, FOLD_LOG2, A->dtype);
     if (WIDE && grid > (unsigned)ctx->num_cu * 4u) grid = (unsigned)ctx->num_cu * 4u;   // few rows, if any: idle waves leave at once
-    hipLaunchKernelGGL((spgemm_topn_pruned_kernel<T, TILE_LOG2, SYM, WIDE, FOLD_LOG2>), dim3(grid), dim3(64), lds, ctx->stream, A->d_indptr,
+    // (SHARE: see the kernel; only the forms that can run in parts have the second instantiation)
+    constexpr bool SPLITS = SYM && !WIDE && FOLD_LOG2 > 0;
+    const bool share = SPLITS && (heavy_count != nullptr || part_cfg != 0u);
+    auto kernel = share ? spgemm_topn_pruned_kernel<T, TILE_LOG2, SYM, WIDE, FOLD_LOG2, SPLITS>
+                        : spgemm_topn_pruned_kernel<T, TILE_LOG2, SYM, WIDE, FOLD_LOG2, false>;
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(64), lds, ctx->stream, A->d_indptr,
                        A->d_indices, (const T *)A->d_data, (uint32_t)A->n_rows, (const uint32_t *)Bt->d_seg,
                        (const uint32_t *)Bt->d_ends, Bt->nt_pad, (uint32_t)Bt->n_terms,
                        (const uint32_t *)Bt->d_filt, Bt->n_tiles, (const SgScoreCtx *)Bt->d_score_ctx, keep, r->stride, thr, s_budget,
@@ -1698,7 +1740,7 @@ static int launch_both(sg_ctx *ctx, const sg_csr *A, const sg_postings *Bt, int3
         }
         if (const char *v = ctx->opt("SG_HEAVY_ROUNDS")) heavy_rounds = (uint32_t)atoi(v) & 0x7fffffffu;
         if (heavy_rounds) {
-            st = sg_alloc(ctx, (size_t)A->n_rows + 8, &heavy);
+            st = sg_alloc(ctx, 2 * (size_t)A->n_rows + 8, &heavy);   // [4, 4 + n): the rows, [4 + n, 4 + 2 n): their first visit for the parts
             if (st == SG_OK && hipMemsetAsync(heavy, 0, 4 * sizeof(uint32_t), ctx->stream) != hipSuccess) st = SG_ERR_HIP;
         }
     }

@@ -26,30 +26,37 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 
 # template arguments <T, TILE_LOG2, SYM, WIDE, FOLD_LOG2> -> mangled fragment (FOLD_LOG2 = 0: the tile-by-tile form)
 KERNELS = {
-    "f32 self-join": "IfLi12ELb1ELb0ELi0EE",
-    "f32 one-sided": "IfLi12ELb0ELb0ELi0EE",
-    "f64 self-join": "IdLi12ELb1ELb0ELi0EE",
-    "f64 one-sided": "IdLi12ELb0ELb0ELi0EE",
+    "f32 self-join": "IfLi12ELb1ELb0ELi0ELb0EE",
+    "f32 one-sided": "IfLi12ELb0ELb0ELi0ELb0EE",
+    "f64 self-join": "IdLi12ELb1ELb0ELi0ELb0EE",
+    "f64 one-sided": "IdLi12ELb0ELb0ELi0ELb0EE",
 }
 # the stream form (FOLD_LOG2 = 3): rounds of four adds, no per-posting re-zeroing
 STREAM_KERNELS = {
-    "f32 self-join": "IfLi12ELb1ELb0ELi3EE",
-    "f32 one-sided": "IfLi12ELb0ELb0ELi3EE",
-    "f64 self-join": "IdLi12ELb1ELb0ELi3EE",
-    "f64 one-sided": "IdLi12ELb0ELb0ELi3EE",
+    "f32 self-join": "IfLi12ELb1ELb0ELi3ELb0EE",
+    "f32 one-sided": "IfLi12ELb0ELb0ELi3ELb0EE",
+    "f64 self-join": "IdLi12ELb1ELb0ELi3ELb0EE",
+    "f64 one-sided": "IdLi12ELb0ELb0ELi3ELb0EE",
 }
 # ... and the second launch over rows of 65 .. 128 non-zeros (WIDE): same loop, checked for its hand-written loads
 STREAM_WIDE_KERNELS = {
-    "f32 self-join wide": "IfLi12ELb1ELb1ELi3EE",
-    "f32 one-sided wide": "IfLi12ELb0ELb1ELi3EE",
-    "f64 self-join wide": "IdLi12ELb1ELb1ELi3EE",
-    "f64 one-sided wide": "IdLi12ELb0ELb1ELi3EE",
+    "f32 self-join wide": "IfLi12ELb1ELb1ELi3ELb0EE",
+    "f32 one-sided wide": "IfLi12ELb0ELb1ELi3ELb0EE",
+    "f64 self-join wide": "IdLi12ELb1ELb1ELi3ELb0EE",
+    "f64 one-sided wide": "IdLi12ELb0ELb1ELi3ELb0EE",
 }
-# vgpr spills allowed (all outside the trip).  f64 -- the reference's DEFAULT dtype -- is built for three waves per SIMD
-# (168 registers) and must keep head-room: no scratch at all and at least 8 spare registers, so that an unrelated edit
-# cannot push its round loop into spills (round 2: 14.9 -> 16.4 ms from one, profiles/r02_sessionAL_f64_bisect.log)
-STREAM_LIMITS = {"f32 self-join": 16, "f32 one-sided": 16, "f64 self-join": 0, "f64 one-sided": 0}
-STREAM_VGPRS = {"f32 self-join": 128, "f32 one-sided": 128, "f64 self-join": 160, "f64 one-sided": 160}   # 4 / 3 waves per SIMD
+# ... and the instantiation for a rank's share of the rows and for the rows in parts (SHARE: the multi-GPU form)
+STREAM_SHARE_KERNELS = {
+    "f32 self-join share": "IfLi12ELb1ELb0ELi3ELb1EE",
+    "f64 self-join share": "IdLi12ELb1ELb0ELi3ELb1EE",
+}
+# vgpr spills allowed (all outside the trip -- the test below checks that no scratch access lies inside it).  f64 -- the
+# reference's DEFAULT dtype -- was built for three waves per SIMD through round 3 (a spill inside its round loop cost
+# 14.9 -> 16.4 ms in round 2, profiles/r02_sessionAL_f64_bisect.log); round 4's loop fits four (7.0 -> 6.5 ms at 663 k).
+STREAM_LIMITS = {"f32 self-join": 16, "f32 one-sided": 16, "f64 self-join": 8, "f64 one-sided": 8,
+                 "f32 self-join share": 16, "f64 self-join share": 8}
+STREAM_VGPRS = {"f32 self-join": 128, "f32 one-sided": 128, "f64 self-join": 128, "f64 one-sided": 128,   # 4 waves per SIMD
+                "f32 self-join share": 128, "f64 self-join share": 128}
 # (vgpr spills allowed, instructions of the fast-path block allowed)
 LIMITS = {"f32 self-join": (16, 95), "f32 one-sided": (16, 95), "f64 self-join": (24, 95), "f64 one-sided": (24, 95)}
 
@@ -140,11 +147,11 @@ def is_stream_round(b):
 
 
 @pytest.mark.timeout(1200)
-@pytest.mark.parametrize("which", list(STREAM_KERNELS))
+@pytest.mark.parametrize("which", list(STREAM_KERNELS) + list(STREAM_SHARE_KERNELS))
 def test_round_loop_of_the_stream_form_keeps_its_shape(asm, which):
     """The stream form's loop: four unrolled rounds, each one block with the four LDS adds of a round and no scratch
     access; the prefetched rounds are waited for by count; spills stay out of the loop."""
-    name, body = kernel_body(asm, STREAM_KERNELS[which])
+    name, body = kernel_body(asm, {**STREAM_KERNELS, **STREAM_SHARE_KERNELS}[which])
     meta = asm[asm.index(".name:           " + name):]
     spills = int(re.search(r"\.vgpr_spill_count:\s*(\d+)", meta).group(1))
     vgprs = int(re.search(r"\.vgpr_count:\s*(\d+)", meta).group(1))
@@ -181,13 +188,13 @@ def _regs_of(text):
 
 
 @pytest.mark.timeout(1200)
-@pytest.mark.parametrize("which", list(STREAM_KERNELS) + list(STREAM_WIDE_KERNELS))
+@pytest.mark.parametrize("which", list(STREAM_KERNELS) + list(STREAM_WIDE_KERNELS) + list(STREAM_SHARE_KERNELS))
 def test_nothing_reads_a_round_between_its_hand_written_load_and_its_wait(asm, which):
     """The stream form loads its rounds with `global_load_dwordx4` in inline assembly and waits for them with a hand-counted
     `s_waitcnt vmcnt(3)`: the compiler does not know that these registers are in flight, so a copy or a spill of one of
     them between the load and the wait would read garbage -- silently.  Every such load must be followed (in layout
     order) by its own wait before anything else names its registers, and there must be exactly four round variables."""
-    name, body = kernel_body(asm, {**STREAM_KERNELS, **STREAM_WIDE_KERNELS}[which])
+    name, body = kernel_body(asm, {**STREAM_KERNELS, **STREAM_WIDE_KERNELS, **STREAM_SHARE_KERNELS}[which])
     raw = body.split("\n")
     loads = []
     for i, x in enumerate(raw):
