@@ -116,7 +116,10 @@ __device__ __forceinline__ void emit_posting(int32_t *out_rows, T *out_vals, uin
         if (fold_log2 > 0) {   // stream form (fb == 16: sg_postings_build only folds tiles of 4096 columns by 8)
             const uint32_t low = ((col >> 1) << 2) | ((col & 1u) << 1) | ((tile & ((1u << fold_log2) - 1u)) << ab);
             uint32_t b24 = (uint32_t)ceilf((float)v * inv_norm_up * (255.0f * 65536.0f) * 1.000002f);
-            if (b24 > 0xFFFFFFu) b24 = 0xFFFFFFu;
+            // v <= norm_up: what lies above 255 * 2^16 is the safety factor's doing.  (Without the cut a row of ONE term --
+            // v = 1 -- in one of a tile's first columns, where `low` is smaller than that excess, got bq = 256: the field
+            // wrapped to 0 and carried into fq, and the row did not find itself.)
+            if (b24 > (255u << 16)) b24 = 255u << 16;
             const uint32_t bq = b24 > low ? (b24 - low + 65535u) >> 16 : 0u;                   // <= 255
             uint32_t f16 = (uint32_t)ceilf(fr * (float)SG_FILT_F16_MAX * 1.000002f);
             if (f16 > SG_FILT_F16_MAX) f16 = SG_FILT_F16_MAX;

@@ -130,7 +130,7 @@ def quantise_right_stream(m, mt, freq_min, norm_up, tile=4096):
     j = mt.indices.astype(np.int64)
     c, fold = j % tile, (j // tile) % (1 << FOLD_LOG2)
     low = ((c >> 1) << 2) | ((c & 1) << 1) | (fold << AB)
-    b24 = np.minimum(0xFFFFFF, np.ceil(f32(v * inv) * f32(255.0 * 65536.0) * f32(1.000002))).astype(np.int64)
+    b24 = np.minimum(255 << 16, np.ceil(f32(v * inv) * f32(255.0 * 65536.0) * f32(1.000002))).astype(np.int64)
     bq = np.where(b24 > low, (b24 - low + 65535) >> 16, 0)
     f16 = np.minimum(F16_MAX, np.ceil(fr[j] * f32(F16_MAX) * f32(1.000002))).astype(np.int64)
     fq = np.where(f16 > bq, (f16 - bq + 255) >> 8, 0)
@@ -243,3 +243,19 @@ def test_stream_form_records_cover_every_oracle_match(thr, delta, freq, tile):
     assert n_true > 0 and n_rec[False] >= n_true
     # as tight as round 3's bounds (the sixteen-bit F is tighter than an 8-bit fq; the value pays for the address bits)
     assert n_rec[False] <= 1.03 * n_rec[True] + 5, n_rec
+
+
+def test_stream_form_posting_of_a_full_value_in_a_tile_s_first_columns():
+    """A row of ONE term has the value 1 = norm_up; the safety factor of the quantisation lifts it a few units above
+    255 * 2^16, and in a column whose address bits are smaller than that excess bq came out as 256 -- the field wrapped
+    to 0 and carried into fq (round 4, caught by the GPU's seeded random jobs: 'ADI' / 'ADI.' did not find themselves)."""
+    import scipy.sparse as sp
+    n = 40
+    rows = np.arange(n)
+    m = sp.csr_matrix((np.ones(n, np.float32), (rows, np.zeros(n, np.int64))), shape=(n, 3))   # every row: term 0, value 1
+    mt = m.T.tocsr()
+    norm_up = np.nextafter(f32(1.0) * f32(1.000001), f32(2))
+    fq8, bq8, postings = quantise_right_stream(m, mt, 1 << 30, norm_up)
+    bq = (postings >> 16) & 0xFF
+    assert (bq == 255).all(), bq
+    assert (((postings >> 24) ^ 0x80) == 0).all()          # no frequent part, and nothing carried into the field
