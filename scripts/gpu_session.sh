@@ -67,6 +67,12 @@ for step in "$@"; do
       python scripts/pmc_traffic.py gpurun_out/${name}_pmc${n}_FETCH_SIZE gpurun_out/${name}_pmc${n}_WRITE_SIZE gpurun_out/${name}_k4_traffic$n.json >> $LOG 2>&1
       rm -rf gpurun_out/${name}_pmc${n}_FETCH_SIZE gpurun_out/${name}_pmc${n}_WRITE_SIZE
       unset ${arg%%=*} ;;
+    pmcsq1)   # only the pass the bench line's valu_issue_frac comes from
+      ( cd /tmp && export TMPDIR=/tmp && timeout 600 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS --output-format csv -d $OLDPWD/gpurun_out/${name}_pmcsq1 -o k -- python $OLDPWD/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-exact-kernel --no-end-to-end --no-side-runs $arg > /dev/null 2> $OLDPWD/gpurun_out/${name}_pmcsq1.err )
+      echo "-- pmc pass rc=$?" >> $LOG
+      python scripts/pmc_summary.py gpurun_out/${name}_pmcsq1 2>&1 | grep -A10 "spgemm_topn_pruned" | head -24 >> $LOG
+      python scripts/pmc_counters.py gpurun_out/${name}_pmcsq1 gpurun_out/${name}_k4_counters.json >> $LOG 2>&1
+      rm -rf gpurun_out/${name}_pmcsq1 ;;
     pmcsq)
       i=0
       for ctrs in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS" \
