@@ -209,10 +209,10 @@ struct sg_postings {
     uint32_t *d_fwd_ptr = nullptr;       // (n_right + 1) x {pointer, the row's own index (position -> row)}
     void *d_blk = nullptr;               // row blocks at a fixed stride (SgScoreCtx::blk)
     uint32_t blk_bytes = 0;
-    // 4-byte "filter postings", same order as the postings proper (only for cosine-like B):
-    //   bits [0, L) column inside the tile (L = tile_log2), [L, 24) bq, [24, 32) fq   with
-    //   b <= bq / bq_max * norm_up   and
-    //   || b_j restricted to the frequent terms (list length >= freq_min) || <= fq / 255 * norm_up
+    // 4-byte "filter postings", same order as the postings proper (only for cosine-like B): the column inside its tile
+    // (or super-tile), the value and the norm of the row's frequent part (terms of list length >= freq_min), both
+    // quantised UPWARDS relative to norm_up.  The fields differ between the tile-by-tile form (fold_log2 == 0) and the
+    // stream form: sg_postings.hip, emit_posting, has both layouts and what the multiply's instructions read from them.
     uint32_t *d_filt = nullptr;
     // Position space (sg_postings.hip, "column permutation").  The multiply's column tiles are ranges of consecutive
     // right-hand rows; on a SORTED list similar names are neighbours, a row's candidates pile up in a few tiles and the

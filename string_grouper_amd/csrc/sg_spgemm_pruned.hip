@@ -26,7 +26,10 @@
 //        x    = (CA * (bq << AB)) >> 32   >=  a * b * 2^15 - 1    CA = ceil(a * norm_b * 2^15 / bq_max * 2^(32 - AB))
 //        tq   = (T0 - C1 * fq) >> 8       <=  (thr - 1e-5) * 2^15 - 2 - ||a_S|| f_j 2^15 - |P|
 // (the |P| pays for the "- 1" of every add: a column receives at most one posting per term of P) and column j
-// survives when its accumulator reaches tq.  Because atomics tolerate collisions, every
+// survives when its accumulator reaches tq.  (These are the tile-by-tile form's formulas; the stream form, the default
+// since round 3, has the same bound in sixteen more bits and its postings' fields cut for the instructions that read
+// them -- round 4: "stream form" in the kernel, emit_posting in sg_postings.hip, tests/test_prune_model.py.)
+// Because atomics tolerate collisions, every
 // lane of the wave carries a posting of whatever term: lanes are dealt to the terms of P in
 // proportion to their list lengths, lane (term g, u of G_g) owns entries lo_g + u, lo_g + u + G_g, ...
 // of its term's list.  ds_add_rtn_u32 returns the previous value, so the lane whose add takes an
