@@ -97,8 +97,12 @@ extern "C" int sg_debug_read_wave_times(unsigned long long *out, int clear) {
 #else
 #define SG_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
 #endif
-#define SG_ROW_PARTS_LOG2 4
-#define SG_ROW_PARTS 16u       // parts of a row in the launch over parts (stream + self-join form)
+// Parts of a row in the launch over parts (stream + self-join form).  Sixteen through most of round 4 -- until per-wave
+// clocks of an eighth share of the 5 M job (profiles/r04_final_wave_times.log) showed the launch over parts ending 4.2 ms
+// after its median wave, on FOUR waves: the heaviest rows of that job are 10 - 50 ms of work each (153 visits), and a
+// sixteenth of that is still milliseconds.  Parts that hold no visit (a row of fewer visits than parts) cost an iteration.
+#define SG_ROW_PARTS_LOG2 6
+#define SG_ROW_PARTS 64u
 #define SG_SURV_CAP 128   // survivors buffered per wave (scored 64 at a time as soon as 64 are there)
 
 // lane mask of a predicate as a wave-uniform scalar (s_and of the compare result, no VALU round trip)
