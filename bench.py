@@ -352,33 +352,13 @@ def run(args):
             # the matches of all `rows` rows are the reference's, bit for bit.
             result["pruning"]["identical_rows_indexed_once"] = {"rows": args.rows, "index_rows": index_rows}
 
-    # measured HBM-side traffic of the same kernel on the same workload, from the committed PMC passes
-    try:
-        with open(os.path.join(ROOT, "profiles", "k4_traffic.json")) as f:
-            tr = json.load(f)
-        if (tr.get("workload_rows") == args.rows and tr.get("dtype") == args.dtype and world == 1
-                and tr.get("kernel", "K4") == (("K4p-sym" if symmetric else "K4p") if pruned else "K4")):
-            result["roofline"]["traffic"] = tr["traffic_bytes_per_launch_raw"]
-            result["roofline"]["traffic_source"] = "committed PMC pass (profiles/k4_traffic.json, written by scripts/pmc_traffic.py); not measured in this run"
-            result["roofline"]["traffic_note"] = tr["source"] + "; " + tr["note"]
-    except Exception:
-        pass
-
-    # VALU issue fraction of the same kernel (the kernel is instruction bound, the HBM fraction is the wrong
-    # yardstick for it): wave-level VALU instructions per launch from the committed PMC pass x 4 cycles / 1024 SIMDs / 2.4 GHz,
-    # over this run's kernel time
-    try:
-        with open(os.path.join(ROOT, "profiles", "k4_counters.json")) as f:
-            kc = json.load(f)
-        if (kc.get("workload_rows") == args.rows and kc.get("dtype") == args.dtype and world == 1
-                and kc.get("kernel", "K4") == (("K4p-sym" if symmetric else "K4p") if pruned else "K4")):
-            valu = float(kc["per_launch"]["SQ_INSTS_VALU"])
-            result["roofline"]["valu_issue_frac"] = valu * 4.0 / 1024.0 / 2.4e9 / (k4_avg_ms * 1e-3)
-            result["roofline"]["valu_insts_per_launch"] = valu
-            result["roofline"]["valu_source"] = ("committed PMC pass (profiles/k4_counters.json, written by scripts/pmc_counters.py); "
-                                                 "instruction counts do not depend on the run, the kernel time is this run's")
-    except Exception:
-        pass
+    # measured memory-side traffic and VALU issue fraction of the same kernel on the same workload, from the committed PMC
+    # passes -- quoted only while the kernel sources are the ones the passes ran on (string_grouper_amd/_provenance.py:
+    # `source_sha`; a later edit of the kernels turns the fields into "stale" instead of carrying old counters along)
+    if world == 1:
+        from string_grouper_amd._provenance import committed_counters
+        result["roofline"].update(committed_counters(ROOT, args.rows, args.dtype,
+                                                     ("K4p-sym" if symmetric else "K4p") if pruned else "K4", k4_avg_ms))
 
     if world == 1 and not args.no_side_runs:
         # the step WITHOUT the collapse of identical rows (every one of the 663 000 rows indexed and multiplied: 16.5 % of

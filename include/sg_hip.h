@@ -147,13 +147,17 @@ int sg_vec_transform(sg_ctx *ctx, const sg_vocab *v, const sg_strings *strings, 
 /* ------------------------------------------------------------------ CSR objects */
 int sg_csr_from_host(sg_ctx *ctx, int64_t n_rows, int64_t n_cols, const int64_t *indptr,
                      const int32_t *indices, const void *data, int32_t dtype, sg_csr **out);
+/* (A wrapped matrix is read where it lies.  The library keeps what it derives from a matrix WITH the sg_csr object --
+ *  its properties, and from 65 536 rows the groups of identical rows a one-sided sg_spgemm_topn multiplies once -- so the
+ *  arrays must not be rewritten while the object lives: wrap the new contents in a new object instead, as for an index.) */
 int sg_csr_from_device(sg_ctx *ctx, int64_t n_rows, int64_t n_cols, int64_t nnz, const int64_t *d_indptr,
                        const int32_t *d_indices, const void *d_data, int32_t dtype, sg_csr **out);
 int sg_csr_dims(const sg_csr *m, int64_t *n_rows, int64_t *n_cols, int64_t *nnz, int32_t *dtype);
 int sg_csr_device_ptrs(const sg_csr *m, const int64_t **d_indptr, const int32_t **d_indices,
                        const void **d_data);
 int sg_csr_to_host(sg_ctx *ctx, const sg_csr *m, int64_t *indptr, int32_t *indices, void *data);
-/* Rows [r0, r1) as a view (no copy); the parent must outlive the view. */
+/* Rows [r0, r1) as a view (no copy); the parent must outlive the view.  (A view derives its own groups of identical
+ * rows when it is multiplied; it never shares the parent's.) */
 int sg_csr_row_block(sg_ctx *ctx, const sg_csr *m, int64_t r0, int64_t r1, sg_csr **out);
 int sg_csr_free(sg_csr *m);
 

@@ -6,6 +6,7 @@ scripts/gpu_session.sh pmcsq) -> a JSON that bench.py reads for roofline.valu_is
 import csv
 import glob
 import json
+import os
 import sys
 from collections import defaultdict
 
@@ -26,7 +27,10 @@ name, ctrs = best
 mean = {c: sum(v) / len(v) for c, v in ctrs.items()}
 sym = ", true, " in name.split("(")[0]
 kind = ("K4p-sym" if sym else "K4p") if "pruned" in name else "K4"
-json.dump({"workload_rows": rows, "dtype": dtype, "kernel": kind, "kernel_name": name.split("(")[0],
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+sys.path.insert(0, ROOT)
+from string_grouper_amd._provenance import kernel_source_sha  # noqa: E402
+json.dump({"workload_rows": rows, "dtype": dtype, "kernel": kind, "source_sha": kernel_source_sha(ROOT), "kernel_name": name.split("(")[0],
            "per_launch": {c: mean[c] for c in sorted(mean)}, "launches_averaged": len(ctrs["SQ_INSTS_VALU"]),
            "source": "scripts/pmc_counters.py over one rocprofv3 --pmc pass (SQ_* counters only, no trace domains) of "
                      "`python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-exact-kernel --no-end-to-end --no-side-runs`",

@@ -9,6 +9,7 @@ Writes the JSON that bench.py reads for roofline.traffic (profiles/k4_traffic.js
 import csv
 import glob
 import json
+import os
 import sys
 
 
@@ -34,7 +35,10 @@ def main():
     write_kb, n2 = per_launch(write_dir, "WRITE_SIZE")
     read_bytes = 2.0 * fetch_kb * 1024.0
     write_bytes = write_kb * 1024.0
-    res = {"workload_rows": rows, "dtype": dtype, "kernel": tag,
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+    from string_grouper_amd._provenance import kernel_source_sha
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+    res = {"workload_rows": rows, "dtype": dtype, "kernel": tag, "source_sha": kernel_source_sha(root),
            "traffic_bytes_per_launch_raw": read_bytes + write_bytes,
            "read_bytes": read_bytes, "write_bytes": write_bytes, "launches_averaged": [n1, n2],
            "source": "scripts/pmc_traffic.py over two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; separate runs, no trace "

@@ -1,0 +1,64 @@
+"""Ties the committed counter passes (profiles/k4_traffic.json, profiles/k4_counters.json) to the kernel source they were
+measured on.  The passes cannot run inside bench.py's timed run (rocprofv3 --pmc is a run of its own), so the bench line
+quotes committed files; `source_sha` -- written by scripts/pmc_traffic.py / pmc_counters.py when they make those files --
+is the SHA-256 of the sources of the multiply's kernels at that moment, and bench.py drops the quoted fields (and says
+"stale") when the sources have changed since."""
+from __future__ import annotations
+
+import hashlib
+import json
+import os
+
+# the files whose code decides what the dominant kernel fetches and issues (K3 lays the index out, K4p reads it)
+KERNEL_SOURCES = ("string_grouper_amd/csrc/sg_spgemm_pruned.hip", "string_grouper_amd/csrc/sg_postings.hip",
+                  "string_grouper_amd/csrc/sg_internal.h", "string_grouper_amd/csrc/sg_k4_device.h")
+
+
+def kernel_source_sha(root: str) -> str:
+    h = hashlib.sha256()
+    for rel in KERNEL_SOURCES:
+        with open(os.path.join(root, rel), "rb") as f:
+            h.update(rel.encode() + b"\0" + f.read() + b"\0")
+    return h.hexdigest()
+
+
+def committed_counters(root: str, rows: int, dtype: str, kernel_tag: str, kernel_ms: float) -> dict:
+    """The roofline fields bench.py takes from the committed passes, for the workload (rows, dtype) and kernel it has just
+    timed: traffic (+ source, note) and valu_issue_frac (+ instructions, source) -- or, for a file whose `source_sha` is
+    not the current sources', `<field>_stale` with both hashes and no number."""
+    out: dict = {}
+    sha = kernel_source_sha(root)
+
+    def load(name):
+        try:
+            with open(os.path.join(root, "profiles", name)) as f:
+                d = json.load(f)
+        except Exception:
+            return None
+        if d.get("workload_rows") != rows or d.get("dtype") != dtype or d.get("kernel", "K4") != kernel_tag:
+            return None
+        return d
+
+    tr = load("k4_traffic.json")
+    if tr is not None:
+        if tr.get("source_sha") == sha:
+            out["traffic"] = tr["traffic_bytes_per_launch_raw"]
+            out["traffic_source"] = ("committed PMC pass (profiles/k4_traffic.json, written by scripts/pmc_traffic.py on "
+                                     f"kernel sources {sha[:12]}); not measured in this run")
+            out["traffic_note"] = tr["source"] + "; " + tr["note"]
+        else:
+            out["traffic"] = None
+            out["traffic_stale"] = {"status": "stale", "measured_on_sources": (tr.get("source_sha") or "unrecorded")[:12],
+                                    "current_sources": sha[:12]}
+    kc = load("k4_counters.json")
+    if kc is not None:
+        if kc.get("source_sha") == sha:
+            valu = float(kc["per_launch"]["SQ_INSTS_VALU"])
+            out["valu_issue_frac"] = valu * 4.0 / 1024.0 / 2.4e9 / (kernel_ms * 1e-3)
+            out["valu_insts_per_launch"] = valu
+            out["valu_source"] = ("committed PMC pass (profiles/k4_counters.json, written by scripts/pmc_counters.py on kernel "
+                                  f"sources {sha[:12]}); instruction counts do not depend on the run, the kernel time is this run's")
+        else:
+            out["valu_stale"] = {"status": "stale", "measured_on_sources": (kc.get("source_sha") or "unrecorded")[:12],
+                                 "current_sources": sha[:12]}
+    return out

@@ -453,6 +453,10 @@ extern "C" int sg_csr_row_block(sg_ctx *ctx, const sg_csr *m, int64_t r0, int64_
     if (!v) return SG_ERR_OOM;
     *v = *m;
     v->owned = false;
+    // a view owns its own groups of identical rows (sg_spgemm_topn makes them on first use): the parent's are indexed by
+    // the PARENT's rows, and sg_csr_free of the view would free them under the parent
+    v->left_groups = nullptr;
+    v->left_state = 0;
     v->n_rows = r1 - r0;
     v->d_indptr = m->d_indptr + r0;
     int64_t ends[2] = {0, 0};
@@ -667,6 +671,9 @@ static int scan_impl(sg_ctx *ctx, const TI *d_in, TO *d_out, int64_t n, TO *d_to
     }
     const int64_t nblocks = (n + SCAN_BLOCK - 1) / SCAN_BLOCK;
     SG_REQUIRE(nblocks < ((int64_t)1 << 31), "scan of more than 2^42 entries");
+    // host threads that share a context launch on one stream: the tickets a launch will draw must be the ones the host
+    // has told it about, in stream order
+    std::lock_guard<std::mutex> scan_lock(ctx->scan_mu);
     if ((size_t)nblocks > ctx->scan_desc_cap) {   // grow the descriptor array (+ the ticket word behind it)
         size_t cap = ctx->scan_desc_cap ? ctx->scan_desc_cap : 4096;
         while (cap < (size_t)nblocks) cap *= 2;
@@ -692,8 +699,8 @@ static int scan_impl(sg_ctx *ctx, const TI *d_in, TO *d_out, int64_t n, TO *d_to
     uint32_t *ticket = reinterpret_cast<uint32_t *>(ctx->d_scan_desc + ctx->scan_desc_cap);
     hipLaunchKernelGGL((scan_lookback_kernel<TI, TO, NONZERO>), dim3((unsigned)nblocks), dim3(SCAN_THREADS), 0, ctx->stream, d_in, d_out, n,
                        d_total, ctx->d_scan_desc, ticket, ctx->scan_ticket_base, ctx->scan_epoch);
+    SG_HIP_TRY(hipGetLastError());                // (a launch that failed has drawn no tickets)
     ctx->scan_ticket_base += (uint32_t)nblocks;   // (mod 2^32, like the device counter)
-    SG_HIP_TRY(hipGetLastError());
     return SG_OK;
 }
 

@@ -54,6 +54,7 @@ struct sg_ctx {
     size_t total_mem = 0;                // device memory, bytes (hipDeviceProp_t::totalGlobalMem)
 
     std::mutex mu;
+    std::mutex scan_mu;                          // the single-pass scan's bookkeeping (epoch, ticket base, descriptor array)
     std::multimap<size_t, void *> free_blocks;   // size -> ptr
     std::map<void *, size_t> live_blocks;        // ptr -> size
 
@@ -87,6 +88,7 @@ struct sg_ctx {
         int64_t n_docs;
         int32_t dtype;
         void *d;
+        bool trusted;                            // every weight positive and finite (checked on the host copy)
     };
     std::vector<IdfTable> idf_tables;
     int inner_multiply_depth = 0;                // > 0: sg_spgemm_topn runs for a wrapper (groups of identical rows) that counts the kept entries itself
@@ -278,6 +280,10 @@ struct sg_vocab {
     uint64_t *d_keys = nullptr;          // n_terms: key of column i (ascending)
     int32_t *d_df = nullptr;             // n_terms
     void *d_idf = nullptr;               // n_terms, params.dtype; null until sg_vocab_set_idf
+    // the weights are positive and finite (checked where they arrive from the caller: sg_vocab_set_idf,
+    // sg_ctx_put_idf_table): only then are the rows K2 makes cosine-like BY CONSTRUCTION (sg_csr_props); otherwise the
+    // matrix is measured like any caller's matrix before the pruned multiply may rely on its bounds
+    bool idf_trusted = false;
     struct VocabImpl *impl = nullptr;    // tokeniser state (sg_vectorize.hip): token caches, character coding, df table
 };
 

@@ -921,6 +921,11 @@ extern "C" int sg_spgemm_topn(sg_ctx *ctx, const sg_csr *A, const sg_postings *B
                                  A->d_data == Bt->b_data);
         const char *sw = ctx->opt("SG_COLLAPSE"), *ls = ctx->opt("SG_COLLAPSE_LEFT");    // (asked on every call: groups kept
         const bool off = (sw && sw[0] == '0') || (ls && ls[0] == '0');                      //  with A do not outlive the switch)
+        if (off && A->left_groups) {   // ... and are given back when it is turned off
+            sg_collapse_free(A->left_groups);
+            A->left_groups = nullptr;
+            A->left_state = 0;
+        }
         if (!self && !off && A->left_state != 1 && A->n_cols == Bt->n_terms && A->dtype == Bt->dtype && top_n >= 1) {
             // (the result is one row per row of A whatever the number of groups: the 32-bit result index must hold it)
             const int64_t n_right = Bt->collapse ? Bt->collapse->n_orig : Bt->n_right;

@@ -1427,10 +1427,26 @@ extern "C" int sg_vocab_byte_alphabet(const sg_vocab *v, uint8_t *byte_of_code, 
     return SG_OK;
 }
 
+// Weights a caller supplies: positive and finite?  (The rows K2 makes are "cosine-like by construction" only then:
+// non-negative entries, norm 1 -- sg_csr_props; a zero, negative or NaN weight sends the matrix through the measured path.)
+static bool weights_positive_and_finite(const void *w, int64_t n, int32_t dtype) {
+    if (dtype == SG_F64) {
+        const double *p = (const double *)w;
+        for (int64_t i = 0; i < n; ++i)
+            if (!(p[i] > 0.0) || !(p[i] <= 1.79e308)) return false;
+    } else {
+        const float *p = (const float *)w;
+        for (int64_t i = 0; i < n; ++i)
+            if (!(p[i] > 0.f) || !(p[i] <= 3.4e38f)) return false;
+    }
+    return true;
+}
+
 extern "C" int sg_vocab_set_idf(sg_ctx *ctx, sg_vocab *v, const void *idf, int32_t dtype) {
     SG_REQUIRE(ctx && v && idf, "null argument");
     SG_REQUIRE(dtype == v->params.dtype, "idf dtype differs from the vectoriser dtype");
     const size_t s = dtype == SG_F64 ? 8 : 4;
+    v->idf_trusted = weights_positive_and_finite(idf, v->n_terms, dtype);
     if (!v->d_idf) SG_TRY(ctx->alloc(((size_t)v->n_terms + 1) * s, &v->d_idf));
     SG_HIP_TRY(hipMemcpyAsync(v->d_idf, idf, s * (size_t)v->n_terms, hipMemcpyHostToDevice, ctx->stream));
     SG_HIP_TRY(hipStreamSynchronize(ctx->stream));
@@ -1460,17 +1476,20 @@ extern "C" int sg_ctx_put_idf_table(sg_ctx *ctx, int64_t n_docs, int32_t dtype, 
         sg_set_error("upload of the idf table failed");
         return SG_ERR_HIP;
     }
+    // (entry 0 -- a term no document holds -- is never gathered for a column of the vocabulary: df >= 1 there)
+    const bool trusted = weights_positive_and_finite((const char *)table + (dtype == SG_F64 ? 8 : 4), n_docs, dtype);
     for (auto &t : ctx->idf_tables)
         if (t.n_docs == n_docs && t.dtype == dtype) {      // replaced (scans in flight are behind the synchronisation above)
             (void)hipFree(t.d);
             t.d = d;
+            t.trusted = trusted;
             return SG_OK;
         }
     if (ctx->idf_tables.size() >= 4) {                      // the oldest goes
         (void)hipFree(ctx->idf_tables.front().d);
         ctx->idf_tables.erase(ctx->idf_tables.begin());
     }
-    ctx->idf_tables.push_back({n_docs, dtype, d});
+    ctx->idf_tables.push_back({n_docs, dtype, d, trusted});
     return SG_OK;
 }
 
@@ -1479,9 +1498,14 @@ extern "C" int sg_vocab_apply_idf_table(sg_ctx *ctx, sg_vocab *v, int32_t *appli
     *applied = 0;
     SG_REQUIRE(v->d_df != nullptr || v->n_terms == 0, "the vocabulary has no document counts (fit first)");
     const void *table = nullptr;
+    bool trusted = false;
     for (const auto &t : ctx->idf_tables)
-        if (t.n_docs == v->n_docs && t.dtype == v->params.dtype) table = t.d;
+        if (t.n_docs == v->n_docs && t.dtype == v->params.dtype) {
+            table = t.d;
+            trusted = t.trusted;
+        }
     if (!table) return SG_OK;
+    v->idf_trusted = trusted;
     const size_t s = v->params.dtype == SG_F64 ? 8 : 4;
     if (!v->d_idf) SG_TRY(ctx->alloc(((size_t)v->n_terms + 1) * s, &v->d_idf));
     if (v->n_terms > 0) {
@@ -1599,7 +1623,7 @@ extern "C" int sg_vec_transform(sg_ctx *ctx, const sg_vocab *v, const sg_strings
         m->d_indices = idx;
         m->d_data = val;
         m->nnz = nnz;
-        m->from_vectoriser = true;
+        m->from_vectoriser = v->idf_trusted;
         // (K2 can leave the largest row norm and the longest row behind; nothing reads them unless the opt-in row blocks
         //  are built -- the matrix is cosine-like by construction, sg_csr_props)
         if (st == SG_OK && ctx->opt("SG_ROW_BLOCKS") && ctx->opt("SG_ROW_BLOCKS")[0] == '1') {

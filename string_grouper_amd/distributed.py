@@ -179,12 +179,27 @@ def broadcast_csr(indptr, indices, data, shape, src: int = 0, device=None, group
 
 def all_gather_csr(indptr, indices, data, n_cols: int, group=None):
     """Concatenate the ranks' CSR row blocks (rank order = row order): returns (indptr, indices, data, shape) of
-    the whole matrix on every rank.  Row pointers are exchanged as row lengths and rebuilt by a prefix sum."""
+    the whole matrix on every rank.  Row pointers travel as row lengths and are rebuilt by a prefix sum.  TWO collectives
+    (round 5; four before): the header exchange (rows, non-zeros of every block) and ONE all-gather of a packed buffer per
+    rank -- [values | column indices | row lengths], padded to the longest rank's."""
     head = all_headers([indptr.numel() - 1, indices.numel()], indptr.device, group)   # rows, non-zeros of every block
     rows, nnz = [h[0] for h in head], [h[1] for h in head]
-    lens = all_gather_ragged((indptr[1:] - indptr[:-1]).to(torch.int32), group, rows)     # (a row holds < 2^31 entries)
-    idx = all_gather_ragged(indices, group, nnz)
-    val = all_gather_ragged(data, group, nnz)
+    s = data.element_size()
+    sizes = [z * (s + 4) + r * 4 for r, z in zip(rows, nnz)]
+    longest = (max(max(sizes), 16) + 15) // 16 * 16            # (every rank's part starts 16-byte aligned: the typed views below)
+    mine = torch.empty(longest, dtype=torch.uint8, device=indptr.device)
+    z, r = indices.numel(), indptr.numel() - 1
+    mine[: z * s] = data.contiguous().view(torch.uint8)
+    mine[z * s: z * (s + 4)] = indices.contiguous().view(torch.uint8)
+    mine[z * (s + 4): z * (s + 4) + r * 4] = (indptr[1:] - indptr[:-1]).to(torch.int32).view(torch.uint8)   # (a row holds < 2^31 entries)
+    out = torch.empty(len(rows) * longest, dtype=torch.uint8, device=indptr.device)
+    _all_gather_into(out, mine, group)
+    val, idx, lens = [], [], []
+    for k, (r, z) in enumerate(zip(rows, nnz)):
+        part = out[k * longest: (k + 1) * longest]
+        val.append(part[: z * s].view(data.dtype))
+        idx.append(part[z * s: z * (s + 4)].view(torch.int32))
+        lens.append(part[z * (s + 4): z * (s + 4) + r * 4].view(torch.int32))
     row_len = torch.cat(lens)
     full_ptr = torch.zeros(row_len.numel() + 1, dtype=torch.int64, device=indptr.device)
     torch.cumsum(row_len, 0, out=full_ptr[1:])
@@ -207,24 +222,25 @@ def sharded_tfidf(ops, local_sets: Sequence, group=None):
     Returns (fit state, [local CSR of each set]).  Raises ``ShardedFitNotApplicable`` -- on all ranks or on none."""
     state = ops.fit_begin(local_sets)
     world = dist.get_world_size(group)
+    n_docs = sum(ops.n_strings(s) for s in local_sets)
     if world > 1:
         # Whether the document-frequency tables can be added up is a property of EVERY rank's block (a block that is
         # pure ASCII gets the shared 7-bit coding, a block with other characters its own alphabet): all ranks learn all
         # ranks' answers from one small exchange and take the same branch -- a rank that raised on its own while the
-        # others entered the all-reduce would hang the job until the collective timed out.
+        # others entered the all-reduce would hang the job until the collective timed out.  The blocks' document counts
+        # ride in the same exchange (round 5: they were an all-reduce of their own).
         shareable, entries = ops.fit_info(state)
-        facts = all_headers([1 if shareable else 0, int(entries)], ops.device, group)
+        facts = all_headers([1 if shareable else 0, int(entries), int(n_docs)], ops.device, group)
         if not all(f[0] == 1 for f in facts) or len({f[1] for f in facts}) != 1:
             raise ShardedFitNotApplicable(
                 "the n-gram keys of some rank's strings are coded over the alphabet of its LOCAL strings (ngram_size > 3, "
                 "or non-ASCII characters kept by normalize_to_ascii=False), or the vocabulary is a sorted one: the document "
-                f"frequencies of the ranks cannot be added up (shareable, table entries per rank: {facts})")
+                f"frequencies of the ranks cannot be added up (shareable, table entries per rank: {[f[:2] for f in facts]})")
+        n_docs = sum(f[2] for f in facts)
     df = ops.df_tensor(state)                                   # dense int32 table over the n-gram key space
-    n_docs = torch.tensor([sum(ops.n_strings(s) for s in local_sets)], dtype=torch.int64, device=df.device)
     if world > 1:
         _all_reduce(df, dist.ReduceOp.SUM, group)
-        _all_reduce(n_docs, dist.ReduceOp.SUM, group)
-    ops.fit_end(state, int(n_docs.item()))
+    ops.fit_end(state, int(n_docs))
     return state, [ops.transform(state, s) for s in local_sets]
 
 

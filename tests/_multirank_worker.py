@@ -66,20 +66,29 @@ def block_of(res, rank, world, n_rows):
     return np.arange(lo, hi), res.to_scipy()
 
 
-def worker(rank: int, world: int, port: int, workdir: str, jobs, ret):
-    """``jobs``: list of dicts (see tests/test_multirank_gpu.py).  ret[rank] = {check name: '' or what went wrong}."""
+def worker(rank: int, world: int, port: int, workdir: str, jobs, ret, backend: str = "gloo"):
+    """``jobs``: list of dicts (see tests/test_multirank_gpu.py).  ret[rank] = {check name: '' or what went wrong}.
+    ``backend``: "gloo" -- all ranks on cuda:0, collectives on a host copy -- or "nccl": one rank per DEVICE (rank r on
+    cuda:r), the product's transport (RCCL over xGMI), device tensors straight into the collectives."""
     out = {}
     try:
         os.environ["MASTER_ADDR"] = "127.0.0.1"
         os.environ["MASTER_PORT"] = str(port)
         os.environ.pop("SG_DIST_SYM", None)
         os.environ.pop("SG_DIST_INTERLEAVE", None)
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # (the host driver only supports dmabuf IPC)
+        import datetime
         import torch
         import torch.distributed as dist
-        torch.cuda.set_device(0)
-        dist.init_process_group("gloo", rank=rank, world_size=world)
+        device = rank if backend == "nccl" else 0
+        torch.cuda.set_device(device)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=240),
+                                    device_id=torch.device("cuda", device))
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
         try:
-            _run(rank, world, workdir, jobs, out)
+            _run(rank, world, workdir, jobs, out, device)
         finally:
             dist.destroy_process_group()
     except BaseException:  # noqa: BLE001 -- reported to the parent, which fails the test with it
@@ -87,7 +96,7 @@ def worker(rank: int, world: int, port: int, workdir: str, jobs, ret):
     ret[rank] = out
 
 
-def _run(rank, world, workdir, jobs, out):
+def _run(rank, world, workdir, jobs, out, device=0):
     import pandas as pd
     import torch
     import torch.distributed as dist
@@ -98,7 +107,8 @@ def _run(rank, world, workdir, jobs, out):
     from string_grouper_amd.synth import synth_names
     from string_grouper_amd.vectorizer import HipTfidfVectorizer
 
-    ctx = N.Context(0)                      # the rank's own context and stream on the shared device
+    ctx = N.Context(device)                 # the rank's own context and stream (gloo: on the shared device; nccl: its own GPU)
+    on_dev = torch.device("cuda", device) if dist.get_backend() == "nccl" else torch.device("cpu")
     for job in jobs:
         tag = job["tag"]
         dtype = np.float64 if job.get("dtype") == "f64" else np.float32
@@ -129,7 +139,7 @@ def _run(rank, world, workdir, jobs, out):
                     out[tag + ":grouped"] = f"index over groups: {grouped}, the job expects {job['grouped']}"
             rows, C = block_of(res, rank, world, len(names))
             out[tag + ":my_rows"] = _same(C, want[rows])
-            n_mine = torch.tensor([len(rows)])
+            n_mine = torch.tensor([len(rows)], device=on_dev)
             dist.all_reduce(n_mine)
             out[tag + ":every_row_once"] = "" if int(n_mine) == len(names) else f"{int(n_mine)} rows in all blocks, {len(names)} names"
             cols, vals, counts = D.gather_topn(ops, res)

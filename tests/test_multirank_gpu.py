@@ -39,12 +39,12 @@ def _expected_match(workdir, key, master, dups, top_n, thr, dtype):
     save_expected(workdir, key, P.sp_matmul_topn_port(A, B.T, top_n, thr, True, N_CPU))
 
 
-def _spawn(world, workdir, jobs):
+def _spawn(world, workdir, jobs, backend="gloo"):
     import torch.multiprocessing as mp
     from tests._multirank_worker import worker
     mgr = mp.Manager()
     ret = mgr.dict()
-    mp.spawn(worker, args=(world, _free_port(), workdir, jobs, ret), nprocs=world, join=True)
+    mp.spawn(worker, args=(world, _free_port(), workdir, jobs, ret, backend), nprocs=world, join=True)
     failures = []
     for r in range(world):
         assert r in ret, f"rank {r} returned nothing"
@@ -124,3 +124,27 @@ def test_three_ranks_with_uneven_shares():
             dict(kind="api", tag="w3_api", top_n=10, thr=0.8, n=20_001, seed=51, n_dups=4_001),
         ]
         _spawn(3, wd, jobs)
+
+
+@pytest.mark.timeout(1500)
+def test_eight_ranks_on_one_device_every_block_and_the_gathered_whole_equal_the_port():
+    """World 8 -- the driver's largest configuration -- on the one GPU over gloo (the 8-rank bench
+    line only compared a match count): 200 000 names, the self-join form over interleaved shares of the groups'
+    positions and the row-block form; every rank's own rows and the gathered whole against the port, bit for bit;
+    master x duplicates with blocks of uneven size."""
+    from string_grouper_amd.synth import synth_names
+    from tests._multirank_worker import _names_of
+    with tempfile.TemporaryDirectory(prefix="sg_mr_") as wd:
+        big = {"n": 200_000, "seed": 1234, "extra": ["", "AB", "ACME HOLDINGS INC"]}         # (200 003: 8 does not divide it)
+        _expected_selfjoin(wd, "big_f32", _names_of(big, synth_names), 10, 0.8, np.float32)
+        master = synth_names(40_003, 61)
+        dups = synth_names(12_001, 62, perturb_of=master, perturb_frac=0.5)
+        _expected_match(wd, "match8_f32", master, dups, 20, 0.7, np.float32)
+        jobs = [
+            dict(kind="selfjoin", tag="w8_groups_interleaved", top_n=10, thr=0.8, expected="big_f32", form="selfjoin", grouped=True, **big),
+            dict(kind="selfjoin", tag="w8_row_block", top_n=10, thr=0.8, expected="big_f32", form="rowblock", env={"SG_DIST_SYM": "0"}, **big),
+            dict(kind="match", tag="w8_master_x_duplicates", top_n=20, thr=0.7, expected="match8_f32", n_master=40_003, n_dups=12_001,
+                 seed=61),
+        ]
+        got = _spawn(8, wd, jobs)
+        assert all(len(got[r]) >= 9 for r in range(8)), got
