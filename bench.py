@@ -265,9 +265,10 @@ def run(args):
     barrier()
     elapsed = time.perf_counter() - t0
     coll_tally = {k: list(v) for k, v in D.COLLECTIVE_TALLY.items()} if distributed else None   # (the timed steps' own)
-    index_rows = None
+    index_rows = index_bytes = None
     if not distributed:
         index_rows = int(ctx.postings_rows(last._keep[1])[0])    # < rows: identical rows indexed once (include/sg_hip.h)
+        index_bytes = ctx.postings_bytes(last._keep[1])          # what the pruned multiply reads of the index while it runs
     if distributed and dist_mode == "sharded":
         # (the multi-GPU self-join form merges the mirrored pairs after the multiply's own count: count the rank's rows)
         out_nnz = int(ops.topn_tensors(last)[2].sum().item())
@@ -332,19 +333,31 @@ def run(args):
         "options": ctx.options(),
         "matches": int(job_nnz),
         "macs": int(job_macs),
+        # `bound` names the roofline the fraction is priced against (the contract knows "hbm" and "mfma"; no dense
+        # contraction here).  `limited_by` says what the counters say of the kernel (profiles/): it
+        # waits for dependent misses at the occupancy its LDS tile allows; `l3_resident`: the index it reads fits the
+        # 256 MiB Infinity Cache, i.e. most of `traffic` (FETCH_SIZE counts Infinity-Cache hits) never reaches HBM.
         "roofline": {"bound": "hbm",
+                     "limited_by": ("memory latency at 16 single-wave workgroups per CU (waves wait for L2 misses about half of "
+                                    "their cycles; VALU issue in valu_issue_frac), not HBM bandwidth"),
+                     "l3_resident": (bool(index_bytes <= 256 * 1024 * 1024) if index_bytes else None),
+                     "index_bytes_read_by_the_kernel": index_bytes,
                      "kernel": ("spgemm_topn_pruned_kernel<SYM> + pair-list pass (K4p, self-join form)" if symmetric else
                                 "spgemm_topn_pruned_kernel (K4p)") if pruned else "spgemm_topn_kernel (K4)",
                      "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
                      "traffic": None, "algorithmic_bytes_per_launch": int(k4_bytes), "avg_ms": k4_avg_ms,
-                     "note": ("algorithmic = 4 B per filter posting streamed + (8 + mean packed row) B per pair scored "
-                              "exactly + A + out; the kernel is latency/occupancy bound, not bandwidth bound (DESIGN.md)")
+                     "note": ("algorithmic = 4 B per filter posting streamed + (16 + 4 x mean row entries) B of the 8-bit copy per "
+                              "candidate of the first filter + one packed row per pair scored exactly + A + out")
                      if pruned else
                      "algorithmic = stream model (4+s) B per intermediate product + A + out"},
     }
     if pruned:
         result["pruning"] = {"rows": stats["prune_rows"], "postings_streamed": stats["prune_postings"],
-                             "of_intermediate_products": stats["macs"], "pairs_scored_exactly": stats["prune_survivors"],
+                             "of_intermediate_products": stats["macs"],
+                             # candidates the first filter records -> pairs the second filter (8-bit copy of the candidate's
+                             # row) lets through to the exact scoring
+                             "candidates_of_the_first_filter": stats["prune_survivors"],
+                             "pairs_scored_exactly": stats["prune_scored"],
                              "rows_handed_to_exact_kernel": stats["exact_rows"], "self_join_form": symmetric}
         if index_rows is not None and index_rows != args.rows:
             # identical strings give identical rows: the index holds one representative per group, the multiply runs on

@@ -58,8 +58,9 @@ typedef struct sg_topn sg_topn;         /* device-resident fixed-stride top-n re
 /* ------------------------------------------------------------------ library / context */
 const char *sg_last_error(void);
 /* Bumped whenever a signature or a struct of this header changes (round 4: 2 -- row_step arguments of round 3, sg_stats
- * grew); a binding compares it with the value it was written for right after loading the library. */
-#define SG_ABI_VERSION 2
+ * grew; round 5: 3 -- sg_stats.prune_scored); a binding compares it with the value it was written for right after loading
+ * the library. */
+#define SG_ABI_VERSION 3
 int sg_abi_version(void);
 int sg_device_count(int *count);
 /* hip_stream: a hipStream_t to launch on (e.g. torch.cuda.current_stream().cuda_stream), or NULL
@@ -285,6 +286,10 @@ int sg_selfjoin_merge(sg_ctx *ctx, sg_topn *res, const sg_postings *Bt, const in
  *     members) are part of the index every rank builds, so a rank expands its own groups without any exchange.
  * (The reference has no analogue: sparse_dot_topn multiplies every duplicate row again, string_grouper.py:728-752.) */
 int sg_postings_rows(const sg_postings *Bt, int64_t *n_index_rows, int64_t *n_caller_rows, const uint32_t **d_group_of_row);
+/* Bytes of the index the PRUNED multiply reads while it runs -- filter postings + their segment-end tables, the 8-bit
+ * copies of the rows (second filter) and the packed rows (exact scoring) -- so that a measurement can say whether they fit
+ * the 256 MiB Infinity Cache (bench.py: roofline.l3_resident).  0 for an index the pruned multiply does not use. */
+int sg_postings_bytes(const sg_postings *Bt, int64_t *pruned_multiply_bytes);
 int sg_topn_expand_groups(sg_ctx *ctx, const sg_postings *Bt, const sg_topn *groups, const int32_t *d_rows, int64_t n_rows,
                           sg_topn **out);
 /* ... the same for the rows of the groups at the positions [pos_lo, pos_hi) -- a rank's range: the library makes the list
@@ -307,12 +312,17 @@ typedef struct {
     /* the most recent multiply, when it took the pruned kernel (all zero otherwise):                */
     int64_t prune_rows;       /* left rows it processed                                             */
     int64_t prune_postings;   /* postings it streamed (of `macs` the exact kernel would)            */
-    int64_t prune_survivors;  /* candidate pairs it scored exactly                                  */
+    int64_t prune_survivors;  /* candidate pairs its first filter recorded (postings' upper bounds) */
     int64_t exact_rows;       /* left rows it handed to the exact kernel                            */
-    int64_t prune_bytes;      /* its algorithmic bytes: 4 per posting streamed + one packed row of  */
-                              /* B (and its two row pointers) per survivor + A + out    */
+    int64_t prune_bytes;      /* its algorithmic bytes: 4 per posting streamed + the 8-bit copy of  */
+                              /* a row per survivor + one packed row of B per pair scored exactly   */
+                              /* (without the second filter: packed row + its two pointers per      */
+                              /* survivor) + A + out                                    */
     int64_t prune_symmetric;  /* != 0: self-join form (every pair scored once, from the row with    */
                               /* the larger index, then both rows' lists built from the pair list)  */
+    int64_t prune_scored;     /* pairs it scored EXACTLY: the survivors the second filter (an 8-bit */
+                              /* copy of the candidate's row, round 5) let through; without that    */
+                              /* filter (SG_Q8=0, terms beyond 24 bits) = prune_survivors           */
 } sg_stats;
 /* Waits for the recorded events, so it is a synchronisation point. */
 int sg_ctx_stats(sg_ctx *ctx, sg_stats *out);

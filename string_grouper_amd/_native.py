@@ -18,7 +18,7 @@ LIB_PATH = os.environ.get("SG_HIP_LIB") or os.path.join(_HERE, "libsg_hip.so")
 
 SG_OK, SG_ERR_BADARG, SG_ERR_OOM, SG_ERR_OVERFLOW, SG_ERR_HIP, SG_ERR_NODEVICE, SG_ERR_UNSUPPORTED = range(7)
 SG_F32, SG_F64 = 0, 1
-ABI_VERSION = 2          # include/sg_hip.h: SG_ABI_VERSION
+ABI_VERSION = 3          # include/sg_hip.h: SG_ABI_VERSION
 SG_K_TOKENIZE, SG_K_WEIGHT, SG_K_POSTINGS, SG_K_SPGEMM, SG_K_ZIP, SG_K_VOCAB, SG_K_SPGEMM_KERNEL, SG_K_COUNT = range(8)
 KERNEL_NAMES = ("tokenize", "weight", "postings", "spgemm_topn", "zip", "vocab", "spgemm_kernel")
 
@@ -32,7 +32,7 @@ class SgStats(C.Structure):
     _fields_ = [("ms", C.c_float * SG_K_COUNT), ("macs", C.c_int64), ("spgemm_bytes", C.c_int64),
                 ("out_nnz", C.c_int64), ("prune_rows", C.c_int64), ("prune_postings", C.c_int64),
                 ("prune_survivors", C.c_int64), ("exact_rows", C.c_int64), ("prune_bytes", C.c_int64),
-                ("prune_symmetric", C.c_int64)]
+                ("prune_symmetric", C.c_int64), ("prune_scored", C.c_int64)]
 
 
 # every symbol include/sg_hip.h declares: name -> (restype, argtypes)
@@ -101,6 +101,7 @@ ABI = {
     "sg_selfjoin_merge": (C.c_int, [_P, _P, _P, _P, C.c_int64, C.c_int32, C.c_int64, C.c_int64, C.c_int64]),
     "sg_postings_permutation": (C.c_int, [_P, _PP, _PP]),
     "sg_postings_rows": (C.c_int, [_P, _P, _P, _PP]),
+    "sg_postings_bytes": (C.c_int, [_P, C.POINTER(C.c_int64)]),
     "sg_topn_expand_groups": (C.c_int, [_P, _P, _P, _P, C.c_int64, _PP]),
     "sg_topn_expand_range": (C.c_int, [_P, _P, _P, C.c_int64, C.c_int64, _PP, _PP, _P, C.c_int64]),
     "sg_device_free": (C.c_int, [_P, _P]),
@@ -356,7 +357,7 @@ class Context:
         d.update(macs=int(st.macs), spgemm_bytes=int(st.spgemm_bytes), out_nnz=int(st.out_nnz),
                  prune_rows=int(st.prune_rows), prune_postings=int(st.prune_postings),
                  prune_survivors=int(st.prune_survivors), exact_rows=int(st.exact_rows),
-                 prune_bytes=int(st.prune_bytes), prune_symmetric=int(st.prune_symmetric))
+                 prune_bytes=int(st.prune_bytes), prune_symmetric=int(st.prune_symmetric), prune_scored=int(st.prune_scored))
         return d
 
     # ---- strings
@@ -544,6 +545,12 @@ class Context:
         a, b, g = C.c_int64(), C.c_int64(), C.c_void_p()
         check(lib().sg_postings_rows(Bt.h, C.byref(a), C.byref(b), C.byref(g)))
         return a.value, b.value, g.value or 0
+
+    def postings_bytes(self, Bt: Postings) -> int:
+        """Bytes of the index the pruned multiply reads while it runs (include/sg_hip.h: sg_postings_bytes)."""
+        b = C.c_int64()
+        check(lib().sg_postings_bytes(Bt.h, C.byref(b)))
+        return int(b.value)
 
     def topn_expand_groups(self, Bt: Postings, groups: "TopN", d_rows: int = 0, n_rows: int = 0) -> "TopN":
         """The rows ``d_rows`` (device int32 row numbers; 0 = all rows) of the result over the caller's rows, from a

@@ -225,8 +225,10 @@ extern "C" int sg_ctx_stats(sg_ctx *ctx, sg_stats *out) {
     out->prune_postings = ctx->h_stat_words[3];
     out->prune_survivors = ctx->h_stat_words[4];
     out->exact_rows = ctx->h_stat_words[5];
+    out->prune_scored = ctx->h_stat_words[6];
     out->prune_bytes = out->prune_rows == 0 ? 0
-                       : out->prune_postings * 4 + (int64_t)((double)out->prune_survivors * ctx->prune_row_bytes) +
+                       : out->prune_postings * 4 + (int64_t)((double)out->prune_survivors * ctx->prune_q8_bytes) +
+                             (int64_t)((double)out->prune_scored * ctx->prune_row_bytes) +
                              ctx->spgemm_fixed_bytes + out->out_nnz * ctx->spgemm_entry_bytes;
     out->prune_symmetric = ctx->prune_symmetric ? 1 : 0;
     out->spgemm_bytes = ctx->spgemm_fixed_bytes + (out->macs + out->out_nnz) * ctx->spgemm_entry_bytes;

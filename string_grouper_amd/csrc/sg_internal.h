@@ -63,10 +63,11 @@ struct sg_ctx {
     bool ev_valid[SG_K_COUNT];
     int64_t spgemm_entry_bytes = 0;              // 4 + s of the most recent multiply
     int64_t spgemm_fixed_bytes = 0;              // its algorithmic bytes that do not scale with MACs
-    double prune_row_bytes = 0.0;                // pruned multiply: bytes read per survivor (row pointers + mean packed row)
+    double prune_row_bytes = 0.0;                // pruned multiply: bytes read per pair scored exactly (row pointers + mean packed row)
+    double prune_q8_bytes = 0.0;                 // ... and per candidate of the first filter checked by the second (mean 8-bit copy; 0: no second filter)
     bool prune_symmetric = false;                // the most recent multiply took the self-join form of the pruned kernel
     double pilot_ms_pruned = 0.0, pilot_ms_exact = 0.0;   // the most recent pruned-or-exact pilot's two estimates (0: none ran)
-    int64_t *d_stat_words = nullptr;             // [0]=macs [1]=out_nnz [2..4]=pruned rows/postings/survivors [5]=rows handed to K4
+    int64_t *d_stat_words = nullptr;             // [0]=macs [1]=out_nnz [2..4]=pruned rows/postings/survivors [5]=rows handed to K4 [6]=pairs scored exactly
     int64_t *h_stat_words = nullptr;             // pinned mirror
 
     // Tuning switches (SG_*): read from the environment ONCE, when the context is created, changed only through
@@ -168,7 +169,24 @@ struct SgScoreCtx {
     // as soon as the header is there.  null: no blocks (a row would need more than 1 KiB): the packed rows above are used.
     const void *blk = nullptr;
     uint32_t blk_bytes = 0;
+    // Second filter (round 5): an 8-bit copy of every right-hand row at a FIXED stride of SG_Q8_STRIDE bytes (two 128-byte
+    // lines), 256-byte aligned, no pointer to fetch first:
+    //   word 0  first entry of the row among the packed rows (`fwd`)        } what the exact scoring needs of the row: a
+    //   word 1  the row's own index (position -> row)                       } candidate that passes costs no pointer fetch
+    //   word 2  the row's entries (bits [0, 31)); bit 31: no 8-bit copy (more than SG_Q8_MAX_ENTRIES entries: always passes)
+    //   word 3  0
+    //   words 4 .. 63  entries in ascending term order, (term << 8) | bq, bq = ceil(value / norm_up * 255) -- rounded UP, so
+    //           sum_k a_k * bq_k * norm_up / 255 is an upper bound of the pair's score; zero behind the row's last entry
+    //           (only the 16-byte units a row uses are written, and read: 28 entries fit the first 128-byte line)
+    // A candidate of the first filter whose bound stays under the threshold is not scored (sg_spgemm_pruned.hip,
+    // drain_survivors).  q8_scale = 255 / norm_up, rounded down.  null: no second filter (terms beyond 24 bits, or switched
+    // off: SG_Q8=0).
+    const uint4 *q8 = nullptr;
+    float q8_scale = 0.f;
+    uint32_t pad_ = 0;
 };
+#define SG_Q8_STRIDE 256u
+#define SG_Q8_MAX_ENTRIES 60u   // 16 units of 16 bytes: the header, then four entries a unit
 
 // Groups of identical right-hand rows (sg_collapse.hip): the index is built over one representative per group.
 struct SgCollapse {
@@ -211,6 +229,7 @@ struct sg_postings {
     uint32_t *d_fwd_ptr = nullptr;       // (n_right + 1) x {pointer, the row's own index (position -> row)}
     void *d_blk = nullptr;               // row blocks at a fixed stride (SgScoreCtx::blk)
     uint32_t blk_bytes = 0;
+    void *d_q8 = nullptr;                // 8-bit copies of the rows at a fixed stride (SgScoreCtx::q8), (n_right + 1) records
     // 4-byte "filter postings", same order as the postings proper (only for cosine-like B): the column inside its tile
     // (or super-tile), the value and the norm of the row's frequent part (terms of list length >= freq_min), both
     // quantised UPWARDS relative to norm_up.  The fields differ between the tile-by-tile form (fold_log2 == 0) and the

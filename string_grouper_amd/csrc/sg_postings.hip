@@ -508,6 +508,49 @@ __global__ void __launch_bounds__(256) permutation_kernel(uint32_t n, uint64_t m
     len_by_pos[p] = (uint32_t)(indptr[j + 1] - indptr[j]);   // (the matrix's own row pointers: final also while its rows are pending)
 }
 
+// ---- the 8-bit copies of the rows for the pruned multiply's SECOND filter (SgScoreCtx::q8, sg_internal.h; round 5)
+// One 16-byte unit of a row's record: unit 0 = {first packed entry, the row's own index, entries | flag, 0}, unit u >= 1 =
+// entries 4u - 4 .. 4u - 1; an entry is (term << 8) | bq with bq = ceil(value / norm_up * 255) -- UP: the factor 1.000002
+// pays for the float roundings of the product (four of 2^-24), the cut at 255 is sound because no value exceeds its
+// row's norm.  Units a row does not reach are neither written nor read.
+__device__ __forceinline__ uint32_t sg_q8_units(int64_t nnz) {
+    return nnz > (int64_t)SG_Q8_MAX_ENTRIES ? 1u : (uint32_t)((nnz + 7) >> 2);   // (the header + four entries a unit)
+}
+template <typename T>
+__device__ __forceinline__ void q8_write_unit(uint4 *__restrict__ rec, uint32_t u, const int32_t *__restrict__ indices,
+                                              const T *__restrict__ data, int64_t src, int64_t nnz, uint32_t first_packed,
+                                              uint32_t name, float inv_norm) {
+    auto entry = [&](int64_t e) -> uint32_t {
+        if (e >= nnz) return 0u;
+        const float q = ceilf((float)data[src + e] * inv_norm * 255.0f * 1.000002f);
+        const uint32_t bq = q >= 255.0f ? 255u : (q >= 1.0f ? (uint32_t)q : 1u);
+        return ((uint32_t)indices[src + e] << 8) | bq;
+    };
+    uint4 w;
+    if (u == 0) {
+        w = make_uint4(first_packed, name, (uint32_t)nnz | (nnz <= (int64_t)SG_Q8_MAX_ENTRIES ? 0u : 0x80000000u), 0u);
+    } else {
+        const int64_t e0 = 4 * (int64_t)u - 4;
+        w = make_uint4(entry(e0), entry(e0 + 1), entry(e0 + 2), entry(e0 + 3));
+    }
+    rec[u] = w;
+}
+
+// (the index without a copy of the rows in position order -- SG_PERMUTE=0, few rows: sixteen lanes per row)
+template <typename T>
+__global__ void __launch_bounds__(256) q8_pack_kernel(const int64_t *__restrict__ indptr, const int32_t *__restrict__ indices,
+                                                      const T *__restrict__ data, int64_t n_rows,
+                                                      const uint32_t *__restrict__ orig_of /* position -> row; null: identity */,
+                                                      uint4 *__restrict__ q8, float inv_norm) {
+    const int64_t p = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+    const uint32_t sub = threadIdx.x & 15;
+    if (p >= n_rows) return;
+    const int64_t base = indptr[0], src = indptr[p], n = indptr[p + 1] - src;
+    if (sub < sg_q8_units(n))
+        q8_write_unit<T>(q8 + p * (SG_Q8_STRIDE / 16), sub, indices, data, src, n, (uint32_t)(src - base),
+                         orig_of ? orig_of[p] : (uint32_t)p, inv_norm);
+}
+
 // Round 4: ONE read of the source rows for every copy of them the index keeps.  Position p of the index holds row
 // g = orig_of[p] of the matrix it is built over; with groups of identical rows that matrix is the representatives' --
 // row g = row rep_rows[g] of the caller's matrix, not written anywhere yet (SgCollapse::pending_src) -- and the copies are
@@ -524,7 +567,8 @@ __global__ void __launch_bounds__(256) gather_rows_kernel(const int64_t *__restr
                                                           T *__restrict__ perm_data,
                                                           const int64_t *__restrict__ uniq_ptr /* null: no copy in row order */,
                                                           int32_t *__restrict__ uniq_indices, T *__restrict__ uniq_data,
-                                                          uint32_t *__restrict__ fwd_ptr /* null: no packed rows */, void *__restrict__ fwd) {
+                                                          uint32_t *__restrict__ fwd_ptr /* null: no packed rows */, void *__restrict__ fwd,
+                                                          uint4 *__restrict__ q8 /* null: no 8-bit copies */, float inv_norm) {
     const int64_t p = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
     const int sub = threadIdx.x & 15;
     if (p > n_rows) return;
@@ -562,6 +606,9 @@ __global__ void __launch_bounds__(256) gather_rows_kernel(const int64_t *__restr
             }
         }
     }
+    // the row's 8-bit copy: lane `sub` writes unit `sub` (the entries come from the cache: the group has just read them)
+    if (q8 && (uint32_t)sub < sg_q8_units(n))
+        q8_write_unit<T>(q8 + p * (SG_Q8_STRIDE / 16), (uint32_t)sub, indices, data, src, n, (uint32_t)dst, (uint32_t)g, inv_norm);
 }
 
 __global__ void score_ctx_kernel(SgScoreCtx v, SgScoreCtx *out) { *out = v; }
@@ -578,7 +625,8 @@ static uint64_t gcd_u64(uint64_t a, uint64_t b) {
 // B with its rows in position order + the two tables; *out_perm stays null when the permutation is off or pointless
 static int build_permuted(sg_ctx *ctx, const sg_csr *B, int64_t tile_cols, sg_csr **out_perm, uint32_t **out_orig_of,
                           uint32_t **out_pos_of, SgCollapse *pending /* B = pending->unique, its rows not written yet; or null */,
-                          uint32_t *fwd_ptr, void *fwd /* packed rows to write along (null: none) */, bool *fwd_done) {
+                          uint32_t *fwd_ptr, void *fwd /* packed rows to write along (null: none) */, bool *fwd_done,
+                          void *q8 = nullptr /* 8-bit copies to write along */, float inv_norm = 0.f) {
     *fwd_done = false;
     *out_perm = nullptr;
     *out_orig_of = *out_pos_of = nullptr;
@@ -611,11 +659,13 @@ static int build_permuted(sg_ctx *ctx, const sg_csr *B, int64_t tile_cols, sg_cs
         if (B->dtype == SG_F64)
             hipLaunchKernelGGL(gather_rows_kernel<double>, dim3(grid), dim3(256), 0, ctx->stream, src->d_indptr, src->d_indices,
                                (const double *)src->d_data, B->n_rows, (const uint32_t *)orig_of, rep_rows, (const int64_t *)ptr, idx,
-                               (double *)val, uniq_ptr, (int32_t *)B->d_indices, (double *)B->d_data, fwd_ptr, fwd);
+                               (double *)val, uniq_ptr, (int32_t *)B->d_indices, (double *)B->d_data, fwd_ptr, fwd,
+                               (uint4 *)(fwd_ptr ? q8 : nullptr), inv_norm);
         else
             hipLaunchKernelGGL(gather_rows_kernel<float>, dim3(grid), dim3(256), 0, ctx->stream, src->d_indptr, src->d_indices,
                                (const float *)src->d_data, B->n_rows, (const uint32_t *)orig_of, rep_rows, (const int64_t *)ptr, idx,
-                               (float *)val, uniq_ptr, (int32_t *)B->d_indices, (float *)B->d_data, fwd_ptr, fwd);
+                               (float *)val, uniq_ptr, (int32_t *)B->d_indices, (float *)B->d_data, fwd_ptr, fwd,
+                               (uint4 *)(fwd_ptr ? q8 : nullptr), inv_norm);
         if (hipGetLastError() != hipSuccess) st = SG_ERR_HIP;
         if (st == SG_OK) {
             if (pending) pending->pending_src = nullptr;     // (the representatives' rows are written now)
@@ -752,6 +802,11 @@ extern "C" int sg_postings_build_flags(sg_ctx *ctx, const sg_csr *B_in, int32_t 
     // the packed rows of the pruned multiply are written by the same pass that copies the rows into position order
     void *early_fwd = nullptr;
     uint32_t *early_fwd_ptr = nullptr;
+    void *early_q8 = nullptr;   // ... and so are the 8-bit copies of the second filter
+    const float norm_up_build = __builtin_nextafterf(sqrtf(max_norm2) * 1.000001f, 2.f);   // (= p->norm_up below)
+    // second filter: terms must fit 24 bits; a sixteenth of the device memory at most; SG_Q8=0 switches it off
+    const bool want_q8 = want_pruned && B_in->n_cols < ((int64_t)1 << 24) && !(ctx->opt("SG_Q8") && ctx->opt("SG_Q8")[0] == '0') &&
+                         (ctx->total_mem == 0 || (size_t)SG_Q8_STRIDE * ((size_t)B_in->n_rows + 1) < ctx->total_mem / 16);
     bool fwd_done = false;
     bool aux_written = false;   // the scoring context and the null postings were written by the tables kernel
     {
@@ -761,25 +816,31 @@ extern "C" int sg_postings_build_flags(sg_ctx *ctx, const sg_csr *B_in, int32_t 
         if (filt && !blk && !(flags & SG_POSTINGS_NO_PERMUTATION) && B_in->n_rows > 0) {
             int st0 = ctx->alloc(((size_t)B_in->nnz + 8) * (B_in->dtype == SG_F64 ? 16 : 8), &early_fwd);
             if (st0 == SG_OK) st0 = sg_alloc(ctx, 2 * ((size_t)B_in->n_rows + 2), &early_fwd_ptr);
+            if (st0 == SG_OK && want_q8) st0 = ctx->alloc((size_t)SG_Q8_STRIDE * ((size_t)B_in->n_rows + 1), &early_q8);
             if (st0 != SG_OK) {
                 ctx->release(early_fwd);
+                ctx->release(early_fwd_ptr);
                 return st0;
             }
         }
     }
     if (!(flags & SG_POSTINGS_NO_PERMUTATION)) {
-        const int stp = build_permuted(ctx, B_in, tile_cols, &permuted, &orig_of, &pos_of, pending, early_fwd_ptr, early_fwd, &fwd_done);
+        const int stp = build_permuted(ctx, B_in, tile_cols, &permuted, &orig_of, &pos_of, pending, early_fwd_ptr, early_fwd, &fwd_done,
+                                       early_q8, 1.0f / norm_up_build);
         if (stp != SG_OK) {
             ctx->release(early_fwd);
             ctx->release(early_fwd_ptr);
+            ctx->release(early_q8);
             return stp;
         }
     }
     if (!fwd_done) {
         ctx->release(early_fwd);
         ctx->release(early_fwd_ptr);
+        ctx->release(early_q8);
         early_fwd = nullptr;
         early_fwd_ptr = nullptr;
+        early_q8 = nullptr;
     }
     if (pending && pending->pending_src) {      // no copy in position order was made: the representatives' rows by themselves
         const int stm = sg_collapse_materialize(ctx, pending);
@@ -796,6 +857,9 @@ extern "C" int sg_postings_build_flags(sg_ctx *ctx, const sg_csr *B_in, int32_t 
         sg_csr_free(permuted);
         ctx->release(orig_of);
         ctx->release(pos_of);
+        ctx->release(early_fwd);
+        ctx->release(early_fwd_ptr);
+        ctx->release(early_q8);
         return SG_ERR_OOM;
     }
     p->permuted = permuted;
@@ -861,11 +925,14 @@ extern "C" int sg_postings_build_flags(sg_ctx *ctx, const sg_csr *B_in, int32_t 
         if (early_fwd && !p->d_blk) {          // written along with the rows' copy in position order (build_permuted)
             p->d_fwd = early_fwd;
             p->d_fwd_ptr = early_fwd_ptr;
+            p->d_q8 = early_q8;
             early_fwd = nullptr;
             early_fwd_ptr = nullptr;
+            early_q8 = nullptr;
         } else {
             if (st == SG_OK && !p->d_blk) st = ctx->alloc(((size_t)B->nnz + 8) * (B->dtype == SG_F64 ? 16 : 8), &p->d_fwd);
             if (st == SG_OK) st = sg_alloc(ctx, 2 * ((size_t)B->n_rows + 2), &p->d_fwd_ptr);   // uint2 per row
+            if (st == SG_OK && want_q8 && !p->d_blk) st = ctx->alloc((size_t)SG_Q8_STRIDE * ((size_t)B->n_rows + 1), &p->d_q8);
             fwd_done = false;
         }
         // slack: the pruned multiply loads a lane's four slots of a segment unconditionally (<= 4 * 63 entries past it)
@@ -883,7 +950,7 @@ extern "C" int sg_postings_build_flags(sg_ctx *ctx, const sg_csr *B_in, int32_t 
             p->nv_pad = (int32_t)((n_super + 3) & ~(int64_t)3);
             if (st == SG_OK) st = sg_alloc(ctx, (size_t)(B->n_cols + 1) * (size_t)p->nv_pad + 4, &p->d_ends8);
         }
-        p->norm_up = __builtin_nextafterf(sqrtf(max_norm2) * 1.000001f, 2.f);
+        p->norm_up = norm_up_build;
         // a term is "frequent" when it occurs in at least this share of the right-hand rows: the suffix of a
         // left row is drawn from frequent terms only, which lets the survivor test use each candidate's own
         // frequent-part norm instead of 1 (profiles/r01_prune_tuning.log)
@@ -892,6 +959,9 @@ extern "C" int sg_postings_build_flags(sg_ctx *ctx, const sg_csr *B_in, int32_t 
         const double fm = frac * (double)B->n_rows;
         p->freq_min = fm < 1.0 ? 1u : (uint32_t)fm;
     }
+    ctx->release(early_fwd);      // (only when the build took another turn than the one they were made for)
+    ctx->release(early_fwd_ptr);
+    ctx->release(early_q8);
     if (st != SG_OK) {
         sg_postings_free(p);
         return st;
@@ -957,6 +1027,8 @@ extern "C" int sg_postings_build_flags(sg_ctx *ctx, const sg_csr *B_in, int32_t 
                         sc.blk = p->d_blk;
                         sc.blk_bytes = p->blk_bytes;
                         sc.orig_of = p->d_orig_of;
+                        sc.q8 = (const uint4 *)p->d_q8;
+                        sc.q8_scale = p->d_q8 ? __builtin_nextafterf((float)(255.0 / (double)p->norm_up * (1.0 - 1e-6)), 0.f) : 0.f;
                     }
                     if (st == SG_OK) {
                         hipLaunchKernelGGL(postings_tables_kernel, dim3(strips1), dim3(1024), 0, ctx->stream, (const uint32_t *)cnt,
@@ -1038,6 +1110,15 @@ extern "C" int sg_postings_build_flags(sg_ctx *ctx, const sg_csr *B_in, int32_t 
             else
                 hipLaunchKernelGGL(fwd_pack<float>, dim3(g2), dim3(256), 0, ctx->stream, B->d_indptr, B->d_indices,
                                    (const float *)B->d_data, B->n_rows, B->nnz, (const uint32_t *)p->d_orig_of, p->d_fwd_ptr, p->d_fwd);
+            if (p->d_q8 && B->n_rows > 0) {
+                const unsigned g4 = (unsigned)((B->n_rows * 16 + 255) / 256);
+                if (B->dtype == SG_F64)
+                    hipLaunchKernelGGL(q8_pack_kernel<double>, dim3(g4), dim3(256), 0, ctx->stream, B->d_indptr, B->d_indices,
+                                       (const double *)B->d_data, B->n_rows, (const uint32_t *)p->d_orig_of, (uint4 *)p->d_q8, 1.0f / p->norm_up);
+                else
+                    hipLaunchKernelGGL(q8_pack_kernel<float>, dim3(g4), dim3(256), 0, ctx->stream, B->d_indptr, B->d_indices,
+                                       (const float *)B->d_data, B->n_rows, (const uint32_t *)p->d_orig_of, (uint4 *)p->d_q8, 1.0f / p->norm_up);
+            }
             if (hipGetLastError() != hipSuccess) st = SG_ERR_HIP;
         }
     }
@@ -1054,6 +1135,8 @@ extern "C" int sg_postings_build_flags(sg_ctx *ctx, const sg_csr *B_in, int32_t 
             sc.blk = p->d_blk;
             sc.blk_bytes = p->blk_bytes;
             sc.orig_of = p->d_orig_of;
+            sc.q8 = (const uint4 *)p->d_q8;
+            sc.q8_scale = p->d_q8 ? __builtin_nextafterf((float)(255.0 / (double)p->norm_up * (1.0 - 1e-6)), 0.f) : 0.f;
             hipLaunchKernelGGL(score_ctx_kernel, dim3(1), dim3(1), 0, ctx->stream, sc, p->d_score_ctx);
             if (hipGetLastError() != hipSuccess) st = SG_ERR_HIP;
         }
@@ -1124,6 +1207,7 @@ extern "C" int sg_postings_free(sg_postings *p) {
     p->ctx->release(p->d_vals);
     p->ctx->release(p->d_fwd);
     p->ctx->release(p->d_blk);
+    p->ctx->release(p->d_q8);
     p->ctx->release(p->d_fwd_ptr);
     p->ctx->release(p->d_filt);
     p->ctx->release(p->d_ends);

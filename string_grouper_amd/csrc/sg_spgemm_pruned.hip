@@ -117,7 +117,10 @@ __device__ __forceinline__ T wave_shfl(T v, int src) {
 // row j of B with INDEPENDENT loads -- eight entries in flight per round, not one dependent load per merge
 // step -- and look every term up in one or two LDS reads.
 #define SG_HASH_SLOTS 128
-__device__ __forceinline__ uint32_t term_hash(int k) { return ((uint32_t)k * 2654435761u) >> 25; }
+// (a 24-bit multiply: full rate, where the 32-bit one takes four passes -- and a lookup is the inner step of both the second
+//  filter and the exact scoring; spreads the terms of a row as well as the 32-bit golden-ratio hash did: 1.19 probes per
+//  unsuccessful lookup on name rows either way)
+__device__ __forceinline__ uint32_t term_hash(int k) { return (__umul24((uint32_t)k & 0xffffffu, 0x9E3779u) >> 17) & 127u; }
 
 // An object of the wave's LDS by its byte address.  The kernel's dynamic LDS is its only LDS and starts at address 0
 // (the accumulator tile first: a posting's address field IS an LDS address).  In the kernel `smem + x` is as good; in the
@@ -128,6 +131,25 @@ template <typename P>
 __device__ __forceinline__ P *lds_object(uint32_t byte_addr) {
     typedef __attribute__((address_space(3))) P lds_t;
     return (P *)(lds_t *)(uintptr_t)byte_addr;
+}
+
+// A pointer into device memory as one of the GLOBAL address space.  Pointers that reach a routine through a struct are
+// generic to the compiler: flat_load instead of global_load -- counted by the LDS counter as well, so that every wait for
+// an LDS read also waits for the loads in flight.
+template <typename P>
+__device__ __forceinline__ const __attribute__((address_space(1))) P *global_ptr(const void *p) {
+    return (const __attribute__((address_space(1))) P *)(uintptr_t)p;
+}
+// (HIP's uint4 / uint2 are classes whose copy constructors take generic references: the loads go through the native vectors)
+typedef uint32_t sg_u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t sg_u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint4 load_global_u4(const void *base, size_t idx) {
+    const sg_u32x4 v = global_ptr<sg_u32x4>(base)[idx];
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ uint2 load_global_u2(const void *base, size_t idx) {
+    const sg_u32x2 v = global_ptr<sg_u32x2>(base)[idx];
+    return make_uint2(v.x, v.y);
 }
 
 // A small struct of launch constants (SgScoreCtx, SgPairSink) read through the SCALAR cache.  The routines below are real
@@ -160,10 +182,9 @@ struct FwdRound<float> {   // 4 loads x 2 entries; q is even
     int k[8];
     float v[8];
     __device__ __forceinline__ void load(const void *fwd, uint32_t q, uint32_t last) {
-        const uint4 *f = reinterpret_cast<const uint4 *>(fwd);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const uint4 w = f[min((q >> 1) + e, last >> 1)];
+            const uint4 w = load_global_u4(fwd, min((q >> 1) + e, last >> 1));
             k[2 * e] = (int)w.x;
             v[2 * e] = __uint_as_float(w.y);
             k[2 * e + 1] = (int)w.z;
@@ -176,10 +197,9 @@ struct FwdRound<double> {   // 8 loads x 1 entry
     int k[8];
     double v[8];
     __device__ __forceinline__ void load(const void *fwd, uint32_t q, uint32_t last) {
-        const uint4 *f = reinterpret_cast<const uint4 *>(fwd);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            const uint4 w = f[min(q + e, last)];
+            const uint4 w = load_global_u4(fwd, min(q + e, last));
             k[e] = (int)w.x;
             v[e] = __longlong_as_double((long long)(((unsigned long long)w.w << 32) | w.z));
         }
@@ -216,23 +236,17 @@ __device__ __forceinline__ T row_value(const int *hk, const T *ha, int key, int 
 // arithmetic.  A term row i does not have contributes a * b with a = 0: sum + 0 == sum exactly (all
 // values are non-negative), so absent terms and the padding of a round need no branch.
 template <typename T, bool WIDE>
-__device__ __forceinline__ T exact_score(int j, const int *hk, const T *ha, int nnz, const uint32_t *__restrict__ fwd_ptr,
-                                         const void *__restrict__ fwd, int &row_of_j) {
+__device__ __forceinline__ T exact_score_packed(bool have, uint32_t pb, uint32_t pe, const int *hk, const T *ha, int nnz,
+                                                const void *__restrict__ fwd) {
     T sum = (T)0;
-    row_of_j = j;
-    if (j >= 0) {
-        // {first entry, the row's own index} of positions j and j + 1: sixteen contiguous bytes
-        const uint2 m0 = reinterpret_cast<const uint2 *>(fwd_ptr)[j], m1 = reinterpret_cast<const uint2 *>(fwd_ptr)[j + 1];
-        const uint32_t pb = m0.x;
-        const uint32_t pe = m1.x;
-        row_of_j = (int)m0.y;
-        // A call is a chain of dependent misses -- the row's pointer, then its entries eight at a time: four in a row for
+    if (have) {
+        // A call is a chain of dependent misses -- (the row's pointer, then) its entries eight at a time: four in a row for
         // a row of 19 entries (the mean of a name list), ~10 us per call of 64 candidates, a fifth of the kernel.  The
         // rounds behind the first are therefore TOUCHED (one dword each, three registers) together with the first round's
         // loads: when their turn comes they arrive from the cache.  (Two rounds in flight by name instead -- 32 registers
         // -- spilled in every kernel of the file.)
         constexpr uint32_t DW = sizeof(T) == 4 ? 2u : 4u;   // dwords per entry
-        const uint32_t *fw = reinterpret_cast<const uint32_t *>(fwd);
+        const auto *fw = global_ptr<uint32_t>(fwd);
         const uint32_t q0 = pb & ~1u;
         uint32_t t1 = 0, t2 = 0, t3 = 0;
         if (q0 + 8u < pe) t1 = fw[(q0 + 8u) * DW];
@@ -253,6 +267,97 @@ __device__ __forceinline__ T exact_score(int j, const int *hk, const T *ha, int 
         asm volatile("" ::"v"(t1), "v"(t2), "v"(t3));
     }
     return sum;
+}
+
+template <typename T, bool WIDE>
+__device__ __forceinline__ T exact_score(int j, const int *hk, const T *ha, int nnz, const uint32_t *__restrict__ fwd_ptr,
+                                         const void *__restrict__ fwd, int &row_of_j) {
+    row_of_j = j;
+    uint32_t pb = 0, pe = 0;
+    if (j >= 0) {
+        // {first entry, the row's own index} of positions j and j + 1: sixteen contiguous bytes
+        const uint2 m0 = load_global_u2(fwd_ptr, (size_t)j), m1 = load_global_u2(fwd_ptr, (size_t)j + 1);
+        pb = m0.x;
+        pe = m1.x;
+        row_of_j = (int)m0.y;
+    }
+    return exact_score_packed<T, WIDE>(j >= 0, pb, pe, hk, ha, nnz, fwd);
+}
+
+// SECOND FILTER (round 5).  The first filter's candidates are mostly false alarms -- sums of eight columns folded onto one
+// accumulator, a bound that knows only the norm of a candidate's frequent part: 31.7 M pairs scored for 1.2 M above the
+// threshold at 663 k -- and every one of them cost the exact scoring a pointer line plus two or three lines of a ~150-byte
+// packed row, fetched one behind the other.  K3 therefore keeps an 8-BIT COPY of every right-hand row at a fixed stride
+// (SgScoreCtx::q8, sg_internal.h; sg_postings.hip: q8_write_unit): one aligned line (two for rows of more than 29
+// entries), addressed by the candidate's position alone.  Its values are rounded UP, so
+//        U = sum_k a_k * bq_k   (over the candidate's entries; a_k = 0 for terms row i does not have)
+// satisfies  score(i, j) <= U * norm_up / 255,  and a candidate with  U < (threshold - 3e-5) * 255 / norm_up  cannot
+// reach the threshold: the exact kernel's float score obeys score~ <= score + 1e-5 (the first filter's own allowance),
+// the float evaluation of U loses at most n * 2^-24 of it (8e-6 at the threshold for 128 terms), the conversion of a
+// double a_k to float 6e-8 of it, q8_scale is rounded down -- 3e-5 covers all of it.  tests/test_prune_model.py restates
+// both sides (no false negative for scores at the threshold +- 1 ulp, hubs, rows beyond the copy's 61 entries, f64).
+// A row without a copy (more than 61 entries) always passes.  The header also holds what the exact scoring needs of the
+// row -- first packed entry, number of entries, the row's own index -- so a candidate that passes costs no pointer fetch.
+template <typename T, bool WIDE>
+__device__ __forceinline__ float q8_unit(uint4 w, const int *hk, const T *ha, int nnz, float ub) {
+    const uint32_t e[4] = {w.x, w.y, w.z, w.w};   // (an entry behind the row's last is 0: term 0 times bq = 0)
+    if (WIDE) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            ub = __builtin_fmaf((float)row_value<T, true>(hk, ha, (int)(e[q] >> 8), nnz), (float)(e[q] & 255u), ub);
+        return ub;
+    }
+    // four lookups side by side: the keys of the four home slots in one go, the (rare) probes behind them, then the four
+    // values -- two LDS round trips per unit where one entry after the other takes eight
+    uint32_t h[4];
+    int k[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) h[q] = term_hash((int)(e[q] >> 8));
+#pragma unroll
+    for (int q = 0; q < 4; ++q) k[q] = hk[h[q]];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        SG_WD_DECL(wd_p);
+        while (k[q] != (int)(e[q] >> 8) && k[q] != -1) {
+            SG_WD(wd_p, SG_HASH_SLOTS + 2, 26)
+            h[q] = (h[q] + 1u) & (SG_HASH_SLOTS - 1);
+            k[q] = hk[h[q]];
+        }
+    }
+    T v[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) v[q] = ha[h[q]];   // (an empty slot's value is whatever LDS holds: selected away below)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) ub = __builtin_fmaf(k[q] == (int)(e[q] >> 8) ? (float)v[q] : 0.f, (float)(e[q] & 255u), ub);
+    return ub;
+}
+
+template <typename T, bool WIDE>
+__device__ __forceinline__ bool q8_passes(int j, const int *hk, const T *ha, int nnz, const uint4 *__restrict__ q8, float bar,
+                                          uint32_t &pb, uint32_t &pe, int &row_of_j) {
+    const bool have = j >= 0;
+    const size_t rec = (size_t)(have ? j : 0) * (SG_Q8_STRIDE / 16u);   // (in 16-byte units)
+    uint4 cur = make_uint4(0u, 0u, 0x80000000u, 0u), nxt = make_uint4(0u, 0u, 0u, 0u);
+    if (have) {   // header and first entries together: the same 128-byte line
+        cur = load_global_u4(q8, rec);
+        nxt = load_global_u4(q8, rec + 1);
+    }
+    const uint32_t n_j = cur.z & 0x7fffffffu;
+    const bool whole = (cur.z >> 31) == 0u;
+    pb = cur.x;
+    pe = cur.x + n_j;
+    row_of_j = have ? (int)cur.y : j;
+    const uint32_t units = whole ? (n_j + 7u) >> 2 : 1u;   // 16-byte units of the record in use (unit 0: the header)
+    float ub = 0.f;
+    SG_WD_DECL(wd_q);
+    for (uint32_t u = 1u;; ++u) {   // the unit behind the one being worked off is on its way (same line: from the cache)
+        SG_WD(wd_q, 20, 25)
+        if (__ballot(u < units) == 0) break;
+        cur = nxt;
+        if (u + 1u < units) nxt = load_global_u4(q8, rec + u + 1u);
+        if (u < units) ub = q8_unit<T, WIDE>(cur, hk, ha, nnz, ub);
+    }
+    return have && (!whole || ub >= bar);
 }
 
 // The same score from the ROW BLOCKS (SgScoreCtx::blk): rows at a fixed stride, 128-byte aligned, header first.  No row
@@ -333,8 +438,21 @@ __device__ __noinline__ TopList<T> drain_survivors(int nnz, T thr, uint32_t row,
     const SgScoreCtx scv = load_launch_constants(sc);
     // what leaves the kernel is the row itself: the top list orders equal scores by the ORIGINAL column, the pairs name rows
     int jo;
-    const T sum = scv.blk ? exact_score_blocks<T, WIDE>(j, hk, ha, nnz, &scv, jo)
-                          : exact_score<T, WIDE>(j, hk, ha, nnz, scv.fwd_ptr, scv.fwd, jo);
+    T sum;
+    if (UNIQ && scv.q8 != nullptr) {   // (stream form) second filter first; the exact scoring only for what it lets through
+        uint32_t pb, pe;
+        const float bar = ((float)thr - 3e-5f) * scv.q8_scale;
+        const bool pass = q8_passes<T, WIDE>(j, hk, ha, nnz, scv.q8, bar, pb, pe, jo);
+        const uint64_t pm = __ballot(pass);
+        // pairs scored exactly, per wave, in the word of the survivor buffer in front of the pair list's (the stream
+        // form buffers 126 columns at most); added to the launch's statistics when the wave ends
+        if (lane == 0) surv[SG_SURV_CAP - 2] += (int)__popcll(pm);
+        sum = pm ? exact_score_packed<T, WIDE>(pass, pb, pe, hk, ha, nnz, scv.fwd) : (T)0;
+    } else {
+        sum = scv.blk ? exact_score_blocks<T, WIDE>(j, hk, ha, nnz, &scv, jo)
+                      : exact_score<T, WIDE>(j, hk, ha, nnz, scv.fwd_ptr, scv.fwd, jo);
+        if (UNIQ && lane == 0) surv[SG_SURV_CAP - 2] += (int)min(n_surv, 64u);
+    }
     uint64_t hm = __ballot(j >= 0 && sum > thr);
     if (SYM) {
         // row i keeps its own matches j <= i in its top list like the one-sided form; what row j < i has to learn -- that
@@ -437,11 +555,14 @@ __device__ __noinline__ FlushOut<T> flush_survivors(int nnz, T thr, uint32_t row
     FlushOut<T> out;
     out.top = top;
     out.n_surv = (uint32_t)__builtin_amdgcn_readfirstlane((int)(n0 + (uint32_t)__popcll(f1)));
-    if (out.n_surv >= 64u) {
+    // (from 63 on, not 64: the caller appends up to 64 columns behind what is left, and the buffer's last two words are not
+    //  columns -- the pair list's position and the count of pairs scored exactly: 62 + 64 = 126)
+    if (out.n_surv >= 63u) {
 #ifndef SG_STREAM_PROBE_NO_SCORE
         out.top = drain_survivors<T, SYM, TILE_LOG2, WIDE, true>(nnz, thr, row, sc, pairs, top, out.n_surv);
 #endif
-        out.n_surv -= 64u;
+        const uint32_t scored = out.n_surv < 64u ? out.n_surv : 64u;
+        out.n_surv = (out.n_surv - scored) | (scored << 16);   // [0, 16) left in the buffer, [16, 32) handed to the scoring
     }
     return out;
 }
@@ -502,7 +623,7 @@ spgemm_topn_pruned_kernel(const int64_t *__restrict__ a_indptr, const int32_t *_
                           uint32_t freq_min /* list length from which a term may join the suffix */,
                           int32_t *__restrict__ out_cols, T *__restrict__ out_vals, int32_t *__restrict__ out_cnt,
                           uint32_t *row_counter, uint32_t *flagged_count, uint32_t *flagged_rows,
-                          unsigned long long *stats /* [0] rows [1] postings streamed [2] survivors */,
+                          unsigned long long *stats /* [0] rows [1] postings streamed [2] survivors [4] pairs scored exactly */,
                           const SgPairSink *__restrict__ pairs /* SYM: the pair list (sg_internal.h), in device memory */,
                           uint32_t pair_chunks /* chunks there are */,
                           uint32_t sym_lo, uint32_t sym_hi /* SYM: the left rows this launch scores: sym_hi - 1, sym_hi - 1 - sym_step, ...
@@ -535,6 +656,7 @@ spgemm_topn_pruned_kernel(const int64_t *__restrict__ a_indptr, const int32_t *_
     const int lane = threadIdx.x;
     for (int x = lane; x < TILE * 2 / 16; x += 64) tab_v[x] = make_uint4(0, 0, 0, 0);
     if (SYM && lane == 0) surv[SG_SURV_CAP - 1] = (int)SG_PAIR_NO_CHUNK;
+    if (FOLD_LOG2 > 0 && lane == 0) surv[SG_SURV_CAP - 2] = 0;   // stream form: pairs this wave scores exactly (drain_survivors)
     const uint64_t lanes_below = (1ull << lane) - 1ull;
     unsigned long long st_rows = 0, st_post = 0, st_surv = 0;
     // the accumulator tile is the kernel's first LDS object (address 0): a posting's address field IS the LDS address
@@ -1161,17 +1283,18 @@ spgemm_topn_pruned_kernel(const int64_t *__restrict__ a_indptr, const int32_t *_
                 asm volatile("s_waitcnt vmcnt(0) ; rounds %0 %1 %2 ends %3 %4" : "+v"(oa.q), "+v"(ob.q), "+v"(oc.q), "+v"(EA), "+v"(EB)::"memory");
                 const FlushOut<T> fo = flush_survivors<T, SYM, TILE_LOG2, WIDE>(nnz, thr, row, sc, pairs, top, n_surv, n_clean);
                 top = fo.top;
+                const uint32_t fo_word = (uint32_t)__builtin_amdgcn_readfirstlane((int)fo.n_surv);   // left | handed to the scoring << 16
 #ifndef SG_STREAM_PROBE_COUNT_ROUNDS
-                st_surv += (n_surv - fo.n_surv) & ~63u;   // 64 if a wave was scored (the rest were repeats)
+                st_surv += fo_word >> 16;
 #endif
                 if (CAN_SPLIT) {
                     // enough candidates for a row (pairs scored ~ the rounds' bar in time): the visit being applied is its
                     // last, the parts take over behind it (the rounds in flight of later visits are dropped by the loop's
                     // own end; once: tv + 3 > v_end from here on)
-                    row_scored += (n_surv - fo.n_surv) & ~63u;
+                    row_scored += fo_word >> 16;
                     if (!part_mode && part_cfg != 0u && tv + 3u <= v_end && ballot64(row_scored >= (part_cfg << 3)) != 0) v_end = tv + 1u;
                 }
-                n_surv = n_clean = (uint32_t)__builtin_amdgcn_readfirstlane((int)fo.n_surv);
+                n_surv = n_clean = fo_word & 0xffffu;
             };
             // `fired`: the lane's own test, `cm` its wave mask.  Written so that nothing of the bookkeeping goes through the
             // VALU that a scalar can do: the mask of the lanes that record is the AND of two compare masks (the ballot of a
@@ -1185,7 +1308,7 @@ spgemm_topn_pruned_kernel(const int64_t *__restrict__ a_indptr, const int32_t *_
                 const bool mine = SYM ? col <= row : col < n_right;
                 cm &= ballot64(mine);
                 const uint32_t n_new = (uint32_t)__popcll(cm);
-                if (n_surv + n_new > (uint32_t)SG_SURV_CAP - 1u) flush_s(oa, ob, oc, tv);   // (leaves fewer than 64)
+                if (n_surv + n_new > (uint32_t)SG_SURV_CAP - 2u) flush_s(oa, ob, oc, tv);   // (leaves fewer than 64; the buffer's last two words are not columns)
                 const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(cm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)cm, 0u));
                 if (fired && mine) surv[n_surv + below] = (int)col;
                 n_surv += n_new;
@@ -1370,6 +1493,10 @@ spgemm_topn_pruned_kernel(const int64_t *__restrict__ a_indptr, const int32_t *_
         if (st_rows) atomicAdd(stats + 0, st_rows);
         if (st_post) atomicAdd(stats + 1, st_post);
         if (st_surv) atomicAdd(stats + 2, st_surv);
+        // [4]: pairs scored exactly (what the second filter let through; without it: every survivor)
+        if (FOLD_LOG2 > 0) {
+            if (surv[SG_SURV_CAP - 2]) atomicAdd(stats + 4, (unsigned long long)(uint32_t)surv[SG_SURV_CAP - 2]);
+        } else if (st_surv) atomicAdd(stats + 4, st_surv);
     }
 #ifdef SG_DEBUG_WAVE_TIMES
     if (SYM && !WIDE && FOLD_LOG2 > 0 && sizeof(T) == 4 && lane == 0 && blockIdx.x < 8192u) {
@@ -1394,6 +1521,7 @@ __device__ __forceinline__ void publish_pass_stats(const unsigned long long *src
         dst[0] = src[0];
         dst[1] = src[1];
         dst[2] = src[2];
+        dst[4] = src[4];
         reinterpret_cast<uint32_t *>(dst + 3)[0] = *word;
     }
 }
@@ -1894,10 +2022,10 @@ int sg_spgemm_pruned_symmetric(sg_ctx *ctx, const sg_csr *A, const sg_postings *
     pl.d_sink = reinterpret_cast<const SgPairSink *>(words + 64);
     static_assert(sizeof(SgPairSink) <= 64, "the pair list's struct must fit the sixteen words reserved for it");
     unsigned long long *d_stats3 = nullptr;   // this pass's own statistics: they only count when the pass does
-    st = sg_alloc(ctx, (size_t)4, &d_stats3);
+    st = sg_alloc(ctx, (size_t)8, &d_stats3);   // [0..2] rows / postings / survivors, [4] pairs scored exactly
     hipError_t e = hipSuccess;
     if (st == SG_OK) {
-        st = SG_ZERO4(ctx, words, (128 + (size_t)pl.chunks) * sizeof(uint32_t), d_stats3, 4 * sizeof(unsigned long long), cnt,
+        st = SG_ZERO4(ctx, words, (128 + (size_t)pl.chunks) * sizeof(uint32_t), d_stats3, 8 * sizeof(unsigned long long), cnt,
                       sizeof(uint32_t) * (size_t)(n + 2), cursor, sizeof(uint32_t) * (size_t)(n + 2));   // (one launch, not four)
     }
     const float s_budget = prune_budget(Bt, threshold, delta);
@@ -1975,6 +2103,8 @@ int sg_spgemm_pruned_symmetric(sg_ctx *ctx, const sg_csr *A, const sg_postings *
                                    (const unsigned long long *)d_stats3, (const uint32_t *)(words + 1), stats);
             if (hipGetLastError() != hipSuccess) st = SG_ERR_HIP;
         } else if (st == SG_OK && (hipMemcpyAsync(stats, d_stats3, 3 * sizeof(unsigned long long), hipMemcpyDeviceToDevice,
+                                                  ctx->stream) != hipSuccess ||
+                                   hipMemcpyAsync(stats + 4, d_stats3 + 4, sizeof(unsigned long long), hipMemcpyDeviceToDevice,
                                                   ctx->stream) != hipSuccess ||
                                    hipMemcpyAsync(stats + 3, words + 1, 4, hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess))
             st = SG_ERR_HIP;   // (no pairs, no export kernel: the statistics go by copy)

@@ -1030,7 +1030,7 @@ extern "C" int sg_spgemm_topn(sg_ctx *ctx, const sg_csr *A, const sg_postings *B
         SgTimer timer(ctx, SG_K_SPGEMM);
         st = SG_OK;
         st = SG_ZERO3(ctx, counters, sizeof(uint32_t) * n_words, r->d_counts, sizeof(int32_t) * (size_t)A->n_rows,
-                      ctx->d_stat_words, 6 * sizeof(int64_t));   // ([0], [1]: written by the counting kernels at the end)
+                      ctx->d_stat_words, 7 * sizeof(int64_t));   // ([0], [1]: written by the counting kernels at the end)
         bool sym_done = false;
         if (symmetric && st == SG_OK)
             st = sg_spgemm_pruned_symmetric(ctx, A, Bt, stride, r, threshold, delta,
@@ -1115,7 +1115,13 @@ extern "C" int sg_spgemm_topn(sg_ctx *ctx, const sg_csr *A, const sg_postings *B
         // the MAC and output terms are added in sg_ctx_stats once the device counters are read
         ctx->spgemm_entry_bytes = (int64_t)(4 + s);
         ctx->spgemm_fixed_bytes = A->nnz * (int64_t)(4 + s) + (A->n_rows + Bt->n_terms + 2) * 4;
-        ctx->prune_row_bytes = 8.0 + (Bt->n_right > 0 ? (double)Bt->nnz / (double)Bt->n_right : 0.0) * (s == 8 ? 16.0 : 8.0);
+        {
+            // what a candidate of the first filter costs: with the second filter its 8-bit copy (header + 4 B an entry), and the
+            // packed row only for those that pass it (no pointer fetch: the header holds it); without: pointer + packed row
+            const double mean_row = Bt->n_right > 0 ? (double)Bt->nnz / (double)Bt->n_right : 0.0;
+            ctx->prune_q8_bytes = Bt->d_q8 && Bt->fold_log2 > 0 ? 16.0 + 4.0 * mean_row : 0.0;
+            ctx->prune_row_bytes = (ctx->prune_q8_bytes > 0.0 ? 0.0 : 8.0) + mean_row * (s == 8 ? 16.0 : 8.0);
+        }
         if (hipGetLastError() != hipSuccess) st = SG_ERR_HIP;
     }
     ctx->release(counters);
@@ -1186,7 +1192,13 @@ extern "C" int sg_selfjoin_range(sg_ctx *ctx, const sg_csr *A, const sg_postings
     const size_t s = A->dtype == SG_F64 ? 8 : 4;
     ctx->spgemm_entry_bytes = (int64_t)(4 + s);
     ctx->spgemm_fixed_bytes = A->nnz * (int64_t)(4 + s) + (A->n_rows + Bt->n_terms + 2) * 4;
-    ctx->prune_row_bytes = 8.0 + (Bt->n_right > 0 ? (double)Bt->nnz / (double)Bt->n_right : 0.0) * (s == 8 ? 16.0 : 8.0);
+    {
+        // what a candidate of the first filter costs: with the second filter its 8-bit copy (header + 4 B an entry), and the
+        // packed row only for those that pass it (no pointer fetch: the header holds it); without: pointer + packed row
+        const double mean_row = Bt->n_right > 0 ? (double)Bt->nnz / (double)Bt->n_right : 0.0;
+        ctx->prune_q8_bytes = Bt->d_q8 && Bt->fold_log2 > 0 ? 16.0 + 4.0 * mean_row : 0.0;
+        ctx->prune_row_bytes = (ctx->prune_q8_bytes > 0.0 ? 0.0 : 8.0) + mean_row * (s == 8 ? 16.0 : 8.0);
+    }
     ctx->prune_symmetric = done;
     if (st != SG_OK || !done) {   // a row for the exact kernel, or the pair list was full: the one-sided form is the caller's
         sg_topn_free(r);
@@ -1205,6 +1217,22 @@ extern "C" int sg_selfjoin_merge(sg_ctx *ctx, sg_topn *res, const sg_postings *B
     SG_REQUIRE(row_lo >= 0 && row_lo <= row_hi && row_hi <= res->n_rows, "row range outside the result");
     SgTimer timer(ctx, SG_K_ZIP);
     return sg_selfjoin_merge_pairs(ctx, res, d_pairs, n_pairs, row_lo, row_hi, Bt ? (const uint32_t *)Bt->d_pos_of : nullptr, row_step);
+}
+
+extern "C" int sg_postings_bytes(const sg_postings *Bt, int64_t *pruned_multiply_bytes) {
+    SG_REQUIRE(Bt && pruned_multiply_bytes, "null argument");
+    int64_t b = 0;
+    if (Bt->d_filt) {
+        const int64_t es = Bt->dtype == SG_F64 ? 16 : 8;
+        b += 4 * (Bt->nnz + 512);                                                        // filter postings
+        b += 4 * (Bt->n_terms + 1) * (int64_t)(Bt->fold_log2 > 0 ? Bt->nv_pad : Bt->nt_pad);   // the segment ends the loop reads
+        if (Bt->d_fwd) b += es * (Bt->nnz + 8);                                          // packed rows
+        if (Bt->d_fwd_ptr) b += 8 * (Bt->n_right + 2);
+        if (Bt->d_blk) b += (int64_t)Bt->blk_bytes * (Bt->n_right + 1);
+        if (Bt->d_q8) b += (int64_t)SG_Q8_STRIDE * (Bt->n_right + 1);                    // 8-bit copies (allocated; ~ half of it is read)
+    }
+    *pruned_multiply_bytes = b;
+    return SG_OK;
 }
 
 extern "C" int sg_postings_rows(const sg_postings *Bt, int64_t *n_index_rows, int64_t *n_caller_rows,

@@ -259,3 +259,135 @@ def test_stream_form_posting_of_a_full_value_in_a_tile_s_first_columns():
     bq = (postings >> 16) & 0xFF
     assert (bq == 255).all(), bq
     assert (((postings >> 24) ^ 0x80) == 0).all()          # no frequent part, and nothing carried into the field
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Round 5: the SECOND filter -- an 8-bit copy of every right-hand row (sg_postings.hip: q8_write_unit) and the bound the
+# multiply computes from it before it scores a candidate exactly (sg_spgemm_pruned.hip: q8_passes).  Restated with the
+# kernels' float32 operations, in their order; the claim under test: a pair whose EXACT score (the reference's
+# arithmetic, in the matrix dtype) is above the threshold always passes.
+Q8_MAX_ENTRIES = 60
+
+
+def q8_quantise(vals, norm_up):
+    """bq of K3: ceil(float(v) * (1 / norm_up) * 255 * 1.000002), cut to [1, 255] -- every product a float32 operation."""
+    inv = f32(1.0) / f32(norm_up)
+    q = np.ceil(((vals.astype(f32) * inv).astype(f32) * f32(255.0)).astype(f32) * f32(1.000002))
+    return np.clip(q, 1, 255).astype(np.int64)
+
+
+def q8_bar(thr, norm_up):
+    """((float)thr - 3e-5f) * q8_scale, q8_scale = 255 / norm_up * (1 - 1e-6) rounded down (sg_postings.hip)."""
+    scale = np.nextafter(f32(255.0 / float(norm_up) * (1.0 - 1e-6)), f32(0))
+    return f32(f32(f32(thr) - f32(3e-5)) * scale)
+
+
+def q8_bound(a_idx, a_val, b_idx, bq):
+    """U of the kernel: over the candidate's entries in ascending term order, ub = fma(float(a_k), float(bq_k), ub)."""
+    a = dict(zip(a_idx.tolist(), a_val.astype(f32).tolist()))
+    ub = f32(0)
+    for k, q in zip(b_idx.tolist(), bq.tolist()):
+        ub = f32(np.float64(a.get(k, 0.0)) * np.float64(q) + np.float64(ub))      # (exact in float64, one rounding: an fma)
+    return ub
+
+
+def exact_score(a_idx, a_val, b_idx, b_val, dtype):
+    """The reference's arithmetic: ascending k over row j, product and sum rounded separately, in the matrix dtype."""
+    a = dict(zip(a_idx.tolist(), a_val.tolist()))
+    s = dtype(0)
+    for k, v in zip(b_idx.tolist(), b_val.tolist()):
+        s = dtype(s + dtype(dtype(a.get(k, 0.0)) * dtype(v)))
+    return s
+
+
+def q8_passes(m, i, j, thr, norm_up):
+    bi, bv = m.indices[m.indptr[j]:m.indptr[j + 1]], m.data[m.indptr[j]:m.indptr[j + 1]]
+    if len(bi) > Q8_MAX_ENTRIES:
+        return True                      # no 8-bit copy: always scored
+    ai, av = m.indices[m.indptr[i]:m.indptr[i + 1]], m.data[m.indptr[i]:m.indptr[i + 1]]
+    return bool(q8_bound(ai, av, bi, q8_quantise(bv, norm_up)) >= q8_bar(thr, norm_up))
+
+
+def _norm_up(m):
+    return np.nextafter(f32(np.sqrt(f32(np.asarray(m.multiply(m).sum(axis=1)).max())) * f32(1.000001)), f32(2))
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("thr", [0.5, 0.8, 0.95])
+def test_second_filter_passes_every_pair_above_the_threshold(dtype, thr):
+    """Every match the oracle keeps -- hubs of identical and near-identical names included -- passes the 8-bit bound, and
+    the bound rejects most of what is far below the threshold (it is a filter, not a formality)."""
+    names = list(synth_names(4000, 321))
+    for k in range(60):                                   # a hub: identical rows and one-character variants
+        names[50 * k] = "NORTHERN LIGHTS HOLDING CO" + ("" if k % 3 else " " + "ABC"[k % 3])
+    (m,), _, _ = O.tfidf_sklearn(names, [names], dtype=dtype)
+    m = m.tocsr()
+    m.sort_indices()
+    norm_up = _norm_up(m)
+    C = O.sp_matmul_topn(m, m.T.tocsr(), 100000, thr, sort=True)
+    rng = np.random.default_rng(7)
+    rows = np.unique(np.concatenate([rng.integers(0, m.shape[0], 500), np.arange(0, 3000, 50)]))
+    kept = 0
+    for i in rows:
+        for j in C.indices[C.indptr[i]:C.indptr[i + 1]]:
+            assert q8_passes(m, i, j, dtype(thr), norm_up), (i, j)
+            kept += 1
+    assert kept > len(rows)
+    rejected = sum(not q8_passes(m, i, j, dtype(thr), norm_up) for i in rows[:200] for j in rng.integers(0, m.shape[0], 20))
+    assert rejected > 0.9 * 200 * 20
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_second_filter_at_the_threshold_plus_and_minus_one_ulp(dtype):
+    """The tightest cases: the threshold set ONE ULP under a pair's exact score (the pair is a match and must pass), for
+    pairs whose 8-bit values are exact (value / norm_up * 255 is an integer up to rounding: the bound has no slack but
+    the 3e-5 allowance) and for rows of the copy's full 60 entries; one ulp ABOVE the score the pair is no match, and
+    whether it passes does not matter.  Also a full-length left row (128 terms): the float sum loses the most there."""
+    rng = np.random.default_rng(11)
+    n_terms = 5000
+    checked = 0
+    for trial in range(400):
+        n_b = int(rng.choice([3, 8, 19, 40, 60]))
+        n_a = int(rng.choice([n_b, 64, 128]))
+        b_idx = np.sort(rng.choice(n_terms, n_b, replace=False))
+        extra = np.setdiff1d(rng.choice(n_terms, n_a, replace=False), b_idx)[: max(n_a - n_b, 0)]
+        a_idx = np.sort(np.concatenate([b_idx, extra]))
+        if trial % 2:                                     # 8-bit exact values: multiples of norm_up / 255
+            q = rng.integers(1, 40, n_b).astype(np.float64)
+            b_val = q / np.sqrt((q * q).sum())
+            norm_up = np.nextafter(f32(f32(1.0) * f32(1.000001)), f32(2))
+            b_val = (np.round(b_val * 255 / float(norm_up)) * float(norm_up) / 255.0)
+            b_val = b_val[b_val > 0] if (b_val > 0).all() else np.maximum(b_val, float(norm_up) / 255.0)
+        else:
+            b_val = rng.random(n_b) + 0.05
+            b_val /= np.sqrt((b_val * b_val).sum())
+            norm_up = np.nextafter(f32(f32(1.0) * f32(1.000001)), f32(2))
+        b_val = b_val.astype(dtype)
+        a_val = np.zeros(len(a_idx))
+        pos = np.searchsorted(a_idx, b_idx)
+        a_val[pos] = b_val * (0.9 + 0.2 * rng.random(n_b))          # a near-copy of b on the shared terms
+        others = np.setdiff1d(np.arange(len(a_idx)), pos)
+        a_val[others] = 0.02 * rng.random(len(others))
+        a_val = (a_val / np.sqrt((a_val * a_val).sum())).astype(dtype)
+        s = exact_score(a_idx, a_val, b_idx, b_val, dtype)
+        if not 0.45 < float(s) < 1.0:
+            continue
+        thr = np.nextafter(s, dtype(0))                   # score > thr by one ulp: a match
+        bq = q8_quantise(b_val, norm_up)
+        assert (bq.astype(np.float64) * float(norm_up) / 255.0 >= b_val.astype(np.float64)).all()      # rounded UP
+        assert q8_bound(a_idx, a_val, b_idx, bq) >= q8_bar(thr, norm_up), (trial, float(s))
+        checked += 1
+    assert checked > 300
+
+
+def test_second_filter_record_layout_restated():
+    """What K3 writes for a row (sg_postings.hip: q8_write_unit / sg_q8_units) -- units in use, the flag of rows without a
+    copy -- as the kernel reads it (q8_passes: units = (n + 7) >> 2, whole = bit 31 clear)."""
+    for nnz, units, whole in ((0, 1, True), (1, 2, True), (4, 2, True), (5, 3, True), (28, 8, True), (29, 9, True),
+                              (60, 16, True), (61, 1, False), (500, 1, False)):
+        k3_units = 1 if nnz > Q8_MAX_ENTRIES else (nnz + 7) >> 2
+        word2 = nnz | (0 if nnz <= Q8_MAX_ENTRIES else 0x80000000)
+        kernel_whole = (word2 >> 31) == 0
+        kernel_units = ((word2 & 0x7fffffff) + 7) >> 2 if kernel_whole else 1
+        assert (k3_units, kernel_whole, kernel_units) == (units, whole, units)
+        assert units * 16 <= 256 and (not whole or 4 * (units - 1) >= nnz)
