@@ -117,10 +117,14 @@ __device__ __forceinline__ T wave_shfl(T v, int src) {
 // row j of B with INDEPENDENT loads -- eight entries in flight per round, not one dependent load per merge
 // step -- and look every term up in one or two LDS reads.
 #define SG_HASH_SLOTS 128
-// (a 24-bit multiply: full rate, where the 32-bit one takes four passes -- and a lookup is the inner step of both the second
-//  filter and the exact scoring; spreads the terms of a row as well as the 32-bit golden-ratio hash did: 1.19 probes per
-//  unsuccessful lookup on name rows either way)
-__device__ __forceinline__ uint32_t term_hash(int k) { return (__umul24((uint32_t)k & 0xffffffu, 0x9E3779u) >> 17) & 127u; }
+// The hash names a BUCKET of four consecutive slots (its first slot: a multiple of four); a term sits in the first slot
+// that was free at or behind it when the row was staged (compare-and-swap, linear from there, wrapping).  So a bucket with
+// a free slot holds every term that hashes to it, and ONE 16-byte LDS read -- the bucket's four keys -- settles a lookup
+// unless the bucket is full and does not hold the term (rare at <= 64 terms in 32 buckets: then the walk goes on slot by
+// slot).  The second filter looks four entries up side by side this way (q8_unit): two LDS round trips per four entries;
+// slot-by-slot probing took seven, and those round trips were most of what the survivor routine cost.
+// (A 24-bit multiply: full rate, where the 32-bit one takes four passes.)
+__device__ __forceinline__ uint32_t term_hash(int k) { return (__umul24((uint32_t)k & 0xffffffu, 0x9E3779u) >> 15) & 124u; }
 
 // An object of the wave's LDS by its byte address.  The kernel's dynamic LDS is its only LDS and starts at address 0
 // (the accumulator tile first: a posting's address field IS an LDS address).  In the kernel `smem + x` is as good; in the
@@ -307,28 +311,51 @@ __device__ __forceinline__ float q8_unit(uint4 w, const int *hk, const T *ha, in
             ub = __builtin_fmaf((float)row_value<T, true>(hk, ha, (int)(e[q] >> 8), nnz), (float)(e[q] & 255u), ub);
         return ub;
     }
-    // four lookups side by side: the keys of the four home slots in one go, the (rare) probes behind them, then the four
-    // values -- two LDS round trips per unit where one entry after the other takes eight
+    // four lookups side by side: the four buckets' keys in one go (16 bytes each), the values behind them
     uint32_t h[4];
-    int k[4];
+    bool found[4];
+    {
+        int4 K[4];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) h[q] = term_hash((int)(e[q] >> 8));
+        for (int q = 0; q < 4; ++q) h[q] = term_hash((int)(e[q] >> 8));
 #pragma unroll
-    for (int q = 0; q < 4; ++q) k[q] = hk[h[q]];
+        for (int q = 0; q < 4; ++q) K[q] = *reinterpret_cast<const int4 *>(hk + h[q]);
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        SG_WD_DECL(wd_p);
-        while (k[q] != (int)(e[q] >> 8) && k[q] != -1) {
-            SG_WD(wd_p, SG_HASH_SLOTS + 2, 26)
-            h[q] = (h[q] + 1u) & (SG_HASH_SLOTS - 1);
-            k[q] = hk[h[q]];
+        for (int q = 0; q < 4; ++q) {
+            const int t = (int)(e[q] >> 8);
+            const bool m1 = K[q].y == t, m2 = K[q].z == t, m3 = K[q].w == t;
+            found[q] = K[q].x == t || m1 || m2 || m3;
+            bool walking = !found[q] && K[q].w != -1;   // the bucket is full and does not hold the term: on, slot by slot
+            h[q] += m1 ? 1u : (m2 ? 2u : (m3 ? 3u : 0u));
+            if (__ballot(walking) != 0) {
+                // (a loop the whole wave leaves together, every lane's state in registers of its own: hipcc 7.2 compiled the
+                //  per-lane `while (k != t && k != -1)` of this walk with `found = k == t` taken from the LAST trip's compare
+                //  mask -- lanes that had left the loop earlier lost their hit, and a row with five terms in one bucket lost
+                //  four matches: scripts/q8_debug.py)
+                uint32_t g = (h[q] + 4u) & (SG_HASH_SLOTS - 1);
+                int k = -1;
+                SG_WD_DECL(wd_p);
+                while (__ballot(walking) != 0) {
+                    SG_WD(wd_p, SG_HASH_SLOTS + 2, 26)
+                    if (walking) {
+                        k = hk[g];
+                        walking = k != t && k != -1;
+                        if (walking) g = (g + 1u) & (SG_HASH_SLOTS - 1);
+                    }
+                }
+                asm volatile("" : "+v"(k), "+v"(g));   // (the hit is read off the key, in a register, after the loop)
+                if (!found[q] && K[q].w != -1) {
+                    found[q] = k == t;
+                    h[q] = g;
+                }
+            }
         }
     }
     T v[4];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) v[q] = ha[h[q]];   // (an empty slot's value is whatever LDS holds: selected away below)
+    for (int q = 0; q < 4; ++q) v[q] = ha[h[q]];   // (the slot of a term that is absent holds whatever: selected away below)
 #pragma unroll
-    for (int q = 0; q < 4; ++q) ub = __builtin_fmaf(k[q] == (int)(e[q] >> 8) ? (float)v[q] : 0.f, (float)(e[q] & 255u), ub);
+    for (int q = 0; q < 4; ++q) ub = __builtin_fmaf(found[q] ? (float)v[q] : 0.f, (float)(e[q] & 255u), ub);
     return ub;
 }
 
@@ -434,7 +461,21 @@ __device__ __noinline__ TopList<T> drain_survivors(int nnz, T thr, uint32_t row,
     const T *ha = lds_object<T>(TILE * 2 + 512);
     int *surv = lds_object<int>(TILE * 2 + 512 + 1024);
     const int lane = threadIdx.x;
-    const int j = (uint32_t)lane < n_surv ? surv[lane] : -1;   // a POSITION: the index is built over a permutation of B's rows
+#ifdef SG_PROBE_NO_DRAIN   // timing probe (wrong results): what the whole routine costs
+    if (n_surv > 64) {
+        const uint32_t rem = n_surv - 64;
+        const int keepv = (uint32_t)lane < rem ? surv[64 + lane] : 0;
+        __builtin_amdgcn_wave_barrier();
+        if ((uint32_t)lane < rem) surv[lane] = keepv;
+    }
+    return top;
+#endif
+    // (bit 31 of `row`: the caller has the row's match with itself already -- self-join, stream form -- and the diagonal
+    //  among the candidates is left alone)
+    const bool own_diag = (row >> 31) != 0u;
+    row &= 0x7fffffffu;
+    int j = (uint32_t)lane < n_surv ? surv[lane] : -1;   // a POSITION: the index is built over a permutation of B's rows
+    if (own_diag && (uint32_t)j == row) j = -1;
     const SgScoreCtx scv = load_launch_constants(sc);
     // what leaves the kernel is the row itself: the top list orders equal scores by the ORIGINAL column, the pairs name rows
     int jo;
@@ -442,7 +483,11 @@ __device__ __noinline__ TopList<T> drain_survivors(int nnz, T thr, uint32_t row,
     if (UNIQ && scv.q8 != nullptr) {   // (stream form) second filter first; the exact scoring only for what it lets through
         uint32_t pb, pe;
         const float bar = ((float)thr - 3e-5f) * scv.q8_scale;
+#ifdef SG_PROBE_Q8_ONLY    // timing probe (wrong results): the second filter without the exact scoring behind it
+        const bool pass = q8_passes<T, WIDE>(j, hk, ha, nnz, scv.q8, bar, pb, pe, jo) && (pb == 0xFFFFFFFFu);
+#else
         const bool pass = q8_passes<T, WIDE>(j, hk, ha, nnz, scv.q8, bar, pb, pe, jo);
+#endif
         const uint64_t pm = __ballot(pass);
         // pairs scored exactly, per wave, in the word of the survivor buffer in front of the pair list's (the stream
         // form buffers 126 columns at most); added to the launch's statistics when the wave ends
@@ -910,6 +955,24 @@ spgemm_topn_pruned_kernel(const int64_t *__restrict__ a_indptr, const int32_t *_
         TopList<T> top;
         top.clear();
         uint32_t n_surv = 0;
+        // Self-join, stream form: the row's match with ITSELF comes from the registers -- the sum of its squares in ascending
+        // term order, product and sum rounded separately: what the exact scoring computes for the pair (i, i), bit for bit
+        // (row i of B holds the same values, and entries a round reads past a row's end add a * 0).  With the second filter
+        // in front of the exact scoring the diagonal was the one candidate of most rows that passed it: a second chain of
+        // dependent misses (packed row, its rounds) at the end of nearly every row, for a number the wave already holds.
+        // The survivor routine is told to leave the diagonal alone (bit 31 of its row argument).  Rows worked off in parts
+        // keep the old way (the part that holds the row's own tile scores it); a row that hands its last visits to the
+        // parts has the pair twice in the pair list's merge, which drops repeats (pairs_select_kernel).
+        uint32_t row_arg = row;
+        if (SYM && FOLD_LOG2 > 0 && !part_mode) {
+            T own = (T)0;
+            for (int q = 0; q < nnz; ++q) {
+                const T aq = (SLOTS == 1 || q < 64) ? wave_read<T>(a[0], q) : wave_read<T>(a[SLOTS - 1], q - 64);
+                own = add_rn<T>(own, mul_rn<T>(aq, aq));
+            }
+            if (own > thr) top.insert(own, (int)row_out, lane);
+            row_arg = row | 0x80000000u;
+        }
 #ifdef SG_K4P_PROBE_NO_COLLECT
         uint64_t probe_sink = 0;
 #endif
@@ -1281,7 +1344,7 @@ spgemm_topn_pruned_kernel(const int64_t *__restrict__ a_indptr, const int32_t *_
             //  that records anything, i.e. most rounds)
             auto flush_s = [&](SBatch &oa, SBatch &ob, SBatch &oc, uint32_t tv) {
                 asm volatile("s_waitcnt vmcnt(0) ; rounds %0 %1 %2 ends %3 %4" : "+v"(oa.q), "+v"(ob.q), "+v"(oc.q), "+v"(EA), "+v"(EB)::"memory");
-                const FlushOut<T> fo = flush_survivors<T, SYM, TILE_LOG2, WIDE>(nnz, thr, row, sc, pairs, top, n_surv, n_clean);
+                const FlushOut<T> fo = flush_survivors<T, SYM, TILE_LOG2, WIDE>(nnz, thr, row_arg, sc, pairs, top, n_surv, n_clean);
                 top = fo.top;
                 const uint32_t fo_word = (uint32_t)__builtin_amdgcn_readfirstlane((int)fo.n_surv);   // left | handed to the scoring << 16
 #ifndef SG_STREAM_PROBE_COUNT_ROUNDS
@@ -1443,7 +1506,7 @@ spgemm_topn_pruned_kernel(const int64_t *__restrict__ a_indptr, const int32_t *_
         if (probe_sink == 0x1234567887654321ull) n_surv = 1;   // keeps the tests alive
 #endif
         if (n_surv > 0) {   // fewer than 64 left
-            top = drain_survivors<T, SYM, TILE_LOG2, WIDE, (FOLD_LOG2 > 0)>(nnz, thr, row, sc, pairs, top, n_surv);
+            top = drain_survivors<T, SYM, TILE_LOG2, WIDE, (FOLD_LOG2 > 0)>(nnz, thr, row_arg, sc, pairs, top, n_surv);
 #ifndef SG_STREAM_PROBE_COUNT_ROUNDS
             st_surv += n_surv;
 #endif
