@@ -25,7 +25,7 @@ def line(tag, st, t_wall, extra=""):
     print(f"{tag}: tokenise {st['ms_tokenize']:.1f} + vocab {st['ms_vocab']:.1f} + weight {st['ms_weight']:.1f} + postings "
           f"{st['ms_postings']:.1f} + multiply {st['ms_spgemm_topn']:.1f} ms (kernel {st['ms_spgemm_kernel']:.1f}); self-join form "
           f"{st['prune_symmetric']}, pruned rows {st['prune_rows']}, rows for the exact kernel {st['exact_rows']}, postings streamed "
-          f"{st['prune_postings']:.3e} of {st['macs']:.3e} products, pairs scored {st['prune_survivors']:.3e}, matches {st['out_nnz']}; "
+          f"{st['prune_postings']:.3e} of {st['macs']:.3e} products, candidates {st['prune_survivors']:.3e}, pairs scored exactly {st['prune_scored']:.3e}, matches {st['out_nnz']}; "
           f"wall {t_wall:.2f} s {extra}", flush=True)
 
 

@@ -22,7 +22,7 @@ m.sort_indices()
 mt = m.T.tocsr()
 mt.sort_indices()
 norm_up = np.nextafter(f32(np.sqrt(f32(np.asarray(m.multiply(m).sum(axis=1)).max())) * f32(1.000001)), f32(2))
-thr, delta, freq = 0.8, 0.03, 0.0045
+thr, delta, freq = 0.8, 0.03, 0.005
 freq_min = max(1, int(freq * n))
 fq, bq, post = T.quantise_right_stream(m, mt, freq_min, norm_up, tile=4096)
 C = O.sp_matmul_topn(m, m.T.tocsr(), 100000, thr, sort=True)

@@ -212,8 +212,8 @@ def records_of_row_stream(a_idx, a_val, Bt_indptr, Bt_rows, bq_t, fq, postings, 
     return np.array(rec, dtype=np.int64), len(cols)
 
 
-@pytest.mark.parametrize("thr,delta,freq,tile", [(0.8, 0.05, 0.0045, 4096), (0.8, 0.05, 0.0045, 16), (0.5, 0.2, 0.01, 16),
-                                                 (0.95, 0.3, 0.05, 64), (0.6, 0.02, 0.0, 16), (0.8, 0.03, 0.0045, 4096)])
+@pytest.mark.parametrize("thr,delta,freq,tile", [(0.8, 0.05, 0.005, 4096), (0.8, 0.05, 0.0045, 16), (0.5, 0.2, 0.01, 16),
+                                                 (0.95, 0.3, 0.05, 64), (0.6, 0.02, 0.0, 16), (0.8, 0.03, 0.005, 4096)])
 def test_stream_form_records_cover_every_oracle_match(thr, delta, freq, tile):
     """`tile` much smaller than the kernel's 4096 folds 3000 columns as heavily as 663 k columns fold in the kernel."""
     names = synth_names(3000, 78)
