@@ -63,6 +63,8 @@ def parse_args():
     ap.add_argument("--no-end-to-end", action="store_true", help="skip the match_strings() wall-clock runs (fp32 + fp64)")
     ap.add_argument("--end-to-end", action="store_true", help=argparse.SUPPRESS)      # round-1 flag: now the default
     ap.add_argument("--no-side-runs", action="store_true", help="skip the SG_COLLAPSE=0 and other-dtype runs of the step")
+    ap.add_argument("--no-config3", action="store_true", help="N > 1: skip the nested 5 M-name block (configs3_5M)")
+    ap.add_argument("--config3-rows", type=int, default=5_000_000, help=argparse.SUPPRESS)
     ap.add_argument("--cpu-cores", type=int, default=4, help="cores of the reference CPU leg (README: 4)")
     ap.add_argument("--cpu-full", action="store_true", help=argparse.SUPPRESS)        # round-3 flag: now the default
     ap.add_argument("--cpu-sample", action="store_true", help="CPU baseline: bounded legs only (a 40 000-name run of the "
@@ -284,6 +286,48 @@ def run(args):
     else:
         job_macs, job_bytes, job_nnz = float(stats["macs"]), float(stats["spgemm_bytes"]), float(out_nnz)
 
+    # N > 1: BASELINE.json names the 5 M self-join (configs[3]) as THE 8-GPU configuration; `value` stays the 663 k job of the
+    # metric, and the same step on 5 M names is timed beside it (every rank: its block of the column in HBM, three timed
+    # steps bracketed like the main region, max over ranks) -- a nested block of the one JSON line.
+    config3 = None
+    if distributed and dist_mode == "sharded" and not args.no_config3 and args.rows < args.config3_rows:
+        last = None
+        try:
+            n3 = args.config3_rows
+            names3 = synth_names(n3, 1234)
+            lo3, hi3 = D.row_block(rank, world, n3)
+            block3 = make_vec().prepare(names3[lo3:hi3])
+            del names3
+            step3 = lambda: D.distributed_self_join(ops, block3, args.top_n, args.min_similarity)[0]   # noqa: E731
+            for _ in range(2):
+                step3().free()
+            ctx.sync()
+            barrier()
+            D.reset_collective_tally()
+            t3 = time.perf_counter()
+            k3 = 3
+            nnz3 = 0
+            for _ in range(k3):
+                r3 = step3()
+                ctx.sync()
+                nnz3 = int(ops.topn_tensors(r3)[2].sum().item())
+                r3.free()
+            barrier()
+            e3 = torch.tensor([time.perf_counter() - t3, float(nnz3)], dtype=torch.float64, device="cuda")
+            tmax = e3[:1].clone()
+            D._all_reduce(tmax, dist.ReduceOp.MAX)
+            tsum = e3[1:].clone()
+            D._all_reduce(tsum, dist.ReduceOp.SUM)
+            sec3 = float(tmax.item()) / k3
+            config3 = {"workload": f"{n3}-name self-join (BASELINE.json configs[3]), same step, same ranks", "rows": n3, "steps": k3,
+                       "ms_per_step": sec3 * 1e3, "rows_per_s": n3 / sec3, "matches": int(tsum.item()),
+                       "collectives_per_step": {k: [v[0] / k3, v[1] / k3] for k, v in D.COLLECTIVE_TALLY.items()},
+                       "form": ("self-join form over interleaved shares" if D.selfjoin_form_wanted(n3, world) else "row blocks")}
+            del block3
+            ctx.trim()
+        except Exception as e:       # the nested block must not lose the line of the metric
+            config3 = {"error": repr(e)[:300]}
+
     if rank != 0:
         if distributed:
             dist.destroy_process_group()
@@ -333,6 +377,7 @@ def run(args):
         "options": ctx.options(),
         "matches": int(job_nnz),
         "macs": int(job_macs),
+        "configs3_5M": config3,
         # `bound` names the roofline the fraction is priced against (the contract knows "hbm" and "mfma"; no dense
         # contraction here).  `limited_by` says what the counters say of the kernel (profiles/): it
         # waits for dependent misses at the occupancy its LDS tile allows; `l3_resident`: the index it reads fits the

@@ -147,4 +147,4 @@ def test_eight_ranks_on_one_device_every_block_and_the_gathered_whole_equal_the_
                  seed=61),
         ]
         got = _spawn(8, wd, jobs)
-        assert all(len(got[r]) >= 9 for r in range(8)), got
+        assert all(len(got[r]) >= 8 for r in range(8)), got      # (3 + 3 + 2 checks per rank, all empty: _spawn has asserted that)
