@@ -92,11 +92,13 @@ extern "C" int sg_debug_read_wave_times(unsigned long long *out, int clear) {
 #ifndef SG_F64_STREAM_WAVES
 #define SG_F64_STREAM_WAVES 4
 #endif
-#ifdef SG_STREAM_NO_SCHED_FENCE   // (A/B: the compiler's own order of a round's four slots)
-#define SG_SCHED_FENCE()
-#else
 #define SG_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
-#endif
+// Probe builds (WRONG results, timing only; a library per probe: scripts/build_variant.sh <name> -D<macro>, A/B through
+// SG_HIP_LIB): the product kernel carries two, both in the survivor routine -- SG_PROBE_NO_DRAIN (the routine returns at
+// once: what candidates cost in all) and SG_PROBE_Q8_ONLY (second filter without the exact scoring behind it) -- and the
+// per-wave clocks of SG_DEBUG_WAVE_TIMES (right results).  The fourteen probes of rounds 2 - 4 (no loads, no LDS, no collect,
+// plain loads, round counts ...) did their work and are gone from the source: profiles/HISTORY.md has what they measured,
+// commit fd184d0 the code.
 // Parts of a row in the launch over parts (stream + self-join form).  Sixteen through most of round 4 -- until per-wave
 // clocks of an eighth share of the 5 M job (profiles/r04_final_wave_times.log) showed the launch over parts ending 4.2 ms
 // after its median wave, on FOUR waves: the heaviest rows of that job are 10 - 50 ms of work each (153 visits), and a
@@ -603,9 +605,7 @@ __device__ __noinline__ FlushOut<T> flush_survivors(int nnz, T thr, uint32_t row
     // (from 63 on, not 64: the caller appends up to 64 columns behind what is left, and the buffer's last two words are not
     //  columns -- the pair list's position and the count of pairs scored exactly: 62 + 64 = 126)
     if (out.n_surv >= 63u) {
-#ifndef SG_STREAM_PROBE_NO_SCORE
         out.top = drain_survivors<T, SYM, TILE_LOG2, WIDE, true>(nnz, thr, row, sc, pairs, top, out.n_surv);
-#endif
         const uint32_t scored = out.n_surv < 64u ? out.n_surv : 64u;
         out.n_surv = (out.n_surv - scored) | (scored << 16);   // [0, 16) left in the buffer, [16, 32) handed to the scoring
     }
@@ -973,9 +973,6 @@ spgemm_topn_pruned_kernel(const int64_t *__restrict__ a_indptr, const int32_t *_
             if (own > thr) top.insert(own, (int)row_out, lane);
             row_arg = row | 0x80000000u;
         }
-#ifdef SG_K4P_PROBE_NO_COLLECT
-        uint64_t probe_sink = 0;
-#endif
 
         // The survivors of one slot of a tile (rare: a few per row): append the crossing lanes' columns, score a
         // full wave of them at once.
@@ -1033,22 +1030,14 @@ spgemm_topn_pruned_kernel(const int64_t *__restrict__ a_indptr, const int32_t *_
             struct __attribute__((packed, aligned(4))) Quad {
                 uint32_t x, y, z, w;
             };
-#ifdef SG_K4P_PROBE_NO_LOADS   // timing probes (wrong results): a build of the library per probe, A/B through SG_HIP_LIB (scripts/gpu_session.sh ab:)
-            Quad q;
-            q.x = q.y = q.z = q.w = bt.base & 0x1ffcu;
-#else
             // (pointing the lanes without a posting at one common line instead made the kernel 2.5 x slower:
             // profiles/r02_sessionR_idle_lanes_one_line.log; loads under an exec mask written in inline assembly, with
             // hand-counted waits, changed nothing: profiles/r02_sessionT_masked_asm_loads.log)
             const Quad q = *reinterpret_cast<const Quad *>(reinterpret_cast<const char *>(filt) + bt.base);
-#endif
             bt.r0 = q.x;
             bt.r1 = q.y;
             bt.r2 = q.z;
             bt.r3 = q.w;
-#ifdef SG_K4P_PROBE_NO_PREFETCH   // latency probe: every batch load is waited for where it is issued
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
         };
         // What one slot adds and what its accumulator must reach: side-effect free, computed for all lanes.
         struct Slot {
@@ -1100,9 +1089,6 @@ spgemm_topn_pruned_kernel(const int64_t *__restrict__ a_indptr, const int32_t *_
             // is the row's whole visit of the tile -- every accumulator it touches ends at zero anyway and DS operations
             // execute in order, after all four adds.  (Under masks every operation cost a saveexec, two taken branches and a
             // restore: 16 branches per tile.)
-#ifdef SG_K4P_PROBE_NO_LDS
-            uint32_t o0 = s0.z + (v0 ? s0.xs : 0u), o1 = s1.z + (v1 ? s1.xs : 0u), o2 = s2.z + (v2 ? s2.xs : 0u), o3 = s3.z + (v3 ? s3.xs : 0u);
-#else
             const uint32_t a0 = v0 ? s0.xs : 0u, a1 = v1 ? s1.xs : 0u, a2 = v2 ? s2.xs : 0u, a3 = v3 ? s3.xs : 0u;
             uint32_t o0 = __hip_atomic_fetch_add(tab_at(s0.z), a0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             uint32_t o1 = __hip_atomic_fetch_add(tab_at(s1.z), a1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -1114,7 +1100,6 @@ spgemm_topn_pruned_kernel(const int64_t *__restrict__ a_indptr, const int32_t *_
             *tab_at(s1.z) = 0u;
             *tab_at(s2.z) = 0u;
             *tab_at(s3.z) = 0u;
-#endif
             asm volatile("" : "+v"(o0), "+v"(o1), "+v"(o2), "+v"(o3));   // the one wait; the tests below stay outside the masks
             // oh < tq && oh + x >= tq  (unsigned wrap when oh >= tq); the mask of a compare ANDed with a scalar mask
             // stays scalar (the mask of a combined predicate would be rebuilt through a VALU select)
@@ -1122,16 +1107,12 @@ spgemm_topn_pruned_kernel(const int64_t *__restrict__ a_indptr, const int32_t *_
             const uint64_t c1m = ballot64(s1.tq1 - __builtin_amdgcn_ubfe(o1, s1.sh, 16u) < s1.x) & m1;
             const uint64_t c2 = ballot64(s2.tq1 - __builtin_amdgcn_ubfe(o2, s2.sh, 16u) < s2.x) & m2;
             const uint64_t c3 = ballot64(s3.tq1 - __builtin_amdgcn_ubfe(o3, s3.sh, 16u) < s3.x) & m3;
-#ifdef SG_K4P_PROBE_NO_COLLECT
-            probe_sink ^= c0 + c1m + c2 + c3;
-#else
             if (c0 | c1m | c2 | c3) {
                 if (c0) collect(c0, bt.r0, t);
                 if (c1m) collect(c1m, bt.r1, t);
                 if (c2) collect(c2, bt.r2, t);
                 if (c3) collect(c3, bt.r3, t);
             }
-#endif
         };
 
         if constexpr (FOLD_LOG2 == 0) {
@@ -1305,13 +1286,7 @@ spgemm_topn_pruned_kernel(const int64_t *__restrict__ a_indptr, const int32_t *_
                 // reads a round's registers between its load and its wait.
                 {
                     const uint32_t at = live ? cur : null_at;
-#if defined(SG_STREAM_PROBE_NO_LOADS)   // timing probes (wrong results): scripts/gpu_session.sh ab:SG_HIP_LIB=...
-                    bt.q = u32x4{at & 0x1ffcu, (at * 5u) & 0x1ffcu, (at * 9u) & 0x1ffcu, (at * 13u) & 0x1ffcu};
-#elif defined(SG_STREAM_PLAIN_LOADS)   // (A/B: the compiler's own loads and wait counts)
-                    bt.q = *reinterpret_cast<const u32x4 __attribute__((aligned(4))) *>(reinterpret_cast<const char *>(filt) + at);
-#else
                     asm volatile("global_load_dwordx4 %0, %1, %2" : "+v"(bt.q) : "v"(at), "s"(filt) : "memory");
-#endif
                 }
                 cur += G16;
                 live = hi > cur;   // (one compare per round: the next round's choice of address is this one's "more to come")
@@ -1347,9 +1322,7 @@ spgemm_topn_pruned_kernel(const int64_t *__restrict__ a_indptr, const int32_t *_
                 const FlushOut<T> fo = flush_survivors<T, SYM, TILE_LOG2, WIDE>(nnz, thr, row_arg, sc, pairs, top, n_surv, n_clean);
                 top = fo.top;
                 const uint32_t fo_word = (uint32_t)__builtin_amdgcn_readfirstlane((int)fo.n_surv);   // left | handed to the scoring << 16
-#ifndef SG_STREAM_PROBE_COUNT_ROUNDS
                 st_surv += fo_word >> 16;
-#endif
                 if (CAN_SPLIT) {
                     // enough candidates for a row (pairs scored ~ the rounds' bar in time): the visit being applied is its
                     // last, the parts take over behind it (the rounds in flight of later visits are dropped by the loop's
@@ -1402,25 +1375,14 @@ spgemm_topn_pruned_kernel(const int64_t *__restrict__ a_indptr, const int32_t *_
             bool dirty = false;   // accumulators of the current visit hold sums
             auto apply_s = [&](SBatch &bt, SBatch &oa, SBatch &ob, SBatch &oc, uint32_t tv, bool last) {
                 // the round's load is waited for HERE, on every path (also when no lane has a posting)
-#if defined(SG_STREAM_PLAIN_LOADS) || defined(SG_STREAM_PROBE_NO_LOADS)
-                asm volatile("" : "+v"(bt.q)::"memory");
-#else
                 asm volatile("s_waitcnt vmcnt(3) ; round %0" : "+v"(bt.q)::"memory");
-#endif
                 const u32x4 q = bt.q;
-#ifdef SG_STREAM_PROBE_COUNT_ROUNDS   // (probe: the statistics' "pairs scored" word counts ROUNDS instead)
-                ++st_surv;
-#endif
                 {
                     dirty = true;
                     // every add leaves as soon as its address and amount are there; the thresholds of the four tests are
                     // computed behind the last add, i.e. inside the LDS round trip (the scheduler, left alone, computes
                     // all four slots first, then sends the four adds, and one threshold behind the wait -- which costs the
                     // same time: profiles/r03_sessionAA_slot_order_ab.log; kept because the ISA now reads as the source)
-#ifdef SG_STREAM_PROBE_NO_LDS
-                    SSlot s0 = prep_s(q.x), s1 = prep_s(q.y), s2 = prep_s(q.z), s3 = prep_s(q.w);
-                    uint32_t o0 = s0.z + s0.xs, o1 = s1.z + s1.xs, o2 = s2.z + s2.xs, o3 = s3.z + s3.xs;
-#else
                     SSlot s0 = prep_s(q.x);
                     uint32_t o0 = __hip_atomic_fetch_add(tab_at(s0.z), s0.xs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     SG_SCHED_FENCE();
@@ -1433,7 +1395,6 @@ spgemm_topn_pruned_kernel(const int64_t *__restrict__ a_indptr, const int32_t *_
                     SSlot s3 = prep_s(q.w);
                     uint32_t o3 = __hip_atomic_fetch_add(tab_at(s3.z), s3.xs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     SG_SCHED_FENCE();
-#endif
                     s0.d = bar_s(q.x);
                     s1.d = bar_s(q.y);
                     s2.d = bar_s(q.z);
@@ -1453,13 +1414,11 @@ spgemm_topn_pruned_kernel(const int64_t *__restrict__ a_indptr, const int32_t *_
                         if (c3) collect_s(f3, c3, q.w, tv, oa, ob, oc);
                     }
                 }
-#ifndef SG_STREAM_PROBE_NO_CLEAR
                 if (last && dirty) {   // the visit is through: its accumulators back to zero (eight stores at constant offsets)
 #pragma unroll
                     for (int x = 0; x < TILE * 2 / 16; x += 64) tab_v[x + lane] = make_uint4(0, 0, 0, 0);
                     dirty = false;
                 }
-#endif
             };
             uint32_t tv0, tv1, tv2, tv3;
             bool la0, la1, la2, la3;
@@ -1502,14 +1461,9 @@ spgemm_topn_pruned_kernel(const int64_t *__restrict__ a_indptr, const int32_t *_
             for (int d = 32; d > 0; d >>= 1) mine += __shfl_xor(mine, d, 64);
             st_post += (unsigned long long)wave_read<uint32_t>(mine, 0);
         }
-#ifdef SG_K4P_PROBE_NO_COLLECT
-        if (probe_sink == 0x1234567887654321ull) n_surv = 1;   // keeps the tests alive
-#endif
         if (n_surv > 0) {   // fewer than 64 left
             top = drain_survivors<T, SYM, TILE_LOG2, WIDE, (FOLD_LOG2 > 0)>(nnz, thr, row_arg, sc, pairs, top, n_surv);
-#ifndef SG_STREAM_PROBE_COUNT_ROUNDS
             st_surv += n_surv;
-#endif
         }
         if (CAN_SPLIT && part_mode) {
             // a part's matches go to the pair list, addressed to the part's own row: pass 2 merges the parts like mirrored matches
