@@ -78,7 +78,8 @@ def main():
     # warm-up of the driver's calls (torch's first kernels, the library's pools): one whole pass + merge, thrown away
     w = ops.selfjoin_range(A, post, 10, 0.8, 0, n_index)
     ops.selfjoin_merge(w, ops.selfjoin_pairs(w).clone(), 0, n_index).free()
-    for world in (1, 2, 4, 8):
+    worlds = tuple(int(x) for x in sys.argv[3].split(",")) if len(sys.argv) > 3 else (1, 2, 4, 8)
+    for world in worlds:
         per_rank = []
         pair_counts = []
         for r in range(world):
@@ -175,7 +176,7 @@ def main():
         # ... and the critical path of the row-block form: no pairs to exchange, nothing to merge
         coll_rb = 0.0 if world == 1 else (2 * table * frac + csr_bytes * frac) / (LINK_GBPS * 1e6) + 2 * COLLECTIVE_LATENCY_MS
         crit_rb = (max(p["vectorise_ms_wall"] + t_post + p["row_block_form_ms_wall"] for p in per_rank) + coll_rb) if world > 1 else float("nan")
-        if world == 1:
+        if world == 1 or one_gpu is None:
             one_gpu = crit
         slow = max(per_rank, key=lambda p: p["pass1_ms_wall"])
         report["ranks"][str(world)] = {"critical_path_ms": crit, "critical_path_ms_kernels_only": crit_kernels,

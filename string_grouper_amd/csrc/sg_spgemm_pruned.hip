@@ -263,6 +263,8 @@ __device__ __forceinline__ T exact_score_packed(bool have, uint32_t pb, uint32_t
             SG_WD(wd_v, 1 << 20, 21)
             FwdRound<T> r;
             r.load(fwd, q, pe - 1u);
+            // (the lookups one after the other: batched like the second filter's -- row_values -- they cost the routine 15 to 30
+            //  registers more, which count against the round loop's kernel, and bought nothing at 663 k: 4.80 against 4.70 ms)
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 T a = (T)0;
@@ -304,29 +306,23 @@ __device__ __forceinline__ T exact_score(int j, const int *hk, const T *ha, int 
 // both sides (no false negative for scores at the threshold +- 1 ulp, hubs, rows beyond the copy's 61 entries, f64).
 // A row without a copy (more than 61 entries) always passes.  The header also holds what the exact scoring needs of the
 // row -- first packed entry, number of entries, the row's own index -- so a candidate that passes costs no pointer fetch.
-template <typename T, bool WIDE>
-__device__ __forceinline__ float q8_unit(uint4 w, const int *hk, const T *ha, int nnz, float ub) {
-    const uint32_t e[4] = {w.x, w.y, w.z, w.w};   // (an entry behind the row's last is 0: term 0 times bq = 0)
-    if (WIDE) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-            ub = __builtin_fmaf((float)row_value<T, true>(hk, ha, (int)(e[q] >> 8), nnz), (float)(e[q] & 255u), ub);
-        return ub;
-    }
-    // four lookups side by side: the four buckets' keys in one go (16 bytes each), the values behind them
-    uint32_t h[4];
-    bool found[4];
+// N terms looked up in row i's hash side by side: the N buckets' keys in one go (16 bytes each), the (rare) walks behind
+// full buckets, then the N values; out[q] = a_k, or 0 for a term row i does not have.  Two LDS round trips per N lookups
+// where one lookup after the other takes two each, or more.  (N = 4 in the second filter.)
+template <typename T, int N>
+__device__ __forceinline__ void row_values(const int *hk, const T *ha, const int (&t)[N], T (&out)[N]) {
+    uint32_t h[N];
+    bool found[N];
     {
-        int4 K[4];
+        int4 K[N];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) h[q] = term_hash((int)(e[q] >> 8));
+        for (int q = 0; q < N; ++q) h[q] = term_hash(t[q]);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) K[q] = *reinterpret_cast<const int4 *>(hk + h[q]);
+        for (int q = 0; q < N; ++q) K[q] = *reinterpret_cast<const int4 *>(hk + h[q]);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int t = (int)(e[q] >> 8);
-            const bool m1 = K[q].y == t, m2 = K[q].z == t, m3 = K[q].w == t;
-            found[q] = K[q].x == t || m1 || m2 || m3;
+        for (int q = 0; q < N; ++q) {
+            const bool m1 = K[q].y == t[q], m2 = K[q].z == t[q], m3 = K[q].w == t[q];
+            found[q] = K[q].x == t[q] || m1 || m2 || m3;
             bool walking = !found[q] && K[q].w != -1;   // the bucket is full and does not hold the term: on, slot by slot
             h[q] += m1 ? 1u : (m2 ? 2u : (m3 ? 3u : 0u));
             if (__ballot(walking) != 0) {
@@ -341,23 +337,39 @@ __device__ __forceinline__ float q8_unit(uint4 w, const int *hk, const T *ha, in
                     SG_WD(wd_p, SG_HASH_SLOTS + 2, 26)
                     if (walking) {
                         k = hk[g];
-                        walking = k != t && k != -1;
+                        walking = k != t[q] && k != -1;
                         if (walking) g = (g + 1u) & (SG_HASH_SLOTS - 1);
                     }
                 }
                 asm volatile("" : "+v"(k), "+v"(g));   // (the hit is read off the key, in a register, after the loop)
                 if (!found[q] && K[q].w != -1) {
-                    found[q] = k == t;
+                    found[q] = k == t[q];
                     h[q] = g;
                 }
             }
         }
     }
-    T v[4];
+    T v[N];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) v[q] = ha[h[q]];   // (the slot of a term that is absent holds whatever: selected away below)
+    for (int q = 0; q < N; ++q) v[q] = ha[h[q]];   // (the slot of a term that is absent holds whatever: selected away)
 #pragma unroll
-    for (int q = 0; q < 4; ++q) ub = __builtin_fmaf(found[q] ? (float)v[q] : 0.f, (float)(e[q] & 255u), ub);
+    for (int q = 0; q < N; ++q) out[q] = found[q] ? v[q] : (T)0;
+}
+
+template <typename T, bool WIDE>
+__device__ __forceinline__ float q8_unit(uint4 w, const int *hk, const T *ha, int nnz, float ub) {
+    const uint32_t e[4] = {w.x, w.y, w.z, w.w};   // (an entry behind the row's last is 0: term 0 times bq = 0)
+    if (WIDE) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            ub = __builtin_fmaf((float)row_value<T, true>(hk, ha, (int)(e[q] >> 8), nnz), (float)(e[q] & 255u), ub);
+        return ub;
+    }
+    const int t[4] = {(int)(e[0] >> 8), (int)(e[1] >> 8), (int)(e[2] >> 8), (int)(e[3] >> 8)};
+    T a[4];
+    row_values<T, 4>(hk, ha, t, a);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) ub = __builtin_fmaf((float)a[q], (float)(e[q] & 255u), ub);
     return ub;
 }
 
@@ -679,7 +691,7 @@ spgemm_topn_pruned_kernel(const int64_t *__restrict__ a_indptr, const int32_t *_
                           uint32_t n_right /* right-hand rows (columns of the result) */,
                           uint32_t *heavy_count, uint32_t *heavy_rows /* stream + self-join form: rows set aside for the launch over parts */,
                           uint32_t sym_step,
-                          uint32_t part_cfg /* 0: every row whole; < 2^31: rows of at least this many rounds are set aside;
+                          uint32_t part_cfg /* 0: every row whole; < 2^31: rows of at least this many rounds (bits [0, 28)) are set aside, and a row that has scored rounds << bits [28, 31) candidates hands its remaining visits on;
                                                bit 31: this IS the launch over parts (rows in row_list, SG_ROW_PARTS items each) */) {
     constexpr int TILE = 1 << TILE_LOG2;
     constexpr int SLOTS = WIDE ? 2 : 1;   // row terms staged per lane
@@ -1195,7 +1207,7 @@ spgemm_topn_pruned_kernel(const int64_t *__restrict__ a_indptr, const int32_t *_
                     float rl = g ? (float)(hi_end - (my_lo << 2)) / (float)G16 : 0.f;
 #pragma unroll
                     for (int d = 32; d > 0; d >>= 1) rl = fmaxf(rl, __shfl_xor(rl, d, 64));
-                    if (wave_read<float>(rl, 0) >= (float)part_cfg) {
+                    if (wave_read<float>(rl, 0) >= (float)(part_cfg & 0x0fffffffu)) {
                         if (lane == 0) {
                             const uint32_t at = atomicAdd(heavy_count, 1u);
                             heavy_rows[at] = row;
@@ -1328,7 +1340,7 @@ spgemm_topn_pruned_kernel(const int64_t *__restrict__ a_indptr, const int32_t *_
                     // last, the parts take over behind it (the rounds in flight of later visits are dropped by the loop's
                     // own end; once: tv + 3 > v_end from here on)
                     row_scored += fo_word >> 16;
-                    if (!part_mode && part_cfg != 0u && tv + 3u <= v_end && ballot64(row_scored >= (part_cfg << 3)) != 0) v_end = tv + 1u;
+                    if (!part_mode && part_cfg != 0u && tv + 3u <= v_end && ballot64(row_scored >= ((part_cfg & 0x0fffffffu) << ((part_cfg >> 28) & 7u))) != 0) v_end = tv + 1u;
                 }
                 n_surv = n_clean = fo_word & 0xffffu;
             };
@@ -1885,12 +1897,23 @@ static int launch_both(sg_ctx *ctx, const sg_csr *A, const sg_postings *Bt, int3
             //  after the others, on single rows.  Also tried and dropped, profiles/r03_sessionAR_parts_first.log: a classify
             //  launch that lists such rows BEFORE the multiply, whose launch then starts with their parts -- 4.5 instead
             //  of 4.15 ms for a half share at 663 k, 1.94 instead of 1.78 for an eighth)
-            const double bar = 0.05 * rows_per_wave * rounds_per_row;
+            double bar_share = 0.05;
+            if (const char *v = ctx->opt("SG_HEAVY_SHARE")) bar_share = atof(v) > 0.0 ? atof(v) : bar_share;
+            const double bar = bar_share * rows_per_wave * rounds_per_row;
             // (never below 128 rounds: at 663 k, eight ranges, bars of 64 / 128 / 256 / 512 rounds give 2.10 / 2.03 / 2.19 /
             //  2.57 ms for the slowest range -- profiles/r03_sessionAG_heavy_bar_ranges.log)
             heavy_rounds = bar < 128.0 ? 128u : (bar > 1.0e9 ? 1000000000u : (uint32_t)bar);
         }
         if (const char *v = ctx->opt("SG_HEAVY_ROUNDS")) heavy_rounds = (uint32_t)atoi(v) & 0x7fffffffu;
+        if (heavy_rounds > 0x0fffffffu) heavy_rounds = 0x0fffffffu;
+        // candidates per round of the bar from which a row hands its remaining visits to the parts (2^shift): about a
+        // thousand candidates at the floor of the bar (128 rounds: the 663 k job), two per round of a large bar -- with the
+        // second filter a candidate costs a fifth of what it did, and what keeps a wave late is a HUB's candidates, which
+        // pass it and are scored exactly (5 M names, 8 shares, scripts/share_knob_sweep.sh: slowest share 23.2 -> 21.4 ms
+        // with 2 instead of 8 per round; the 663 k shares lose 0.1 of 1.5 ms that way).  SG_HANDOVER_SHIFT overrides.
+        uint32_t handover_shift = heavy_rounds >= 512u ? 1u : (heavy_rounds >= 256u ? 2u : 3u);
+        if (const char *v = ctx->opt("SG_HANDOVER_SHIFT")) handover_shift = (uint32_t)atoi(v) & 7u;
+        if (heavy_rounds) heavy_rounds |= handover_shift << 28;
         if (heavy_rounds) {
             st = sg_alloc(ctx, 2 * (size_t)A->n_rows + 8, &heavy);   // [4, 4 + n): the rows, [4 + n, 4 + 2 n): their first visit for the parts
             if (st == SG_OK && hipMemsetAsync(heavy, 0, 4 * sizeof(uint32_t), ctx->stream) != hipSuccess) st = SG_ERR_HIP;
