@@ -246,7 +246,7 @@ struct sg_postings {
     uint32_t *d_orig_of = nullptr, *d_pos_of = nullptr;
     // what the pruned multiply's survivor routine needs of the index, as ONE struct in device memory: that routine is a
     // real call inside the tile loop, and every argument it takes is a register the loop cannot use at the call sites
-    struct SgScoreCtx *d_score_ctx = nullptr;
+    struct SgScoreCtx *d_score_ctx = nullptr;   // [0] with the second filter (when built), [1] without
     // per term a 16-byte aligned row of nt_pad entries: d_ends[k * nt_pad + t] = BYTE offset into d_filt of the end
     // of segment (k, t) (entries past the last tile repeat the end of the list): one 16-byte load = four tiles
     uint32_t *d_ends = nullptr;
@@ -313,7 +313,8 @@ int sg_matchlist_device_view(const sg_matchlist *ml, int64_t *n_rows, int64_t *n
 // sg_spgemm_pruned.hip
 int sg_csr_props(sg_ctx *ctx, const sg_csr *m, bool *cosine_like, float *max_norm2, uint32_t *max_nnz = nullptr);
 bool sg_pruned_supports_tile(int32_t tile_log2);
-int sg_postings_ensure_full(sg_ctx *ctx, const sg_postings *p);   // sg_postings.hip: the exact kernel's postings, on demand
+int sg_postings_ensure_full(sg_ctx *ctx, const sg_postings *p);
+bool sg_q8_applies(const sg_ctx *ctx, const sg_postings *Bt, double threshold);   // sg_spgemm_pruned.hip: second filter in this call?   // sg_postings.hip: the exact kernel's postings, on demand
 int sg_spgemm_pruned_launch(sg_ctx *ctx, const sg_csr *A, const sg_postings *Bt, int32_t keep, sg_topn *r,
                             double threshold, double delta, uint32_t *row_counter,
                             uint32_t *flagged_count, uint32_t *flagged_rows, unsigned long long *stats);

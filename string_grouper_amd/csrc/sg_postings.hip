@@ -266,7 +266,12 @@ __global__ void __launch_bounds__(1024) postings_tables_kernel(const uint32_t *_
                                                                uint32_t *__restrict__ null_slack /* null: none */) {
     __shared__ uint32_t tile[64][66];
     if (blockIdx.x == 0) {   // two one-line kernels of the build ride along: the scoring context as a struct in device memory
-        if (sc_out && threadIdx.x == 0) *sc_out = sc;                       // (score_ctx_kernel)
+        if (sc_out && threadIdx.x == 0) {                                   // (score_ctx_kernel)
+            sc_out[0] = sc;
+            sc.q8 = nullptr;                                                // [1]: the same without the second filter (the
+            sc.q8_scale = 0.f;                                              //      multiply chooses per call: sg_q8_applies)
+            sc_out[1] = sc;
+        }
         if (null_slack && threadIdx.x < 512) null_slack[threadIdx.x] = sg_null_posting(threadIdx.x);   // (null_postings_kernel)
     }
     const int x = threadIdx.x & 63, y = threadIdx.x >> 6;   // y: 0 .. 15
@@ -611,7 +616,12 @@ __global__ void __launch_bounds__(256) gather_rows_kernel(const int64_t *__restr
         q8_write_unit<T>(q8 + p * (SG_Q8_STRIDE / 16), (uint32_t)sub, indices, data, src, n, (uint32_t)dst, (uint32_t)g, inv_norm);
 }
 
-__global__ void score_ctx_kernel(SgScoreCtx v, SgScoreCtx *out) { *out = v; }
+__global__ void score_ctx_kernel(SgScoreCtx v, SgScoreCtx *out) {
+    out[0] = v;
+    v.q8 = nullptr;          // [1]: the same without the second filter (the multiply chooses per call: sg_q8_applies)
+    v.q8_scale = 0.f;
+    out[1] = v;
+}
 
 static uint64_t gcd_u64(uint64_t a, uint64_t b) {
     while (b) {
@@ -805,7 +815,12 @@ extern "C" int sg_postings_build_flags(sg_ctx *ctx, const sg_csr *B_in, int32_t 
     void *early_q8 = nullptr;   // ... and so are the 8-bit copies of the second filter
     const float norm_up_build = __builtin_nextafterf(sqrtf(max_norm2) * 1.000001f, 2.f);   // (= p->norm_up below)
     // second filter: terms must fit 24 bits; a sixteenth of the device memory at most; SG_Q8=0 switches it off
+    // ... and rows of a name list's length: the filter walks the candidate's entries like the exact scoring does and saves its
+    // memory round trips -- on rows of 60 entries (a record of two lines, fifteen units) it costs more than it saves (100 k
+    // long names, SG_Q8 = 1 / 0: 8.9 / 5.8 ms; profiles/r05_family_sweep_q8.log).  SG_Q8=1 forces it for any length.
+    const bool q8_forced = ctx->opt("SG_Q8") && ctx->opt("SG_Q8")[0] == '1';
     const bool want_q8 = want_pruned && B_in->n_cols < ((int64_t)1 << 24) && !(ctx->opt("SG_Q8") && ctx->opt("SG_Q8")[0] == '0') &&
+                         (q8_forced || (double)B_in->nnz <= 40.0 * (double)B_in->n_rows) &&
                          (ctx->total_mem == 0 || (size_t)SG_Q8_STRIDE * ((size_t)B_in->n_rows + 1) < ctx->total_mem / 16);
     bool fwd_done = false;
     bool aux_written = false;   // the scoring context and the null postings were written by the tables kernel

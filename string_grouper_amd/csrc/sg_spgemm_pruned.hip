@@ -126,7 +126,11 @@ __device__ __forceinline__ T wave_shfl(T v, int src) {
 // slot).  The second filter looks four entries up side by side this way (q8_unit): two LDS round trips per four entries;
 // slot-by-slot probing took seven, and those round trips were most of what the survivor routine cost.
 // (A 24-bit multiply: full rate, where the 32-bit one takes four passes.)
+#ifdef SG_HASH_FINE   // (probe: a home SLOT instead of a home bucket; only with SG_Q8=0 -- the second filter reads buckets)
+__device__ __forceinline__ uint32_t term_hash(int k) { return (__umul24((uint32_t)k & 0xffffffu, 0x9E3779u) >> 15) & 127u; }
+#else
 __device__ __forceinline__ uint32_t term_hash(int k) { return (__umul24((uint32_t)k & 0xffffffu, 0x9E3779u) >> 15) & 124u; }
+#endif
 
 // An object of the wave's LDS by its byte address.  The kernel's dynamic LDS is its only LDS and starts at address 0
 // (the accumulator tile first: a posting's address field IS an LDS address).  In the kernel `smem + x` is as good; in the
@@ -1819,6 +1823,17 @@ __global__ void pair_sink_kernel(SgPairSink v, SgPairSink *out) { *out = v; }
 // single-wave workgroups of the pruned kernel: as many as the LDS of the chip holds
 // LDS of one wave: accumulator tile, row hash (keys 512 B, values up to 1 KiB), survivor buffer; the stream form adds its
 // 512-byte table of recorded columns, which for f32 fits the unused half of the value slots
+// The second filter per call: built with the index (name-length rows, sg_postings.hip), used in the stream form, and only at
+// thresholds where most candidates of the first filter are false alarms -- at 0.6 a fifth of them are matches or close, the
+// filter's pass over their entries is then work done twice (200 k names, top 20 at 0.6: 5.5 ms without, 6.0 with;
+// at 0.7 and above it pays: 10 M x 1 M at 0.7 - 20 %).  SG_Q8_MIN_THRESHOLD moves the bar.
+bool sg_q8_applies(const sg_ctx *ctx, const sg_postings *Bt, double threshold) {
+    if (!Bt->d_q8 || Bt->fold_log2 <= 0) return false;
+    double bar = 0.65;
+    if (const char *v = ctx->opt("SG_Q8_MIN_THRESHOLD")) bar = atof(v);
+    return threshold >= bar;
+}
+
 static size_t pruned_lds(int32_t tile_log2, int32_t fold_log2, int32_t dtype) {
     return ((size_t)2 << tile_log2) + 512 + 1024 + (size_t)SG_SURV_CAP * 4 + (fold_log2 > 0 && dtype == SG_F64 ? 512 : 0);
 }
@@ -1850,7 +1865,8 @@ static int launch_pruned(sg_ctx *ctx, const sg_csr *A, const sg_postings *Bt, in
     hipLaunchKernelGGL(kernel, dim3(grid), dim3(64), lds, ctx->stream, A->d_indptr,
                        A->d_indices, (const T *)A->d_data, (uint32_t)A->n_rows, (const uint32_t *)Bt->d_seg,
                        (const uint32_t *)Bt->d_ends, Bt->nt_pad, (uint32_t)Bt->n_terms,
-                       (const uint32_t *)Bt->d_filt, Bt->n_tiles, (const SgScoreCtx *)Bt->d_score_ctx, keep, r->stride, thr, s_budget,
+                       (const uint32_t *)Bt->d_filt, Bt->n_tiles,
+                       (const SgScoreCtx *)Bt->d_score_ctx + (sg_q8_applies(ctx, Bt, (double)thr) ? 0 : 1), keep, r->stride, thr, s_budget,
                        Bt->norm_up, Bt->freq_min, r->d_cols,
                        (T *)r->d_vals,
                        r->d_counts, row_counter, flagged_count, flagged_rows, stats, pl.d_sink, pl.chunks, pl.row_lo, pl.row_hi, row_list,

@@ -1119,7 +1119,7 @@ extern "C" int sg_spgemm_topn(sg_ctx *ctx, const sg_csr *A, const sg_postings *B
             // what a candidate of the first filter costs: with the second filter its 8-bit copy (header + 4 B an entry), and the
             // packed row only for those that pass it (no pointer fetch: the header holds it); without: pointer + packed row
             const double mean_row = Bt->n_right > 0 ? (double)Bt->nnz / (double)Bt->n_right : 0.0;
-            ctx->prune_q8_bytes = Bt->d_q8 && Bt->fold_log2 > 0 ? 16.0 + 4.0 * mean_row : 0.0;
+            ctx->prune_q8_bytes = sg_q8_applies(ctx, Bt, s == 8 ? threshold : (double)(float)threshold) ? 16.0 + 4.0 * mean_row : 0.0;
             ctx->prune_row_bytes = (ctx->prune_q8_bytes > 0.0 ? 0.0 : 8.0) + mean_row * (s == 8 ? 16.0 : 8.0);
         }
         if (hipGetLastError() != hipSuccess) st = SG_ERR_HIP;
@@ -1196,7 +1196,7 @@ extern "C" int sg_selfjoin_range(sg_ctx *ctx, const sg_csr *A, const sg_postings
         // what a candidate of the first filter costs: with the second filter its 8-bit copy (header + 4 B an entry), and the
         // packed row only for those that pass it (no pointer fetch: the header holds it); without: pointer + packed row
         const double mean_row = Bt->n_right > 0 ? (double)Bt->nnz / (double)Bt->n_right : 0.0;
-        ctx->prune_q8_bytes = Bt->d_q8 && Bt->fold_log2 > 0 ? 16.0 + 4.0 * mean_row : 0.0;
+        ctx->prune_q8_bytes = sg_q8_applies(ctx, Bt, s == 8 ? threshold : (double)(float)threshold) ? 16.0 + 4.0 * mean_row : 0.0;
         ctx->prune_row_bytes = (ctx->prune_q8_bytes > 0.0 ? 0.0 : 8.0) + mean_row * (s == 8 ? 16.0 : 8.0);
     }
     ctx->prune_symmetric = done;
