@@ -1822,3 +1822,50 @@ def test_config5_asymmetric_10M_x_1M_fp64_more_than_100k_rows_equal_the_port(ctx
     for h in (res, post, A, B):
         h.free()
     ctx.trim()
+
+
+def test_second_filter_is_used_where_it_pays_and_changes_no_result(ctx):
+    """Round 5: the 8-bit copies of the right-hand rows (sg_internal.h: SgScoreCtx::q8).  Same rows with the filter on, off
+    (SG_Q8=0) and forced; `sg_stats` says what happened: at a name-matching threshold it rejects most candidates of the first
+    filter; under 0.65 it is not used (every candidate is scored); for rows of more than 40 entries on average the records
+    are not built unless forced."""
+    names = _names(120000, seed=5)
+    A = _tfidf(names, np.float32)
+    want = {thr: P.sp_matmul_topn_port(A, A.T, 10, thr, True, 16) for thr in (0.8, 0.6)}
+    seen = {}
+    for q8 in (None, "0", "1"):
+        ctx.set_option("SG_Q8", q8)
+        dA = ctx.csr_from_scipy(A)
+        post = ctx.postings_build(dA)
+        for thr in (0.8, 0.6):
+            res = ctx.spgemm_topn(dA, post, 10, thr, True)
+            st = ctx.stats()
+            assert_csr_identical(res.to_scipy(), want[thr], f"SG_Q8={q8} threshold {thr}")
+            seen[(q8, thr)] = (st["prune_survivors"], st["prune_scored"], ctx.postings_bytes(post))
+            res.free()
+        post.free()
+        dA.free()
+    ctx.reset_options()
+    for q8 in (None, "1"):
+        cand, scored, _ = seen[(q8, 0.8)]
+        assert cand > 100000 and scored * 10 < cand, seen          # most candidates never reach the exact scoring
+        cand, scored, _ = seen[(q8, 0.6)]
+        assert scored == cand, seen                                # under 0.65: filter not used, every candidate scored
+    assert seen[("0", 0.8)][1] == seen[("0", 0.8)][0] and seen[("0", 0.8)][2] < seen[(None, 0.8)][2], seen   # no records built
+    # rows of ~60 entries: no records unless forced; the result is the port's either way
+    long_names = [" ".join(names[3 * i:3 * i + 3]) for i in range(20000)]
+    L = _tfidf(long_names, np.float32)
+    want_l = P.sp_matmul_topn_port(L, L.T, 10, 0.8, True, 16)
+    sizes = {}
+    for q8 in (None, "1"):
+        ctx.set_option("SG_Q8", q8)
+        dL = ctx.csr_from_scipy(L)
+        post = ctx.postings_build(dL)
+        res = ctx.spgemm_topn(dL, post, 10, 0.8, True)
+        st = ctx.stats()
+        assert_csr_identical(res.to_scipy(), want_l, f"long names, SG_Q8={q8}")
+        sizes[q8] = (ctx.postings_bytes(post), st["prune_survivors"], st["prune_scored"])
+        for h in (res, post, dL):
+            h.free()
+    ctx.reset_options()
+    assert sizes[None][0] < sizes["1"][0] and sizes[None][1] == sizes[None][2] and sizes["1"][2] < sizes["1"][1], sizes
