@@ -77,9 +77,11 @@ def worker(rank: int, world: int, port: int, workdir: str, jobs, ret, backend: s
         os.environ.pop("SG_DIST_SYM", None)
         os.environ.pop("SG_DIST_INTERLEAVE", None)
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # (the host driver only supports dmabuf IPC)
+        os.environ.setdefault("OMP_NUM_THREADS", "2")                # (eight ranks on a box of sixteen cores: no 8 x 16 threads)
         import datetime
         import torch
         import torch.distributed as dist
+        torch.set_num_threads(2)
         device = rank if backend == "nccl" else 0
         torch.cuda.set_device(device)
         if backend == "nccl":

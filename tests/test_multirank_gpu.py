@@ -129,23 +129,23 @@ def test_three_ranks_with_uneven_shares():
 @pytest.mark.timeout(1500)
 def test_eight_ranks_on_one_device_every_block_and_the_gathered_whole_equal_the_port():
     """World 8 -- the driver's largest configuration -- on the one GPU over gloo (the 8-rank bench
-    line only compared a match count): 90 003 names (8 does not divide it; the self-join form is forced, as it would be
+    line only compared a match count): 40 003 names (8 does not divide it; the self-join form is forced, as it would be
     taken from 131 072 names on), the self-join form over interleaved shares of the groups' positions and the row-block
     form; every rank's own rows and the gathered whole against the port, bit for bit; master x duplicates with blocks of
     uneven size."""
     from string_grouper_amd.synth import synth_names
     from tests._multirank_worker import _names_of
     with tempfile.TemporaryDirectory(prefix="sg_mr_") as wd:
-        big = {"n": 90_000, "seed": 1234, "extra": ["", "AB", "ACME HOLDINGS INC"]}
+        big = {"n": 40_000, "seed": 1234, "extra": ["", "AB", "ACME HOLDINGS INC"]}
         _expected_selfjoin(wd, "big_f32", _names_of(big, synth_names), 10, 0.8, np.float32)
-        master = synth_names(40_003, 61)
-        dups = synth_names(12_001, 62, perturb_of=master, perturb_frac=0.5)
+        master = synth_names(20_003, 61)
+        dups = synth_names(6_001, 62, perturb_of=master, perturb_frac=0.5)
         _expected_match(wd, "match8_f32", master, dups, 20, 0.7, np.float32)
         jobs = [
             dict(kind="selfjoin", tag="w8_groups_interleaved", top_n=10, thr=0.8, expected="big_f32", form="selfjoin", grouped=True,
                  env={"SG_DIST_SYM": "1"}, **big),
             dict(kind="selfjoin", tag="w8_row_block", top_n=10, thr=0.8, expected="big_f32", form="rowblock", env={"SG_DIST_SYM": "0"}, **big),
-            dict(kind="match", tag="w8_master_x_duplicates", top_n=20, thr=0.7, expected="match8_f32", n_master=40_003, n_dups=12_001,
+            dict(kind="match", tag="w8_master_x_duplicates", top_n=20, thr=0.7, expected="match8_f32", n_master=20_003, n_dups=6_001,
                  seed=61),
         ]
         got = _spawn(8, wd, jobs)
