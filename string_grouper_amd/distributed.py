@@ -189,9 +189,11 @@ def all_gather_csr(indptr, indices, data, n_cols: int, group=None):
     longest = (max(max(sizes), 16) + 15) // 16 * 16            # (every rank's part starts 16-byte aligned: the typed views below)
     mine = torch.empty(longest, dtype=torch.uint8, device=indptr.device)
     z, r = indices.numel(), indptr.numel() - 1
-    mine[: z * s] = data.contiguous().view(torch.uint8)
-    mine[z * s: z * (s + 4)] = indices.contiguous().view(torch.uint8)
-    mine[z * (s + 4): z * (s + 4) + r * 4] = (indptr[1:] - indptr[:-1]).to(torch.int32).view(torch.uint8)   # (a row holds < 2^31 entries)
+    if z > 0:       # (an empty block -- fewer rows than ranks, a block of empty strings -- has nothing to view as bytes)
+        mine[: z * s] = data.contiguous().reshape(-1).view(torch.uint8)
+        mine[z * s: z * (s + 4)] = indices.contiguous().reshape(-1).view(torch.uint8)
+    if r > 0:
+        mine[z * (s + 4): z * (s + 4) + r * 4] = (indptr[1:] - indptr[:-1]).to(torch.int32).contiguous().view(torch.uint8)   # (a row holds < 2^31 entries)
     out = torch.empty(len(rows) * longest, dtype=torch.uint8, device=indptr.device)
     _all_gather_into(out, mine, group)
     val, idx, lens = [], [], []

@@ -245,3 +245,38 @@ def test_shares_of_the_self_join_form_partition_the_positions(monkeypatch):
                 if interleave == "1" and world > 1 and n >= world:
                     sizes = [len(D.share_positions(*D.selfjoin_share(n, r, world))) for r in range(world)]
                     assert max(sizes) - min(sizes) <= 1            # equal shares without a cost model
+
+
+def _csr_gather_worker(rank, world, port, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        ok = True
+        for dtype, cuts in ((np.float32, (0, 5, 5, 17)), (np.float64, (0, 1, 12, 17)), (np.float64, (0, 0, 0, 17))):
+            # (blocks of uneven size, an EMPTY block, an odd number of non-zeros in front of an f64 block: the packed
+            #  payload -- values | indices | row lengths, padded to the longest -- is cut into typed views by offset)
+            rng = np.random.default_rng(3)
+            M = sp.random(17, 40, density=0.3, format="csr", random_state=rng, dtype=np.float64).astype(dtype)
+            M.sort_indices()
+            blk = M[cuts[rank]:cuts[rank + 1]]
+            ip = torch.from_numpy(blk.indptr.astype(np.int64))
+            ix = torch.from_numpy(blk.indices.astype(np.int32))
+            d = torch.from_numpy(blk.data.copy())
+            fp, fi, fd, shape = D.all_gather_csr(ip, ix, d, 40)
+            got = sp.csr_matrix((fd.numpy(), fi.numpy(), fp.numpy()), shape=shape)
+            ok = ok and shape == (17, 40) and fd.numpy().dtype == dtype and np.array_equal(got.indptr, M.indptr) \
+                and np.array_equal(got.indices, M.indices) and np.array_equal(got.data, M.data)
+        ret[rank] = bool(ok)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_all_gather_csr_packs_every_block_into_one_payload_world3():
+    """Round 5: the CSR blocks travel as ONE packed buffer per rank behind one header exchange (two collectives, four
+    before): uneven blocks, an empty block, blocks that are all empty but one, fp32 and fp64."""
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_csr_gather_worker, args=(3, _free_port(), ret), nprocs=3, join=True)
+    assert dict(ret) == {0: True, 1: True, 2: True}, dict(ret)
