@@ -56,8 +56,14 @@ for step in "$@"; do
         ( cd /tmp && export TMPDIR=/tmp && timeout 900 rocprofv3 --pmc $c --output-format csv -d $OLDPWD/gpurun_out/${name}_pmc${n}_$c -o run -- python $OLDPWD/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-exact-kernel --no-end-to-end --no-side-runs $arg > /dev/null 2> $OLDPWD/gpurun_out/${name}_pmc${n}_$c.err )
         echo "pmc $c rc=$?" >> $LOG
       done
-      python scripts/pmc_traffic.py gpurun_out/${name}_pmc${n}_FETCH_SIZE gpurun_out/${name}_pmc${n}_WRITE_SIZE gpurun_out/${name}_k4_traffic$n.json >> $LOG 2>&1
+      prow=663000; [[ "$arg" =~ --rows[\ =]([0-9]+) ]] && prow=${BASH_REMATCH[1]}
+      python scripts/pmc_traffic.py gpurun_out/${name}_pmc${n}_FETCH_SIZE gpurun_out/${name}_pmc${n}_WRITE_SIZE gpurun_out/${name}_k4_traffic$n.json $prow >> $LOG 2>&1
       rm -rf gpurun_out/${name}_pmc${n}_FETCH_SIZE gpurun_out/${name}_pmc${n}_WRITE_SIZE ;;
+    pmctcc)   # only the L2 pass (requests, hits, misses, memory-side reads), e.g. pmctcc:--rows 5000000
+      ( cd /tmp && export TMPDIR=/tmp && timeout 900 rocprofv3 --pmc TCP_TCC_READ_REQ_sum TCC_HIT_sum TCC_MISS_sum TCC_EA_RDREQ_sum --output-format csv -d $OLDPWD/gpurun_out/${name}_pmctcc$n -o k -- python $OLDPWD/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-exact-kernel --no-end-to-end --no-side-runs $arg > /dev/null 2> $OLDPWD/gpurun_out/${name}_pmctcc$n.err )
+      echo "-- pmc tcc pass rc=$?" >> $LOG
+      python scripts/pmc_summary.py gpurun_out/${name}_pmctcc$n 2>&1 | grep -A8 "spgemm_topn_pruned" | head -24 >> $LOG
+      rm -rf gpurun_out/${name}_pmctcc$n ;;
     envpmc)   # envpmc:VAR=value  -- the traffic passes with one environment variable set
       export ${arg}
       for c in FETCH_SIZE WRITE_SIZE; do

@@ -323,6 +323,19 @@ class Context:
         check(lib().sg_ctx_create(int(device), C.c_void_p(stream) if stream else None, C.byref(out)))
         self.h = out
         self.device = device
+        # how often a fit of (documents, dtype) has come by without an idf table being installed (vectorizer._finish_fit:
+        # the table is uploaded when the same shape comes a second time); guarded by `lock` -- two threads may share a context
+        self.lock = threading.Lock()
+        self.idf_fits_seen: dict = {}
+
+    def note_idf_fit(self, n_docs: int, dtype_str: str) -> int:
+        """Count one fit of (documents, dtype) that found no idf table; returns how many there have been."""
+        with self.lock:
+            if len(self.idf_fits_seen) > 64:
+                self.idf_fits_seen.clear()
+            key = (int(n_docs), dtype_str)
+            self.idf_fits_seen[key] = self.idf_fits_seen.get(key, 0) + 1
+            return self.idf_fits_seen[key]
 
     def close(self):
         if self.h is not None:

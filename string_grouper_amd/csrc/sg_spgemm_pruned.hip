@@ -307,8 +307,8 @@ __device__ __forceinline__ T exact_score(int j, const int *hk, const T *ha, int 
 // reach the threshold: the exact kernel's float score obeys score~ <= score + 1e-5 (the first filter's own allowance),
 // the float evaluation of U loses at most n * 2^-24 of it (8e-6 at the threshold for 128 terms), the conversion of a
 // double a_k to float 6e-8 of it, q8_scale is rounded down -- 3e-5 covers all of it.  tests/test_prune_model.py restates
-// both sides (no false negative for scores at the threshold +- 1 ulp, hubs, rows beyond the copy's 61 entries, f64).
-// A row without a copy (more than 61 entries) always passes.  The header also holds what the exact scoring needs of the
+// both sides (no false negative for scores at the threshold +- 1 ulp, hubs, rows beyond the copy's 60 entries, f64).
+// A row without a copy (more than SG_Q8_MAX_ENTRIES = 60 entries) always passes.  The header also holds what the exact scoring needs of the
 // row -- first packed entry, number of entries, the row's own index -- so a candidate that passes costs no pointer fetch.
 // N terms looked up in row i's hash side by side: the N buckets' keys in one go (16 bytes each), the (rare) walks behind
 // full buckets, then the N values; out[q] = a_k, or 0 for a term row i does not have.  Two LDS round trips per N lookups
@@ -1344,7 +1344,7 @@ spgemm_topn_pruned_kernel(const int64_t *__restrict__ a_indptr, const int32_t *_
                     // last, the parts take over behind it (the rounds in flight of later visits are dropped by the loop's
                     // own end; once: tv + 3 > v_end from here on)
                     row_scored += fo_word >> 16;
-                    if (!part_mode && part_cfg != 0u && tv + 3u <= v_end && ballot64(row_scored >= ((part_cfg & 0x0fffffffu) << ((part_cfg >> 28) & 7u))) != 0) v_end = tv + 1u;
+                    if (!part_mode && part_cfg != 0u && tv + 3u <= v_end && ballot64((uint64_t)row_scored >= ((uint64_t)(part_cfg & 0x0fffffffu) << ((part_cfg >> 28) & 7u))) != 0) v_end = tv + 1u;   // (64 bits: 2^28 rounds << 7 does not fit 32)
                 }
                 n_surv = n_clean = fo_word & 0xffffu;
             };

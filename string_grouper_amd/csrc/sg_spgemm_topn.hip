@@ -684,11 +684,11 @@ static int prune_pilot(sg_ctx *ctx, const sg_csr *A, const sg_postings *Bt, int3
     sg_topn *scratch = nullptr;
     SG_TRY(topn_alloc(ctx, block, Bt->n_right, stride, A->dtype, &scratch));
     uint32_t *words = nullptr;            // [0] row counter [1] flagged count, then flagged rows
-    unsigned long long *d_stats = nullptr;   // [0] rows [1] postings [2] survivors [3] MACs of the whole multiply
+    unsigned long long *d_stats = nullptr;   // [0] rows [1] postings [2] survivors [3] MACs of the whole multiply [4] pairs scored exactly (the kernel's; eight words like sg_spgemm_pruned_symmetric)
     int st = sg_alloc(ctx, (size_t)block + 8, &words);
-    if (st == SG_OK) st = sg_alloc(ctx, (size_t)4, &d_stats);
+    if (st == SG_OK) st = sg_alloc(ctx, (size_t)8, &d_stats);
     hipError_t e = hipSuccess;
-    if (st == SG_OK) e = hipMemsetAsync(d_stats, 0, 4 * sizeof(unsigned long long), ctx->stream);
+    if (st == SG_OK) e = hipMemsetAsync(d_stats, 0, 8 * sizeof(unsigned long long), ctx->stream);
     const int64_t starts[3] = {0, (A->n_rows - block) / 2, A->n_rows - block};
     for (int b = 0; b < 3 && st == SG_OK && e == hipSuccess; ++b) {
         sg_csr view = *A;

@@ -181,9 +181,13 @@ def all_gather_csr(indptr, indices, data, n_cols: int, group=None):
     """Concatenate the ranks' CSR row blocks (rank order = row order): returns (indptr, indices, data, shape) of
     the whole matrix on every rank.  Row pointers travel as row lengths and are rebuilt by a prefix sum.  TWO collectives
     (round 5; four before): the header exchange (rows, non-zeros of every block) and ONE all-gather of a packed buffer per
-    rank -- [values | column indices | row lengths], padded to the longest rank's."""
+    rank -- [values | column indices | row lengths], padded to the longest rank's.  Peak memory: the gathered buffer
+    (world x the longest rank's part) and the concatenated arrays made from it are alive together -- about twice the whole
+    matrix -- until this function returns (round 4's three smaller gathers peaked lower; 5 M names: 2 x 0.8 GB of 288)."""
     head = all_headers([indptr.numel() - 1, indices.numel()], indptr.device, group)   # rows, non-zeros of every block
     rows, nnz = [h[0] for h in head], [h[1] for h in head]
+    if indices.dtype != torch.int32:
+        raise TypeError(f"all_gather_csr packs 4-byte column indices; got {indices.dtype}")
     s = data.element_size()
     sizes = [z * (s + 4) + r * 4 for r, z in zip(rows, nnz)]
     longest = (max(max(sizes), 16) + 15) // 16 * 16            # (every rank's part starts 16-byte aligned: the typed views below)
