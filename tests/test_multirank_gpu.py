@@ -141,7 +141,11 @@ def test_eight_ranks_on_one_device_every_block_and_the_gathered_whole_equal_the_
         master = synth_names(20_003, 61)
         dups = synth_names(6_001, 62, perturb_of=master, perturb_frac=0.5)
         _expected_match(wd, "match8_f32", master, dups, 20, 0.7, np.float32)
+        # ... and the form as it is CHOSEN: 140 000 names (>= 131 072), nothing forced, self-join form only
+        auto = {"n": 140_000, "seed": 99, "extra": ["", "AB"]}
+        _expected_selfjoin(wd, "auto_f32", _names_of(auto, synth_names), 10, 0.8, np.float32)
         jobs = [
+            dict(kind="selfjoin", tag="w8_automatic_form_140k", top_n=10, thr=0.8, expected="auto_f32", form="selfjoin", grouped=True, **auto),
             dict(kind="selfjoin", tag="w8_groups_interleaved", top_n=10, thr=0.8, expected="big_f32", form="selfjoin", grouped=True,
                  env={"SG_DIST_SYM": "1"}, **big),
             dict(kind="selfjoin", tag="w8_row_block", top_n=10, thr=0.8, expected="big_f32", form="rowblock", env={"SG_DIST_SYM": "0"}, **big),
@@ -149,4 +153,4 @@ def test_eight_ranks_on_one_device_every_block_and_the_gathered_whole_equal_the_
                  seed=61),
         ]
         got = _spawn(8, wd, jobs)
-        assert all(len(got[r]) >= 8 for r in range(8)), got      # (3 + 3 + 2 checks per rank, all empty: _spawn has asserted that)
+        assert all(len(got[r]) >= 11 for r in range(8)), got      # (3 + 3 + 3 + 2 checks per rank, all empty: _spawn has asserted that)
