@@ -22,18 +22,14 @@
 // Off when fewer than 3 % of the rows are repeats (the grouping costs ~0.3 ms at 663 k, the multiply grows with the
 // square of the rows): SG_COLLAPSE=0 / 1 force it.
 #include "sg_internal.h"
+#include "sg_scan.h"
 
 template <typename T>
 __global__ void __launch_bounds__(256) row_hash_kernel(const int64_t *__restrict__ indptr, const int32_t *__restrict__ indices,
                                                        const T *__restrict__ data, int64_t n_rows, uint64_t *__restrict__ hash,
-                                                       uint32_t *__restrict__ row_id /* null: not wanted */,
-                                                       uint32_t *__restrict__ table /* null, or the slots to mark empty */,
-                                                       uint64_t table_size) {
+                                                       uint32_t *__restrict__ row_id /* null: not wanted */) {
     const int64_t r = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
     const int sub = threadIdx.x & 15;
-    if (table)   // (the table of the grouping below: cleared here instead of by a launch of its own)
-        for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < table_size; i += (uint64_t)gridDim.x * blockDim.x)
-            table[i] = 0xFFFFFFFFu;
     uint64_t h = 0;
     if (r < n_rows) {
         const int64_t lo = indptr[r], hi = indptr[r + 1];
@@ -71,59 +67,128 @@ __global__ void __launch_bounds__(256) row_hash_kernel(const int64_t *__restrict
 // members ascending as before: members are scattered in arrival order and every group of several members is sorted
 // (two members: a swap; up to 32: by its thread; up to 8192: by a workgroup in LDS; a larger one -- a hub -- by a
 // flag / prefix-sum / scatter pass of its own; a list with dozens of such hubs takes the sort-based path).
-#define SG_GROUP_EMPTY 0xFFFFFFFFu
 #define SG_GROUP_SORT_LDS 8192
 #define SG_GROUP_LARGE_MAX 28u      // very large groups listed per call (more: the sort-based path)
-__global__ void __launch_bounds__(256) group_insert_kernel(const uint64_t *__restrict__ hash, int64_t n_rows, uint32_t *table,
-                                                           uint32_t mask, uint32_t *__restrict__ slot_of_row) {
-    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= n_rows) return;
-    const uint64_t h = hash[r];
-    uint32_t s = (uint32_t)(h ^ (h >> 29)) & mask;
-    for (;;) {
-        uint32_t cur = __hip_atomic_load(&table[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (cur == SG_GROUP_EMPTY) {
-            cur = atomicCAS(&table[s], SG_GROUP_EMPTY, (uint32_t)r);
-            if (cur == SG_GROUP_EMPTY) break;                 // the slot is this hash's now
-        }
-        if (hash[cur] == h) {                                 // (whoever holds the slot has the slot's hash)
-            // (a hub of 66 000 identical names is 66 000 rows at ONE slot: only a row below what the slot shows sends an
-            //  atomic -- the value only ever falls, so a stale reading only costs an atomic that changes nothing)
-            if ((uint32_t)r < cur) atomicMin(&table[s], (uint32_t)r);
-            break;
-        }
-        s = (s + 1u) & mask;
-    }
-    slot_of_row[r] = s;
-}
+#define SG_GROUP_NO_SLOT 0xFFFFFFFFu
 
-// rep_of_row[r] = the lowest row with r's content (r itself when it is that row, or when its hash's slot names a row of
-// other content); is_rep[r] = 1 for representatives.  Sixteen lanes per row.
+// Round 6: hash, insert and verify in ONE pass over the rows (rounds 4-5: row_hash_kernel, group_insert_kernel,
+// group_verify_kernel -- the rows read twice, 0.15 ms of the 0.3 ms the grouping cost at 663 k, 1.1 of 1.8 ms at 5 M).
+// A slot is 64 bits, {tag = upper half of the row's hash, ~row}, 0 = empty: the tag tells whose slot it is without a
+// hash array to look the holder's hash up in, and with ~row in the low half an atomic MAX over rows of one tag keeps the
+// LOWEST row.  Sixteen lanes per row: they hash the row, then walk the table together -- an empty slot is claimed
+// (compare-and-swap), a slot of another tag is passed, a slot of the row's own tag names a row whose CONTENT is compared
+// entry by entry on the spot: equal -> the row joins the slot (and lowers it if it is the lower row), different -> a
+// collision of 53 bits of hash: the row becomes a group of its own, as before.  Every row that ever held or joined a slot
+// has been compared equal to a row that held it before, so all of them are equal and the slot's final holder -- the
+// lowest -- is their representative: nothing is merged on the hash alone.  slot_of_row[r] = the slot, or SG_GROUP_NO_SLOT
+// for a row that stands alone.
+// The walk is a loop the WAVE leaves together, every group's state in registers (hipcc 7.2 and
+// per-lane loops whose result is read behind them).
 template <typename T>
-__global__ void __launch_bounds__(256) group_verify_kernel(const int64_t *__restrict__ indptr, const int32_t *__restrict__ indices,
-                                                           const T *__restrict__ data, int64_t n_rows,
-                                                           const uint32_t *__restrict__ table, const uint32_t *__restrict__ slot_of_row,
-                                                           uint32_t *__restrict__ rep_of_row, uint32_t *__restrict__ is_rep) {
+__global__ void __launch_bounds__(256) group_rows_kernel(const int64_t *__restrict__ indptr, const int32_t *__restrict__ indices,
+                                                         const T *__restrict__ data, int64_t n_rows, unsigned long long *table,
+                                                         uint32_t mask, uint32_t *__restrict__ slot_of_row) {
     const int64_t r = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
     const int sub = threadIdx.x & 15;
-    if (r >= n_rows) return;
-    const int64_t rep = table[slot_of_row[r]];
-    bool same = true;
-    if (rep != r) {
-        const int64_t la = indptr[r], lb = indptr[rep];
-        const int64_t n = indptr[r + 1] - la;
-        same = n == indptr[rep + 1] - lb;
-        if (same)
-            for (int64_t e = sub; e < n; e += 16) same = same && indices[la + e] == indices[lb + e] && data[la + e] == data[lb + e];
+    const bool valid = r < n_rows;
+    int64_t lo = 0;
+    int32_t len = 0;
+    uint64_t h = 0;
+    // the row's first two rounds of entries stay in registers for the comparisons (rows of up to 32 entries: all of it)
+    int32_t k0 = -1, k1 = -1;
+    T v0 = (T)0, v1 = (T)0;
+    if (valid) {
+        lo = indptr[r];
+        len = (int32_t)(indptr[r + 1] - lo);
+        if (sub < len) {
+            k0 = indices[lo + sub];
+            v0 = data[lo + sub];
+        }
+        if (sub + 16 < len) {
+            k1 = indices[lo + sub + 16];
+            v1 = data[lo + sub + 16];
+        }
+        for (int32_t e = sub; e < len; e += 16) {
+            const int32_t k = e < 16 ? k0 : (e < 32 ? k1 : indices[lo + e]);
+            const T v = e < 16 ? v0 : (e < 32 ? v1 : data[lo + e]);
+            uint64_t vb;
+            if (sizeof(T) == 4) vb = (uint64_t)__float_as_uint((float)v);
+            else vb = (uint64_t)__double_as_longlong((double)v);
+            uint64_t x = ((uint64_t)(uint32_t)k << 32) ^ vb ^ ((uint64_t)e * 0x9E3779B97F4A7C15ull);
+            x ^= x >> 33;
+            x *= 0xff51afd7ed558ccdull;
+            x ^= x >> 33;
+            x *= 0xc4ceb9fe1a85ec53ull;
+            x ^= x >> 33;
+            h += x;   // (the position is mixed in: the sum over the lanes is order-free but not content-free)
+        }
+    }
 #pragma unroll
-        for (int d = 8; d > 0; d >>= 1) same = same && (__shfl_xor((int)same, d, 64) != 0);
+    for (int d = 8; d > 0; d >>= 1) {
+        const uint32_t lo32 = (uint32_t)__shfl_xor((int)(uint32_t)h, d, 64), hi32 = (uint32_t)__shfl_xor((int)(uint32_t)(h >> 32), d, 64);
+        h += ((uint64_t)hi32 << 32) | lo32;
     }
-    if (sub == 0) {
-        const bool own = rep == r || !same;
-        rep_of_row[r] = own ? (uint32_t)r : (uint32_t)rep;
-        is_rep[r] = own ? 1u : 0u;
+    h ^= (uint64_t)(uint32_t)len * 0xD6E8FEB86659FD93ull;
+    h ^= h >> 31;
+    const unsigned long long mine = ((unsigned long long)(uint32_t)(h >> 32) << 32) | (unsigned long long)(~(uint32_t)r);
+    uint32_t s = (uint32_t)h & mask;
+    uint32_t result = SG_GROUP_NO_SLOT;
+    bool walking = valid;
+    while (__ballot(walking) != 0) {
+        if (walking) {
+            unsigned long long cur = 0;
+            if (sub == 0) {
+                cur = __hip_atomic_load(&table[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (cur == 0ull) cur = atomicCAS(&table[s], 0ull, mine);     // (0: the slot is this row's now)
+            }
+            const uint32_t c_lo = (uint32_t)__shfl((int)(uint32_t)cur, threadIdx.x & 48, 64);
+            const uint32_t c_hi = (uint32_t)__shfl((int)(uint32_t)(cur >> 32), threadIdx.x & 48, 64);
+            if (c_lo == 0u && c_hi == 0u) {
+                result = s;
+                walking = false;
+            } else if (c_hi == (uint32_t)(mine >> 32)) {
+                // the holder has this row's tag: the same content?
+                const int64_t o = (int64_t)(~c_lo);
+                const int64_t olo = indptr[o];
+                bool same = (int32_t)(indptr[o + 1] - olo) == len;
+                if (same) {
+                    if (sub < len) same = indices[olo + sub] == k0 && data[olo + sub] == v0;
+                    if (sub + 16 < len) same = same && indices[olo + sub + 16] == k1 && data[olo + sub + 16] == v1;
+                    for (int32_t e = sub + 32; e < len; e += 16)
+                        same = same && indices[olo + e] == indices[lo + e] && data[olo + e] == data[lo + e];
+                }
+#pragma unroll
+                for (int d = 8; d > 0; d >>= 1) same = same && (__shfl_xor((int)same, d, 64) != 0);
+                if (same) {
+                    if (sub == 0 && o > r) atomicMax(&table[s], mine);   // (~row: the max keeps the lowest row)
+                    result = s;
+                }
+                walking = false;     // (different content under one tag: the row stands alone)
+            } else {
+                s = (s + 1u) & mask;
+            }
+        }
     }
+    if (valid && sub == 0) slot_of_row[r] = result;
 }
+
+// the representative of row r once every row has been through group_rows_kernel
+__device__ __forceinline__ uint32_t sg_group_rep(const unsigned long long *__restrict__ table, const uint32_t *__restrict__ slot_of_row,
+                                                 int64_t r) {
+    const uint32_t s = slot_of_row[r];
+    return s == SG_GROUP_NO_SLOT ? (uint32_t)r : ~(uint32_t)table[s];
+}
+// the scan over "row r is a representative" computes its input itself and leaves rep_of_row behind
+struct GroupRepLoad {
+    const unsigned long long *table;
+    const uint32_t *slot_of_row;
+    uint32_t *rep_of_row;
+    __device__ __forceinline__ uint32_t operator()(int64_t r) const {
+        const uint32_t rep = sg_group_rep(table, slot_of_row, r);
+        rep_of_row[r] = rep;
+        return rep == (uint32_t)r ? 1u : 0u;
+    }
+};
 
 // members in arrival order (a group of one needs no ticket)
 __global__ void __launch_bounds__(256) group_scatter_kernel(const uint32_t *__restrict__ gid, const uint32_t *__restrict__ group_ptr,
@@ -153,10 +218,11 @@ __global__ void __launch_bounds__(256) large_group_fill_kernel(const uint32_t *_
 
 // a thread per group: members ascending.  Groups of more than 32 are queued for the workgroup sort; words[0] = queue
 // length, words[1] = largest group.
-__global__ void __launch_bounds__(256) group_sort_small_kernel(const uint32_t *__restrict__ group_ptr, int64_t n_u, uint32_t *members,
-                                                               uint32_t *words, uint32_t *__restrict__ queue) {
+__global__ void __launch_bounds__(256) group_sort_small_kernel(const uint32_t *__restrict__ group_ptr,
+                                                               const uint32_t *__restrict__ n_u_dev /* the number of groups: known to the device, not yet to the host */,
+                                                               uint32_t *members, uint32_t *words, uint32_t *__restrict__ queue) {
     const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= n_u) return;
+    if (g >= (int64_t)*n_u_dev) return;
     const uint32_t lo = group_ptr[g], m = group_ptr[g + 1] - lo;
     if (m < 2u) return;
     if (m == 2u) {
@@ -262,23 +328,43 @@ __global__ void __launch_bounds__(256) group_members_kernel(const uint32_t *__re
     if (head[s]) is_rep[row] = 1u;
 }
 
-// gid[row] = number of representatives below the row's representative; sizes counted; rep_rows[gid] = representative
+// gid[row] = number of representatives below the row's representative; sizes counted; rep_rows[gid] = representative.
+// Table path (indptr given): a representative also leaves where its row starts in the source and how long it is -- what
+// the index build's one read of the rows (sg_postings.hip, gather_rows_kernel) and the lazy matrix of the representatives
+// need --, and the lengths are summed into the 32 counters of nnz_total (one atomic per wave).
 __global__ void __launch_bounds__(256) group_ids_kernel(const uint32_t *__restrict__ rep_of_row, const uint32_t *__restrict__ rep_excl,
-                                                        const uint32_t *__restrict__ is_rep, int64_t n_rows,
-                                                        uint32_t *__restrict__ gid, uint32_t *__restrict__ size,
-                                                        uint32_t *__restrict__ rep_rows) {
+                                                        const uint32_t *__restrict__ is_rep /* null: rep_of_row[r] == r says so */,
+                                                        int64_t n_rows, uint32_t *__restrict__ gid, uint32_t *__restrict__ size,
+                                                        uint32_t *__restrict__ rep_rows, const int64_t *__restrict__ indptr,
+                                                        int64_t *__restrict__ rep_start, int32_t *__restrict__ rep_len,
+                                                        unsigned long long *nnz_total) {
     const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const bool valid = r < n_rows;
     uint32_t g = 0xFFFFFFFFu;
     bool rep = false;
+    uint32_t my_len = 0;
     if (valid) {
-        g = rep_excl[rep_of_row[r]];
+        const uint32_t ro = rep_of_row[r];
+        g = rep_excl[ro];
         gid[r] = g;
-        rep = is_rep[r] != 0u;
+        rep = is_rep ? is_rep[r] != 0u : ro == (uint32_t)r;
         if (rep) {
             rep_rows[g] = (uint32_t)r;
             atomicAdd(&size[g], 1u);          // (one representative per group: an address of its own)
+            if (indptr) {
+                const int64_t lo = indptr[r];
+                my_len = (uint32_t)(indptr[r + 1] - lo);
+                rep_start[g] = lo;
+                rep_len[g] = (int32_t)my_len;
+            }
         }
+    }
+    if (nnz_total) {
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) my_len += (uint32_t)__shfl_xor((int)my_len, d, 64);
+        // (32 counters, one per workgroup mod 32: ten thousand waves on ONE word are served one at a time, ~12 ns each --
+        //  0.12 ms at 663 k; the host adds the 32 up)
+        if ((threadIdx.x & 63) == 0 && my_len) atomicAdd(nnz_total + (blockIdx.x & 31u), (unsigned long long)my_len);
     }
     // the other members: the lanes of a wave that belong to one group send ONE atomic between them -- a hub of 66 000
     // identical names was 66 000 atomics on one word, which are served one at a time (~12 ns each: 0.8 ms of a 2 ms build)
@@ -324,6 +410,8 @@ int sg_collapse_materialize(sg_ctx *ctx, SgCollapse *c) {
     if (!c || !c->pending_src) return SG_OK;
     const sg_csr *B = c->pending_src;
     sg_csr *m = c->unique;
+    // (table path, round 6: the row pointers are pending too -- nothing on the way to the self-join's index reads them)
+    if (c->d_rep_len) SG_TRY(sg_exclusive_scan_i32_to_i64(ctx, c->d_rep_len, (int64_t *)m->d_indptr, c->n_u));
     const unsigned gu = (unsigned)((c->n_u * 16 + 255) / 256);
     if (B->dtype == SG_F64)
         hipLaunchKernelGGL(unique_rows_kernel<double>, dim3(gu), dim3(256), 0, ctx->stream, B->d_indptr, B->d_indices,
@@ -338,6 +426,13 @@ int sg_collapse_materialize(sg_ctx *ctx, SgCollapse *c) {
     return SG_OK;
 }
 
+// The rows of a matrix that may be the representatives' matrix of some groups, not written yet: before anything READS them
+// (the one-sided kernels, the pilot, the exact kernel; the self-join form reads the index's own copy in position order).
+int sg_csr_ensure_rows(sg_ctx *ctx, const sg_csr *m) {
+    if (m && m->rows_of && m->rows_of->pending_src) return sg_collapse_materialize(ctx, m->rows_of);
+    return SG_OK;
+}
+
 void sg_collapse_free(SgCollapse *c) {
     if (!c) return;
     sg_ctx *ctx = c->ctx;
@@ -345,6 +440,8 @@ void sg_collapse_free(SgCollapse *c) {
     ctx->release(c->d_group_ptr);
     ctx->release(c->d_members);
     ctx->release(c->d_rep_rows);
+    ctx->release(c->d_rep_start);
+    ctx->release(c->d_rep_len);
     sg_csr_free(c->unique);
     delete c;
 }
@@ -378,35 +475,180 @@ int sg_collapse_build(sg_ctx *ctx, const sg_csr *B, SgCollapse **out, bool left_
     return st;
 }
 
-// One of the two ways to the groups; *out stays null when grouping is not worth it (or, table path, when a group is too
-// large for it: ctx->group_table_overflow says so).
+// the representatives' matrix of the groups `c` (n_u rows, nnz_u entries): arrays allocated, rows written unless deferred
+static int collapse_unique_matrix(sg_ctx *ctx, const sg_csr *B, SgCollapse *c, int64_t nnz_u, int64_t *ptr /* given: filled already */,
+                                  bool defer_rows) {
+    const int64_t n_u = c->n_u;
+    int32_t *idx = nullptr;
+    void *val = nullptr;
+    const size_t vs = B->dtype == SG_F64 ? 8 : 4;
+    int st = SG_OK;
+    if (!ptr) st = sg_alloc(ctx, (size_t)n_u + 2, &ptr);
+    if (st == SG_OK) st = sg_alloc(ctx, (size_t)nnz_u + 64, &idx);
+    if (st == SG_OK) st = ctx->alloc(((size_t)nnz_u + 64) * vs, &val);
+    sg_csr *m = st == SG_OK ? new (std::nothrow) sg_csr() : nullptr;
+    if (st == SG_OK && !m) st = SG_ERR_OOM;
+    if (st != SG_OK) {
+        ctx->release(ptr);
+        ctx->release(idx);
+        ctx->release(val);
+        return st;
+    }
+    m->ctx = ctx;
+    m->n_rows = n_u;
+    m->n_cols = B->n_cols;
+    m->nnz = nnz_u;
+    m->dtype = B->dtype;
+    m->d_indptr = ptr;
+    m->d_indices = idx;
+    m->d_data = val;
+    m->owned = true;
+    m->props_state = B->props_state;          // a subset of B's rows: cosine-like if B is; the maxima are upper bounds
+    m->props_max_norm2 = B->props_max_norm2;
+    m->props_max_nnz = B->props_max_nnz;
+    m->rows_of = c;
+    c->unique = m;
+    c->pending_src = B;       // (written by sg_collapse_materialize: now, or when somebody asks sg_csr_ensure_rows)
+    if (!defer_rows) return sg_collapse_materialize(ctx, c);
+    return SG_OK;
+}
+
+// Grouping through the hash table (see group_rows_kernel).  ONE host round trip: the number of groups, the entries of
+// their representatives and what the member sort found arrive together, after everything has been queued on upper bounds
+// (n rows for n_u groups); rounds 4-5 stopped twice.  *out stays null when grouping is not worth it, or when a group is too
+// large for this path (ctx->group_table_overflow says so: the caller takes the sort-based one).
+static int collapse_groups_table(sg_ctx *ctx, const sg_csr *B, bool forced, bool defer_rows, SgCollapse **out) {
+    *out = nullptr;
+    ctx->group_table_overflow = false;
+    const int64_t n = B->n_rows;
+    uint64_t table_size = 1024;
+    while (table_size < 2 * (uint64_t)n) table_size <<= 1;
+    unsigned long long *table = nullptr;
+    uint32_t *slot_of_row = nullptr, *rep_of_row = nullptr, *rep_excl = nullptr, *size = nullptr, *cursor = nullptr, *queue = nullptr;
+    uint32_t *totals = nullptr;   // [0] groups, [4 .. 36) the member sort's words, [40 .. 104) entries of the representatives (32 partial sums of 64 bits)
+    SgCollapse *c = new (std::nothrow) SgCollapse();
+    if (!c) return SG_ERR_OOM;
+    c->ctx = ctx;
+    c->n_orig = n;
+    int st = sg_alloc(ctx, (size_t)table_size, &table);
+    if (st == SG_OK) st = sg_alloc(ctx, (size_t)n + 1, &slot_of_row);
+    if (st == SG_OK) st = sg_alloc(ctx, (size_t)n + 1, &rep_of_row);
+    if (st == SG_OK) st = sg_alloc(ctx, (size_t)n + 1, &rep_excl);
+    if (st == SG_OK) st = sg_alloc(ctx, (size_t)n + 2, &size);
+    if (st == SG_OK) st = sg_alloc(ctx, (size_t)n + 2, &cursor);
+    if (st == SG_OK) st = sg_alloc(ctx, (size_t)n + 2, &queue);
+    if (st == SG_OK) st = sg_alloc(ctx, (size_t)104, &totals);
+    // (sized for n groups: the number is not known to the host while these are queued)
+    if (st == SG_OK) st = sg_alloc(ctx, (size_t)n + 1, &c->d_gid);
+    if (st == SG_OK) st = sg_alloc(ctx, (size_t)n + 2, &c->d_group_ptr);
+    if (st == SG_OK) st = sg_alloc(ctx, (size_t)n + 1, &c->d_members);
+    if (st == SG_OK) st = sg_alloc(ctx, (size_t)n + 1, &c->d_rep_rows);
+    if (st == SG_OK) st = sg_alloc(ctx, (size_t)n + 2, &c->d_rep_start);
+    if (st == SG_OK) st = sg_alloc(ctx, (size_t)n + 2, &c->d_rep_len);
+    auto cleanup = [&]() {
+        ctx->release(table);
+        ctx->release(slot_of_row);
+        ctx->release(rep_of_row);
+        ctx->release(rep_excl);
+        ctx->release(size);
+        ctx->release(cursor);
+        ctx->release(queue);
+        ctx->release(totals);
+    };
+    const unsigned g1 = (unsigned)((n + 255) / 256), g16 = (unsigned)((n * 16 + 255) / 256);
+    if (st == SG_OK)
+        st = SG_ZERO4(ctx, table, sizeof(unsigned long long) * (size_t)table_size, size, sizeof(uint32_t) * (size_t)(n + 2), cursor,
+                      sizeof(uint32_t) * (size_t)(n + 2), totals, 104 * sizeof(uint32_t));
+    if (st == SG_OK) {
+        if (B->dtype == SG_F64)
+            hipLaunchKernelGGL(group_rows_kernel<double>, dim3(g16), dim3(256), 0, ctx->stream, B->d_indptr, B->d_indices,
+                               (const double *)B->d_data, n, table, (uint32_t)(table_size - 1), slot_of_row);
+        else
+            hipLaunchKernelGGL(group_rows_kernel<float>, dim3(g16), dim3(256), 0, ctx->stream, B->d_indptr, B->d_indices,
+                               (const float *)B->d_data, n, table, (uint32_t)(table_size - 1), slot_of_row);
+        // representatives flagged and counted by the scan that needs the flags (totals[0] = number of groups)
+        st = sg_scan_launch<uint32_t>(ctx, GroupRepLoad{table, slot_of_row, rep_of_row}, SgScanStoreArray<uint32_t>{rep_excl}, n, totals);
+    }
+    if (st == SG_OK) {
+        hipLaunchKernelGGL(group_ids_kernel, dim3(g1), dim3(256), 0, ctx->stream, (const uint32_t *)rep_of_row, (const uint32_t *)rep_excl,
+                           (const uint32_t *)nullptr, n, c->d_gid, size, c->d_rep_rows, B->d_indptr, c->d_rep_start, c->d_rep_len,
+                           (unsigned long long *)(totals + 40));
+        // (over n + 1 sizes, zeros behind the last group: group_ptr[n_u] = n comes out by itself)
+        st = sg_exclusive_scan_u32(ctx, size, c->d_group_ptr, n + 1, nullptr);
+    }
+    if (st == SG_OK) {
+        hipLaunchKernelGGL(group_scatter_kernel, dim3(g1), dim3(256), 0, ctx->stream, (const uint32_t *)c->d_gid,
+                           (const uint32_t *)c->d_group_ptr, n, cursor, c->d_members);
+        hipLaunchKernelGGL(group_sort_small_kernel, dim3(g1), dim3(256), 0, ctx->stream, (const uint32_t *)c->d_group_ptr,
+                           (const uint32_t *)totals, c->d_members, totals + 4, queue);
+        hipLaunchKernelGGL(group_sort_lds_kernel, dim3(512), dim3(256), 0, ctx->stream, (const uint32_t *)c->d_group_ptr, c->d_members,
+                           (const uint32_t *)(totals + 4), (const uint32_t *)queue);
+        if (hipGetLastError() != hipSuccess) st = SG_ERR_HIP;
+    }
+    uint32_t h[104];
+    for (auto &w : h) w = 0;
+    if (st == SG_OK) {
+        if (hipMemcpyAsync(h, totals, sizeof(h), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+            hipStreamSynchronize(ctx->stream) != hipSuccess)
+            st = SG_ERR_HIP;
+    }
+    const uint32_t n_groups = h[0];
+    int64_t nnz_u = 0;
+    for (int q = 0; q < 32; ++q) nnz_u += (int64_t)(((uint64_t)h[41 + 2 * q] << 32) | (uint64_t)h[40 + 2 * q]);
+    const uint32_t *h_words = h + 4;      // [0] groups queued for the LDS sort, [1] the largest group, [2] very large groups, [3 ..] which
+    if (st != SG_OK || n_groups == 0 || (!forced && (double)n_groups > 0.97 * (double)n) || (int64_t)n_groups == n) {
+        cleanup();
+        sg_collapse_free(c);
+        return st;
+    }
+    if (h_words[2] > SG_GROUP_LARGE_MAX) {
+        // dozens of very large groups: the sort-based path lists any number of them in one go -- the caller takes it
+        ctx->group_table_overflow = true;
+        cleanup();
+        sg_collapse_free(c);
+        return SG_OK;
+    }
+    c->n_u = n_groups;
+    for (uint32_t q = 0; q < h_words[2] && st == SG_OK; ++q) {
+        // a group too large for the workgroup sort: flag / prefix sum / scatter of its own (size and rep_excl have served)
+        const uint32_t g = h_words[3 + q];
+        hipLaunchKernelGGL(large_group_flag_kernel, dim3(g1), dim3(256), 0, ctx->stream, (const uint32_t *)c->d_gid, n, g, size);
+        st = sg_exclusive_scan_u32(ctx, size, rep_excl, n, nullptr);
+        if (st == SG_OK) {
+            hipLaunchKernelGGL(large_group_fill_kernel, dim3(g1), dim3(256), 0, ctx->stream, (const uint32_t *)c->d_gid,
+                               (const uint32_t *)rep_excl, n, g, (const uint32_t *)c->d_group_ptr, c->d_members);
+            if (hipGetLastError() != hipSuccess) st = SG_ERR_HIP;
+        }
+    }
+    cleanup();
+    if (st == SG_OK) st = collapse_unique_matrix(ctx, B, c, nnz_u, nullptr, defer_rows);
+    if (st != SG_OK) {
+        sg_collapse_free(c);
+        return st;
+    }
+    *out = c;
+    return SG_OK;
+}
+
+// The sort-based way to the groups (lists with dozens of very large groups; SG_GROUP_SORT=1); *out stays null when grouping
+// is not worth it.
 static int collapse_groups(sg_ctx *ctx, const sg_csr *B, bool forced, bool by_table, bool defer_rows, SgCollapse **out) {
+    if (by_table) return collapse_groups_table(ctx, B, forced, defer_rows, out);
     *out = nullptr;
     ctx->group_table_overflow = false;
     const int64_t n = B->n_rows;
     uint64_t *hash = nullptr, *hash_sorted = nullptr;
     uint32_t *row_id = nullptr, *row_sorted = nullptr, *head = nullptr, *run_excl = nullptr, *head_pos = nullptr;
     uint32_t *rep_of_row = nullptr, *rank_of_row = nullptr, *is_rep = nullptr, *rep_excl = nullptr, *size = nullptr;
-    uint32_t *totals = nullptr, *table = nullptr, *slot_of_row = nullptr, *cursor = nullptr, *queue = nullptr;
+    uint32_t *totals = nullptr;
     SgCollapse *c = nullptr;
-    uint64_t table_size = 0;
     int st = sg_alloc(ctx, (size_t)n + 1, &hash);
     if (st == SG_OK) st = sg_alloc(ctx, (size_t)40, &totals);
-    if (by_table) {
-        table_size = 1024;
-        while (table_size < 2 * (uint64_t)n) table_size <<= 1;
-        if (st == SG_OK) st = sg_alloc(ctx, (size_t)table_size, &table);
-        if (st == SG_OK) st = sg_alloc(ctx, (size_t)n + 1, &slot_of_row);
-        if (st == SG_OK) st = sg_alloc(ctx, (size_t)n + 1, &rep_of_row);
-        if (st == SG_OK) st = sg_alloc(ctx, (size_t)n + 1, &is_rep);
-        if (st == SG_OK) st = sg_alloc(ctx, (size_t)n + 1, &rep_excl);
-    } else {
-        if (st == SG_OK) st = sg_alloc(ctx, (size_t)n + 1, &hash_sorted);
-        if (st == SG_OK) st = sg_alloc(ctx, (size_t)n + 1, &row_id);
-        if (st == SG_OK) st = sg_alloc(ctx, (size_t)n + 1, &row_sorted);
-        if (st == SG_OK) st = sg_alloc(ctx, (size_t)n + 1, &head);
-        if (st == SG_OK) st = sg_alloc(ctx, (size_t)n + 1, &run_excl);
-    }
+    if (st == SG_OK) st = sg_alloc(ctx, (size_t)n + 1, &hash_sorted);
+    if (st == SG_OK) st = sg_alloc(ctx, (size_t)n + 1, &row_id);
+    if (st == SG_OK) st = sg_alloc(ctx, (size_t)n + 1, &row_sorted);
+    if (st == SG_OK) st = sg_alloc(ctx, (size_t)n + 1, &head);
+    if (st == SG_OK) st = sg_alloc(ctx, (size_t)n + 1, &run_excl);
     auto cleanup = [&]() {
         ctx->release(hash);
         ctx->release(hash_sorted);
@@ -421,41 +663,25 @@ static int collapse_groups(sg_ctx *ctx, const sg_csr *B, bool forced, bool by_ta
         ctx->release(rep_excl);
         ctx->release(size);
         ctx->release(totals);
-        ctx->release(table);
-        ctx->release(slot_of_row);
-        ctx->release(cursor);
-        ctx->release(queue);
     };
     const unsigned g1 = (unsigned)((n + 255) / 256), g16 = (unsigned)((n * 16 + 255) / 256);
     if (st == SG_OK) {
         if (B->dtype == SG_F64)
             hipLaunchKernelGGL(row_hash_kernel<double>, dim3(g16), dim3(256), 0, ctx->stream, B->d_indptr, B->d_indices,
-                               (const double *)B->d_data, n, hash, row_id, table, table_size);
+                               (const double *)B->d_data, n, hash, row_id);
         else
             hipLaunchKernelGGL(row_hash_kernel<float>, dim3(g16), dim3(256), 0, ctx->stream, B->d_indptr, B->d_indices,
-                               (const float *)B->d_data, n, hash, row_id, table, table_size);
-    }
-    if (st == SG_OK && by_table) {
-        hipLaunchKernelGGL(group_insert_kernel, dim3(g1), dim3(256), 0, ctx->stream, (const uint64_t *)hash, n, table,
-                           (uint32_t)(table_size - 1), slot_of_row);
-        if (B->dtype == SG_F64)
-            hipLaunchKernelGGL(group_verify_kernel<double>, dim3(g16), dim3(256), 0, ctx->stream, B->d_indptr, B->d_indices,
-                               (const double *)B->d_data, n, (const uint32_t *)table, (const uint32_t *)slot_of_row, rep_of_row, is_rep);
-        else
-            hipLaunchKernelGGL(group_verify_kernel<float>, dim3(g16), dim3(256), 0, ctx->stream, B->d_indptr, B->d_indices,
-                               (const float *)B->d_data, n, (const uint32_t *)table, (const uint32_t *)slot_of_row, rep_of_row, is_rep);
-        st = sg_exclusive_scan_u32(ctx, is_rep, rep_excl, n, totals);   // totals[0] = number of groups
-    } else if (st == SG_OK) {
+                               (const float *)B->d_data, n, hash, row_id);
         st = sg_sort_pairs_u64_u32(ctx, hash, row_id, n, hash_sorted, row_sorted);
-        if (st == SG_OK) {
-            if (B->dtype == SG_F64)
-                hipLaunchKernelGGL(group_heads_kernel<double>, dim3(g1), dim3(256), 0, ctx->stream, B->d_indptr, B->d_indices,
-                                   (const double *)B->d_data, n, (const uint64_t *)hash_sorted, (const uint32_t *)row_sorted, head);
-            else
-                hipLaunchKernelGGL(group_heads_kernel<float>, dim3(g1), dim3(256), 0, ctx->stream, B->d_indptr, B->d_indices,
-                                   (const float *)B->d_data, n, (const uint64_t *)hash_sorted, (const uint32_t *)row_sorted, head);
-            st = sg_exclusive_scan_u32(ctx, head, run_excl, n, totals);   // totals[0] = number of groups
-        }
+    }
+    if (st == SG_OK) {
+        if (B->dtype == SG_F64)
+            hipLaunchKernelGGL(group_heads_kernel<double>, dim3(g1), dim3(256), 0, ctx->stream, B->d_indptr, B->d_indices,
+                               (const double *)B->d_data, n, (const uint64_t *)hash_sorted, (const uint32_t *)row_sorted, head);
+        else
+            hipLaunchKernelGGL(group_heads_kernel<float>, dim3(g1), dim3(256), 0, ctx->stream, B->d_indptr, B->d_indices,
+                               (const float *)B->d_data, n, (const uint64_t *)hash_sorted, (const uint32_t *)row_sorted, head);
+        st = sg_exclusive_scan_u32(ctx, head, run_excl, n, totals);   // totals[0] = number of groups
     }
     uint32_t n_groups = 0;
     if (st == SG_OK) {
@@ -481,127 +707,56 @@ static int collapse_groups(sg_ctx *ctx, const sg_csr *B, bool forced, bool by_ta
     if (st == SG_OK) st = sg_alloc(ctx, (size_t)n_u + 2, &c->d_group_ptr);
     if (st == SG_OK) st = sg_alloc(ctx, (size_t)n + 1, &c->d_members);
     if (st == SG_OK) st = sg_alloc(ctx, (size_t)n_u + 1, &c->d_rep_rows);
-    if (by_table) {
-        if (st == SG_OK) st = sg_alloc(ctx, (size_t)n_u + 1, &cursor);
-        if (st == SG_OK) st = sg_alloc(ctx, (size_t)n_u + 1, &queue);
-        if (st == SG_OK)
-            st = SG_ZERO3(ctx, size, sizeof(uint32_t) * (size_t)(n_u + 1), cursor, sizeof(uint32_t) * (size_t)(n_u + 1), totals + 4,
-                          32 * sizeof(uint32_t));
-    } else {
-        if (st == SG_OK) st = sg_alloc(ctx, (size_t)n_u + 1, &head_pos);
-        if (st == SG_OK) st = sg_alloc(ctx, (size_t)n + 1, &rep_of_row);
-        if (st == SG_OK) st = sg_alloc(ctx, (size_t)n + 1, &rank_of_row);
-        if (st == SG_OK) st = sg_alloc(ctx, (size_t)n + 1, &is_rep);
-        if (st == SG_OK) st = sg_alloc(ctx, (size_t)n + 1, &rep_excl);
-        if (st == SG_OK) st = SG_ZERO2(ctx, is_rep, sizeof(uint32_t) * (size_t)(n + 1), size, sizeof(uint32_t) * (size_t)(n_u + 1));
-        if (st == SG_OK) {
-            hipLaunchKernelGGL(head_pos_kernel, dim3(g1), dim3(256), 0, ctx->stream, (const uint32_t *)head, (const uint32_t *)run_excl, n,
-                               head_pos);
-            hipLaunchKernelGGL(group_members_kernel, dim3(g1), dim3(256), 0, ctx->stream, (const uint32_t *)head,
-                               (const uint32_t *)run_excl, (const uint32_t *)head_pos, (const uint32_t *)row_sorted, n, rep_of_row,
-                               rank_of_row, is_rep);
-            st = sg_exclusive_scan_u32(ctx, is_rep, rep_excl, n, nullptr);
-        }
+    if (st == SG_OK) st = sg_alloc(ctx, (size_t)n_u + 1, &head_pos);
+    if (st == SG_OK) st = sg_alloc(ctx, (size_t)n + 1, &rep_of_row);
+    if (st == SG_OK) st = sg_alloc(ctx, (size_t)n + 1, &rank_of_row);
+    if (st == SG_OK) st = sg_alloc(ctx, (size_t)n + 1, &is_rep);
+    if (st == SG_OK) st = sg_alloc(ctx, (size_t)n + 1, &rep_excl);
+    if (st == SG_OK) st = SG_ZERO2(ctx, is_rep, sizeof(uint32_t) * (size_t)(n + 1), size, sizeof(uint32_t) * (size_t)(n_u + 1));
+    if (st == SG_OK) {
+        hipLaunchKernelGGL(head_pos_kernel, dim3(g1), dim3(256), 0, ctx->stream, (const uint32_t *)head, (const uint32_t *)run_excl, n,
+                           head_pos);
+        hipLaunchKernelGGL(group_members_kernel, dim3(g1), dim3(256), 0, ctx->stream, (const uint32_t *)head,
+                           (const uint32_t *)run_excl, (const uint32_t *)head_pos, (const uint32_t *)row_sorted, n, rep_of_row,
+                           rank_of_row, is_rep);
+        st = sg_exclusive_scan_u32(ctx, is_rep, rep_excl, n, nullptr);
     }
     if (st == SG_OK) {
         hipLaunchKernelGGL(group_ids_kernel, dim3(g1), dim3(256), 0, ctx->stream, (const uint32_t *)rep_of_row,
-                           (const uint32_t *)rep_excl, (const uint32_t *)is_rep, n, c->d_gid, size, c->d_rep_rows);
+                           (const uint32_t *)rep_excl, (const uint32_t *)is_rep, n, c->d_gid, size, c->d_rep_rows,
+                           (const int64_t *)nullptr, (int64_t *)nullptr, (int32_t *)nullptr, (unsigned long long *)nullptr);
         st = sg_exclusive_scan_u32(ctx, size, c->d_group_ptr, n_u, c->d_group_ptr + n_u);
     }
-    if (st == SG_OK && by_table) {
-        const unsigned gu1 = (unsigned)((n_u + 255) / 256);
-        hipLaunchKernelGGL(group_scatter_kernel, dim3(g1), dim3(256), 0, ctx->stream, (const uint32_t *)c->d_gid,
-                           (const uint32_t *)c->d_group_ptr, n, cursor, c->d_members);
-        hipLaunchKernelGGL(group_sort_small_kernel, dim3(gu1), dim3(256), 0, ctx->stream, (const uint32_t *)c->d_group_ptr, n_u,
-                           c->d_members, totals + 4, queue);
-        hipLaunchKernelGGL(group_sort_lds_kernel, dim3(512), dim3(256), 0, ctx->stream, (const uint32_t *)c->d_group_ptr, c->d_members,
-                           (const uint32_t *)(totals + 4), (const uint32_t *)queue);
-        if (hipGetLastError() != hipSuccess) st = SG_ERR_HIP;
-    } else if (st == SG_OK) {
+    if (st == SG_OK) {
         hipLaunchKernelGGL(group_fill_kernel, dim3(g1), dim3(256), 0, ctx->stream, (const uint32_t *)c->d_gid,
                            (const uint32_t *)rank_of_row, (const uint32_t *)c->d_group_ptr, n, c->d_members);
         if (hipGetLastError() != hipSuccess) st = SG_ERR_HIP;
     }
-    // the matrix of the representatives
+    // the matrix of the representatives: its row pointers here (one more round trip for the number of entries)
     int32_t *len = nullptr;
     int64_t *ptr = nullptr;
-    int32_t *idx = nullptr;
-    void *val = nullptr;
-    const size_t vs = B->dtype == SG_F64 ? 8 : 4;
+    int64_t nnz_u = 0;
     if (st == SG_OK) st = sg_alloc(ctx, (size_t)n_u + 1, &len);
     if (st == SG_OK) st = sg_alloc(ctx, (size_t)n_u + 2, &ptr);
-    if (st == SG_OK) st = sg_alloc(ctx, (size_t)B->nnz + 64, &idx);
-    if (st == SG_OK) st = ctx->alloc(((size_t)B->nnz + 64) * vs, &val);
-    int64_t nnz_u = 0;
     if (st == SG_OK) {
         hipLaunchKernelGGL(unique_len_kernel, dim3((unsigned)((n_u + 255) / 256)), dim3(256), 0, ctx->stream, B->d_indptr,
                            (const uint32_t *)c->d_rep_rows, n_u, len);
         st = sg_exclusive_scan_i32_to_i64(ctx, len, ptr, n_u);
     }
-    if (st == SG_OK) {
-        const unsigned gu = (unsigned)((n_u * 16 + 255) / 256);
-        if (defer_rows)
-            c->pending_src = B;       // (written by the index build, or by sg_collapse_materialize)
-        else if (B->dtype == SG_F64)
-            hipLaunchKernelGGL(unique_rows_kernel<double>, dim3(gu), dim3(256), 0, ctx->stream, B->d_indptr, B->d_indices,
-                               (const double *)B->d_data, (const uint32_t *)c->d_rep_rows, n_u, (const int64_t *)ptr, idx,
-                               (double *)val);
-        else
-            hipLaunchKernelGGL(unique_rows_kernel<float>, dim3(gu), dim3(256), 0, ctx->stream, B->d_indptr, B->d_indices,
-                               (const float *)B->d_data, (const uint32_t *)c->d_rep_rows, n_u, (const int64_t *)ptr, idx, (float *)val);
-        uint32_t h_words[32];      // table path: [0] groups queued for the LDS sort, [1] the largest group, [2] very large groups, [3 ..] which
-        for (auto &w : h_words) w = 0;
-        if (hipMemcpyAsync(&nnz_u, ptr + n_u, 8, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
-            (by_table && hipMemcpyAsync(h_words, totals + 4, sizeof(h_words), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) ||
-            hipStreamSynchronize(ctx->stream) != hipSuccess)
-            st = SG_ERR_HIP;
-        if (st == SG_OK && by_table && h_words[2] > SG_GROUP_LARGE_MAX) {
-            // dozens of very large groups: the sort-based path lists any number of them in one go -- the caller takes it
-            ctx->group_table_overflow = true;
-            ctx->release(len);
-            ctx->release(ptr);
-            ctx->release(idx);
-            ctx->release(val);
-            cleanup();
-            sg_collapse_free(c);
-            return SG_OK;
-        }
-        for (uint32_t q = 0; q < h_words[2] && st == SG_OK && by_table; ++q) {
-            // (is_rep / rep_excl have served: flag and positions of the group's rows)
-            const uint32_t g = h_words[3 + q];
-            hipLaunchKernelGGL(large_group_flag_kernel, dim3(g1), dim3(256), 0, ctx->stream, (const uint32_t *)c->d_gid, n, g, is_rep);
-            st = sg_exclusive_scan_u32(ctx, is_rep, rep_excl, n, nullptr);
-            if (st == SG_OK) {
-                hipLaunchKernelGGL(large_group_fill_kernel, dim3(g1), dim3(256), 0, ctx->stream, (const uint32_t *)c->d_gid,
-                                   (const uint32_t *)rep_excl, n, g, (const uint32_t *)c->d_group_ptr, c->d_members);
-                if (hipGetLastError() != hipSuccess) st = SG_ERR_HIP;
-            }
-        }
-    }
+    if (st == SG_OK && (hipMemcpyAsync(&nnz_u, ptr + n_u, 8, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+                        hipStreamSynchronize(ctx->stream) != hipSuccess))
+        st = SG_ERR_HIP;
     ctx->release(len);
     cleanup();
-    sg_csr *m = st == SG_OK ? new (std::nothrow) sg_csr() : nullptr;
-    if (st == SG_OK && !m) st = SG_ERR_OOM;
+    if (st == SG_OK) {
+        st = collapse_unique_matrix(ctx, B, c, nnz_u, ptr, defer_rows);
+        ptr = nullptr;    // (the matrix's, or released by collapse_unique_matrix)
+    }
+    ctx->release(ptr);
     if (st != SG_OK) {
-        ctx->release(ptr);
-        ctx->release(idx);
-        ctx->release(val);
         sg_collapse_free(c);
         return st;
     }
-    m->ctx = ctx;
-    m->n_rows = n_u;
-    m->n_cols = B->n_cols;
-    m->nnz = nnz_u;
-    m->dtype = B->dtype;
-    m->d_indptr = ptr;
-    m->d_indices = idx;
-    m->d_data = val;
-    m->owned = true;
-    m->props_state = B->props_state;          // a subset of B's rows: cosine-like if B is; the maxima are upper bounds
-    m->props_max_norm2 = B->props_max_norm2;
-    m->props_max_nnz = B->props_max_nnz;
-    c->unique = m;
     *out = c;
     return SG_OK;
 }
@@ -645,6 +800,58 @@ __global__ void __launch_bounds__(256) expand_simple_kernel(const int32_t *__res
         prev = v;
     }
     cnt[r] = out;
+}
+
+// The same with SIXTEEN lanes per output row (rows of up to sixteen groups: top_n <= 16, the common case): lane e takes the
+// row's e-th group -- the row over groups is read as one contiguous run instead of a 40-byte stride per thread --, the
+// members' places come from a prefix sum over the sixteen sizes, and neighbouring lanes write neighbouring columns
+// (round 6: 0.072 -> ms at 663 k for 53 MB written).
+template <typename T>
+__global__ void __launch_bounds__(256) expand_rows16_kernel(const int32_t *__restrict__ u_cols, const T *__restrict__ u_vals,
+                                                            const int32_t *__restrict__ u_cnt, int32_t u_stride,
+                                                            const uint32_t *__restrict__ gid, const int32_t *__restrict__ row_list,
+                                                            const uint32_t *__restrict__ group_ptr, const uint32_t *__restrict__ members,
+                                                            int64_t n_out, int32_t stride, int32_t *__restrict__ cols,
+                                                            T *__restrict__ vals, int32_t *__restrict__ cnt,
+                                                            uint32_t *__restrict__ slow_count, uint32_t *__restrict__ slow_rows) {
+    const int64_t r = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+    const int sub = threadIdx.x & 15;
+    if (r >= n_out) return;
+    const int64_t row = row_list ? (int64_t)row_list[r] : r;
+    const int64_t ur = gid ? (int64_t)gid[row] : row;
+    const int32_t m = u_cnt[ur];
+    const int32_t *uc = u_cols + ur * u_stride;
+    const T *uv = u_vals + ur * u_stride;
+    const bool have = sub < m;
+    uint32_t lo = 0, size = 0;
+    T v = (T)0;
+    bool tie = false;
+    if (have) {
+        const uint32_t g = (uint32_t)uc[sub];
+        v = uv[sub];
+        lo = group_ptr[g];
+        size = group_ptr[g + 1] - lo;
+        // (see expand_simple_kernel: only a group of several members that TIES with a neighbour needs the merge by column)
+        tie = size != 1u && ((sub > 0 && uv[sub - 1] == v) || (sub + 1 < m && uv[sub + 1] == v));
+    }
+    uint32_t any_tie = tie ? 1u : 0u, at = size;
+#pragma unroll
+    for (int d = 1; d < 16; d <<= 1) {
+        any_tie |= (uint32_t)__shfl_xor((int)any_tie, d, 64);
+        const uint32_t up = (uint32_t)__shfl_up((int)at, d, 16);
+        if (sub >= d) at += up;
+    }
+    if (any_tie) {
+        if (sub == 0) slow_rows[atomicAdd(slow_count, 1u)] = (uint32_t)r;
+        return;
+    }
+    const uint32_t total = (uint32_t)__shfl((int)at, (int)(threadIdx.x & 48u) + 15, 64);
+    uint32_t out = at - size;      // exclusive
+    for (uint32_t p = lo; p < lo + size && out < (uint32_t)stride; ++p, ++out) {
+        cols[r * stride + out] = (int32_t)members[p];
+        vals[r * stride + out] = v;
+    }
+    if (sub == 0) cnt[r] = (int32_t)(total < (uint32_t)stride ? total : (uint32_t)stride);
 }
 
 // Wave per queued row: the groups of one score are merged by column (every lane holds one group's next member, the
@@ -744,10 +951,12 @@ int sg_collapse_expand(sg_ctx *ctx, const SgCollapse *c, const sg_topn *ru, bool
     // (the output's counts and the slow-row queue's head in one launch; the callers do not clear the counts themselves)
     int st = SG_ZERO2(ctx, out->d_counts, sizeof(int32_t) * (size_t)(n_out + 1), slow, 16);
     if (st == SG_OK) {
-        const unsigned g1 = (unsigned)((n_out + 255) / 256);
+        const unsigned g1 = (unsigned)((n_out + 255) / 256), g16 = (unsigned)((n_out * 16 + 255) / 256);
+        const bool narrow = ru->stride <= 16;     // (a row over groups holds at most sixteen of them: a lane each)
         const uint32_t *gid = rows_are_groups ? c->d_gid : nullptr;
         if (out->dtype == SG_F64) {
-            hipLaunchKernelGGL(expand_simple_kernel<double>, dim3(g1), dim3(256), 0, ctx->stream, (const int32_t *)ru->d_cols,
+            hipLaunchKernelGGL(narrow ? expand_rows16_kernel<double> : expand_simple_kernel<double>, dim3(narrow ? g16 : g1), dim3(256), 0,
+                               ctx->stream, (const int32_t *)ru->d_cols,
                                (const double *)ru->d_vals, (const int32_t *)ru->d_counts, ru->stride, gid, row_list,
                                (const uint32_t *)c->d_group_ptr, (const uint32_t *)c->d_members, n_out, out->stride, out->d_cols,
                                (double *)out->d_vals, out->d_counts, slow, slow + 4);
@@ -756,7 +965,8 @@ int sg_collapse_expand(sg_ctx *ctx, const SgCollapse *c, const sg_topn *ru, bool
                                (const uint32_t *)c->d_group_ptr, (const uint32_t *)c->d_members, out->stride, out->d_cols,
                                (double *)out->d_vals, out->d_counts, (const uint32_t *)slow, (const uint32_t *)(slow + 4));
         } else {
-            hipLaunchKernelGGL(expand_simple_kernel<float>, dim3(g1), dim3(256), 0, ctx->stream, (const int32_t *)ru->d_cols,
+            hipLaunchKernelGGL(narrow ? expand_rows16_kernel<float> : expand_simple_kernel<float>, dim3(narrow ? g16 : g1), dim3(256), 0,
+                               ctx->stream, (const int32_t *)ru->d_cols,
                                (const float *)ru->d_vals, (const int32_t *)ru->d_counts, ru->stride, gid, row_list,
                                (const uint32_t *)c->d_group_ptr, (const uint32_t *)c->d_members, n_out, out->stride, out->d_cols,
                                (float *)out->d_vals, out->d_counts, slow, slow + 4);

@@ -155,6 +155,7 @@ struct sg_csr {
     // 1 looked at and not worth it / not possible, 2 `left_groups` holds them (owned, also by views)
     mutable int left_state = 0;
     mutable struct SgCollapse *left_groups = nullptr;
+    struct SgCollapse *rows_of = nullptr;   // this matrix is `unique` of these groups: its rows may be pending (sg_csr_ensure_rows)
 };
 
 struct SgScoreCtx {
@@ -196,10 +197,15 @@ struct SgCollapse {
     uint32_t *d_group_ptr = nullptr;     // n_u + 1
     uint32_t *d_members = nullptr;       // n_orig: rows of group g = members[group_ptr[g] .. group_ptr[g + 1]), ascending
     uint32_t *d_rep_rows = nullptr;      // n_u: lowest row of every group
+    int64_t *d_rep_start = nullptr;      // (table path) n_u: where the representative's row starts in the caller's arrays
+    int32_t *d_rep_len = nullptr;        //              n_u: and its entries -- one load level for whoever copies the rows
     struct sg_csr *unique = nullptr;     // the representatives' rows (owned)
     // round 4: the rows of `unique` may not have been WRITTEN yet (row pointers and sizes are final): they are the rows
     // d_rep_rows of pending_src, and the index build writes them together with its own copies of them (one read of the
     // source instead of three passes: sg_postings.hip, gather_rows_kernel); sg_collapse_materialize writes them alone
+    // round 6: NOBODY on the way to the self-join's index reads them, so the index build no longer writes them either
+    // (88 MB at 663 k): whoever does read the representatives' matrix asks sg_csr_ensure_rows first.  With d_rep_len set the
+    // row POINTERS of `unique` are pending as well.
     const struct sg_csr *pending_src = nullptr;
 };
 
@@ -352,6 +358,7 @@ int sg_spgemm_exact_selfjoin_rows(sg_ctx *ctx, const sg_csr *A, const sg_posting
 // sg_collapse.hip
 int sg_collapse_build(sg_ctx *ctx, const sg_csr *B, SgCollapse **out, bool left_side = false, bool defer_rows = false);
 int sg_collapse_materialize(sg_ctx *ctx, SgCollapse *c);
+int sg_csr_ensure_rows(sg_ctx *ctx, const sg_csr *m);
 void sg_collapse_free(SgCollapse *c);
 int sg_collapse_expand(sg_ctx *ctx, const SgCollapse *c, const sg_topn *ru, bool rows_are_groups, sg_topn *out,
                        const int32_t *row_list = nullptr);   // row_list: output row k is the caller's row row_list[k]

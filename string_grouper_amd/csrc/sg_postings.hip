@@ -17,6 +17,7 @@
 #include <stdlib.h>
 
 #include "sg_internal.h"
+#include "sg_scan.h"
 
 // Thread -> right-hand row.  Consecutive rows share a column tile, hence the bins of the frequent terms:
 // with thread i on row i a whole wave hammers the same counter.  Consecutive threads are therefore dealt
@@ -502,16 +503,20 @@ __global__ void __launch_bounds__(256) null_postings_kernel(uint32_t *__restrict
 // ---- position space: a fixed permutation of the right-hand rows (see sg_postings in sg_internal.h)
 // pos_of[j] = j * M mod n with gcd(M, n) = 1, M ~ 0.618 n: neighbours land 0.618 n apart and any run of rows spreads
 // evenly over the positions (a low-discrepancy sequence) -- what a sorted list needs, and harmless on any other.
-__global__ void __launch_bounds__(256) permutation_kernel(uint32_t n, uint64_t mult, uint32_t *__restrict__ pos_of,
-                                                          uint32_t *__restrict__ orig_of, const int64_t *__restrict__ indptr,
-                                                          uint32_t *__restrict__ len_by_pos) {
-    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= n) return;
-    const uint32_t p = (uint32_t)(((uint64_t)j * mult) % (uint64_t)n);
-    pos_of[j] = p;
-    orig_of[p] = j;
-    len_by_pos[p] = (uint32_t)(indptr[j + 1] - indptr[j]);   // (the matrix's own row pointers: final also while its rows are pending)
-}
+// Round 6: no launch of its own -- the prefix sum over the rows' lengths in position order (the row pointers of the matrix in
+// position order) computes the permutation as it loads: position p holds row g = p * M^-1 mod n.
+struct PermutedLenLoad {
+    uint64_t n, minv;
+    const int32_t *len_of_row;     // lengths by row (groups: SgCollapse::d_rep_len); null: from the row pointers
+    const int64_t *indptr;
+    uint32_t *pos_of, *orig_of;
+    __device__ __forceinline__ int64_t operator()(int64_t p) const {
+        const uint32_t g = (uint32_t)(((uint64_t)p * minv) % n);
+        orig_of[p] = g;
+        pos_of[g] = (uint32_t)p;
+        return len_of_row ? (int64_t)len_of_row[g] : indptr[g + 1] - indptr[g];
+    }
+};
 
 // ---- the 8-bit copies of the rows for the pruned multiply's SECOND filter (SgScoreCtx::q8, sg_internal.h; round 5)
 // One 16-byte unit of a row's record: unit 0 = {first packed entry, the row's own index, entries | flag, 0}, unit u >= 1 =
@@ -556,64 +561,137 @@ __global__ void __launch_bounds__(256) q8_pack_kernel(const int64_t *__restrict_
                          orig_of ? orig_of[p] : (uint32_t)p, inv_norm);
 }
 
-// Round 4: ONE read of the source rows for every copy of them the index keeps.  Position p of the index holds row
-// g = orig_of[p] of the matrix it is built over; with groups of identical rows that matrix is the representatives' --
-// row g = row rep_rows[g] of the caller's matrix, not written anywhere yet (SgCollapse::pending_src) -- and the copies are
-//   * the representatives' matrix itself (rows in group order; the left side of a one-sided fallback, the exact kernel),
+// ONE read of the source rows for every copy of them the index keeps (round 4).  Position p of the index holds row
+// g = orig_of[p] of the matrix it is built over; with groups of identical rows that matrix is the representatives' -- row g
+// = row rep_rows[g] of the caller's matrix -- and the copies are
 //   * the matrix in position order (what the index and the self-join form read),
-//   * its packed rows {term, value} + {pointer, row} per position (the exact scoring of the pruned multiply).
-// Rounds 2-3 made them one after the other: unique_rows, permute_rows, fwd_pack -- 530 MB moved for 350.
+//   * its packed rows {term, value} + {pointer, row} per position (the exact scoring of the pruned multiply),
+//   * the 8-bit records of the second filter.
+// Round 6: (a) the representatives' matrix in GROUP order is no longer written here -- nothing on the self-join's way reads
+// it (sg_csr_ensure_rows writes it for whoever does): 88 of 420 MB at 663 k; (b) where a row starts in the source and how
+// long it is come from two arrays the grouping leaves per group (rep_start, rep_len): the chain position -> group ->
+// representative -> row pointers -> entries was four dependent loads deep, now two; (c) TWO rows per sixteen lanes with all
+// loads of a stage issued before the first is used, and a row's first 32 entries in flight together: the kernel ran at the
+// latency of its chain (0.21 ms for 0.4 GB); (d) the 8-bit records are put together from the registers that hold the
+// entries (four shuffles a round), not by reading the row a second time.
+#define SG_GATHER_ROWS 2
+template <typename T>
+__device__ __forceinline__ uint32_t q8_entry_of(int32_t k, T v, bool have, float inv_norm) {
+    if (!have) return 0u;
+    const float q = ceilf((float)v * inv_norm * 255.0f * 1.000002f);
+    const uint32_t bq = q >= 255.0f ? 255u : (q >= 1.0f ? (uint32_t)q : 1u);
+    return ((uint32_t)k << 8) | bq;
+}
+// round r of a row (entries 16 r .. 16 r + 15, one per lane: wq) -> units 4 r + 1 .. 4 r + 4 of its record, written by the
+// lanes of those numbers (unit u = entries 4 u - 4 .. 4 u - 1)
+__device__ __forceinline__ void q8_write_round(uint4 *__restrict__ rec, int r, uint32_t wq, int sub, uint32_t units) {
+    const int q = (sub - 4 * r - 1) & 3;
+    const int base = (int)(threadIdx.x & 48u) + 4 * q;
+    const uint32_t x0 = (uint32_t)__shfl((int)wq, base, 64), x1 = (uint32_t)__shfl((int)wq, base + 1, 64);
+    const uint32_t x2 = (uint32_t)__shfl((int)wq, base + 2, 64), x3 = (uint32_t)__shfl((int)wq, base + 3, 64);
+    if (sub >= 4 * r + 1 && sub <= 4 * r + 4 && (uint32_t)sub < units) rec[sub] = make_uint4(x0, x1, x2, x3);
+}
+template <typename T>
+__device__ __forceinline__ void store_packed(void *__restrict__ fwd, int64_t at, int32_t k, T v) {
+    if (sizeof(T) == 4) {
+        reinterpret_cast<int2 *>(fwd)[at] = make_int2(k, __float_as_int((float)v));
+    } else {
+        const long long bits = __double_as_longlong((double)v);
+        reinterpret_cast<int4 *>(fwd)[at] = make_int4(k, 0, (int)(bits & 0xffffffffll), (int)(bits >> 32));
+    }
+}
 template <typename T>
 __global__ void __launch_bounds__(256) gather_rows_kernel(const int64_t *__restrict__ indptr, const int32_t *__restrict__ indices,
                                                           const T *__restrict__ data, int64_t n_rows,
                                                           const uint32_t *__restrict__ orig_of,
                                                           const uint32_t *__restrict__ rep_rows /* null: the source IS the matrix */,
+                                                          const int64_t *__restrict__ rep_start /* null: from rep_rows / the row pointers */,
+                                                          const int32_t *__restrict__ rep_len,
                                                           const int64_t *__restrict__ perm_ptr, int32_t *__restrict__ perm_indices,
                                                           T *__restrict__ perm_data,
-                                                          const int64_t *__restrict__ uniq_ptr /* null: no copy in row order */,
-                                                          int32_t *__restrict__ uniq_indices, T *__restrict__ uniq_data,
                                                           uint32_t *__restrict__ fwd_ptr /* null: no packed rows */, void *__restrict__ fwd,
                                                           uint4 *__restrict__ q8 /* null: no 8-bit copies */, float inv_norm) {
-    const int64_t p = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+    const int64_t grp = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
     const int sub = threadIdx.x & 15;
-    if (p > n_rows) return;
-    if (p == n_rows) {
-        if (fwd_ptr && sub == 0) reinterpret_cast<uint2 *>(fwd_ptr)[p] = make_uint2((uint32_t)perm_ptr[n_rows], 0u);
-        // the exact scoring reads packed rows in rounds of eight entries and multiplies what lies past a row's end by a = 0:
-        // the pad behind the LAST row must hold finite values (0 * NaN would poison that row's score)
-        if (fwd && sub < 8) {
-            const int64_t at = perm_ptr[n_rows] + sub;
-            if (sizeof(T) == 4) reinterpret_cast<int2 *>(fwd)[at] = make_int2(0, 0);
-            else reinterpret_cast<int4 *>(fwd)[at] = make_int4(0, 0, 0, 0);
-        }
-        return;
+    const int64_t p0 = grp * SG_GATHER_ROWS;
+    if (p0 > n_rows) return;
+    bool valid[SG_GATHER_ROWS];
+    uint32_t g[SG_GATHER_ROWS];
+    int64_t src[SG_GATHER_ROWS], dst[SG_GATHER_ROWS];
+    int32_t n[SG_GATHER_ROWS];
+#pragma unroll
+    for (int i = 0; i < SG_GATHER_ROWS; ++i) {
+        valid[i] = p0 + i < n_rows;
+        g[i] = valid[i] ? orig_of[p0 + i] : 0u;
+        dst[i] = p0 + i <= n_rows ? perm_ptr[p0 + i] : 0;
     }
-    const int64_t g = orig_of[p];
-    const int64_t j = rep_rows ? (int64_t)rep_rows[g] : g;
-    const int64_t src = indptr[j], n = indptr[j + 1] - src, dst = perm_ptr[p];
-    const int64_t udst = uniq_ptr ? uniq_ptr[g] : 0;
-    if (fwd_ptr && sub == 0) reinterpret_cast<uint2 *>(fwd_ptr)[p] = make_uint2((uint32_t)dst, (uint32_t)g);
-    for (int64_t e = sub; e < n; e += 16) {
-        const int32_t k = indices[src + e];
-        const T v = data[src + e];
-        perm_indices[dst + e] = k;
-        perm_data[dst + e] = v;
-        if (uniq_ptr) {
-            uniq_indices[udst + e] = k;
-            uniq_data[udst + e] = v;
+    if (rep_start) {
+#pragma unroll
+        for (int i = 0; i < SG_GATHER_ROWS; ++i) {
+            src[i] = valid[i] ? rep_start[g[i]] : 0;
+            n[i] = valid[i] ? rep_len[g[i]] : 0;
         }
-        if (fwd) {
-            if (sizeof(T) == 4) {
-                reinterpret_cast<int2 *>(fwd)[dst + e] = make_int2(k, __float_as_int((float)v));
-            } else {
-                const long long bits = __double_as_longlong((double)v);
-                reinterpret_cast<int4 *>(fwd)[dst + e] = make_int4(k, 0, (int)(bits & 0xffffffffll), (int)(bits >> 32));
+    } else {
+        int64_t j[SG_GATHER_ROWS];
+#pragma unroll
+        for (int i = 0; i < SG_GATHER_ROWS; ++i) j[i] = (valid[i] && rep_rows) ? (int64_t)rep_rows[g[i]] : (int64_t)g[i];
+#pragma unroll
+        for (int i = 0; i < SG_GATHER_ROWS; ++i) {
+            src[i] = valid[i] ? indptr[j[i]] : 0;
+            n[i] = valid[i] ? (int32_t)(indptr[j[i] + 1] - src[i]) : 0;
+        }
+    }
+    // a row's first two rounds of entries: all loads before the first use
+    int32_t k[SG_GATHER_ROWS][2];
+    T v[SG_GATHER_ROWS][2];
+#pragma unroll
+    for (int i = 0; i < SG_GATHER_ROWS; ++i)
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const bool have = sub + 16 * r < n[i];
+            k[i][r] = have ? indices[src[i] + sub + 16 * r] : 0;
+            v[i][r] = have ? data[src[i] + sub + 16 * r] : (T)0;
+        }
+#pragma unroll
+    for (int i = 0; i < SG_GATHER_ROWS; ++i) {
+        const int64_t p = p0 + i;
+        if (p == n_rows) {     // the sentinel position behind the last row
+            if (fwd_ptr && sub == 0) reinterpret_cast<uint2 *>(fwd_ptr)[p] = make_uint2((uint32_t)dst[i], 0u);
+            // the exact scoring reads packed rows in rounds of eight entries and multiplies what lies past a row's end by a = 0:
+            // the pad behind the LAST row must hold finite values (0 * NaN would poison that row's score)
+            if (fwd && sub < 8) store_packed<T>(fwd, dst[i] + sub, 0, (T)0);
+        }
+        if (!valid[i]) continue;
+        const uint32_t units = q8 ? sg_q8_units(n[i]) : 0u;
+        uint4 *rec = q8 ? q8 + p * (SG_Q8_STRIDE / 16) : nullptr;
+        if (sub == 0) {
+            if (fwd_ptr) reinterpret_cast<uint2 *>(fwd_ptr)[p] = make_uint2((uint32_t)dst[i], g[i]);
+            if (q8) rec[0] = make_uint4((uint32_t)dst[i], g[i], (uint32_t)n[i] | (n[i] <= (int32_t)SG_Q8_MAX_ENTRIES ? 0u : 0x80000000u), 0u);
+        }
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int32_t e = sub + 16 * r;
+            const bool have = e < n[i];
+            if (have) {
+                perm_indices[dst[i] + e] = k[i][r];
+                perm_data[dst[i] + e] = v[i][r];
+                if (fwd) store_packed<T>(fwd, dst[i] + e, k[i][r], v[i][r]);
             }
+            if (units > 1u && 16 * r < n[i]) q8_write_round(rec, r, q8_entry_of<T>(k[i][r], v[i][r], have, inv_norm), sub, units);
+        }
+        for (int r = 2; 16 * r < n[i]; ++r) {     // rows beyond 32 entries
+            const int32_t e = sub + 16 * r;
+            const bool have = e < n[i];
+            const int32_t kk = have ? indices[src[i] + e] : 0;
+            const T vv = have ? data[src[i] + e] : (T)0;
+            if (have) {
+                perm_indices[dst[i] + e] = kk;
+                perm_data[dst[i] + e] = vv;
+                if (fwd) store_packed<T>(fwd, dst[i] + e, kk, vv);
+            }
+            if (units > 1u && r < 4) q8_write_round(rec, r, q8_entry_of<T>(kk, vv, have, inv_norm), sub, units);
         }
     }
-    // the row's 8-bit copy: lane `sub` writes unit `sub` (the entries come from the cache: the group has just read them)
-    if (q8 && (uint32_t)sub < sg_q8_units(n))
-        q8_write_unit<T>(q8 + p * (SG_Q8_STRIDE / 16), (uint32_t)sub, indices, data, src, n, (uint32_t)dst, (uint32_t)g, inv_norm);
 }
 
 __global__ void score_ctx_kernel(SgScoreCtx v, SgScoreCtx *out) {
@@ -645,42 +723,52 @@ static int build_permuted(sg_ctx *ctx, const sg_csr *B, int64_t tile_cols, sg_cs
     const uint64_t n = (uint64_t)B->n_rows;
     uint64_t mult = (uint64_t)(0.6180339887498949 * (double)n) | 1ull;
     while (gcd_u64(mult, n) != 1) mult += 2;
+    mult %= n;
+    // position p holds row p * mult^-1 mod n (extended Euclid; n < 2^31)
+    uint64_t minv = 0;
+    {
+        long long t0 = 0, t1 = 1, r0 = (long long)n, r1 = (long long)mult;
+        while (r1 != 0) {
+            const long long q = r0 / r1, t2 = t0 - q * t1, r2 = r0 - q * r1;
+            t0 = t1;
+            t1 = t2;
+            r0 = r1;
+            r1 = r2;
+        }
+        minv = (uint64_t)(t0 < 0 ? t0 + (long long)n : t0);
+    }
     uint32_t *orig_of = nullptr, *pos_of = nullptr, *len_by_pos = nullptr;
     int64_t *ptr = nullptr;
     int32_t *idx = nullptr;
     void *val = nullptr;
     const size_t vs = B->dtype == SG_F64 ? 8 : 4;
+    // the rows of B itself, or -- B the representatives' matrix of `pending`, not written -- of the matrix they come from
+    const bool from_groups = pending && pending->pending_src;
+    const bool by_group = from_groups && pending->d_rep_len != nullptr;   // (table path: start and length per group; else B's row pointers are there)
     int st = sg_alloc(ctx, (size_t)n + 1, &orig_of);
     if (st == SG_OK) st = sg_alloc(ctx, (size_t)n + 1, &pos_of);
-    if (st == SG_OK) st = sg_alloc(ctx, (size_t)n + 1, &len_by_pos);
     if (st == SG_OK) st = sg_alloc(ctx, (size_t)n + 2, &ptr);
     if (st == SG_OK) st = sg_alloc(ctx, (size_t)B->nnz + 64, &idx);
     if (st == SG_OK) st = ctx->alloc(((size_t)B->nnz + 64) * vs, &val);
+    if (st == SG_OK)
+        st = sg_scan_launch<int64_t>(ctx, PermutedLenLoad{n, minv, by_group ? pending->d_rep_len : (const int32_t *)nullptr, B->d_indptr, pos_of, orig_of},
+                                     SgScanStoreArray<int64_t>{ptr}, (int64_t)n, ptr + n);
     if (st == SG_OK) {
-        hipLaunchKernelGGL(permutation_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, (uint32_t)n, mult, pos_of,
-                           orig_of, B->d_indptr, len_by_pos);
-        st = sg_exclusive_scan_i32_to_i64(ctx, (const int32_t *)len_by_pos, ptr, (int64_t)n);
-    }
-    if (st == SG_OK) {
-        const unsigned grid = (unsigned)(((n + 1) * 16 + 255) / 256);
-        const sg_csr *src = pending && pending->pending_src ? pending->pending_src : B;
-        const uint32_t *rep_rows = pending && pending->pending_src ? pending->d_rep_rows : nullptr;
-        const int64_t *uniq_ptr = rep_rows ? B->d_indptr : nullptr;
+        const unsigned grid = (unsigned)((((n + 1 + SG_GATHER_ROWS - 1) / SG_GATHER_ROWS) * 16 + 255) / 256);
+        const sg_csr *src = from_groups ? pending->pending_src : B;
+        const uint32_t *rep_rows = from_groups ? pending->d_rep_rows : nullptr;
+        const int64_t *rep_start = by_group ? pending->d_rep_start : nullptr;
+        const int32_t *rep_len = by_group ? pending->d_rep_len : nullptr;
         if (B->dtype == SG_F64)
             hipLaunchKernelGGL(gather_rows_kernel<double>, dim3(grid), dim3(256), 0, ctx->stream, src->d_indptr, src->d_indices,
-                               (const double *)src->d_data, B->n_rows, (const uint32_t *)orig_of, rep_rows, (const int64_t *)ptr, idx,
-                               (double *)val, uniq_ptr, (int32_t *)B->d_indices, (double *)B->d_data, fwd_ptr, fwd,
-                               (uint4 *)(fwd_ptr ? q8 : nullptr), inv_norm);
+                               (const double *)src->d_data, B->n_rows, (const uint32_t *)orig_of, rep_rows, rep_start, rep_len,
+                               (const int64_t *)ptr, idx, (double *)val, fwd_ptr, fwd, (uint4 *)(fwd_ptr ? q8 : nullptr), inv_norm);
         else
             hipLaunchKernelGGL(gather_rows_kernel<float>, dim3(grid), dim3(256), 0, ctx->stream, src->d_indptr, src->d_indices,
-                               (const float *)src->d_data, B->n_rows, (const uint32_t *)orig_of, rep_rows, (const int64_t *)ptr, idx,
-                               (float *)val, uniq_ptr, (int32_t *)B->d_indices, (float *)B->d_data, fwd_ptr, fwd,
-                               (uint4 *)(fwd_ptr ? q8 : nullptr), inv_norm);
+                               (const float *)src->d_data, B->n_rows, (const uint32_t *)orig_of, rep_rows, rep_start, rep_len,
+                               (const int64_t *)ptr, idx, (float *)val, fwd_ptr, fwd, (uint4 *)(fwd_ptr ? q8 : nullptr), inv_norm);
         if (hipGetLastError() != hipSuccess) st = SG_ERR_HIP;
-        if (st == SG_OK) {
-            if (pending) pending->pending_src = nullptr;     // (the representatives' rows are written now)
-            *fwd_done = fwd_ptr != nullptr;
-        }
+        if (st == SG_OK) *fwd_done = fwd_ptr != nullptr;     // (the representatives' matrix in group order stays pending)
     }
     ctx->release(len_by_pos);
     sg_csr *m = st == SG_OK ? new (std::nothrow) sg_csr() : nullptr;
@@ -857,7 +945,7 @@ extern "C" int sg_postings_build_flags(sg_ctx *ctx, const sg_csr *B_in, int32_t 
         early_fwd_ptr = nullptr;
         early_q8 = nullptr;
     }
-    if (pending && pending->pending_src) {      // no copy in position order was made: the representatives' rows by themselves
+    if (pending && pending->pending_src && !permuted) {      // no copy in position order was made: the index reads the representatives' matrix itself
         const int stm = sg_collapse_materialize(ctx, pending);
         if (stm != SG_OK) {
             sg_csr_free(permuted);

@@ -2010,6 +2010,7 @@ int sg_spgemm_pruned_symmetric(sg_ctx *ctx, const sg_csr *A, const sg_postings *
     *done = false;
     // the self-join runs in position space: its left matrix is the one the index was built over (sg_postings.hip)
     if (Bt->permuted) A = Bt->permuted;
+    else SG_TRY(sg_csr_ensure_rows(ctx, A));   // (no copy in position order: the rows of A itself are read)
     const size_t vs = A->dtype == SG_F64 ? 8 : 4;
     const int64_t n = A->n_rows;
     if (row_hi < 0) row_hi = n;   // the whole matrix

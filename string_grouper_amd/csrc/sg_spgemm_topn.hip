@@ -1007,7 +1007,8 @@ extern "C" int sg_spgemm_topn(sg_ctx *ctx, const sg_csr *A, const sg_postings *B
     if (prune && A->n_rows >= 32768 && A->nnz > 0 && Bt->n_terms > 0 &&
         (double)A->nnz / (double)A->n_rows > 0.004 * (double)Bt->n_terms && env_int(ctx, "SG_PRUNE_PILOT", 1) != 0) {
         bool keep_pruned = true;
-        const int pst = prune_pilot(ctx, A, Bt, stride, threshold, delta, symmetric, &keep_pruned);
+        int pst = sg_csr_ensure_rows(ctx, A);     // (the pilot runs the one-sided kernel over blocks of A's rows)
+        if (pst == SG_OK) pst = prune_pilot(ctx, A, Bt, stride, threshold, delta, symmetric, &keep_pruned);
         if (pst != SG_OK) {
             sg_topn_free(r);
             return pst;
@@ -1036,6 +1037,9 @@ extern "C" int sg_spgemm_topn(sg_ctx *ctx, const sg_csr *A, const sg_postings *B
             st = sg_spgemm_pruned_symmetric(ctx, A, Bt, stride, r, threshold, delta,
                                             (unsigned long long *)(ctx->d_stat_words + 2), &sym_done);
         ctx->prune_symmetric = sym_done;
+        // everything below reads the rows of A itself (the self-join form read the index's copy in position order): the
+        // representatives' matrix of an index over groups is written now if it is still pending
+        if (!sym_done && st == SG_OK) st = sg_csr_ensure_rows(ctx, A);
         if (prune && !sym_done && st == SG_OK) {
             SgTimer kt(ctx, SG_K_SPGEMM_KERNEL);
             st = sg_spgemm_pruned_launch(ctx, A, Bt, stride < SG_TOPN_LANES ? stride : SG_TOPN_LANES, r, threshold, delta,

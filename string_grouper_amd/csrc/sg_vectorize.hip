@@ -71,6 +71,13 @@ struct TokenCache {             // tokenised strings in the padded layout
     bool keys_are_columns = false; // d_keys holds column ids instead of n-gram keys (dense mode, after the fit's df pass)
     uint32_t *d_longs = nullptr;   // [0] how many strings are still to be tokenised by the workgroup-per-string kernel, then
                                    // their rows: kept while that question is open (tokenize_set_t, defer_longs)
+    // Round 6: the row pointers of the matrix a transform of THESE strings will return (a column of the fit keeps every
+    // n-gram: prefix sums of d_cnt), made by the fit's end so that their last entry -- the matrix's non-zeros, which the
+    // transform needs on the host to size its arrays -- comes back with the synchronisation the fit makes anyway (the size
+    // of the vocabulary); the transform asked on its own before: one of the step's five host round trips.  Handed to the
+    // first transform that wants them (its matrix owns them from then on).
+    int64_t *d_indptr = nullptr;
+    int64_t nnz = -1;
 };
 
 struct VocabImpl {
@@ -885,6 +892,7 @@ static void free_cache(sg_ctx *ctx, TokenCache &c) {
     ctx->release(c.d_cnt);
     ctx->release(c.d_keys);
     ctx->release(c.d_tf);
+    ctx->release(c.d_indptr);
     c = TokenCache();
 }
 
@@ -1330,12 +1338,24 @@ extern "C" int sg_vec_fit_end(sg_ctx *ctx, sg_vocab *v, int64_t n_docs_total) {
             uint32_t n_terms = 0;
             for (int attempt = 0; attempt < 2 && st == SG_OK; ++attempt) {
                 // the size of the vocabulary and -- the question fit_begin left open -- whether any column holds strings for the
-                // last tokeniser stage: ONE synchronisation
+                // last tokeniser stage: ONE synchronisation; the row pointers of the columns' matrices ride along (TokenCache)
                 std::vector<uint32_t> n_long(im->caches.size(), 0u);
+                std::vector<int64_t> nnz_of(im->caches.size(), -1);
+                for (size_t q = 0; q < im->caches.size() && st == SG_OK; ++q) {
+                    TokenCache &c = im->caches[q];
+                    if (c.n <= 0) continue;
+                    if (!c.d_indptr) st = sg_alloc(ctx, (size_t)c.n + 1, &c.d_indptr);
+                    if (st == SG_OK) st = sg_exclusive_scan_i32_to_i64(ctx, c.d_cnt, c.d_indptr, c.n);
+                }
+                if (st != SG_OK) break;
                 hipError_t e = hipMemcpyAsync(&n_terms, d_total, 4, hipMemcpyDeviceToHost, ctx->stream);
-                for (size_t q = 0; q < im->caches.size() && e == hipSuccess; ++q)
+                for (size_t q = 0; q < im->caches.size() && e == hipSuccess; ++q) {
                     if (im->caches[q].d_longs) e = hipMemcpyAsync(&n_long[q], im->caches[q].d_longs, 4, hipMemcpyDeviceToHost, ctx->stream);
+                    if (e == hipSuccess && im->caches[q].d_indptr)
+                        e = hipMemcpyAsync(&nnz_of[q], im->caches[q].d_indptr + im->caches[q].n, 8, hipMemcpyDeviceToHost, ctx->stream);
+                }
                 if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+                for (size_t q = 0; q < im->caches.size(); ++q) im->caches[q].nnz = nnz_of[q];
                 if (e != hipSuccess) {
                     sg_set_error("reading the vocabulary size failed: %s", hipGetErrorString(e));
                     st = SG_ERR_HIP;
@@ -1348,7 +1368,8 @@ extern "C" int sg_vec_fit_end(sg_ctx *ctx, sg_vocab *v, int64_t n_docs_total) {
                     st = resolve_longs(ctx, v, im->caches[q], im->d_df_table, 0, im->df_stride, n_long[q]);   // (marks: replicas 0)
                 }
                 if (!any_long || st != SG_OK) break;
-                // long strings have marked keys of their own: the vocabulary is taken again
+                // long strings have marked keys of their own: the vocabulary is taken again (and their rows' counts were not
+                // final when the row pointers were summed: the next attempt sums them again)
                 const unsigned grid = (unsigned)((v->key_space + 255) / 256);
                 (void)grid;
                 st = sg_exclusive_scan_positive_i32(ctx, im->d_df_table, (uint32_t *)v->d_key_to_col, v->key_space, d_total);
@@ -1591,9 +1612,19 @@ extern "C" int sg_vec_transform(sg_ctx *ctx, const sg_vocab *v, const sg_strings
         SgTimer timer(ctx, SG_K_WEIGHT);
         // the tokens of a column that was part of fit() are all in the vocabulary (min_df = 1): kept == distinct n-grams
         const bool all_kept = tc != &local;
+        TokenCache *fitted = all_kept ? const_cast<TokenCache *>(tc) : nullptr;
+        const bool have_ptr = fitted && fitted->d_indptr && fitted->nnz >= 0 && n > 0;   // (summed and read by the fit's end)
+        if (have_ptr) {
+            indptr = fitted->d_indptr;
+            nnz = fitted->nnz;
+            fitted->d_indptr = nullptr;      // the matrix owns them now; a second transform of the column sums again
+            fitted->nnz = -1;
+        }
         if (!all_kept) st = sg_alloc(ctx, (size_t)n + 1, &kept);
-        if (st == SG_OK) st = sg_alloc(ctx, (size_t)n + 1, &indptr);
-        if (st == SG_OK && n > 0) {
+        if (st == SG_OK && !have_ptr) st = sg_alloc(ctx, (size_t)n + 1, &indptr);
+        if (have_ptr) {
+            ;
+        } else if (st == SG_OK && n > 0) {
             const unsigned grid = (unsigned)((n + 255) / 256);
             if (all_kept)
                 ;
@@ -1609,7 +1640,7 @@ extern "C" int sg_vec_transform(sg_ctx *ctx, const sg_vocab *v, const sg_strings
         } else if (st == SG_OK) {
             (void)hipMemsetAsync(indptr, 0, sizeof(int64_t), ctx->stream);
         }
-        if (st == SG_OK) {
+        if (st == SG_OK && !have_ptr) {
             if (hipMemcpyAsync(&nnz, indptr + n, sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
                 hipStreamSynchronize(ctx->stream) != hipSuccess)
                 st = SG_ERR_HIP;

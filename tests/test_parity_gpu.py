@@ -1869,3 +1869,58 @@ def test_second_filter_is_used_where_it_pays_and_changes_no_result(ctx):
             h.free()
     ctx.reset_options()
     assert sizes[None][0] < sizes["1"][0] and sizes[None][1] == sizes[None][2] and sizes["1"][2] < sizes["1"][1], sizes
+
+
+def test_bucket_walk_behind_a_full_bucket_keeps_every_hit(ctx):
+    """Regression for the compiler finding of round 5 (scripts/q8_debug.py): hipcc 7.2 compiled the per-lane
+    walk behind a FULL bucket of row i's hash with the hit read off the last trip's compare mask, and a row with five terms in
+    one bucket lost four matches -- on exactly this list (20 000 synthetic names, seed 1234, every row indexed).  The walk is
+    now a loop the wave leaves together; a toolchain bump that brings the miscompile back (in row_values or in any other
+    divergent walk over the hash) fails here: second filter on == off == forced == the port, bit for bit, and the same on
+    a list built to put MANY terms into one bucket."""
+    names = _names(20000, seed=1234)
+    A = _tfidf(names, np.float32)
+    want = P.sp_matmul_topn_port(A, A.T, 10, 0.8, True, 16)
+    for q8 in ("1", "0", None):
+        ctx.set_option("SG_Q8", q8)
+        ctx.set_option("SG_COLLAPSE", "0")
+        dA = ctx.csr_from_scipy(A)
+        post = ctx.postings_build(dA)
+        res = ctx.spgemm_topn(dA, post, 10, 0.8, True)
+        assert_csr_identical(res.to_scipy(), want, f"20 000 names, every row indexed, SG_Q8={q8}")
+        for h in (res, post, dA):
+            h.free()
+    ctx.reset_options()
+    # rows whose terms crowd a few buckets (the kernel's term_hash, restated: a bucket is four slots, five or more of a row's
+    # terms in one bucket make lookups walk past it)
+    rng = np.random.default_rng(7)
+    n, V = 6000, 1 << 15
+    bucket = (((np.arange(V, dtype=np.uint64) * np.uint64(0x9E3779)) & np.uint64(0xFFFFFFFF)) >> np.uint64(15)) & np.uint64(124)
+    by_bucket = [np.flatnonzero(bucket == b) for b in range(0, 128, 4)]
+    base_rows = []
+    for _ in range(600):
+        picks = [rng.choice(by_bucket[b], 7, replace=False) for b in rng.choice(32, 3, replace=False)]
+        base_rows.append(np.unique(np.concatenate(picks + [rng.integers(0, V, 3)])))
+    rows, cols, vals = [], [], []
+    for i in range(n):
+        k = base_rows[i % 600].copy()
+        if i >= 600:                                   # near-duplicates: drop one term, add one
+            k = np.unique(np.concatenate([np.delete(k, rng.integers(0, len(k))), [int(rng.integers(0, V))]]))
+        v = rng.random(len(k)).astype(np.float32) + 0.5
+        v /= np.float32(np.sqrt(np.sum(v.astype(np.float64) ** 2)) * 1.0000002)
+        rows += [i] * len(k)
+        cols += k.tolist()
+        vals += v.tolist()
+    M = sp.csr_matrix((np.asarray(vals, np.float32), (rows, cols)), shape=(n, V))
+    M.sort_indices()
+    want_m = P.sp_matmul_topn_port(M, M.T, 10, 0.6, True, 16)
+    for q8 in ("1", "0"):
+        ctx.set_option("SG_Q8", q8)
+        ctx.set_option("SG_Q8_MIN_THRESHOLD", "0.5")
+        dM = ctx.csr_from_scipy(M)
+        post = ctx.postings_build(dM)
+        res = ctx.spgemm_topn(dM, post, 10, 0.6, True)
+        assert_csr_identical(res.to_scipy(), want_m, f"crowded buckets, SG_Q8={q8}")
+        for h in (res, post, dM):
+            h.free()
+    ctx.reset_options()
