@@ -65,6 +65,9 @@ def parse_args():
     ap.add_argument("--no-side-runs", action="store_true", help="skip the SG_COLLAPSE=0 and other-dtype runs of the step")
     ap.add_argument("--no-config3", action="store_true", help="N > 1: skip the nested 5 M-name block (configs3_5M)")
     ap.add_argument("--config3-rows", type=int, default=5_000_000, help=argparse.SUPPRESS)
+    ap.add_argument("--dup-frac", type=float, default=None,
+                    help="share of names whose TF-IDF row repeats an earlier name's (SynthNames-v1 as surveyed: 0.165; the "
+                         "reference's README: 0.0026); given: string_grouper_amd.synth.synth_names(dup_frac=...) is the workload")
     ap.add_argument("--cpu-cores", type=int, default=4, help="cores of the reference CPU leg (README: 4)")
     ap.add_argument("--cpu-full", action="store_true", help=argparse.SUPPRESS)        # round-3 flag: now the default
     ap.add_argument("--cpu-sample", action="store_true", help="CPU baseline: bounded legs only (a 40 000-name run of the "
@@ -166,7 +169,7 @@ def run(args):
     stream = torch.cuda.current_stream().cuda_stream
     ctx = N.Context(local_rank, stream=stream if stream else None)
 
-    names = synth_names(args.rows, 1234)
+    names = synth_names(args.rows, 1234, dup_frac=args.dup_frac)
     make_vec = lambda: HipTfidfVectorizer(dtype=dtype, ctx=ctx)  # noqa: E731
     dist_mode = os.environ.get("SG_BENCH_DIST_MODE", "sharded")
     whole_column_here = (not distributed) or (rank == 0 and dist_mode != "sharded")
@@ -202,26 +205,27 @@ def run(args):
             return res
         return one_gpu_step(make_vec)
 
-    def one_gpu_step(factory):
+    def one_gpu_step(factory, prep=None):
+        prep = prepared if prep is None else prep
         vec = factory()
-        vec.fit_prepared([prepared])
-        A = vec.transform_prepared(prepared)
+        vec.fit_prepared([prep])
+        A = vec.transform_prepared(prep)
         post = ctx.postings_build(A)
         res = ctx.spgemm_topn(A, post, args.top_n, args.min_similarity, True)
         ctx.sync()
         res._keep = (A, post, vec)
         return res
 
-    def side_run(factory, k=12):
-        """The same step under another setting (other dtype, a switch of the context), timed like the main region on a
-        shorter one: (ms per step, the dominant kernel's ms, its stats)."""
-        one_gpu_step(factory).free()
-        one_gpu_step(factory).free()
+    def side_run(factory, k=12, prep=None):
+        """The same step under another setting (other dtype, a switch of the context, another list), timed like the main
+        region on a shorter one: (ms per step, the dominant kernel's ms, its stats)."""
+        one_gpu_step(factory, prep).free()
+        one_gpu_step(factory, prep).free()
         torch.cuda.synchronize()
         t = time.perf_counter()
         kms, st = [], None
         for _ in range(k):
-            r = one_gpu_step(factory)
+            r = one_gpu_step(factory, prep)
             st = ctx.stats()
             kms.append(st["ms_spgemm_kernel"] or st["ms_spgemm_topn"])
             r.free()
@@ -362,7 +366,8 @@ def run(args):
         # what rank 0's collectives moved per step: {kind: [calls, bytes received]} (string_grouper_amd/distributed.py)
         "collectives_per_step": ({k: [v[0] / args.steps, v[1] / args.steps] for k, v in coll_tally.items()}
                                  if distributed else None),
-        "data": "synthetic (SynthNames-v1 seed 1234; sec__edgar names are not distributable)",
+        "data": "synthetic (SynthNames-v1 seed 1234; sec__edgar names are not distributable)" +
+                ("" if args.dup_frac is None else f"; repeats thinned to {args.dup_frac:g} of the names (synth_names(dup_frac=...))"),
         "config": {"workload": f"{args.rows}-name self-join (BASELINE.json configs[2] on the synthetic stand-in)",
                    "ngram_size": 3, "max_n_matches": args.top_n, "min_similarity": args.min_similarity,
                    "parallelism": "single GPU" if world == 1 else
@@ -386,7 +391,14 @@ def run(args):
         "roofline": {"bound": "hbm",
                      "limited_by": ("memory latency at 16 single-wave workgroups per CU (waves wait for L2 misses about half of "
                                     "their cycles; VALU issue in valu_issue_frac), not HBM bandwidth"),
+                     # (what the kernel READS of the index -- the 8-bit records at the units their rows reach, not the 256 B a
+                     #  record is allocated at; sg_postings_bytes)
                      "l3_resident": (bool(index_bytes <= 256 * 1024 * 1024) if index_bytes else None),
+                     "hbm_share": (("unmeasured: the index the kernel reads fits the Infinity Cache, `traffic` is what crosses "
+                                    "the L2's memory side and counts Infinity-Cache hits")
+                                   if index_bytes and index_bytes <= 256 * 1024 * 1024 else
+                                   ("unmeasured: no counter separates Infinity-Cache hits from HBM reads; the index is larger than "
+                                    "the cache, `traffic` is an upper bound of the HBM bytes")),
                      "index_bytes_read_by_the_kernel": index_bytes,
                      "kernel": ("spgemm_topn_pruned_kernel<SYM> + pair-list pass (K4p, self-join form)" if symmetric else
                                 "spgemm_topn_pruned_kernel (K4p)") if pruned else "spgemm_topn_kernel (K4)",
@@ -426,9 +438,25 @@ def run(args):
         ms, kms, st_nc = side_run(make_vec)
         ctx.set_option("SG_COLLAPSE", None)
         nc_bytes = st_nc["prune_bytes"] if st_nc["prune_rows"] > 0 else st_nc["spgemm_bytes"]
+        # (first-class since round 6: what carries over to a list that does not repeat itself)
+        result["value_without_identical_rows"] = args.rows / (ms * 1e-3)
         result["without_row_collapse"] = {"ms_per_step": ms, "rows_per_s": args.rows / (ms * 1e-3), "kernel_ms": kms,
                                           "kernel_frac_of_hbm_peak": nc_bytes / (kms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
                                           "steps": 12, "option": "SG_COLLAPSE=0"}
+        # ... on the list with the repeats of a REAL company list: 0.3 % of the names (the reference's README.md:80-95 counts
+        # 1 747 names in groups of identical names among 663 000), the library's defaults otherwise
+        if args.dup_frac is None:
+            names_lo = synth_names(args.rows, 1234, dup_frac=0.003)
+            prep_lo = make_vec().prepare(names_lo)
+            del names_lo
+            ms, kms, st_lo = side_run(make_vec, prep=prep_lo)
+            lo_bytes = st_lo["prune_bytes"] if st_lo["prune_rows"] > 0 else st_lo["spgemm_bytes"]
+            result["low_duplicates"] = {"dup_frac": 0.003, "ms_per_step": ms, "rows_per_s": args.rows / (ms * 1e-3), "kernel_ms": kms,
+                                        "kernel_frac_of_hbm_peak": lo_bytes / (kms * 1e-3) / 1e9 / HBM_PEAK_GBPS, "steps": 12,
+                                        "matches": st_lo["out_nnz"], "rows_indexed": st_lo["prune_rows"] + 1,
+                                        "workload": "synth_names(rows, 1234, dup_frac=0.003): every repeat of SynthNames-v1 beyond "
+                                                    "0.3 % of the names replaced by a fresh name"}
+            del prep_lo
         # ... and in the other value type (fp64 is the reference's DEFAULT tfidf_matrix_dtype, string_grouper.py:18)
         other = "f64" if args.dtype == "f32" else "f32"
         odt = np.float64 if other == "f64" else np.float32

@@ -48,7 +48,7 @@ for step in "$@"; do
       ( cd /tmp && export TMPDIR=/tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OLDPWD/gpurun_out/${name}_prof -o run -- python $OLDPWD/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-exact-kernel --no-end-to-end --no-side-runs $arg > $OLDPWD/gpurun_out/${name}_prof.json 2> $OLDPWD/gpurun_out/${name}_prof.err )
       echo "rc=$?" >> $LOG
       f=$(find gpurun_out/${name}_prof -name "*kernel_stats.csv" | head -1)
-      [ -n "$f" ] && cp $f gpurun_out/${name}_kernel_stats.csv && head -25 $f >> $LOG
+      [ -n "$f" ] && cp $f gpurun_out/${name}_kernel_stats$n.csv && head -12 $f | cut -c1-200 >> $LOG
       rm -rf gpurun_out/${name}_prof
       short < gpurun_out/${name}_prof.json >> $LOG 2>&1 ;;
     pmc)

@@ -29,34 +29,39 @@ def committed_counters(root: str, rows: int, dtype: str, kernel_tag: str, kernel
     out: dict = {}
     sha = kernel_source_sha(root)
 
-    def load(name):
-        try:
-            with open(os.path.join(root, "profiles", name)) as f:
-                d = json.load(f)
-        except Exception:
-            return None
-        if d.get("workload_rows") != rows or d.get("dtype") != dtype or d.get("kernel", "K4") != kernel_tag:
-            return None
-        return d
+    def load(prefix):
+        """The committed pass of this workload: profiles/<prefix>.json (the headline's) or profiles/<prefix>_<tag>.json
+        (other sizes: k4_traffic_5M.json ...), whichever names (rows, dtype, kernel)."""
+        import glob
+        for path in sorted(glob.glob(os.path.join(root, "profiles", prefix + "*.json"))):
+            try:
+                with open(path) as f:
+                    d = json.load(f)
+            except Exception:
+                continue
+            if d.get("workload_rows") == rows and d.get("dtype") == dtype and d.get("kernel", "K4") == kernel_tag:
+                d["_file"] = os.path.basename(path)
+                return d
+        return None
 
-    tr = load("k4_traffic.json")
+    tr = load("k4_traffic")
     if tr is not None:
         if tr.get("source_sha") == sha:
             out["traffic"] = tr["traffic_bytes_per_launch_raw"]
-            out["traffic_source"] = ("committed PMC pass (profiles/k4_traffic.json, written by scripts/pmc_traffic.py on "
+            out["traffic_source"] = (f"committed PMC pass (profiles/{tr['_file']}, written by scripts/pmc_traffic.py on "
                                      f"kernel sources {sha[:12]}); not measured in this run")
             out["traffic_note"] = tr["source"] + "; " + tr["note"]
         else:
             out["traffic"] = None
             out["traffic_stale"] = {"status": "stale", "measured_on_sources": (tr.get("source_sha") or "unrecorded")[:12],
                                     "current_sources": sha[:12]}
-    kc = load("k4_counters.json")
+    kc = load("k4_counters")
     if kc is not None:
         if kc.get("source_sha") == sha:
             valu = float(kc["per_launch"]["SQ_INSTS_VALU"])
             out["valu_issue_frac"] = valu * 4.0 / 1024.0 / 2.4e9 / (kernel_ms * 1e-3)
             out["valu_insts_per_launch"] = valu
-            out["valu_source"] = ("committed PMC pass (profiles/k4_counters.json, written by scripts/pmc_counters.py on kernel "
+            out["valu_source"] = (f"committed PMC pass (profiles/{kc['_file']}, written by scripts/pmc_counters.py on kernel "
                                   f"sources {sha[:12]}); instruction counts do not depend on the run, the kernel time is this run's")
         else:
             out["valu_stale"] = {"status": "stale", "measured_on_sources": (kc.get("source_sha") or "unrecorded")[:12],

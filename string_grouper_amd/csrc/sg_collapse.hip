@@ -363,8 +363,8 @@ __global__ void __launch_bounds__(256) group_ids_kernel(const uint32_t *__restri
 #pragma unroll
         for (int d = 32; d > 0; d >>= 1) my_len += (uint32_t)__shfl_xor((int)my_len, d, 64);
         // (32 counters, one per workgroup mod 32: ten thousand waves on ONE word are served one at a time, ~12 ns each --
-        //  0.12 ms at 663 k; the host adds the 32 up)
-        if ((threadIdx.x & 63) == 0 && my_len) atomicAdd(nnz_total + (blockIdx.x & 31u), (unsigned long long)my_len);
+        //  0.12 ms at 663 k; and every counter on a 128-byte line of its own: atomics on ONE LINE queue up just the same)
+        if ((threadIdx.x & 63) == 0 && my_len) atomicAdd(nnz_total + 16u * (blockIdx.x & 31u), (unsigned long long)my_len);
     }
     // the other members: the lanes of a wave that belong to one group send ONE atomic between them -- a hub of 66 000
     // identical names was 66 000 atomics on one word, which are served one at a time (~12 ns each: 0.8 ms of a 2 ms build)
@@ -525,7 +525,7 @@ static int collapse_groups_table(sg_ctx *ctx, const sg_csr *B, bool forced, bool
     while (table_size < 2 * (uint64_t)n) table_size <<= 1;
     unsigned long long *table = nullptr;
     uint32_t *slot_of_row = nullptr, *rep_of_row = nullptr, *rep_excl = nullptr, *size = nullptr, *cursor = nullptr, *queue = nullptr;
-    uint32_t *totals = nullptr;   // [0] groups, [4 .. 36) the member sort's words, [40 .. 104) entries of the representatives (32 partial sums of 64 bits)
+    uint32_t *totals = nullptr;   // [0] groups, [4 .. 36) the member sort's words, [64 .. 64 + 32 * 32) entries of the representatives (32 partial sums of 64 bits, 128 bytes apart)
     SgCollapse *c = new (std::nothrow) SgCollapse();
     if (!c) return SG_ERR_OOM;
     c->ctx = ctx;
@@ -537,7 +537,7 @@ static int collapse_groups_table(sg_ctx *ctx, const sg_csr *B, bool forced, bool
     if (st == SG_OK) st = sg_alloc(ctx, (size_t)n + 2, &size);
     if (st == SG_OK) st = sg_alloc(ctx, (size_t)n + 2, &cursor);
     if (st == SG_OK) st = sg_alloc(ctx, (size_t)n + 2, &queue);
-    if (st == SG_OK) st = sg_alloc(ctx, (size_t)104, &totals);
+    if (st == SG_OK) st = sg_alloc(ctx, (size_t)(64 + 32 * 32), &totals);
     // (sized for n groups: the number is not known to the host while these are queued)
     if (st == SG_OK) st = sg_alloc(ctx, (size_t)n + 1, &c->d_gid);
     if (st == SG_OK) st = sg_alloc(ctx, (size_t)n + 2, &c->d_group_ptr);
@@ -558,7 +558,7 @@ static int collapse_groups_table(sg_ctx *ctx, const sg_csr *B, bool forced, bool
     const unsigned g1 = (unsigned)((n + 255) / 256), g16 = (unsigned)((n * 16 + 255) / 256);
     if (st == SG_OK)
         st = SG_ZERO4(ctx, table, sizeof(unsigned long long) * (size_t)table_size, size, sizeof(uint32_t) * (size_t)(n + 2), cursor,
-                      sizeof(uint32_t) * (size_t)(n + 2), totals, 104 * sizeof(uint32_t));
+                      sizeof(uint32_t) * (size_t)(n + 2), totals, (64 + 32 * 32) * sizeof(uint32_t));
     if (st == SG_OK) {
         if (B->dtype == SG_F64)
             hipLaunchKernelGGL(group_rows_kernel<double>, dim3(g16), dim3(256), 0, ctx->stream, B->d_indptr, B->d_indices,
@@ -572,7 +572,7 @@ static int collapse_groups_table(sg_ctx *ctx, const sg_csr *B, bool forced, bool
     if (st == SG_OK) {
         hipLaunchKernelGGL(group_ids_kernel, dim3(g1), dim3(256), 0, ctx->stream, (const uint32_t *)rep_of_row, (const uint32_t *)rep_excl,
                            (const uint32_t *)nullptr, n, c->d_gid, size, c->d_rep_rows, B->d_indptr, c->d_rep_start, c->d_rep_len,
-                           (unsigned long long *)(totals + 40));
+                           (unsigned long long *)(totals + 64));
         // (over n + 1 sizes, zeros behind the last group: group_ptr[n_u] = n comes out by itself)
         st = sg_exclusive_scan_u32(ctx, size, c->d_group_ptr, n + 1, nullptr);
     }
@@ -585,7 +585,7 @@ static int collapse_groups_table(sg_ctx *ctx, const sg_csr *B, bool forced, bool
                            (const uint32_t *)(totals + 4), (const uint32_t *)queue);
         if (hipGetLastError() != hipSuccess) st = SG_ERR_HIP;
     }
-    uint32_t h[104];
+    uint32_t h[64 + 32 * 32];
     for (auto &w : h) w = 0;
     if (st == SG_OK) {
         if (hipMemcpyAsync(h, totals, sizeof(h), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
@@ -594,7 +594,7 @@ static int collapse_groups_table(sg_ctx *ctx, const sg_csr *B, bool forced, bool
     }
     const uint32_t n_groups = h[0];
     int64_t nnz_u = 0;
-    for (int q = 0; q < 32; ++q) nnz_u += (int64_t)(((uint64_t)h[41 + 2 * q] << 32) | (uint64_t)h[40 + 2 * q]);
+    for (int q = 0; q < 32; ++q) nnz_u += (int64_t)(((uint64_t)h[64 + 32 * q + 1] << 32) | (uint64_t)h[64 + 32 * q]);
     const uint32_t *h_words = h + 4;      // [0] groups queued for the LDS sort, [1] the largest group, [2] very large groups, [3 ..] which
     if (st != SG_OK || n_groups == 0 || (!forced && (double)n_groups > 0.97 * (double)n) || (int64_t)n_groups == n) {
         cleanup();
@@ -802,58 +802,6 @@ __global__ void __launch_bounds__(256) expand_simple_kernel(const int32_t *__res
     cnt[r] = out;
 }
 
-// The same with SIXTEEN lanes per output row (rows of up to sixteen groups: top_n <= 16, the common case): lane e takes the
-// row's e-th group -- the row over groups is read as one contiguous run instead of a 40-byte stride per thread --, the
-// members' places come from a prefix sum over the sixteen sizes, and neighbouring lanes write neighbouring columns
-// (round 6: 0.072 -> ms at 663 k for 53 MB written).
-template <typename T>
-__global__ void __launch_bounds__(256) expand_rows16_kernel(const int32_t *__restrict__ u_cols, const T *__restrict__ u_vals,
-                                                            const int32_t *__restrict__ u_cnt, int32_t u_stride,
-                                                            const uint32_t *__restrict__ gid, const int32_t *__restrict__ row_list,
-                                                            const uint32_t *__restrict__ group_ptr, const uint32_t *__restrict__ members,
-                                                            int64_t n_out, int32_t stride, int32_t *__restrict__ cols,
-                                                            T *__restrict__ vals, int32_t *__restrict__ cnt,
-                                                            uint32_t *__restrict__ slow_count, uint32_t *__restrict__ slow_rows) {
-    const int64_t r = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
-    const int sub = threadIdx.x & 15;
-    if (r >= n_out) return;
-    const int64_t row = row_list ? (int64_t)row_list[r] : r;
-    const int64_t ur = gid ? (int64_t)gid[row] : row;
-    const int32_t m = u_cnt[ur];
-    const int32_t *uc = u_cols + ur * u_stride;
-    const T *uv = u_vals + ur * u_stride;
-    const bool have = sub < m;
-    uint32_t lo = 0, size = 0;
-    T v = (T)0;
-    bool tie = false;
-    if (have) {
-        const uint32_t g = (uint32_t)uc[sub];
-        v = uv[sub];
-        lo = group_ptr[g];
-        size = group_ptr[g + 1] - lo;
-        // (see expand_simple_kernel: only a group of several members that TIES with a neighbour needs the merge by column)
-        tie = size != 1u && ((sub > 0 && uv[sub - 1] == v) || (sub + 1 < m && uv[sub + 1] == v));
-    }
-    uint32_t any_tie = tie ? 1u : 0u, at = size;
-#pragma unroll
-    for (int d = 1; d < 16; d <<= 1) {
-        any_tie |= (uint32_t)__shfl_xor((int)any_tie, d, 64);
-        const uint32_t up = (uint32_t)__shfl_up((int)at, d, 16);
-        if (sub >= d) at += up;
-    }
-    if (any_tie) {
-        if (sub == 0) slow_rows[atomicAdd(slow_count, 1u)] = (uint32_t)r;
-        return;
-    }
-    const uint32_t total = (uint32_t)__shfl((int)at, (int)(threadIdx.x & 48u) + 15, 64);
-    uint32_t out = at - size;      // exclusive
-    for (uint32_t p = lo; p < lo + size && out < (uint32_t)stride; ++p, ++out) {
-        cols[r * stride + out] = (int32_t)members[p];
-        vals[r * stride + out] = v;
-    }
-    if (sub == 0) cnt[r] = (int32_t)(total < (uint32_t)stride ? total : (uint32_t)stride);
-}
-
 // Wave per queued row: the groups of one score are merged by column (every lane holds one group's next member, the
 // smallest of all lanes is written, that lane advances), score after score, until top_n columns are out.
 template <typename T>
@@ -951,12 +899,12 @@ int sg_collapse_expand(sg_ctx *ctx, const SgCollapse *c, const sg_topn *ru, bool
     // (the output's counts and the slow-row queue's head in one launch; the callers do not clear the counts themselves)
     int st = SG_ZERO2(ctx, out->d_counts, sizeof(int32_t) * (size_t)(n_out + 1), slow, 16);
     if (st == SG_OK) {
-        const unsigned g1 = (unsigned)((n_out + 255) / 256), g16 = (unsigned)((n_out * 16 + 255) / 256);
-        const bool narrow = ru->stride <= 16;     // (a row over groups holds at most sixteen of them: a lane each)
+        // (tried in round 6: sixteen lanes per output row, contiguous reads and writes -- 0.82 instead of 0.64 ms at 5 M: a
+        //  chain of four dependent loads per row with one row per sixteen lanes in flight; a thread per row keeps ten going)
+        const unsigned g1 = (unsigned)((n_out + 255) / 256);
         const uint32_t *gid = rows_are_groups ? c->d_gid : nullptr;
         if (out->dtype == SG_F64) {
-            hipLaunchKernelGGL(narrow ? expand_rows16_kernel<double> : expand_simple_kernel<double>, dim3(narrow ? g16 : g1), dim3(256), 0,
-                               ctx->stream, (const int32_t *)ru->d_cols,
+            hipLaunchKernelGGL(expand_simple_kernel<double>, dim3(g1), dim3(256), 0, ctx->stream, (const int32_t *)ru->d_cols,
                                (const double *)ru->d_vals, (const int32_t *)ru->d_counts, ru->stride, gid, row_list,
                                (const uint32_t *)c->d_group_ptr, (const uint32_t *)c->d_members, n_out, out->stride, out->d_cols,
                                (double *)out->d_vals, out->d_counts, slow, slow + 4);
@@ -965,8 +913,7 @@ int sg_collapse_expand(sg_ctx *ctx, const SgCollapse *c, const sg_topn *ru, bool
                                (const uint32_t *)c->d_group_ptr, (const uint32_t *)c->d_members, out->stride, out->d_cols,
                                (double *)out->d_vals, out->d_counts, (const uint32_t *)slow, (const uint32_t *)(slow + 4));
         } else {
-            hipLaunchKernelGGL(narrow ? expand_rows16_kernel<float> : expand_simple_kernel<float>, dim3(narrow ? g16 : g1), dim3(256), 0,
-                               ctx->stream, (const int32_t *)ru->d_cols,
+            hipLaunchKernelGGL(expand_simple_kernel<float>, dim3(g1), dim3(256), 0, ctx->stream, (const int32_t *)ru->d_cols,
                                (const float *)ru->d_vals, (const int32_t *)ru->d_counts, ru->stride, gid, row_list,
                                (const uint32_t *)c->d_group_ptr, (const uint32_t *)c->d_members, n_out, out->stride, out->d_cols,
                                (float *)out->d_vals, out->d_counts, slow, slow + 4);

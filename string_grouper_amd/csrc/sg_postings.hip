@@ -106,35 +106,37 @@ __device__ __forceinline__ uint32_t sg_null_posting(uint32_t i) { return ((i >> 
 //                    with its top bit flipped (F - 32768 as int16) for v_mad_i32_i16, which then gives the column's whole
 //                    survivor threshold in ONE instruction (the 8-bit form: byte select + multiply, subtract, shift)
 #define SG_FILT_F16_MAX 65280u   // 255 * 256
+// the 32-bit filter posting of value v in column `col` of tile `tile` (the layouts above)
+__device__ __forceinline__ uint32_t filter_posting(uint32_t col, float v, float fr, int32_t tile_log2, float inv_norm_up, uint32_t tile,
+                                                   int32_t fold_log2) {
+    const int32_t ab = tile_log2 + 1, fb = ab + fold_log2;
+    if (fold_log2 > 0) {   // stream form (fb == 16: sg_postings_build only folds tiles of 4096 columns by 8)
+        const uint32_t low = ((col >> 1) << 2) | ((col & 1u) << 1) | ((tile & ((1u << fold_log2) - 1u)) << ab);
+        uint32_t b24 = (uint32_t)ceilf(v * inv_norm_up * (255.0f * 65536.0f) * 1.000002f);
+        // v <= norm_up: what lies above 255 * 2^16 is the safety factor's doing.  (Without the cut a row of ONE term --
+        // v = 1 -- in one of a tile's first columns, where `low` is smaller than that excess, got bq = 256: the field
+        // wrapped to 0 and carried into fq, and the row did not find itself.)
+        if (b24 > (255u << 16)) b24 = 255u << 16;
+        const uint32_t bq = b24 > low ? (b24 - low + 65535u) >> 16 : 0u;                   // <= 255
+        uint32_t f16 = (uint32_t)ceilf(fr * (float)SG_FILT_F16_MAX * 1.000002f);
+        if (f16 > SG_FILT_F16_MAX) f16 = SG_FILT_F16_MAX;
+        const uint32_t fq = f16 > bq ? (f16 - bq + 255u) >> 8 : 0u;                        // <= 255
+        return low | (bq << 16) | ((fq ^ 0x80u) << 24);
+    }
+    const uint32_t bq_max = (1u << (24 - fb)) - 1u;   // the bits the address and fq leave
+    uint32_t bq = (uint32_t)ceilf(v * inv_norm_up * (float)bq_max * 1.000002f);
+    if (bq > bq_max) bq = bq_max;
+    uint32_t fq = (uint32_t)ceilf(fr * 255.0f * 1.000002f);
+    if (fq > 255u) fq = 255u;
+    return ((col >> 1) << 2) | (col & 1u) | (bq << fb) | (fq << 24);
+}
 template <typename T>
 __device__ __forceinline__ void emit_posting(int32_t *out_rows, T *out_vals, uint32_t *out_filt, uint32_t pos, uint32_t col,
                                              T v, float fr, int32_t tile_log2, float inv_norm_up, uint32_t tile,
                                              int32_t fold_log2) {
     // the multiply wants the byte offset of the accumulator inside its LDS tile, not j itself
     if (out_vals) store_posting<T>(out_rows, out_vals, pos, (int32_t)(col * (uint32_t)sizeof(T)), v);   // (null: filter postings only)
-    if (out_filt) {
-        const int32_t ab = tile_log2 + 1, fb = ab + fold_log2;
-        if (fold_log2 > 0) {   // stream form (fb == 16: sg_postings_build only folds tiles of 4096 columns by 8)
-            const uint32_t low = ((col >> 1) << 2) | ((col & 1u) << 1) | ((tile & ((1u << fold_log2) - 1u)) << ab);
-            uint32_t b24 = (uint32_t)ceilf((float)v * inv_norm_up * (255.0f * 65536.0f) * 1.000002f);
-            // v <= norm_up: what lies above 255 * 2^16 is the safety factor's doing.  (Without the cut a row of ONE term --
-            // v = 1 -- in one of a tile's first columns, where `low` is smaller than that excess, got bq = 256: the field
-            // wrapped to 0 and carried into fq, and the row did not find itself.)
-            if (b24 > (255u << 16)) b24 = 255u << 16;
-            const uint32_t bq = b24 > low ? (b24 - low + 65535u) >> 16 : 0u;                   // <= 255
-            uint32_t f16 = (uint32_t)ceilf(fr * (float)SG_FILT_F16_MAX * 1.000002f);
-            if (f16 > SG_FILT_F16_MAX) f16 = SG_FILT_F16_MAX;
-            const uint32_t fq = f16 > bq ? (f16 - bq + 255u) >> 8 : 0u;                        // <= 255
-            out_filt[pos] = low | (bq << 16) | ((fq ^ 0x80u) << 24);
-            return;
-        }
-        const uint32_t bq_max = (1u << (24 - fb)) - 1u;   // the bits the address and fq leave
-        uint32_t bq = (uint32_t)ceilf((float)v * inv_norm_up * (float)bq_max * 1.000002f);
-        if (bq > bq_max) bq = bq_max;
-        uint32_t fq = (uint32_t)ceilf(fr * 255.0f * 1.000002f);
-        if (fq > 255u) fq = 255u;
-        out_filt[pos] = ((col >> 1) << 2) | (col & 1u) | (bq << fb) | (fq << 24);
-    }
+    if (out_filt) out_filt[pos] = filter_posting(col, (float)v, fr, tile_log2, inv_norm_up, tile, fold_log2);
 }
 
 template <typename T>
@@ -404,6 +406,247 @@ __global__ void __launch_bounds__(1024) postings_fill_lds(const int64_t *__restr
     }
 }
 
+// ---- Round 6: the filter postings STAGED in LDS and written cell by cell.
+// postings_fill_lds stores every posting where its cursor says: 4 bytes to a line of its own -- the term-major order the
+// multiply streams puts the postings of one row 18 300 lists apart --, and those stores were half the kernel (0.12 of 0.27 ms
+// at 663 k, probe builds of round 4; 1.9 ms at 5 M).  But the entries of a (term, part) CELL are neighbours in the index, and
+// most entries live in cells of many (frequent terms: a part of 1024 rows holds 4.3 entries per non-empty cell, 56 % of the
+// entries in cells of eight or more).  So a workgroup works its part off in CHUNKS of rows whose postings fit the LDS beside
+// the counters: (1) the chunk's entries are counted per term in packed 16-bit counters (and the rows' frequent-part norms
+// computed); (2) a prefix sum turns the counts into the cells' places inside the chunk; (3) every posting is made and put
+// at its place in LDS; (4) waves copy the staged run out, 64 consecutive staged postings a trip: lanes in the same cell write
+// neighbouring words, a trip touches ~15 lines instead of 64.  Where a cell starts in the index is the workgroup's row of
+// `cnt` (entries in earlier workgroups) + the term's start, advanced by the chunk's count -- the row is this workgroup's
+// alone, and the tables the multiply reads are written from `cnt` BEFORE this kernel runs.  A chunk that does not fit the
+// stage (rows far longer than the build's mean) is written posting by posting through the same cursors.
+// Filter postings only: the exact kernel's postings, when they are wanted at all, keep postings_fill_lds.
+__device__ __forceinline__ uint32_t lds_get16(const uint32_t *w, uint32_t k) { return (w[k >> 1] >> ((k & 1u) << 4)) & 0xffffu; }
+template <typename T>
+__global__ void __launch_bounds__(1024) postings_fill_staged(const int64_t *__restrict__ indptr, const int32_t *__restrict__ indices,
+                                                             const T *__restrict__ data, int64_t n_rows, int32_t tile_log2,
+                                                             int32_t n_terms, int32_t split, int32_t chunk_rows, uint32_t stage_cap,
+                                                             uint32_t *cnt /* [wgs][n_terms] */, const uint32_t *__restrict__ term_start,
+                                                             const uint8_t *__restrict__ is_frequent, uint32_t *__restrict__ out_filt,
+                                                             float inv_norm_up, int32_t fold_log2) {
+    extern __shared__ uint32_t lds[];
+    const uint32_t w16 = ((uint32_t)n_terms + 1u) >> 1;            // words of packed 16-bit counters
+    uint32_t *lcnt = lds;
+    uint32_t *freq_bits = lcnt + ((w16 + 3u) & ~3u);
+    float *fqrow = reinterpret_cast<float *>(freq_bits + (((uint32_t)n_terms + 31u) >> 5));
+    uint32_t *wave_tot = reinterpret_cast<uint32_t *>(fqrow + chunk_rows);
+    uint32_t *stage = wave_tot + 32;
+    const int64_t t = blockIdx.x / split;
+    const int32_t part = blockIdx.x % split;
+    uint32_t *mine = cnt + (int64_t)blockIdx.x * n_terms;
+    for (uint32_t k = threadIdx.x; k < (((uint32_t)n_terms + 31u) >> 5); k += blockDim.x) freq_bits[k] = 0;
+    __syncthreads();
+    for (int k = threadIdx.x; k < n_terms; k += blockDim.x)
+        if (is_frequent[k]) atomicOr(&freq_bits[k >> 5], 1u << (k & 31));
+    __syncthreads();
+    const int64_t part_rows = ((int64_t)1 << tile_log2) / split;
+    const int64_t j0 = (t << tile_log2) + part * part_rows;
+    int64_t j1 = j0 + part_rows;
+    if (j1 > n_rows) j1 = n_rows;
+    const int lane = threadIdx.x & 63, sub = lane & 15, wave = threadIdx.x >> 6;
+    const int64_t groups = blockDim.x >> 4;
+    const uint32_t last_k = (uint32_t)n_terms - 1u;
+    for (int64_t c0 = j0; c0 < j1; c0 += chunk_rows) {
+        const int64_t c1 = c0 + chunk_rows < j1 ? c0 + chunk_rows : j1;
+        const int64_t e_base = indptr[c0];
+        const uint32_t E = (uint32_t)(indptr[c1] - e_base);
+        // every wave makes the same number of trips, so that the cross-lane sums below always run with all lanes
+        const int64_t trips = (c1 - c0 + groups * SG_POST_ROWS - 1) / (groups * SG_POST_ROWS);
+        if (E > stage_cap || E > 65535u) {
+            // (a chunk of rows far longer than the build expected: posting by posting through the workgroup's cursors)
+            for (int64_t it = 0; it < trips; ++it) {
+                const int64_t jb = c0 + (it * groups + (threadIdx.x >> 4)) * SG_POST_ROWS;
+#pragma unroll
+                for (int r = 0; r < SG_POST_ROWS; ++r) {
+                    const bool valid = jb + r < c1;
+                    const int64_t lo = valid ? indptr[jb + r] : 0, hi = valid ? indptr[jb + r + 1] : 0;
+                    double f2 = 0.0;
+                    for (int64_t p = lo + sub; p < hi; p += 16) {
+                        const int32_t k = indices[p];
+                        if ((freq_bits[k >> 5] >> (k & 31)) & 1u) f2 += (double)data[p] * (double)data[p];
+                    }
+#pragma unroll
+                    for (int d = 8; d > 0; d >>= 1) {
+                        const uint64_t bits = (uint64_t)__double_as_longlong(f2);
+                        const uint32_t l = (uint32_t)__shfl_xor((int)(uint32_t)bits, d, 64), h = (uint32_t)__shfl_xor((int)(uint32_t)(bits >> 32), d, 64);
+                        f2 += __longlong_as_double((long long)(((uint64_t)h << 32) | l));
+                    }
+                    const float fq = frequent_norm_ratio_of(f2, inv_norm_up);
+                    const uint32_t col = (uint32_t)(jb + r - (t << tile_log2));
+                    for (int64_t p = lo + sub; p < hi; p += 16) {
+                        const int32_t k = indices[p];
+                        const uint32_t pos = term_start[k] + atomicAdd(&mine[k], 1u);
+                        out_filt[pos] = filter_posting(col, (float)data[p], fq, tile_log2, inv_norm_up, (uint32_t)t, fold_log2);
+                    }
+                }
+            }
+            __threadfence();
+            __syncthreads();
+            continue;
+        }
+        for (uint32_t w = threadIdx.x; w < w16; w += blockDim.x) lcnt[w] = 0;
+        __syncthreads();
+        // ---- (1) count per term; the rows' frequent-part norms
+        for (int64_t it = 0; it < trips; ++it) {
+            const int64_t jb = c0 + (it * groups + (threadIdx.x >> 4)) * SG_POST_ROWS;
+            int64_t lo[SG_POST_ROWS], hi[SG_POST_ROWS];
+#pragma unroll
+            for (int r = 0; r < SG_POST_ROWS; ++r) {
+                const bool valid = jb + r < c1;
+                lo[r] = valid ? indptr[jb + r] : 0;
+                hi[r] = valid ? indptr[jb + r + 1] : 0;
+            }
+            int32_t k0[SG_POST_ROWS];
+            T v0[SG_POST_ROWS];
+#pragma unroll
+            for (int r = 0; r < SG_POST_ROWS; ++r) {
+                const bool have = lo[r] + sub < hi[r];
+                k0[r] = have ? indices[lo[r] + sub] : -1;
+                v0[r] = have ? data[lo[r] + sub] : (T)0;
+            }
+#pragma unroll
+            for (int r = 0; r < SG_POST_ROWS; ++r) {
+                // norm of the row's frequent part relative to norm_up, rounded up (the order of the additions is free: the
+                // result is rounded up with a margin far above the rounding of a double sum)
+                double f2 = 0.0;
+                if (k0[r] >= 0) {
+                    atomicAdd(&lcnt[(uint32_t)k0[r] >> 1], 1u << (((uint32_t)k0[r] & 1u) << 4));
+                    if ((freq_bits[k0[r] >> 5] >> (k0[r] & 31)) & 1u) f2 = (double)v0[r] * (double)v0[r];
+                }
+                for (int64_t p = lo[r] + sub + 16; p < hi[r]; p += 16) {
+                    const int32_t k = indices[p];
+                    atomicAdd(&lcnt[(uint32_t)k >> 1], 1u << (((uint32_t)k & 1u) << 4));
+                    if ((freq_bits[k >> 5] >> (k & 31)) & 1u) f2 += (double)data[p] * (double)data[p];
+                }
+#pragma unroll
+                for (int d = 8; d > 0; d >>= 1) {
+                    const uint64_t bits = (uint64_t)__double_as_longlong(f2);
+                    const uint32_t l = (uint32_t)__shfl_xor((int)(uint32_t)bits, d, 64), h = (uint32_t)__shfl_xor((int)(uint32_t)(bits >> 32), d, 64);
+                    f2 += __longlong_as_double((long long)(((uint64_t)h << 32) | l));
+                }
+                if (sub == 0 && jb + r < c1) fqrow[jb + r - c0] = frequent_norm_ratio_of(f2, inv_norm_up);
+            }
+        }
+        __syncthreads();
+        // ---- (2) counts -> where every term's cell starts inside the chunk (a thread takes a run of words)
+        {
+            const uint32_t per = (w16 + blockDim.x - 1u) / blockDim.x;
+            const uint32_t wa = threadIdx.x * per, wb = wa + per < w16 ? wa + per : w16;
+            uint32_t sum = 0;
+            for (uint32_t w = wa; w < wb; ++w) sum += (lcnt[w] & 0xffffu) + (lcnt[w] >> 16);
+            uint32_t tot;
+            uint32_t run = block_exclusive_scan<uint32_t>(sum, wave_tot, &tot);
+            for (uint32_t w = wa; w < wb; ++w) {
+                const uint32_t c = lcnt[w];
+                const uint32_t a = run;
+                run += c & 0xffffu;
+                const uint32_t b = run;
+                run += c >> 16;
+                lcnt[w] = a | (b << 16);
+            }
+        }
+        __syncthreads();
+        // ---- (3) the postings, each at its place in LDS (the returning add leaves every counter at its cell's END)
+        for (int64_t it = 0; it < trips; ++it) {
+            const int64_t jb = c0 + (it * groups + (threadIdx.x >> 4)) * SG_POST_ROWS;
+            int64_t lo[SG_POST_ROWS], hi[SG_POST_ROWS];
+#pragma unroll
+            for (int r = 0; r < SG_POST_ROWS; ++r) {
+                const bool valid = jb + r < c1;
+                lo[r] = valid ? indptr[jb + r] : 0;
+                hi[r] = valid ? indptr[jb + r + 1] : 0;
+            }
+            int32_t k0[SG_POST_ROWS];
+            T v0[SG_POST_ROWS];
+#pragma unroll
+            for (int r = 0; r < SG_POST_ROWS; ++r) {
+                const bool have = lo[r] + sub < hi[r];
+                k0[r] = have ? indices[lo[r] + sub] : -1;
+                v0[r] = have ? data[lo[r] + sub] : (T)0;
+            }
+#pragma unroll
+            for (int r = 0; r < SG_POST_ROWS; ++r) {
+                const float fq = jb + r < c1 ? fqrow[jb + r - c0] : 0.f;
+                const uint32_t col = (uint32_t)(jb + r - (t << tile_log2));
+                if (k0[r] >= 0) {
+                    const uint32_t sh = ((uint32_t)k0[r] & 1u) << 4;
+                    const uint32_t pos = (atomicAdd(&lcnt[(uint32_t)k0[r] >> 1], 1u << sh) >> sh) & 0xffffu;
+                    stage[pos] = filter_posting(col, (float)v0[r], fq, tile_log2, inv_norm_up, (uint32_t)t, fold_log2);
+                }
+                for (int64_t p = lo[r] + sub + 16; p < hi[r]; p += 16) {
+                    const uint32_t k = (uint32_t)indices[p];
+                    const uint32_t sh = (k & 1u) << 4;
+                    const uint32_t pos = (atomicAdd(&lcnt[k >> 1], 1u << sh) >> sh) & 0xffffu;
+                    stage[pos] = filter_posting(col, (float)data[p], fq, tile_log2, inv_norm_up, (uint32_t)t, fold_log2);
+                }
+            }
+        }
+        __syncthreads();
+        // ---- (4) out: a wave takes 64 terms at a time, whose cells are one run of the stage.  Where the cells start in the
+        // index (the workgroup's cursors: a round trip to the L2) is fetched for EIGHT such groups before the first is copied:
+        // one group after the other, the kernel waited for that load eighteen times a chunk (0.26 of its 0.27 ms at 663 k).
+        {
+            constexpr int FB = 8;
+            const uint32_t n_tg = ((uint32_t)n_terms + 63u) >> 6, waves = (uint32_t)(blockDim.x >> 6);
+            for (uint32_t tg0 = (uint32_t)wave; tg0 < n_tg; tg0 += waves * FB) {
+                uint32_t end_k[FB], start_k[FB], before[FB], G[FB];
+                bool mine_has[FB];
+#pragma unroll
+                for (int b = 0; b < FB; ++b) {
+                    const uint32_t tg = tg0 + (uint32_t)b * waves;
+                    const uint32_t k = tg * 64u + (uint32_t)lane;
+                    const bool live = tg < n_tg;
+                    const uint32_t kc = k < last_k ? k : last_k;                   // (lanes past the last term: empty cells at the end)
+                    end_k[b] = live ? lds_get16(lcnt, kc) : 0u;
+                    start_k[b] = (!live || k == 0u) ? 0u : lds_get16(lcnt, (k - 1u) < last_k ? k - 1u : last_k);
+                    mine_has[b] = live && k <= last_k && end_k[b] > start_k[b];
+                }
+#pragma unroll
+                for (int b = 0; b < FB; ++b) {
+                    const uint32_t k = (tg0 + (uint32_t)b * waves) * 64u + (uint32_t)lane;
+                    // (through the L2, like the atomics of a chunk written posting by posting: the L1 is not coherent with them)
+                    before[b] = mine_has[b] ? __hip_atomic_load(&mine[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+                    G[b] = mine_has[b] ? term_start[k] : 0u;
+                }
+#pragma unroll
+                for (int b = 0; b < FB; ++b) {
+                    const uint32_t tg = tg0 + (uint32_t)b * waves;
+                    if (tg >= n_tg) break;
+                    const uint32_t k = tg * 64u + (uint32_t)lane;
+                    G[b] += before[b];
+                    const uint32_t S = (uint32_t)__builtin_amdgcn_readlane((int)start_k[b], 0);
+                    const uint32_t Eg = (uint32_t)__builtin_amdgcn_readlane((int)end_k[b], 63);
+                    for (uint32_t e0 = S; e0 < Eg; e0 += 64u) {
+                        const uint32_t e = e0 + (uint32_t)lane;
+                        // the cell of staged posting e: the first of the 64 terms whose end lies behind e
+                        uint32_t lo = 0u, hi = 63u;
+#pragma unroll
+                        for (int step = 0; step < 6; ++step) {
+                            const uint32_t mid = (lo + hi) >> 1;
+                            const uint32_t km = tg * 64u + mid;
+                            const bool right = lds_get16(lcnt, km < last_k ? km : last_k) > e;
+                            hi = right ? mid : hi;
+                            lo = right ? lo : mid + 1u;
+                        }
+                        const uint32_t tsel = lo < 63u ? lo : 63u;
+                        const uint32_t kt = tg * 64u + tsel;
+                        const uint32_t start_t = kt == 0u ? 0u : lds_get16(lcnt, (kt - 1u) < last_k ? kt - 1u : last_k);
+                        const uint32_t G_t = (uint32_t)__shfl((int)G[b], (int)tsel, 64);
+                        if (e < Eg) out_filt[G_t + (e - start_t)] = stage[e];
+                    }
+                    if (mine_has[b]) __hip_atomic_store(&mine[k], before[b] + (end_k[b] - start_k[b]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+        }
+        __threadfence();
+        __syncthreads();
+    }
+}
+
 __global__ void __launch_bounds__(256) term_len_kernel(const uint32_t *__restrict__ seg, int64_t n_terms, int32_t n_tiles,
                                                        uint32_t *__restrict__ term_len) {
     const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -506,12 +749,16 @@ __global__ void __launch_bounds__(256) null_postings_kernel(uint32_t *__restrict
 // Round 6: no launch of its own -- the prefix sum over the rows' lengths in position order (the row pointers of the matrix in
 // position order) computes the permutation as it loads: position p holds row g = p * M^-1 mod n.
 struct PermutedLenLoad {
-    uint64_t n, minv;
+    uint64_t n, minv, magic;       // magic = floor((2^64 - 1) / n) + 1: p * minv mod n by one multiply-high (a 64-bit `%` is ~100 instructions)
     const int32_t *len_of_row;     // lengths by row (groups: SgCollapse::d_rep_len); null: from the row pointers
     const int64_t *indptr;
     uint32_t *pos_of, *orig_of;
     __device__ __forceinline__ int64_t operator()(int64_t p) const {
-        const uint32_t g = (uint32_t)(((uint64_t)p * minv) % n);
+        const uint64_t x = (uint64_t)p * minv;                    // < 2^62
+        const uint64_t q = __umul64hi(x, magic);                  // floor(x / n) or one more
+        int64_t rem = (int64_t)(x - q * n);
+        if (rem < 0) rem += (int64_t)n;
+        const uint32_t g = (uint32_t)rem;
         orig_of[p] = g;
         pos_of[g] = (uint32_t)p;
         return len_of_row ? (int64_t)len_of_row[g] : indptr[g + 1] - indptr[g];
@@ -751,7 +998,7 @@ static int build_permuted(sg_ctx *ctx, const sg_csr *B, int64_t tile_cols, sg_cs
     if (st == SG_OK) st = sg_alloc(ctx, (size_t)B->nnz + 64, &idx);
     if (st == SG_OK) st = ctx->alloc(((size_t)B->nnz + 64) * vs, &val);
     if (st == SG_OK)
-        st = sg_scan_launch<int64_t>(ctx, PermutedLenLoad{n, minv, by_group ? pending->d_rep_len : (const int32_t *)nullptr, B->d_indptr, pos_of, orig_of},
+        st = sg_scan_launch<int64_t>(ctx, PermutedLenLoad{n, minv, (uint64_t)(~0ull / n) + 1ull, by_group ? pending->d_rep_len : (const int32_t *)nullptr, B->d_indptr, pos_of, orig_of},
                                      SgScanStoreArray<int64_t>{ptr}, (int64_t)n, ptr + n);
     if (st == SG_OK) {
         const unsigned grid = (unsigned)((((n + 1 + SG_GATHER_ROWS - 1) / SG_GATHER_ROWS) * 16 + 255) / 256);
@@ -1084,13 +1331,44 @@ extern "C" int sg_postings_build_flags(sg_ctx *ctx, const sg_csr *B_in, int32_t 
                 (void)hipFuncSetAttribute((const void *)postings_count_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 124 * 1024);
                 (void)hipFuncSetAttribute((const void *)postings_fill_lds<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 124 * 1024);
                 (void)hipFuncSetAttribute((const void *)postings_fill_lds<double>, hipFuncAttributeMaxDynamicSharedMemorySize, 124 * 1024);
+                (void)hipFuncSetAttribute((const void *)postings_fill_staged<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                (void)hipFuncSetAttribute((const void *)postings_fill_staged<double>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
                 attr_done = true;
+            }
+            // Round 6: filter postings staged in LDS and written cell by cell (postings_fill_staged) -- when only the filter
+            // postings are written (the exact kernel's are lazy) and a chunk of at least 64 rows fits the stage.  The stage
+            // takes what the packed counters leave of 158 KiB: one workgroup per CU, so tiles are split until there are two
+            // workgroups per CU (parts of >= 512 rows) and a launch does not end with a few CUs working alone.
+            bool staged = p->d_filt != nullptr && p->d_vals == nullptr && !(ctx->opt("SG_FILL_STAGED") && ctx->opt("SG_FILL_STAGED")[0] == '0');
+            uint32_t stage_cap = 0;
+            int32_t chunk_rows = 0;
+            size_t staged_lds = 0;
+            const double mean_nnz = B->n_rows > 0 ? (double)B->nnz / (double)B->n_rows : 1.0;
+            if (staged) {
+                const size_t fixed0 = ((((size_t)B->n_cols + 1) / 2 + 3) & ~(size_t)3) * 4 + (((size_t)B->n_cols + 31) / 32) * 4 + 32 * 4;
+                chunk_rows = 2048;
+                for (;;) {
+                    const size_t fixed = fixed0 + (size_t)chunk_rows * 4;
+                    const size_t room = fixed + 16384 < 158 * 1024 ? 158 * 1024 - fixed : 0;
+                    stage_cap = (uint32_t)(room / 4);
+                    if (stage_cap > 65535u) stage_cap = 65535u;
+                    if ((double)chunk_rows * mean_nnz * 1.2 + 64.0 <= (double)stage_cap || chunk_rows <= 64) break;
+                    chunk_rows >>= 1;
+                }
+                staged = (double)chunk_rows * mean_nnz * 1.2 + 64.0 <= (double)stage_cap;
+                staged_lds = fixed0 + (size_t)chunk_rows * 4 + (size_t)stage_cap * 4;
+                if (const char *v = ctx->opt("SG_FILL_STAGE_CAP"))    // test hook: chunks that do not fit go posting by posting
+                    if (atoi(v) > 0 && (uint32_t)atoi(v) < stage_cap) stage_cap = (uint32_t)atoi(v);
             }
             // fewer tiles than CUs: split every tile between 2 or 4 workgroups (parts of >= 1024 rows)
             int32_t split = 1;
             while (split < 4 && (int64_t)p->n_tiles * split < ctx->num_cu && (tile_cols / (split * 2)) >= 1024 &&
                    (n_bins * split * 2 + 1) < ((int64_t)1 << 31))
                 split *= 2;
+            if (staged)
+                while (split < 8 && (int64_t)p->n_tiles * split < 2 * (int64_t)ctx->num_cu && (tile_cols / (split * 2)) >= 512 &&
+                       (n_bins * split * 2 + 1) < ((int64_t)1 << 31))
+                    split *= 2;
             if (const char *e = ctx->opt("SG_POSTINGS_SPLIT")) {
                 const int o = atoi(e);
                 if ((o == 1 || o == 2 || o == 4) && tile_cols / o >= 64 && n_bins * o + 1 < ((int64_t)1 << 31)) split = o;
@@ -1112,7 +1390,9 @@ extern "C" int sg_postings_build_flags(sg_ctx *ctx, const sg_csr *B_in, int32_t 
                 // the terms' lists back to back: starts of the lists, the last entry receives the total (= nnz)
                 st = sg_exclusive_scan_u32(ctx, p->d_term_len, p->d_term_start, B->n_cols, p->d_term_start + B->n_cols);
                 if (st == SG_OK) {
-                    if (B->dtype == SG_F64)
+                    if (staged)
+                        ;     // (after the tables: the staged fill advances the workgroups' rows of `cnt`)
+                    else if (B->dtype == SG_F64)
                         hipLaunchKernelGGL(postings_fill_lds<double>, dim3(wgs), dim3(1024), lds, ctx->stream, B->d_indptr,
                                            B->d_indices, (const double *)B->d_data, B->n_rows, tile_log2, (int32_t)B->n_cols, split,
                                            (const uint32_t *)cnt, (const uint32_t *)p->d_term_start, (const uint8_t *)is_frequent,
@@ -1138,6 +1418,16 @@ extern "C" int sg_postings_build_flags(sg_ctx *ctx, const sg_csr *B_in, int32_t 
                                            (const uint32_t *)p->d_term_start, (int32_t)B->n_cols, p->n_tiles, split, p->d_seg, p->d_ends,
                                            p->nt_pad, p->d_ends8, p->nv_pad, p->fold_log2, sc, p->d_score_ctx,
                                            p->d_filt ? p->d_filt + B->nnz : (uint32_t *)nullptr);
+                        if (staged && B->dtype == SG_F64)
+                            hipLaunchKernelGGL(postings_fill_staged<double>, dim3(wgs), dim3(1024), staged_lds, ctx->stream, B->d_indptr,
+                                               B->d_indices, (const double *)B->d_data, B->n_rows, tile_log2, (int32_t)B->n_cols, split,
+                                               chunk_rows, stage_cap, cnt, (const uint32_t *)p->d_term_start, (const uint8_t *)is_frequent,
+                                               p->d_filt, inv_norm, p->fold_log2);
+                        else if (staged)
+                            hipLaunchKernelGGL(postings_fill_staged<float>, dim3(wgs), dim3(1024), staged_lds, ctx->stream, B->d_indptr,
+                                               B->d_indices, (const float *)B->d_data, B->n_rows, tile_log2, (int32_t)B->n_cols, split,
+                                               chunk_rows, stage_cap, cnt, (const uint32_t *)p->d_term_start, (const uint8_t *)is_frequent,
+                                               p->d_filt, inv_norm, p->fold_log2);
                         if (hipGetLastError() != hipSuccess) st = SG_ERR_HIP;
                         aux_written = st == SG_OK;
                     }

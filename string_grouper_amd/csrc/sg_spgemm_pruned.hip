@@ -736,7 +736,15 @@ spgemm_topn_pruned_kernel(const int64_t *__restrict__ a_indptr, const int32_t *_
     // with (scripts/range_probe.py).  A part keeps its matches in its list like a row and hands them to the pair list,
     // addressed to its own row; the second pass merges the parts' lists like mirrored matches.
     constexpr bool CAN_SPLIT = SYM && !WIDE && FOLD_LOG2 > 0 && SHARE;
-    const bool part_mode = CAN_SPLIT && (part_cfg >> 31) != 0u;
+    // Round 6 -- ONE launch per share: a wave of the launch over rows that finds no row left does not leave; it takes PARTS of
+    // the rows its launch has set aside so far (`stealing`: part mode inside the launch over rows), until every wave has
+    // left the rows and every part is taken.  The launch over rows ended with waves idling behind its slowest rows and the
+    // launch over parts had a ramp and a tail of its own: two tails per share, 17 % above an eighth of the whole at 5 M on
+    // eight ranks.  The launch over parts stays (it continues the same ticket counter) and finds nothing to do unless waves
+    // gave up waiting (a tail row that hands nothing on).
+    bool part_mode = CAN_SPLIT && (part_cfg >> 31) != 0u;
+    bool stealing = false;
+    const uint32_t *part_list = row_list;        // part mode: the rows in parts ([n_left ..): their first visit); stealing: heavy_rows
 #ifdef SG_DEBUG_WAVE_TIMES
     const unsigned long long dbg_t0 = __builtin_amdgcn_s_memrealtime();
     unsigned long long dbg_worst = 0, dbg_worst_row = 0;
@@ -752,18 +760,93 @@ spgemm_topn_pruned_kernel(const int64_t *__restrict__ a_indptr, const int32_t *_
     // all against 10.0 ms for the whole -- tails of four-row helpings).
     const uint32_t n_single = min(n_here, 2u * gridDim.x);
     const uint32_t n_quads = (n_here - n_single) >> 2;     // helpings [0, n_quads) hold four rows, the rest one
-    for (uint32_t hlp = next_row(row_counter, lane);; hlp = next_row(row_counter, lane)) {
-    const uint32_t row0 = hlp < n_quads ? hlp << 2 : (n_quads << 2) + (hlp - n_quads);
-    if (row0 >= n_here || hlp >= 0x10000000u) break;       // (the second: the pass was called off, see the pair list below)
-    for (uint32_t rr = row0; rr < row0 + (hlp < n_quads ? 4u : 1u); ++rr) {   // (rows behind the quads go singly)
+    for (;;) {
+    uint32_t rr_lo, rr_hi;
+    if (!(CAN_SPLIT && stealing)) {
+        const uint32_t hlp = next_row(row_counter, lane);
+        const uint32_t row0 = hlp < n_quads ? hlp << 2 : (n_quads << 2) + (hlp - n_quads);
+        if (row0 >= n_here || hlp >= 0x10000000u) {        // (the second: the pass was called off, see the pair list below)
+            if (CAN_SPLIT && !part_mode && part_cfg != 0u && heavy_count != nullptr && hlp < 0x10000000u &&
+                __builtin_amdgcn_readfirstlane((int)heavy_count[3]) == 0) {   // ([3] != 0: SG_SHARE_STEAL=0, the two launches of round 5)
+                // no row left for this wave: what it has set aside is visible before it says so (heavy_count[2] = waves that
+                // have left the rows), then it takes parts
+                if (lane == 0) {
+                    __threadfence();
+                    __hip_atomic_fetch_add(heavy_count + 2, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                stealing = true;
+                part_mode = true;
+                part_list = heavy_rows;
+                continue;
+            }
+            break;
+        }
+        rr_lo = row0;
+        rr_hi = row0 + (hlp < n_quads ? 4u : 1u);          // (rows behind the quads go singly)
+    } else {
+        // a ticket of the parts' counter (heavy_count[1]) that names a row already set aside: taken by compare-and-swap, so
+        // that a wave never holds a ticket whose row may not come (the launch over parts continues the same counter)
+        uint32_t ticket = 0xFFFFFFFFu;
+        if (lane == 0) {
+            // Thousands of waves may be waiting here: accesses to one line are served one at a time (~12 ns), so a wave looks
+            // with ONE 64-bit load {rows set aside, tickets taken} and sleeps longer every time it finds nothing (7 -> 110 us).
+            uint32_t idle = 0, nap = 2;
+            for (;;) {
+                if (__hip_atomic_load(row_counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= 0x10000000u) break;   // called off
+                const unsigned long long both = __hip_atomic_load(reinterpret_cast<unsigned long long *>(heavy_count), __ATOMIC_ACQUIRE,
+                                                                  __HIP_MEMORY_SCOPE_AGENT);
+                const uint32_t have = (uint32_t)both << SG_ROW_PARTS_LOG2, nxt = (uint32_t)(both >> 32);
+                if (nxt < have) {
+                    if (atomicCAS(heavy_count + 1, nxt, nxt + 1u) == nxt) {
+                        ticket = nxt;
+                        break;
+                    }
+                    continue;
+                }
+                // nothing to take now: done when every wave has left the rows (nobody sets a row aside any more) and the
+                // counters still say so
+                if (__hip_atomic_load(heavy_count + 2, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) >= gridDim.x) {
+                    const unsigned long long again = __hip_atomic_load(reinterpret_cast<unsigned long long *>(heavy_count), __ATOMIC_ACQUIRE,
+                                                                       __HIP_MEMORY_SCOPE_AGENT);
+                    if ((uint32_t)(again >> 32) >= ((uint32_t)again << SG_ROW_PARTS_LOG2)) break;
+                    continue;
+                }
+                // (bounded, ~5 ms: a launch whose waves are not all resident must not wait for waves that cannot start, and a
+                //  tail row that hands nothing on is not waited for; what is left goes to the launch over parts)
+                idle += nap;
+                if (idle > 1500u) break;
+                for (uint32_t q = 0; q < nap; ++q) __builtin_amdgcn_s_sleep(127);
+                if (nap < 32u) nap <<= 1;
+            }
+        }
+        ticket = (uint32_t)__builtin_amdgcn_readfirstlane((int)ticket);
+        if (ticket == 0xFFFFFFFFu) break;
+        rr_lo = ticket;
+        rr_hi = ticket + 1u;
+    }
+    for (uint32_t rr = rr_lo; rr < rr_hi; ++rr) {
         SG_WD(wd_rows, n_left + 2, 11)
-        const uint32_t row = WIDE ? (uint32_t)__builtin_amdgcn_readfirstlane((int)row_list[rr])
-                                  : part_mode ? (uint32_t)__builtin_amdgcn_readfirstlane((int)row_list[rr >> SG_ROW_PARTS_LOG2])
-                                              : (SYM ? sym_hi - 1u - rr * sym_step : rr);
+        uint32_t row;
+        if (WIDE) {
+            row = (uint32_t)__builtin_amdgcn_readfirstlane((int)row_list[rr]);
+        } else if (CAN_SPLIT && part_mode) {
+            // (stealing: the entry may still be on its way -- its writer has counted it already: a short wait for the row)
+            uint32_t rw = 0;
+            if (lane == 0) {
+                rw = __hip_atomic_load(part_list + (rr >> SG_ROW_PARTS_LOG2), __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+                while (stealing && rw == 0xFFFFFFFFu) {
+                    __builtin_amdgcn_s_sleep(2);
+                    rw = __hip_atomic_load(part_list + (rr >> SG_ROW_PARTS_LOG2), __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+            row = (uint32_t)__builtin_amdgcn_readfirstlane((int)rw);
+        } else {
+            row = SYM ? sym_hi - 1u - rr * sym_step : rr;
+        }
         uint32_t part_lo = 0, part_hi = 0;   // part mode: the visits [part_lo, part_hi) of the row
         if (CAN_SPLIT && part_mode) {
             // (the visits in front of `from` the row has done itself, in the launch over rows: see `deferred` below)
-            const uint32_t from = (uint32_t)__builtin_amdgcn_readfirstlane((int)row_list[n_left + (rr >> SG_ROW_PARTS_LOG2)]);
+            const uint32_t from = (uint32_t)__builtin_amdgcn_readfirstlane((int)part_list[n_left + (rr >> SG_ROW_PARTS_LOG2)]);
             const uint32_t nv = (((row >> TILE_LOG2) + (1u << FOLD_LOG2)) >> FOLD_LOG2) - from;   // visits of the row (self-join form) left
             const uint32_t part = rr & (SG_ROW_PARTS - 1u);
             part_lo = from + ((part * nv) >> SG_ROW_PARTS_LOG2);
@@ -1214,8 +1297,8 @@ spgemm_topn_pruned_kernel(const int64_t *__restrict__ a_indptr, const int32_t *_
                     if (wave_read<float>(rl, 0) >= (float)(part_cfg & 0x0fffffffu)) {
                         if (lane == 0) {
                             const uint32_t at = atomicAdd(heavy_count, 1u);
-                            heavy_rows[at] = row;
                             heavy_rows[n_left + at] = 0u;   // from its first visit
+                            __hip_atomic_store(heavy_rows + at, row, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);   // (the row last: waves take parts while this launch runs)
                         }
                         continue;
                     }
@@ -1463,8 +1546,8 @@ spgemm_topn_pruned_kernel(const int64_t *__restrict__ a_indptr, const int32_t *_
             if (n_surv > n_clean) flush_s(sb1, sb2, sb3, v_end);   // repeats out of what is left (scored below; everything has landed)
             if (CAN_SPLIT && !part_mode && v_end != n_visits && lane == 0) {   // handed on
                 const uint32_t at = atomicAdd(heavy_count, 1u);
-                heavy_rows[at] = row;
                 heavy_rows[n_left + at] = v_end;
+                __hip_atomic_store(heavy_rows + at, row, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
         {   // postings streamed = entries of P's lists in the tiles visited
@@ -1931,8 +2014,15 @@ static int launch_both(sg_ctx *ctx, const sg_csr *A, const sg_postings *Bt, int3
         if (const char *v = ctx->opt("SG_HANDOVER_SHIFT")) handover_shift = (uint32_t)atoi(v) & 7u;
         if (heavy_rounds) heavy_rounds |= handover_shift << 28;
         if (heavy_rounds) {
-            st = sg_alloc(ctx, 2 * (size_t)A->n_rows + 8, &heavy);   // [4, 4 + n): the rows, [4 + n, 4 + 2 n): their first visit for the parts
-            if (st == SG_OK && hipMemsetAsync(heavy, 0, 4 * sizeof(uint32_t), ctx->stream) != hipSuccess) st = SG_ERR_HIP;
+            // [0] rows set aside [1] the parts' ticket counter [2] waves that have left the rows; [4, 4 + n): the rows (0xFFFFFFFF:
+            // not written yet -- waves take parts while the launch over rows still appends), [4 + n, 4 + 2 n): their first visit for the parts
+            st = sg_alloc(ctx, 2 * (size_t)A->n_rows + 8, &heavy);
+            if (st == SG_OK && (hipMemsetAsync(heavy, 0, 4 * sizeof(uint32_t), ctx->stream) != hipSuccess ||
+                                hipMemsetAsync(heavy + 4, 0xFF, sizeof(uint32_t) * (size_t)A->n_rows, ctx->stream) != hipSuccess))
+                st = SG_ERR_HIP;
+            if (st == SG_OK && ctx->opt("SG_SHARE_STEAL") && ctx->opt("SG_SHARE_STEAL")[0] == '0' &&
+                hipMemsetAsync(heavy + 3, 0x01, sizeof(uint32_t), ctx->stream) != hipSuccess)    // (A/B: waves leave when the rows run out)
+                st = SG_ERR_HIP;
         }
     }
     if (st == SG_OK)

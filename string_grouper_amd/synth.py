@@ -62,11 +62,26 @@ def _perturb(name: str, kind: int, u1: float, u2: float) -> str:
     return name + " " + str(1 + int(u1 * 29))            # numbered series
 
 
+def _row_key(name: str) -> str:
+    """What decides a name's TF-IDF row under the reference's defaults (lower case, regex '[,-./]|\\s' deleted,
+    string_grouper.py:190-197): two names of one key have identical rows."""
+    return "".join(c for c in name.lower() if c not in ",-./" and not c.isspace())
+
+
 def synth_names(n: int, seed: int = 1234, perturb_of: Optional[Sequence[str]] = None,
-                perturb_frac: float = 0.30) -> List[str]:
+                perturb_frac: float = 0.30, dup_frac: Optional[float] = None) -> List[str]:
     """Generate ``n`` names.  ``perturb_of`` given: perturbations are drawn from that list
     (used for the 'duplicates' side of config 5 with perturb_frac=0.5) instead of from the
-    names generated so far."""
+    names generated so far.
+
+    ``dup_frac`` (round 6): SynthNames-v1 repeats itself far more than a real company list -- 16.5 % of its names have the TF-IDF
+    row of an earlier name (exact copies, punctuation variants, one-word names drawn twice), where the reference's README
+    counts 1 747 names in groups of identical names among 663 000 (0.26 %).  With ``dup_frac`` given only the first
+    ``dup_frac * n`` such repeats stay; every later one is replaced by a FRESH name (words drawn from the same lexicon by a
+    stream of its own, ``seed + 7919``) whose row no earlier name has.  ``None``: the survey's generator as it is."""
+    if dup_frac is not None:
+        base = synth_names(n, seed, perturb_of, perturb_frac)
+        return _thin_repeats(base, seed, float(dup_frac))
     rng = np.random.default_rng(seed)
     lex = _lexicon(rng)
     ranks = np.arange(_LEXICON_SIZE, dtype=np.float64)
@@ -100,4 +115,50 @@ def synth_names(n: int, seed: int = 1234, perturb_of: Optional[Sequence[str]] = 
                 parts.append(suf_names[int(suffix_ids[i])])
             out.append(" ".join(parts))
         wpos += k
+    return out
+
+
+def _thin_repeats(names: List[str], seed: int, dup_frac: float) -> List[str]:
+    rng = np.random.default_rng(seed + 7919)
+    lex = _lexicon(np.random.default_rng(seed))           # (the list's own lexicon: the first thing its stream draws)
+    ranks = np.arange(_LEXICON_SIZE, dtype=np.float64)
+    pw = 1.0 / (ranks + 5.0) ** 0.95
+    pw /= pw.sum()
+    suf_names = [s for s, _ in _SUFFIXES]
+    sw = np.array([w for _, w in _SUFFIXES], dtype=np.float64)
+    sw /= sw.sum()
+    keep = int(dup_frac * len(names))
+    seen, out, kept = set(), list(names), 0
+    redo = []
+    for i, name in enumerate(names):
+        key = _row_key(name)
+        if key in seen:
+            if kept < keep:
+                kept += 1
+            else:
+                redo.append(i)
+        else:
+            seen.add(key)
+    # (drawn in bulk: a draw from the 20 000-word law per name is a second per thousand names)
+    m = int(len(redo) * 1.3) + 64
+    ks = rng.choice(np.array([2, 3, 4]), size=m, p=[0.5, 0.35, 0.15])             # (one-word names are what collides)
+    words = rng.choice(_LEXICON_SIZE, size=int(ks.sum()), p=pw)
+    has_suffix = rng.random(m) < 0.8
+    suffix_ids = rng.choice(len(suf_names), size=m, p=sw)
+    starts = np.concatenate([[0], np.cumsum(ks)])
+    at = 0
+    for i in redo:
+        while True:
+            if at >= m:
+                raise RuntimeError("synth_names(dup_frac=...): ran out of fresh names")
+            parts = [lex[w] for w in words[starts[at]:starts[at + 1]]]
+            if has_suffix[at]:
+                parts.append(suf_names[int(suffix_ids[at])])
+            at += 1
+            cand = " ".join(parts)
+            key = _row_key(cand)
+            if key not in seen:
+                seen.add(key)
+                out[i] = cand
+                break
     return out

@@ -212,11 +212,14 @@ def test_vectoriser_matches_sklearn_bitexact(ctx, dtype):
 
 
 @pytest.mark.parametrize("env", [{"SG_DF_MARKS": "0"}, {"SG_K2_PLAIN": "1"}, {"SG_POSTINGS_SPLIT": "1"},
-                                 {"SG_POSTINGS_SPLIT": "4"}, {"SG_POSTINGS_LDS": "0"}])
+                                 {"SG_POSTINGS_SPLIT": "4"}, {"SG_POSTINGS_LDS": "0"}, {"SG_FILL_STAGED": "0"},
+                                 {"SG_FILL_STAGE_CAP": "3000"}, {"SG_FILL_STAGE_CAP": "19500"},
+                                 {"SG_POSTINGS_SPLIT": "1", "SG_FILL_STAGE_CAP": "19500"}])
 def test_alternative_forms_of_k1_k2_k3_give_the_same_bits(ctx, env, monkeypatch):
     """Every kernel that got a faster form in round 2 keeps its first form behind a switch (document frequencies by
     global atomics -- the form the multi-GPU fit uses --, K2 with a thread per row, K3 without the tile split / without
-    LDS counters): each must still reproduce sklearn and the port bit for bit."""
+    LDS counters; round 6: filter postings written one by one instead of staged in LDS, and chunks that do not fit the stage):
+    each must still reproduce sklearn and the port bit for bit."""
     from string_grouper_amd.vectorizer import HipTfidfVectorizer
     for k, v in env.items():
         monkeypatch.setenv(k, v)
@@ -1333,12 +1336,14 @@ def test_rows_worked_off_in_parts_give_the_same_rows(ctx, dtype):
     ctx.set_option("SG_COLLAPSE", "0")
     ctx.set_option("SG_SYM", "1")
     ops = D.HipOps(ctx, lambda: HipTfidfVectorizer(dtype=dtype, ctx=ctx))
-    for bar in ("0", "2", "40"):
+    # (round 6: waves that run out of rows take parts inside the launch over rows; SG_SHARE_STEAL=0: the two launches of round 5)
+    for bar, steal in (("0", None), ("2", None), ("2", "0"), ("40", None), ("40", "0")):
         ctx.set_option("SG_HEAVY_ROUNDS", bar)
+        ctx.set_option("SG_SHARE_STEAL", steal)
         post = ctx.postings_build(dA)
         res = ctx.spgemm_topn(dA, post, 10, 0.8, True)
         assert ctx.stats()["prune_symmetric"] == 1
-        assert_csr_identical(res.to_scipy(), want, f"whole matrix, rows of >= {bar} rounds in parts")
+        assert_csr_identical(res.to_scipy(), want, f"whole matrix, rows of >= {bar} rounds in parts, SG_SHARE_STEAL={steal}")
         res.free()
         bounds = D.selfjoin_row_ranges(n, 3)
         parts = [ops.selfjoin_range(dA, post, 10, 0.8, int(bounds[r]), int(bounds[r + 1])) for r in range(3)]
@@ -1351,7 +1356,7 @@ def test_rows_worked_off_in_parts_give_the_same_rows(ctx, dtype):
             rows.append(blk.to_scipy())
             blk.free()
         C = sp.vstack(rows).tocsr()[np.argsort(orig_of.cpu().numpy(), kind="stable")]
-        assert_csr_identical(C, want, f"three ranges, rows of >= {bar} rounds in parts")
+        assert_csr_identical(C, want, f"three ranges, rows of >= {bar} rounds in parts, SG_SHARE_STEAL={steal}")
         post.free()
     dA.free()
 
