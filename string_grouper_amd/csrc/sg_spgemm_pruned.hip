@@ -663,6 +663,67 @@ __device__ __noinline__ void emit_part_matches(const SgPairSink *__restrict__ pa
     if (lane == 0) surv[SG_SURV_CAP - 1] = (int)(pos + (uint32_t)cnt);
 }
 
+// One launch per share (see the kernel): a ticket of the parts' counter (heavy[1]) that names a row already set aside
+// (heavy[0] rows, SG_ROW_PARTS tickets each), or 0xFFFFFFFF: nothing left to take -- every wave has left the rows
+// (heavy[2] == waves of the launch) and every ticket is out -- or nothing came for ~5 ms.  Taken by compare-and-swap, so that
+// a wave never holds a ticket whose row may not come (the launch over parts continues the same counter).  Wave-uniform.
+// Not inlined: the loop below must not cost the round loop's kernel a register -- and written INTO the kernel (first form of
+// round 6) the kernel faulted on its first launch as a share even with this path switched off at run time (hipcc 7.2;
+// scripts/debug_fault.py: the same source with the condition in front of it compiled to `false` ran): the two waiting loops
+// live in functions of their own, every value they return goes through readfirstlane at the call.
+__device__ __noinline__ uint32_t steal_part_ticket(uint32_t *heavy, const uint32_t *row_counter, uint32_t n_waves) {
+    uint32_t ticket = 0xFFFFFFFFu;
+    if (threadIdx.x == 0) {
+        // Thousands of waves may be waiting here: accesses to one line are served one at a time (~12 ns), so a wave looks
+        // with ONE 64-bit load {rows set aside, tickets taken} and sleeps longer every time it finds nothing (7 -> 110 us).
+        uint32_t idle = 0, nap = 2;
+        bool looking = true;
+        while (looking) {
+            if (__hip_atomic_load(row_counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= 0x10000000u) {   // called off
+                looking = false;
+            } else {
+                const unsigned long long both = __hip_atomic_load(reinterpret_cast<unsigned long long *>(heavy), __ATOMIC_ACQUIRE,
+                                                                  __HIP_MEMORY_SCOPE_AGENT);
+                const uint32_t have = (uint32_t)both << SG_ROW_PARTS_LOG2, nxt = (uint32_t)(both >> 32);
+                if (nxt < have) {
+                    if (atomicCAS(heavy + 1, nxt, nxt + 1u) == nxt) {
+                        ticket = nxt;
+                        looking = false;
+                    }
+                } else if (__hip_atomic_load(heavy + 2, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) >= n_waves) {
+                    // nobody sets a row aside any more: done if the counters still say that nothing is left
+                    const unsigned long long again = __hip_atomic_load(reinterpret_cast<unsigned long long *>(heavy), __ATOMIC_ACQUIRE,
+                                                                       __HIP_MEMORY_SCOPE_AGENT);
+                    if ((uint32_t)(again >> 32) >= ((uint32_t)again << SG_ROW_PARTS_LOG2)) looking = false;
+                } else {
+                    // (bounded, ~5 ms: a launch whose waves are not all resident must not wait for waves that cannot start,
+                    //  and a tail row that hands nothing on is not waited for; what is left goes to the launch over parts)
+                    idle += nap;
+                    if (idle > 1500u) looking = false;
+                    else
+                        for (uint32_t q = 0; q < nap; ++q) __builtin_amdgcn_s_sleep(127);
+                    if (nap < 32u) nap <<= 1;
+                }
+            }
+        }
+    }
+    return (uint32_t)__builtin_amdgcn_readfirstlane((int)ticket);
+}
+// ... and the row a ticket names: its writer has counted it before writing it (0xFFFFFFFF: not there yet -- a short wait)
+__device__ __noinline__ uint32_t stolen_part_row(const uint32_t *entry) {
+    uint32_t rw = 0;
+    if (threadIdx.x == 0) {
+        rw = __hip_atomic_load(entry, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+        bool waiting = rw == 0xFFFFFFFFu;
+        while (waiting) {
+            __builtin_amdgcn_s_sleep(2);
+            rw = __hip_atomic_load(entry, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+            waiting = rw == 0xFFFFFFFFu;
+        }
+    }
+    return (uint32_t)__builtin_amdgcn_readfirstlane((int)rw);
+}
+
 // WIDE: the second launch, over the rows the first one could not take because they have 65 .. 128 non-zeros: every lane
 // stages two of the row's terms; still one posting list per lane, so the row's prefix P must fit 64 lanes.
 // 16 single-wave workgroups per CU (the LDS limit) = 4 waves per SIMD: <= 128 VGPRs.  The f64 stream form has 10.5 KiB of LDS
@@ -784,41 +845,7 @@ spgemm_topn_pruned_kernel(const int64_t *__restrict__ a_indptr, const int32_t *_
         rr_lo = row0;
         rr_hi = row0 + (hlp < n_quads ? 4u : 1u);          // (rows behind the quads go singly)
     } else {
-        // a ticket of the parts' counter (heavy_count[1]) that names a row already set aside: taken by compare-and-swap, so
-        // that a wave never holds a ticket whose row may not come (the launch over parts continues the same counter)
-        uint32_t ticket = 0xFFFFFFFFu;
-        if (lane == 0) {
-            // Thousands of waves may be waiting here: accesses to one line are served one at a time (~12 ns), so a wave looks
-            // with ONE 64-bit load {rows set aside, tickets taken} and sleeps longer every time it finds nothing (7 -> 110 us).
-            uint32_t idle = 0, nap = 2;
-            for (;;) {
-                if (__hip_atomic_load(row_counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= 0x10000000u) break;   // called off
-                const unsigned long long both = __hip_atomic_load(reinterpret_cast<unsigned long long *>(heavy_count), __ATOMIC_ACQUIRE,
-                                                                  __HIP_MEMORY_SCOPE_AGENT);
-                const uint32_t have = (uint32_t)both << SG_ROW_PARTS_LOG2, nxt = (uint32_t)(both >> 32);
-                if (nxt < have) {
-                    if (atomicCAS(heavy_count + 1, nxt, nxt + 1u) == nxt) {
-                        ticket = nxt;
-                        break;
-                    }
-                    continue;
-                }
-                // nothing to take now: done when every wave has left the rows (nobody sets a row aside any more) and the
-                // counters still say so
-                if (__hip_atomic_load(heavy_count + 2, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) >= gridDim.x) {
-                    const unsigned long long again = __hip_atomic_load(reinterpret_cast<unsigned long long *>(heavy_count), __ATOMIC_ACQUIRE,
-                                                                       __HIP_MEMORY_SCOPE_AGENT);
-                    if ((uint32_t)(again >> 32) >= ((uint32_t)again << SG_ROW_PARTS_LOG2)) break;
-                    continue;
-                }
-                // (bounded, ~5 ms: a launch whose waves are not all resident must not wait for waves that cannot start, and a
-                //  tail row that hands nothing on is not waited for; what is left goes to the launch over parts)
-                idle += nap;
-                if (idle > 1500u) break;
-                for (uint32_t q = 0; q < nap; ++q) __builtin_amdgcn_s_sleep(127);
-                if (nap < 32u) nap <<= 1;
-            }
-        }
+        uint32_t ticket = steal_part_ticket(heavy_count, row_counter, gridDim.x);
         ticket = (uint32_t)__builtin_amdgcn_readfirstlane((int)ticket);
         if (ticket == 0xFFFFFFFFu) break;
         rr_lo = ticket;
@@ -830,15 +857,10 @@ spgemm_topn_pruned_kernel(const int64_t *__restrict__ a_indptr, const int32_t *_
         if (WIDE) {
             row = (uint32_t)__builtin_amdgcn_readfirstlane((int)row_list[rr]);
         } else if (CAN_SPLIT && part_mode) {
-            // (stealing: the entry may still be on its way -- its writer has counted it already: a short wait for the row)
-            uint32_t rw = 0;
-            if (lane == 0) {
-                rw = __hip_atomic_load(part_list + (rr >> SG_ROW_PARTS_LOG2), __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
-                while (stealing && rw == 0xFFFFFFFFu) {
-                    __builtin_amdgcn_s_sleep(2);
-                    rw = __hip_atomic_load(part_list + (rr >> SG_ROW_PARTS_LOG2), __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
-                }
-            }
+            // (stealing: the entry may still be on its way -- stolen_part_row waits for it)
+            uint32_t rw;
+            if (stealing) rw = stolen_part_row(part_list + (rr >> SG_ROW_PARTS_LOG2));
+            else rw = part_list[rr >> SG_ROW_PARTS_LOG2];
             row = (uint32_t)__builtin_amdgcn_readfirstlane((int)rw);
         } else {
             row = SYM ? sym_hi - 1u - rr * sym_step : rr;

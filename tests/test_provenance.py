@@ -57,3 +57,16 @@ def test_files_without_a_recorded_sha_count_as_stale(tmp_path):
 def test_the_committed_files_of_this_tree_either_match_the_sources_or_are_reported_stale():
     got = PV.committed_counters(ROOT, 663000, "f32", "K4p-sym", 5.0)
     assert ("traffic_stale" in got) != (got.get("traffic") is not None)
+
+
+def test_a_pass_of_another_size_is_found_under_its_own_file_name(tmp_path):
+    """Round 6: profiles/k4_traffic_5M.json (the 5 M self-join, past the Infinity Cache) next to the headline's file --
+    the bench line of --rows 5000000 quotes it, the headline's line does not."""
+    tmp = str(tmp_path)
+    sha = _copy_tree(tmp)
+    json.dump({"workload_rows": 5000000, "dtype": "f32", "kernel": "K4p-sym", "source_sha": sha,
+               "traffic_bytes_per_launch_raw": 9.5e11, "source": "s", "note": "n"},
+              open(os.path.join(tmp, "profiles", "k4_traffic_5M.json"), "w"))
+    big = PV.committed_counters(tmp, 5000000, "f32", "K4p-sym", 147.0)
+    assert big["traffic"] == 9.5e11 and "k4_traffic_5M.json" in big["traffic_source"] and "valu_issue_frac" not in big
+    assert PV.committed_counters(tmp, 663000, "f32", "K4p-sym", 5.0)["traffic"] == 2.0e10
