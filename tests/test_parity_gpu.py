@@ -1336,14 +1336,12 @@ def test_rows_worked_off_in_parts_give_the_same_rows(ctx, dtype):
     ctx.set_option("SG_COLLAPSE", "0")
     ctx.set_option("SG_SYM", "1")
     ops = D.HipOps(ctx, lambda: HipTfidfVectorizer(dtype=dtype, ctx=ctx))
-    # (round 6: waves that run out of rows take parts inside the launch over rows; SG_SHARE_STEAL=0: the two launches of round 5)
-    for bar, steal in (("0", None), ("2", None), ("2", "0"), ("40", None), ("40", "0")):
+    for bar in ("0", "2", "40"):
         ctx.set_option("SG_HEAVY_ROUNDS", bar)
-        ctx.set_option("SG_SHARE_STEAL", steal)
         post = ctx.postings_build(dA)
         res = ctx.spgemm_topn(dA, post, 10, 0.8, True)
         assert ctx.stats()["prune_symmetric"] == 1
-        assert_csr_identical(res.to_scipy(), want, f"whole matrix, rows of >= {bar} rounds in parts, SG_SHARE_STEAL={steal}")
+        assert_csr_identical(res.to_scipy(), want, f"whole matrix, rows of >= {bar} rounds in parts")
         res.free()
         bounds = D.selfjoin_row_ranges(n, 3)
         parts = [ops.selfjoin_range(dA, post, 10, 0.8, int(bounds[r]), int(bounds[r + 1])) for r in range(3)]
@@ -1356,7 +1354,7 @@ def test_rows_worked_off_in_parts_give_the_same_rows(ctx, dtype):
             rows.append(blk.to_scipy())
             blk.free()
         C = sp.vstack(rows).tocsr()[np.argsort(orig_of.cpu().numpy(), kind="stable")]
-        assert_csr_identical(C, want, f"three ranges, rows of >= {bar} rounds in parts, SG_SHARE_STEAL={steal}")
+        assert_csr_identical(C, want, f"three ranges, rows of >= {bar} rounds in parts")
         post.free()
     dA.free()
 
