@@ -100,6 +100,13 @@ def to_arrow_buffers(strings):
             arr = arr.cast(pa.large_string())
     else:
         values = strings.to_numpy() if hasattr(strings, "to_numpy") else np.asarray(strings, dtype=object)
+        # (round 6: a column of ASCII str objects -- every list of company names -- is copied out by a few host threads,
+        #  _hostops.ascii_column_bytes; anything else in it and pyarrow looks at the column: 18 -> ms at 663 k names)
+        if isinstance(values, np.ndarray) and values.dtype == object:
+            from . import _hostops
+            fast = _hostops.ascii_column_bytes(values)
+            if fast is not None:
+                return fast
         arr = pa.array(values, type=pa.large_string())
     if arr.null_count:
         raise TypeError("input contains null values; only strings are accepted")

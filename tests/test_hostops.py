@@ -1,0 +1,69 @@
+"""string_grouper_amd/_hostops.py (libsg_host.so): the threaded object gather and the ASCII column copy return exactly what
+the numpy / pyarrow code they stand in for returns -- the same objects, the same bytes -- and step aside for anything else."""
+import sys
+
+import numpy as np
+import pandas as pd
+import pytest
+
+from string_grouper_amd import _hostops as H
+from string_grouper_amd import strprep
+from string_grouper_amd.synth import synth_names
+
+needs_lib = pytest.mark.skipif(H._load() is None, reason="libsg_host.so not built (python __graft_entry__.py)")
+
+
+@needs_lib
+def test_gather_returns_the_same_objects_and_keeps_the_reference_counts_right():
+    names = synth_names(70000, 3)
+    names[17] = "".join(["PROBE ", "OBJECT ", "OF ITS OWN"])           # (the generator hands out one object for exact repeats)
+    arr = np.array(names, dtype=object)
+    rng = np.random.default_rng(1)
+    idx = rng.integers(0, len(arr), 200000).astype(np.int64)
+    none_before, probe_before = sys.getrefcount(None), sys.getrefcount(names[17])
+    got = H.take_objects(arr, idx)
+    uses = int((idx == 17).sum())
+    after = sys.getrefcount(names[17])       # (measured outside the assert: pytest's rewriting keeps its operands alive)
+    assert after == probe_before + uses                                   # one new reference per use
+    want = arr.take(idx)
+    assert got.dtype == object and got.shape == want.shape
+    same = [a is b for a, b in zip(got.tolist(), want.tolist())]
+    assert all(same)
+    del got, want, same
+    after = sys.getrefcount(names[17])
+    assert after == probe_before
+    none_after = sys.getrefcount(None)
+    assert abs(none_after - none_before) < 64                             # the fresh array's references to None were given back
+    # other index types, and what numpy refuses
+    assert all(a is b for a, b in zip(H.take_objects(arr, idx.astype(np.int32)).tolist(), arr.take(idx).tolist()))
+    bad = idx.copy()
+    bad[5] = len(arr)
+    with pytest.raises(IndexError):
+        H.take_objects(arr, bad)
+
+
+@needs_lib
+def test_ascii_columns_are_copied_out_and_everything_else_goes_the_general_way():
+    names = synth_names(50000, 5) + ["", "a", "x" * 5000]
+    arr = np.array(names, dtype=object)
+    data, off = H.ascii_column_bytes(arr)
+    assert off[0] == 0 and off[-1] == len(data) == sum(len(s) for s in names)
+    assert bytes(data[off[123]:off[124]]).decode() == names[123] and data[off[-2]:].tobytes() == b"x" * 5000
+    for odd in ("ÀbracâDABRÀ", 3, None, b"bytes", np.str_("numpy str")):
+        mixed = arr.copy()
+        mixed[777] = odd
+        assert H.ascii_column_bytes(mixed) is None
+    # through the column preparation: the same buffers with and without the helper
+    s = pd.Series(names)
+    d1, o1 = strprep.to_arrow_buffers(s)
+    saved, H._lib = H._lib, None
+    try:
+        d2, o2 = strprep.to_arrow_buffers(s)
+    finally:
+        H._lib = saved
+    assert np.array_equal(d1, d2) and np.array_equal(o1, o2)
+    uni = pd.Series(names[:5000] + ["Ünïcödé GmbH"])
+    d3, o3 = strprep.to_arrow_buffers(uni)
+    assert bytes(d3[o3[-2]:]).decode("utf-8") == "Ünïcödé GmbH"
+    with pytest.raises(TypeError):
+        strprep.to_arrow_buffers(pd.Series(names[:5000] + [None], dtype=object))
