@@ -5,8 +5,8 @@
 // of 2.1 M match rows: a random access to a PyObject header per element to raise its reference count, one thread) and 18 ms
 // in the conversion of the string column to UTF-8 bytes + offsets (profiles/r06_e2e_profile.log).  Both are gathers over
 // immutable objects; neither needs the interpreter:
-//   * sg_host_gather_objects: dst[i] = src[idx[i]] with the reference counts raised by T threads, every thread owning a
-//     RANGE OF SOURCE OBJECTS (it walks all of idx and takes the elements that point into its range), so that no two
+//   * sg_host_gather_objects: dst[i] = src[idx[i]] with the reference counts raised by T threads, every thread owning the
+//     OBJECTS whose address hashes to it (it walks all of idx and takes the elements that are its own), so that no two
 //     threads ever touch the same counter;
 //   * sg_host_ascii_lengths / sg_host_ascii_copy: lengths, then bytes, of a column of compact-ASCII str objects (read-only
 //     on the objects).  Anything else in the column -- a non-ASCII str, a non-str -- is reported and the caller takes the
@@ -28,18 +28,19 @@ int sg_host_gather_objects(PyObject **src, int64_t n_src, const int64_t *idx, in
     int bad = 0;
 #pragma omp parallel num_threads(threads) reduction(| : bad)
     {
-        const int t = omp_get_thread_num(), T = omp_get_num_threads();
-        const int64_t lo = n_src * t / T, hi = n_src * (t + 1) / T;
+        const uint64_t t = (uint64_t)omp_get_thread_num(), T = (uint64_t)omp_get_num_threads();
         for (int64_t i = 0; i < n; ++i) {
             const int64_t j = idx[i];
             if (j < 0 || j >= n_src) {
                 bad = 1;
                 continue;
             }
-            if (j >= lo && j < hi) {
-                PyObject *o = src[j];
+            PyObject *o = src[j];
+            // the owner of an OBJECT, not of a position of the source array: one str may sit at several positions (a list that
+            // repeats a name holds the same object twice) and must still be counted by one thread only
+            if ((((uint64_t)(uintptr_t)o >> 4) * 0x9E3779B97F4A7C15ull >> 40) % T == t) {
                 dst[i] = o;
-                ++o->ob_refcnt;         // (this thread alone raises the counters of objects lo .. hi)
+                ++o->ob_refcnt;
             }
         }
     }

@@ -826,7 +826,9 @@ __global__ void __launch_bounds__(256) q8_pack_kernel(const int64_t *__restrict_
 // loads of a stage issued before the first is used, and a row's first 32 entries in flight together: the kernel ran at the
 // latency of its chain (0.21 ms for 0.4 GB); (d) the 8-bit records are put together from the registers that hold the
 // entries (four shuffles a round), not by reading the row a second time.
+#ifndef SG_GATHER_ROWS     // (A/B knob of the build: scripts/build_variant.sh)
 #define SG_GATHER_ROWS 2
+#endif
 template <typename T>
 __device__ __forceinline__ uint32_t q8_entry_of(int32_t k, T v, bool have, float inv_norm) {
     if (!have) return 0u;
