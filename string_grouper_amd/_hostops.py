@@ -30,6 +30,8 @@ def _load():
         lib = C.PyDLL(path)
         lib.sg_host_gather_objects.restype = C.c_int
         lib.sg_host_gather_objects.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int]
+        lib.sg_host_all_exact_str.restype = C.c_int
+        lib.sg_host_all_exact_str.argtypes = [C.c_void_p, C.c_int64, C.c_int]
         lib.sg_host_ascii_lengths.restype = C.c_int
         lib.sg_host_ascii_lengths.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int]
         lib.sg_host_ascii_copy.restype = None
@@ -45,7 +47,7 @@ def _threads() -> int:
         n = len(os.sched_getaffinity(0))
     except AttributeError:
         n = os.cpu_count() or 1
-    return max(1, min(8, n))
+    return max(1, min(16, n))
 
 
 def take_objects(values: np.ndarray, positions: np.ndarray) -> np.ndarray:
@@ -77,3 +79,12 @@ def ascii_column_bytes(values: np.ndarray) -> Optional[Tuple[np.ndarray, np.ndar
     data = np.empty(int(offsets[-1]), dtype=np.uint8)
     lib.sg_host_ascii_copy(values.ctypes.data, n, offsets.ctypes.data, data.ctypes.data, t)
     return data, offsets
+
+
+def all_exact_str(values: np.ndarray) -> bool:
+    """True when every element of the object array is exactly a ``str``; False: something else is in it, or the helper is
+    not there (the caller then looks for itself)."""
+    lib = _load()
+    if lib is None or len(values) < 4096 or values.dtype != object or values.ndim != 1 or not values.flags.c_contiguous:
+        return False
+    return bool(lib.sg_host_all_exact_str(values.ctypes.data, len(values), _threads()))

@@ -5,9 +5,8 @@
 // of 2.1 M match rows: a random access to a PyObject header per element to raise its reference count, one thread) and 18 ms
 // in the conversion of the string column to UTF-8 bytes + offsets (profiles/r06_e2e_profile.log).  Both are gathers over
 // immutable objects; neither needs the interpreter:
-//   * sg_host_gather_objects: dst[i] = src[idx[i]] with the reference counts raised by T threads, every thread owning the
-//     OBJECTS whose address hashes to it (it walks all of idx and takes the elements that are its own), so that no two
-//     threads ever touch the same counter;
+//   * sg_host_gather_objects: dst[i] = src[idx[i]] by T threads, then the reference counts raised by T threads, every
+//     thread owning the OBJECTS whose address hashes to it, so that no two threads ever touch the same counter;
 //   * sg_host_ascii_lengths / sg_host_ascii_copy: lengths, then bytes, of a column of compact-ASCII str objects (read-only
 //     on the objects).  Anything else in the column -- a non-ASCII str, a non-str -- is reported and the caller takes the
 //     general path (pyarrow), which also raises the reference's TypeError for non-strings.
@@ -20,36 +19,45 @@
 #include <omp.h>
 
 // 0 ok; 1 an index is out of range; 2 dst does not hold n references to None (a fresh np.empty(n, object) does)
+// Two passes: the pointers (every thread a run of positions: a plain gather), then the reference counts -- every thread
+// walks ALL of dst and counts the objects whose address hashes to it, so that one object is only ever counted by one
+// thread however many positions (of src and of dst) hold it.
 int sg_host_gather_objects(PyObject **src, int64_t n_src, const int64_t *idx, int64_t n, PyObject **dst, int threads) {
     if (n <= 0) return 0;
     if (dst[0] != Py_None || dst[n - 1] != Py_None) return 2;
     if (threads < 1) threads = 1;
     if (threads > 64) threads = 64;
     int bad = 0;
-#pragma omp parallel num_threads(threads) reduction(| : bad)
+#pragma omp parallel for num_threads(threads) schedule(static) reduction(| : bad)
+    for (int64_t i = 0; i < n; ++i) {
+        const int64_t j = idx[i];
+        if (j < 0 || j >= n_src) bad = 1;
+    }
+    if (bad) return 1;                   // (nothing written yet: the caller lets numpy raise)
+#pragma omp parallel num_threads(threads)
     {
+#pragma omp for schedule(static)
+        for (int64_t i = 0; i < n; ++i) dst[i] = src[idx[i]];
         const uint64_t t = (uint64_t)omp_get_thread_num(), T = (uint64_t)omp_get_num_threads();
         for (int64_t i = 0; i < n; ++i) {
-            const int64_t j = idx[i];
-            if (j < 0 || j >= n_src) {
-                bad = 1;
-                continue;
-            }
-            PyObject *o = src[j];
-            // the owner of an OBJECT, not of a position of the source array: one str may sit at several positions (a list that
-            // repeats a name holds the same object twice) and must still be counted by one thread only
-            if ((((uint64_t)(uintptr_t)o >> 4) * 0x9E3779B97F4A7C15ull >> 40) % T == t) {
-                dst[i] = o;
-                ++o->ob_refcnt;
-            }
+            PyObject *o = dst[i];
+            if ((((uint64_t)(uintptr_t)o >> 4) * 0x9E3779B97F4A7C15ull >> 40) % T == t) ++o->ob_refcnt;
         }
-    }
-    if (bad) {
-        // (entries of the bad indices still hold None; the others hold new references: the caller drops the array)
-        return 1;
     }
     Py_None->ob_refcnt -= n;            // the n references to None the fresh array held are gone
     return 0;
+}
+
+// 1 when every element is exactly a str (the reference's isinstance(x, str) test, string_grouper.py:351-362, on the common
+// case; a subclass of str, or anything else, and the caller asks pandas)
+int sg_host_all_exact_str(PyObject **objs, int64_t n, int threads) {
+    if (threads < 1) threads = 1;
+    if (threads > 64) threads = 64;
+    int other = 0;
+#pragma omp parallel for num_threads(threads) schedule(static) reduction(| : other)
+    for (int64_t i = 0; i < n; ++i)
+        if (!PyUnicode_CheckExact(objs[i])) other = 1;
+    return other ? 0 : 1;
 }
 
 // offsets[0 .. n]: running byte lengths; returns 0 when every element is a compact ASCII str, 1 otherwise

@@ -759,6 +759,8 @@ class StringGrouper(object):
         # inference answers the same question ("string" only when every element is a str, no missing values)
         if len(series_to_test) == 0:
             return True                       # nothing in it that is not a str (the reference: any() of nothing)
+        if series_to_test.dtype == object and _hostops.all_exact_str(series_to_test.to_numpy()):
+            return True                       # (round 6: the type test on a few host threads, 7 -> 1 ms at 663 k; anything but str: below)
         kind = pd.api.types.infer_dtype(series_to_test, skipna=False)
         if kind == "string":
             # an extension string dtype may hold pd.NA, which the inference does not report
