@@ -51,6 +51,8 @@ def committed_counters(root: str, rows: int, dtype: str, kernel_tag: str, kernel
             out["traffic_source"] = (f"committed PMC pass (profiles/{tr['_file']}, written by scripts/pmc_traffic.py on "
                                      f"kernel sources {sha[:12]}); not measured in this run")
             out["traffic_note"] = tr["source"] + "; " + tr["note"]
+            if isinstance(tr.get("tcc"), dict) and "hit_frac" in tr["tcc"]:      # (an L2 pass of the same session, where one was made)
+                out["tcc_hit_frac"] = tr["tcc"]["hit_frac"]
         else:
             out["traffic"] = None
             out["traffic_stale"] = {"status": "stale", "measured_on_sources": (tr.get("source_sha") or "unrecorded")[:12],
