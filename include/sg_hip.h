@@ -287,8 +287,9 @@ int sg_selfjoin_merge(sg_ctx *ctx, sg_topn *res, const sg_postings *Bt, const in
  * (The reference has no analogue: sparse_dot_topn multiplies every duplicate row again, string_grouper.py:728-752.) */
 int sg_postings_rows(const sg_postings *Bt, int64_t *n_index_rows, int64_t *n_caller_rows, const uint32_t **d_group_of_row);
 /* Bytes of the index the PRUNED multiply reads while it runs -- filter postings + their segment-end tables, the 8-bit
- * copies of the rows (second filter) and the packed rows (exact scoring) -- so that a measurement can say whether they fit
- * the 256 MiB Infinity Cache (bench.py: roofline.l3_resident).  0 for an index the pruned multiply does not use. */
+ * copies of the rows (second filter: the header and the 16-byte units a row's entries reach -- what is written and read, not
+ * the 256 bytes a record is allocated at) and the packed rows (exact scoring) -- so that a measurement can say whether they
+ * fit the 256 MiB Infinity Cache (bench.py: roofline.l3_resident).  0 for an index the pruned multiply does not use. */
 int sg_postings_bytes(const sg_postings *Bt, int64_t *pruned_multiply_bytes);
 int sg_topn_expand_groups(sg_ctx *ctx, const sg_postings *Bt, const sg_topn *groups, const int32_t *d_rows, int64_t n_rows,
                           sg_topn **out);
