@@ -277,6 +277,16 @@ struct sg_postings {
     sg_csr caller_b_copy;                // the struct itself, copied (the caller may free its handle's wrapper, not the arrays)
     int64_t n_right_caller = 0;
     mutable sg_postings *plain = nullptr;
+    // The exact kernel's own layout of the same rows (its tile: twice the waves per CU of the pruned multiply's 4096 columns;
+    // postings proper only), built on demand when the exact kernel runs the whole product in the self-join form --
+    // thresholds below the pruned kernel's envelope: 14.6 -> 12.1 ms at 200 k names and 0.4 (scripts/exact_sym_probe.py).
+    mutable sg_postings *exact_native = nullptr;
+    // The pruned multiply's TILE-BY-TILE form of the same rows (2048-column tiles, an accumulator per column), built on demand
+    // for self-joins at thresholds below SG_ALT_FORM_BELOW (0.65): the stream form folds eight tiles onto one accumulator tile
+    // and its false alarms grow as the threshold falls -- 200 k names at 0.5: 9.6 ms against 5.6 (scripts/form_sweep.py).
+    mutable sg_postings *alt_tile = nullptr;
+    bool tile_form = false;              // this index IS such a one (SG_POSTINGS_TILE_FORM)
+    const sg_postings *view_of = nullptr;   // a shallow copy (the index seen without its groups): the object that owns what is built on demand
     int32_t build_tile_cols = 0, build_flags = 0;
 };
 
@@ -316,6 +326,8 @@ struct sg_vocab {
 int sg_matchlist_device_view(const sg_matchlist *ml, int64_t *n_rows, int64_t *n_cols, int64_t *n_entries, int32_t *dtype,
                              const int64_t **row_ptr, const int32_t **cols, const void **vals);
 
+#define SG_POSTINGS_TILE_FORM (1 << 11)    // sg_postings_build_flags (internal): the pruned multiply's tile-by-tile form, 2048-column tiles, no 8-bit rows
+#define SG_POSTINGS_EXACT_ONLY (1 << 10)   // sg_postings_build_flags (internal): no filter postings, packed rows, 8-bit rows
 // sg_spgemm_pruned.hip
 int sg_csr_props(sg_ctx *ctx, const sg_csr *m, bool *cosine_like, float *max_norm2, uint32_t *max_nnz = nullptr);
 bool sg_pruned_supports_tile(int32_t tile_log2);
@@ -328,7 +340,8 @@ int sg_spgemm_pruned_launch(sg_ctx *ctx, const sg_csr *A, const sg_postings *Bt,
 int sg_spgemm_pruned_symmetric(sg_ctx *ctx, const sg_csr *A, const sg_postings *Bt, int32_t keep, sg_topn *r,
                                double threshold, double delta, unsigned long long *stats, bool *done, int64_t row_lo = 0,
                                int64_t row_hi = -1 /* the whole matrix */, int32_t **export_pairs = nullptr,
-                               int64_t *export_n = nullptr, int64_t row_step = 1 /* rows row_hi - 1, row_hi - 1 - step, ... */);
+                               int64_t *export_n = nullptr, int64_t row_step = 1 /* rows row_hi - 1, row_hi - 1 - step, ... */,
+                               bool exact_all = false /* every row through the exact kernel's self-join launch (thresholds below the pruned kernel's) */);
 int sg_selfjoin_merge_pairs(sg_ctx *ctx, sg_topn *r, const int32_t *d_pairs, int64_t n_pairs, int64_t row_lo, int64_t row_hi,
                             const uint32_t *pos_of /* row -> position when the range is one of positions; null: rows */,
                             int64_t row_step = 1);
@@ -350,10 +363,10 @@ struct SgPairSink {
 };
 // sg_spgemm_topn.hip: the rows of `row_list` (device-side length) through the exact kernel in its self-join form --
 // a row keeps its matches j <= i and appends the mirrored pairs to the sink, exactly as the pruned kernel's rows do.
-unsigned sg_spgemm_exact_selfjoin_grid(const sg_ctx *ctx);
+unsigned sg_spgemm_exact_selfjoin_grid(const sg_ctx *ctx, const sg_postings *Bt = nullptr /* given: the grid of a launch over ALL rows */);
 int sg_spgemm_exact_selfjoin_rows(sg_ctx *ctx, const sg_csr *A, const sg_postings *Bt, int32_t keep, sg_topn *r,
                                   double threshold, uint32_t *row_counter, const uint32_t *row_list,
-                                  const uint32_t *row_list_len, const SgPairSink &sink);
+                                  const uint32_t *row_list_len, const SgPairSink &sink, bool all_rows = false);
 
 // sg_collapse.hip
 int sg_collapse_build(sg_ctx *ctx, const sg_csr *B, SgCollapse **out, bool left_side = false, bool defer_rows = false);

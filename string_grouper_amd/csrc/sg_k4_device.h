@@ -101,6 +101,37 @@ struct TopList {   // lane r holds the r-th best (score, col); empty slots are (
     }
 };
 
+// Two register lists behind each other: lane r holds the r-th and the (64 + r)-th best -- a row's result of 65 .. 128
+// entries (the second pass of the self-join form, top_n above one register list).  What drops off the first list's end is
+// the second list's new head.
+template <typename T>
+struct TopListWide {
+    TopList<T> lo, hi;
+    __device__ __forceinline__ void clear() {
+        lo.clear();
+        hi.clear();
+    }
+    __device__ __forceinline__ void insert(T ns, int nc, int lane) {
+        const bool mine_first = (lo.s > ns) || (lo.s == ns && lo.c < nc);
+        const int pos = __popcll(__ballot(mine_first));
+        if (pos >= SG_TOPN_LANES) {
+            hi.insert(ns, nc, lane);
+            return;
+        }
+        const T es = wave_read<T>(lo.s, SG_TOPN_LANES - 1);
+        const int ec = wave_read<int>(lo.c, SG_TOPN_LANES - 1);
+        lo.insert(ns, nc, lane);
+        if (ec != INT32_MAX) hi.insert(es, ec, lane);   // (ranks ahead of every entry of `hi`: position 0)
+    }
+    __device__ __forceinline__ void insert_unique(T ns, int nc, int lane) {
+        if (__ballot(lo.c == nc || hi.c == nc) != 0) return;
+        insert(ns, nc, lane);
+    }
+    __device__ __forceinline__ int count() const {
+        return __popcll(__ballot(lo.c != INT32_MAX)) + __popcll(__ballot(hi.c != INT32_MAX));
+    }
+};
+
 // Posting entry (written by K3): f32 -> packed {uint32 slot, float value}, one 8-byte load per lane;
 // f64 -> slots[] (uint32) + vals[] (double).  "slot" is the BYTE offset of the entry's accumulator
 // inside its column tile, (j mod TILE) * sizeof(T): the multiply never needs j itself -- the tile

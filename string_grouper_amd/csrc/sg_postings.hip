@@ -1060,6 +1060,7 @@ extern "C" int sg_postings_build(sg_ctx *ctx, const sg_csr *B, int32_t tile_cols
 // internal flags of sg_postings_build_flags (above the public ones)
 #define SG_POSTINGS_NO_COLLAPSE (1 << 8)   // index every row (the collapse wrapper's own inner call; the on-demand plain index)
 #define SG_POSTINGS_INNER (1 << 9)         // called by the collapse wrapper: the wrapper's timer covers the build
+// (SG_POSTINGS_EXACT_ONLY, sg_internal.h: nothing of the pruned multiply's -- the exact kernel's own tile and postings)
 
 // the groups whose representatives' rows the inner build of sg_postings_build_flags is to write (handed from the outer call
 // to the inner one of the same thread)
@@ -1115,12 +1116,13 @@ extern "C" int sg_postings_build_flags(sg_ctx *ctx, const sg_csr *B_in, int32_t 
     float max_norm2 = 0.f;
     SG_TRY(sg_csr_props(ctx, B, &cosine_like, &max_norm2));
     const char *pr = ctx->opt("SG_PRUNE");
-    const bool want_pruned = cosine_like && !(pr && pr[0] == '0');
+    const bool want_pruned = cosine_like && !(pr && pr[0] == '0') && !(flags & SG_POSTINGS_EXACT_ONLY);
     if (tile_cols == 0) {
         tile_cols = B->dtype == SG_F64 ? 1024 : 2048;
         if (want_pruned) {
-            tile_cols = 4096;
-            if (const char *v = ctx->opt("SG_PRUNE_TILE")) tile_cols = atoi(v) == 13 ? 8192 : (atoi(v) == 11 ? 2048 : 4096);
+            tile_cols = (flags & SG_POSTINGS_TILE_FORM) ? 2048 : 4096;
+            if (flags & SG_POSTINGS_TILE_FORM) {
+            } else if (const char *v = ctx->opt("SG_PRUNE_TILE")) tile_cols = atoi(v) == 13 ? 8192 : (atoi(v) == 11 ? 2048 : 4096);
         }
     }
     SG_REQUIRE(tile_cols >= 256 && tile_cols <= 32768 && (tile_cols & (tile_cols - 1)) == 0,
@@ -1161,7 +1163,7 @@ extern "C" int sg_postings_build_flags(sg_ctx *ctx, const sg_csr *B_in, int32_t 
     // memory round trips -- on rows of 60 entries (a record of two lines, fifteen units) it costs more than it saves (100 k
     // long names, SG_Q8 = 1 / 0: 8.9 / 5.8 ms; profiles/r05_family_sweep_q8.log).  SG_Q8=1 forces it for any length.
     const bool q8_forced = ctx->opt("SG_Q8") && ctx->opt("SG_Q8")[0] == '1';
-    const bool want_q8 = want_pruned && B_in->n_cols < ((int64_t)1 << 24) && !(ctx->opt("SG_Q8") && ctx->opt("SG_Q8")[0] == '0') &&
+    const bool want_q8 = want_pruned && !(flags & SG_POSTINGS_TILE_FORM) && B_in->n_cols < ((int64_t)1 << 24) && !(ctx->opt("SG_Q8") && ctx->opt("SG_Q8")[0] == '0') &&
                          (q8_forced || (double)B_in->nnz <= 40.0 * (double)B_in->n_rows) &&
                          (ctx->total_mem == 0 || (size_t)SG_Q8_STRIDE * ((size_t)B_in->n_rows + 1) < ctx->total_mem / 16);
     bool fwd_done = false;
@@ -1228,6 +1230,7 @@ extern "C" int sg_postings_build_flags(sg_ctx *ctx, const sg_csr *B_in, int32_t 
     p->nnz = B->nnz;
     p->dtype = B->dtype;
     p->tile_log2 = tile_log2;
+    p->tile_form = (flags & SG_POSTINGS_TILE_FORM) != 0;
     p->n_tiles = (int32_t)n_tiles64;
     p->b_indptr = B_in->d_indptr;      // the caller's matrix: what "A is the matrix the postings were built from" compares
     p->b_indices = B_in->d_indices;
@@ -1618,6 +1621,8 @@ extern "C" int sg_postings_free(sg_postings *p) {
     sg_csr_free(p->permuted);
     sg_collapse_free(p->collapse);
     if (p->plain) sg_postings_free(p->plain);
+    if (p->exact_native) sg_postings_free(p->exact_native);
+    if (p->alt_tile) sg_postings_free(p->alt_tile);
     delete p;
     return SG_OK;
 }

@@ -490,8 +490,11 @@ __device__ __noinline__ TopList<T> drain_survivors(int nnz, T thr, uint32_t row,
 #endif
     // (bit 31 of `row`: the caller has the row's match with itself already -- self-join, stream form -- and the diagonal
     //  among the candidates is left alone)
+    // (bit 30: top_n above one register list -- the row's own matches j < i go to the pair list as well, addressed to the row
+    //  itself, and the second pass, whose lists hold 128, selects: pairs_select_kernel.  Positions stay below 2^30.)
     const bool own_diag = (row >> 31) != 0u;
-    row &= 0x7fffffffu;
+    const bool both = SYM && ((row >> 30) & 1u) != 0u;
+    row &= 0x3fffffffu;
     int j = (uint32_t)lane < n_surv ? surv[lane] : -1;   // a POSITION: the index is built over a permutation of B's rows
     if (own_diag && (uint32_t)j == row) j = -1;
     const SgScoreCtx scv = load_launch_constants(sc);
@@ -527,7 +530,7 @@ __device__ __noinline__ TopList<T> drain_survivors(int nnz, T thr, uint32_t row,
             // kernel a fifth of its time).  Where it stands -- chunk << 9 | entries used -- lives in LDS, in the last word
             // of the survivor buffer (which holds at most 127 columns).
             uint32_t pos = (uint32_t)surv[SG_SURV_CAP - 1];
-            const uint32_t n_hit = (uint32_t)__popcll(mm);
+            const uint32_t n_hit = (uint32_t)__popcll(mm) << (both ? 1 : 0);
             const SgPairSink pv = load_launch_constants(pairs);
             uint32_t *const pair_i = pv.d_i, *const pair_j = pv.d_j, *const pair_row_count = pv.d_row_count;
             T *const pair_s = reinterpret_cast<T *>(pv.d_s);
@@ -546,15 +549,23 @@ __device__ __noinline__ TopList<T> drain_survivors(int nnz, T thr, uint32_t row,
                 pos = (uint32_t)__builtin_amdgcn_readfirstlane((int)c) << 9;
             }
             if (((mm >> lane) & 1ull) && (pos >> 9) < pair_chunks) {   // past the capacity nothing is written: the caller falls back
-                const size_t o = (size_t)(pos >> 9) * SG_PAIR_CHUNK + (pos & 511u) + (uint32_t)__popcll(mm & ((1ull << lane) - 1ull));
+                const size_t o = (size_t)(pos >> 9) * SG_PAIR_CHUNK + (pos & 511u) +
+                                 ((uint32_t)__popcll(mm & ((1ull << lane) - 1ull)) << (both ? 1 : 0));
                 pair_i[o] = row_name;
                 pair_j[o] = (uint32_t)jo;
                 pair_s[o] = sum;
                 atomicAdd(&pair_row_count[jo], 1u);   // how many mirrored matches row j will receive (pass 2 scans these)
+                if (both) {   // "row i receives column j"
+                    pair_i[o + 1] = (uint32_t)jo;
+                    pair_j[o + 1] = row_name;
+                    pair_s[o + 1] = sum;
+                }
             }
+            if (both && lane == 0 && (pos >> 9) < pair_chunks) atomicAdd(&pair_row_count[row_name], n_hit >> 1);
             __builtin_amdgcn_wave_barrier();
             if (lane == 0) surv[SG_SURV_CAP - 1] = (int)(pos + n_hit);
         }
+        if (both) hm &= ~mm;   // (what is left: the diagonal, if the caller has not taken it)
     }
     SG_WD_DECL(wd_h);
     while (hm) {
@@ -979,7 +990,7 @@ spgemm_topn_pruned_kernel(const int64_t *__restrict__ a_indptr, const int32_t *_
         // The survivor routine is told to leave the diagonal alone (bit 31 of its row argument).  Rows worked off in parts
         // keep the old way (the part that holds the row's own tile scores it); a row that hands its last visits to the
         // parts has the pair twice in the pair list's merge, which drops repeats (pairs_select_kernel).
-        uint32_t row_arg = row;
+        uint32_t row_arg = row | ((SYM && keep > SG_TOPN_LANES) ? 0x40000000u : 0u);   // (bit 30: see drain_survivors)
         if (SYM && FOLD_LOG2 > 0 && !part_mode) {
             T own = (T)0;
             for (int q = 0; q < nnz; ++q) {
@@ -987,7 +998,7 @@ spgemm_topn_pruned_kernel(const int64_t *__restrict__ a_indptr, const int32_t *_
                 own = add_rn<T>(own, mul_rn<T>(aq, aq));
             }
             if (own > thr) top.insert(own, (int)row_out, lane);
-            row_arg = row | 0x80000000u;
+            row_arg |= 0x80000000u;
         }
 
         // The survivors of one slot of a tile (rare: a few per row): append the crossing lanes' columns, score a
@@ -1002,7 +1013,7 @@ spgemm_topn_pruned_kernel(const int64_t *__restrict__ a_indptr, const int32_t *_
             if (cross) surv[n_surv + __popcll(cm & lanes_below)] = col;
             n_surv += __popcll(cm);
             if (n_surv >= 64) {
-                top = drain_survivors<T, SYM, TILE_LOG2, WIDE, (FOLD_LOG2 > 0)>(nnz, thr, row, sc, pairs, top, n_surv);
+                top = drain_survivors<T, SYM, TILE_LOG2, WIDE, (FOLD_LOG2 > 0)>(nnz, thr, row_arg, sc, pairs, top, n_surv);
                 st_surv += 64;
                 n_surv -= 64;
             }
@@ -1690,6 +1701,36 @@ __global__ void __launch_bounds__(64) pairs_select_kernel(const uint32_t *__rest
                 if (lane == 0) out_cnt[row] = distinct < keep ? distinct : keep;
                 continue;
             }
+            if (keep > SG_TOPN_LANES) {   // top_n of 65 .. 128: two register lists (the pass has sent the row's own matches here as well)
+                TopListWide<T> wide;
+                wide.clear();
+                for (int base = 0; base < own; base += 64) {
+                    const bool have = base + lane < own;
+                    const T s = have ? out_vals[obase + base + lane] : (T)0;
+                    const int c = have ? out_cols[obase + base + lane] : 0;
+                    const int mm = min(64, own - base);
+                    for (int q = 0; q < mm; ++q) wide.insert_unique(wave_read<T>(s, q), wave_read<int>(c, q), lane);
+                }
+                for (uint32_t base = lo; base < hi; base += 64) {
+                    const bool have = base + (uint32_t)lane < hi;
+                    const T s = have ? lval[base + lane] : (T)0;
+                    const int c = have ? lcol[base + lane] : 0;
+                    const int mm = (int)min(64u, hi - base);
+                    for (int q = 0; q < mm; ++q) wide.insert_unique(wave_read<T>(s, q), wave_read<int>(c, q), lane);
+                }
+                int cnt = wide.count();
+                if (cnt > keep) cnt = keep;
+                if (lane < cnt) {
+                    out_vals[obase + lane] = wide.lo.s;
+                    out_cols[obase + lane] = wide.lo.c;
+                }
+                if (lane + 64 < cnt) {
+                    out_vals[obase + 64 + lane] = wide.hi.s;
+                    out_cols[obase + 64 + lane] = wide.hi.c;
+                }
+                if (lane == 0) out_cnt[row] = cnt;
+                continue;
+            }
             TopList<T> top;
             top.clear();
             {
@@ -2004,10 +2045,20 @@ int sg_spgemm_pruned_launch(sg_ctx *ctx, const sg_csr *A, const sg_postings *Bt,
 // count, chunks handed out) + pass 2 (lists, top-n).
 // *done == false: nothing usable was produced (too many pairs for the list) and the caller runs the one-sided
 // form; the statistics words are untouched then (the result rows are overwritten by that form).
+// exact_all: every row is handed to the exact kernel's self-join launch, from the last position down (a row's cost grows
+// with its position) -- thresholds below the pruned kernel's envelope, or products its pilot prices dearer than the exact
+// multiply: half the (row, tile) visits of the one-sided exact kernel, the same pair list and second pass.
+__global__ void __launch_bounds__(256) all_rows_descending_kernel(uint32_t n, uint32_t *__restrict__ rows, uint32_t *count) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) rows[i] = n - 1u - i;
+    if (i == 0) *count = n;
+}
+
 int sg_spgemm_pruned_symmetric(sg_ctx *ctx, const sg_csr *A, const sg_postings *Bt, int32_t keep, sg_topn *r,
                                double threshold, double delta, unsigned long long *stats, bool *done, int64_t row_lo,
-                               int64_t row_hi, int32_t **export_pairs, int64_t *export_n, int64_t row_step) {
+                               int64_t row_hi, int32_t **export_pairs, int64_t *export_n, int64_t row_step, bool exact_all) {
     *done = false;
+    if (A->n_rows >= ((int64_t)1 << 30)) return SG_OK;   // (positions carry two flag bits on their way to the survivor routine)
     // the self-join runs in position space: its left matrix is the one the index was built over (sg_postings.hip)
     if (Bt->permuted) A = Bt->permuted;
     else SG_TRY(sg_csr_ensure_rows(ctx, A));   // (no copy in position order: the rows of A itself are read)
@@ -2022,7 +2073,11 @@ int sg_spgemm_pruned_symmetric(sg_ctx *ctx, const sg_csr *A, const sg_postings *
     // grow with the list (5 M synthetic names: 53 M pairs above 0.8 for 18 M matches kept -- with room for 8 n pairs the
     // pass was thrown away after 630 ms and the one-sided form took another 1300; scripts/full_configs.py).  The list
     // costs nothing until it is written: room for 64 n pairs, at most a sixteenth of the device memory.
-    int64_t cap = 64 * n + ((int64_t)1 << 20);
+    // (every row through the exact kernel = thresholds below the pruned kernel's: at 0.3 a name has 70 and more matches
+    //  above it on average, 200 k names overran 64 n: room for 512 n there)
+    // ... and where a row's own matches travel through the list as well (top_n above one register list), or the threshold is
+    //  below the name-matching range (the tile-by-tile form's index): 256 n
+    int64_t cap = (exact_all ? 512 : ((keep > SG_TOPN_LANES || Bt->tile_form) ? 256 : 64)) * n + ((int64_t)1 << 20);
     if (ctx->total_mem > 0) {
         const int64_t by_memory = (int64_t)(ctx->total_mem / 16 / (8 + vs));
         if (cap > by_memory) cap = by_memory;
@@ -2037,7 +2092,8 @@ int sg_spgemm_pruned_symmetric(sg_ctx *ctx, const sg_csr *A, const sg_postings *
     if (cap >= ((int64_t)1 << 31)) cap = ((int64_t)1 << 31) - 1;   // list offsets are 32-bit
     // every wave of the kernel holds one open chunk: count those in
     pl.chunks = (uint32_t)(cap / SG_PAIR_CHUNK);
-    if (!cap_forced) pl.chunks += 2u * pruned_grid(ctx, Bt->tile_log2, n, Bt->fold_log2, A->dtype) + (uint32_t)ctx->num_cu * 4u + sg_spgemm_exact_selfjoin_grid(ctx);
+    if (!cap_forced) pl.chunks += 2u * pruned_grid(ctx, Bt->tile_log2, n, Bt->fold_log2, A->dtype) + (uint32_t)ctx->num_cu * 4u +
+                                  sg_spgemm_exact_selfjoin_grid(ctx, exact_all ? Bt : nullptr);
     if (pl.chunks < 1) pl.chunks = 1;
     cap = (int64_t)pl.chunks * SG_PAIR_CHUNK;
     // [0] row counter [1] flagged count [2..3] pairs [4] chunks handed out [5] row counter of the exact kernel's launch;
@@ -2099,7 +2155,17 @@ int sg_spgemm_pruned_symmetric(sg_ctx *ctx, const sg_csr *A, const sg_postings *
         hipLaunchKernelGGL(pair_sink_kernel, dim3(1), dim3(1), 0, ctx->stream, sink, (SgPairSink *)(words + 64));
         if (hipGetLastError() != hipSuccess) st = SG_ERR_HIP;
     }
-    if (st == SG_OK) {
+    if (st == SG_OK && exact_all) {
+        SgTimer kt(ctx, SG_K_SPGEMM_KERNEL);
+        st = sg_postings_ensure_full(ctx, Bt);
+        if (st == SG_OK && n > 0) {
+            hipLaunchKernelGGL(all_rows_descending_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, (uint32_t)n,
+                               flagged_rows, words + 1);
+            if (hipGetLastError() != hipSuccess) st = SG_ERR_HIP;
+        }
+        if (st == SG_OK && n > 0)
+            st = sg_spgemm_exact_selfjoin_rows(ctx, A, Bt, keep, r, threshold, words + 5, flagged_rows, words + 1, sink, /*all_rows=*/true);
+    } else if (st == SG_OK) {
         SgTimer kt(ctx, SG_K_SPGEMM_KERNEL);   // the kernel alone (the launch group's timer also covers the second pass)
         if (A->dtype == SG_F64)
             st = dispatch_pruned<double, true>(ctx, A, Bt, keep, r, (double)threshold, s_budget, words, words + 1, flagged_rows,
@@ -2118,7 +2184,7 @@ int sg_spgemm_pruned_symmetric(sg_ctx *ctx, const sg_csr *A, const sg_postings *
         }
     };
     if (st == SG_OK) read_back();
-    if (st == SG_OK && (uint32_t)(h[0] >> 32) > 0) {
+    if (st == SG_OK && (uint32_t)(h[0] >> 32) > 0 && !exact_all) {
         // the rows neither launch of the pruned kernel could take (more than 128 non-zeros, more than 64 prefix terms, no
         // room for the fixed-point filter, or -- stream form -- none at all): through the exact kernel, in the same form --
         // pairs (i, j <= i), mirrored ones into the pair list.  Its postings are written now if the index build left them

@@ -153,12 +153,17 @@ __device__ __forceinline__ void segment_batch(T *acc, const char *vals, const ch
     }
 }
 
-// Self-join launch (SELF): one mirrored pair (row, j < row, s) into the wave's chunk of the pair list -- the protocol of
-// the pruned kernel's drain_survivors (sg_spgemm_pruned.hip); all arguments are wave-uniform, `pos` = chunk << 9 |
-// entries used is the wave's state.
+// Self-join launch (SELF): the mirrored pairs of the lanes in `mm` into the wave's chunk of the pair list -- the protocol of
+// the pruned kernel's drain_survivors (sg_spgemm_pruned.hip); `pos` = chunk << 9 | entries used is the wave's state.
+// Lane: row `rec` receives column `col` with score s; both: and row `col` receives
+// column `rec` -- top_n above one register list, where a row's own matches go through the list as well): every lane writes
+// its own entry, one chunk test and one count for the wave.  (One pair at a time by lane 0 was the whole cost of a hit: at a
+// threshold of 0.4 a row has dozens.)
 template <typename T>
-__device__ __forceinline__ void emit_mirrored_pair(const SgPairSink &sk, uint32_t &pos, uint32_t row, uint32_t j, T s, int lane) {
-    if (pos == SG_PAIR_NO_CHUNK || (pos & 511u) >= SG_PAIR_CHUNK) {
+__device__ __forceinline__ void emit_pairs(const SgPairSink &sk, uint32_t &pos, uint64_t mm, uint32_t col, uint32_t rec, T s,
+                                           bool both, uint32_t col_uniform /* both: `col` is this one in every lane */, int lane) {
+    const uint32_t n_hit = (uint32_t)__popcll(mm) << (both ? 1 : 0);   // <= 128
+    if (pos == SG_PAIR_NO_CHUNK || (pos & 511u) + n_hit > SG_PAIR_CHUNK) {
         uint32_t c = 0;
         if (lane == 0) {
             if (pos != SG_PAIR_NO_CHUNK && (pos >> 9) < sk.chunks) {
@@ -169,14 +174,21 @@ __device__ __forceinline__ void emit_mirrored_pair(const SgPairSink &sk, uint32_
         }
         pos = (uint32_t)__builtin_amdgcn_readfirstlane((int)c) << 9;
     }
-    if (lane == 0 && (pos >> 9) < sk.chunks) {   // past the capacity nothing is written: the caller falls back
-        const size_t o = (size_t)(pos >> 9) * SG_PAIR_CHUNK + (pos & 511u);
-        sk.d_i[o] = row;
-        sk.d_j[o] = j;
+    if (((mm >> lane) & 1ull) && (pos >> 9) < sk.chunks) {   // past the capacity nothing is written: the caller falls back
+        const size_t o = (size_t)(pos >> 9) * SG_PAIR_CHUNK + (pos & 511u) +
+                         ((uint32_t)__popcll(mm & ((1ull << lane) - 1ull)) << (both ? 1 : 0));
+        sk.d_i[o] = col;
+        sk.d_j[o] = rec;
         reinterpret_cast<T *>(sk.d_s)[o] = s;
-        atomicAdd(&sk.d_row_count[j], 1u);
+        atomicAdd(&sk.d_row_count[rec], 1u);
+        if (both) {
+            sk.d_i[o + 1] = rec;
+            sk.d_j[o + 1] = col;
+            reinterpret_cast<T *>(sk.d_s)[o + 1] = s;
+        }
     }
-    pos += 1u;
+    if (both && lane == 0 && (pos >> 9) < sk.chunks) atomicAdd(&sk.d_row_count[col_uniform], n_hit >> 1);
+    pos += n_hit;
 }
 
 // SELF: the row scores the columns j <= row only (the tiles up to its own), keeps those matches and hands the
@@ -295,19 +307,31 @@ __device__ __forceinline__ void process_row(T *acc, uint32_t row, const int64_t 
                         if (__ballot(any_above<T>(v, thr)) != 0) {   // rare: an accumulator of this stripe passes
 #pragma unroll
                             for (int e = 0; e < VEC; ++e) {
-                                uint64_t hm = __ballot(v[e] > thr);
+                                // every lane's own hit: its position and -- one load for the wave, not one per hit -- the row
+                                // behind it (equal scores are ordered by the ROW)
+                                const int np_l = col_base + (x0 + lane) * VEC + e;
+                                bool hit = v[e] > thr;
+                                if (SELF) hit = hit && (uint32_t)np_l <= row;   // the pair (i, j > i) is row j's to score
+                                uint64_t hm = __ballot(hit);
+                                if (hm == 0) continue;
+                                int nc_l = np_l;
+                                if (orig_of && hit) nc_l = (int)orig_of[np_l];
+                                if (SELF) {
+                                    // the mirrored pairs ("row j receives column i") in one go; top_n above one register list:
+                                    // the row's own matches through the pair list as well ("row i receives column j") -- the
+                                    // second pass selects with lists of 128
+                                    const uint64_t mm = __ballot(hit && (uint32_t)np_l < row);
+                                    const bool both = keep > SG_TOPN_LANES;
+                                    if (mm) emit_pairs<T>(*sink, *pair_pos, mm, row_out, (uint32_t)nc_l, v[e], both, row_out, lane);
+                                    if (both) hm &= ~mm;   // (what is left: the diagonal)
+                                }
                                 SG_WD_DECL(wd_h);
                                 while (hm) {
                                     SG_WD(wd_h, 70, 9)
                                     const int src = __builtin_ctzll(hm);
                                     hm &= hm - 1;
                                     const T ns = wave_read<T>(v[e], src);
-                                    const int np = col_base + (x0 + src) * VEC + e;   // position
-                                    const int nc = orig_of ? (int)orig_of[np] : np;   // the row: equal scores are ordered by IT
-                                    if (SELF) {
-                                        if ((uint32_t)np > row) continue;   // the pair (i, j > i) is row j's to score
-                                        if ((uint32_t)np < row) emit_mirrored_pair<T>(*sink, *pair_pos, row_out, (uint32_t)nc, ns, lane);
-                                    }
+                                    const int nc = wave_read<int>(nc_l, src);
                                     if (ns < floor_s || (ns == floor_s && nc > floor_c)) top.insert(ns, nc, lane);
                                 }
                             }
@@ -389,6 +413,9 @@ spgemm_topn_selfjoin_rows_kernel(const int64_t *__restrict__ a_indptr, const int
         const uint32_t row = (uint32_t)__builtin_amdgcn_readfirstlane((int)row_list[idx]);
         process_row<T, TILE_LOG2, NB, true>(acc, row, a_indptr, a_indices, a_data, seg, post_rows, post_vals, n_tiles, 0,
                                             n_tiles, keep, 0, out_stride, thr, out_cols, out_vals, out_cnt, lane, &sink, &pos, orig_of);
+        // the pair list is full (this wave was handed a chunk past its end): the pass is thrown away by the caller, every
+        // wave leaves at its next row (as in the pruned kernel)
+        if (pos != SG_PAIR_NO_CHUNK && (pos >> 9) >= sink.chunks && lane == 0) atomicMax(row_counter, 0x20000000u);
     }
     if (lane == 0 && pos != SG_PAIR_NO_CHUNK && (pos >> 9) < sink.chunks) {   // close the wave's last chunk
         sink.d_chunk_count[pos >> 9] = pos & 511u;
@@ -610,12 +637,20 @@ static int dispatch_spgemm(sg_ctx *ctx, const sg_csr *A, const sg_postings *Bt, 
 }
 
 // ---- the exact kernel's self-join launch over a device-side row list (see spgemm_topn_selfjoin_rows_kernel)
-unsigned sg_spgemm_exact_selfjoin_grid(const sg_ctx *ctx) { return (unsigned)ctx->num_cu * 2u; }
+unsigned sg_spgemm_exact_selfjoin_grid(const sg_ctx *ctx, const sg_postings *Bt) {
+    if (!Bt) return (unsigned)ctx->num_cu * 2u;   // a handful of rows, if any
+    // every row of the matrix: as many single-wave workgroups as the accumulator tiles leave room for, like the one-sided launch
+    const size_t lds = (size_t)(Bt->dtype == SG_F64 ? 8 : 4) << Bt->tile_log2;
+    int waves_per_cu = (int)(ctx->lds_per_cu / lds);
+    if (waves_per_cu > 32) waves_per_cu = 32;
+    if (waves_per_cu < 1) waves_per_cu = 1;
+    return (unsigned)ctx->num_cu * (unsigned)waves_per_cu;
+}
 
 template <typename T, int TILE_LOG2>
 static int launch_selfjoin_rows(sg_ctx *ctx, const sg_csr *A, const sg_postings *Bt, int32_t keep, sg_topn *r, T thr,
                                 uint32_t *row_counter, const uint32_t *row_list, const uint32_t *row_list_len,
-                                const SgPairSink &sink) {
+                                const SgPairSink &sink, bool all_rows) {
     const size_t lds = sizeof(T) << TILE_LOG2;
     auto kern = spgemm_topn_selfjoin_rows_kernel<T, TILE_LOG2, 8>;
     if (lds > 48 * 1024) {
@@ -625,7 +660,7 @@ static int launch_selfjoin_rows(sg_ctx *ctx, const sg_csr *A, const sg_postings 
             done = true;
         }
     }
-    hipLaunchKernelGGL(kern, dim3(sg_spgemm_exact_selfjoin_grid(ctx)), dim3(64), lds, ctx->stream, A->d_indptr, A->d_indices,
+    hipLaunchKernelGGL(kern, dim3(sg_spgemm_exact_selfjoin_grid(ctx, all_rows ? Bt : nullptr)), dim3(64), lds, ctx->stream, A->d_indptr, A->d_indices,
                        (const T *)A->d_data, (const uint32_t *)Bt->d_seg, (const int32_t *)Bt->d_rows, (const T *)Bt->d_vals,
                        Bt->n_tiles, keep, r->stride, thr, r->d_cols, (T *)r->d_vals, r->d_counts, row_counter, row_list,
                        row_list_len, sink, (const uint32_t *)Bt->d_orig_of);
@@ -636,23 +671,24 @@ static int launch_selfjoin_rows(sg_ctx *ctx, const sg_csr *A, const sg_postings 
 template <typename T>
 static int dispatch_selfjoin_rows(sg_ctx *ctx, const sg_csr *A, const sg_postings *Bt, int32_t keep, sg_topn *r, T thr,
                                   uint32_t *row_counter, const uint32_t *row_list, const uint32_t *row_list_len,
-                                  const SgPairSink &sink) {
+                                  const SgPairSink &sink, bool all_rows) {
     switch (Bt->tile_log2) {
-        case 11: return launch_selfjoin_rows<T, 11>(ctx, A, Bt, keep, r, thr, row_counter, row_list, row_list_len, sink);
-        case 12: return launch_selfjoin_rows<T, 12>(ctx, A, Bt, keep, r, thr, row_counter, row_list, row_list_len, sink);
-        case 13: return launch_selfjoin_rows<T, 13>(ctx, A, Bt, keep, r, thr, row_counter, row_list, row_list_len, sink);
+        case 10: return launch_selfjoin_rows<T, 10>(ctx, A, Bt, keep, r, thr, row_counter, row_list, row_list_len, sink, all_rows);
+        case 11: return launch_selfjoin_rows<T, 11>(ctx, A, Bt, keep, r, thr, row_counter, row_list, row_list_len, sink, all_rows);
+        case 12: return launch_selfjoin_rows<T, 12>(ctx, A, Bt, keep, r, thr, row_counter, row_list, row_list_len, sink, all_rows);
+        case 13: return launch_selfjoin_rows<T, 13>(ctx, A, Bt, keep, r, thr, row_counter, row_list, row_list_len, sink, all_rows);
         default:
-            sg_set_error("postings tile of 2^%d columns is not supported by the self-join form (2^11..2^13)", Bt->tile_log2);
+            sg_set_error("postings tile of 2^%d columns is not supported by the self-join form (2^10..2^13)", Bt->tile_log2);
             return SG_ERR_UNSUPPORTED;
     }
 }
 
 int sg_spgemm_exact_selfjoin_rows(sg_ctx *ctx, const sg_csr *A, const sg_postings *Bt, int32_t keep, sg_topn *r,
                                   double threshold, uint32_t *row_counter, const uint32_t *row_list,
-                                  const uint32_t *row_list_len, const SgPairSink &sink) {
+                                  const uint32_t *row_list_len, const SgPairSink &sink, bool all_rows) {
     if (A->dtype == SG_F64)
-        return dispatch_selfjoin_rows<double>(ctx, A, Bt, keep, r, (double)threshold, row_counter, row_list, row_list_len, sink);
-    return dispatch_selfjoin_rows<float>(ctx, A, Bt, keep, r, (float)threshold, row_counter, row_list, row_list_len, sink);
+        return dispatch_selfjoin_rows<double>(ctx, A, Bt, keep, r, (double)threshold, row_counter, row_list, row_list_len, sink, all_rows);
+    return dispatch_selfjoin_rows<float>(ctx, A, Bt, keep, r, (float)threshold, row_counter, row_list, row_list_len, sink, all_rows);
 }
 
 static int topn_alloc(sg_ctx *ctx, int64_t n_rows, int64_t n_cols, int32_t stride, int32_t dtype, sg_topn **out) {
@@ -734,19 +770,30 @@ static int prune_pilot(sg_ctx *ctx, const sg_csr *A, const sg_postings *Bt, int3
     return SG_OK;
 }
 
+// Threshold from which the pruned multiply takes a product: 0.45 in the stream form (below, its filter passes too much:
+// profiles/r01_prune_tuning.log), 0.40 for a self-join that can run the tile-by-tile form on an index of its own (200 k names
+// at 0.4: 9.9 ms against 12.1 for the exact kernel in the self-join form and 20.8 one-sided; at 0.35 the two are level:
+// profiles/r06b_form_sweep.log).  SG_PRUNE_MIN_THRESHOLD overrides both.
+static double prune_min_threshold(const sg_ctx *ctx, bool tile_form) { return env_double(ctx, "SG_PRUNE_MIN_THRESHOLD", tile_form ? 0.40 : 0.45); }
 // Can the pruned multiply (sg_spgemm_pruned.hip) take this product -- both sides cosine-like, one register list holds a
 // row's result, room below the threshold for its survivor bound -- and can it take its self-join form?
+// below_envelope (the one-GPU multiply asks): set when the threshold ALONE keeps the pruned kernel out -- *symmetric then says
+// whether the exact kernel can run the product in its self-join form (sg_spgemm_pruned_symmetric, exact_all); the same
+// caller's self-join form also takes a top_n of 65 .. 128 (the pass sends a row's own matches through the pair list, whose
+// second pass selects with two register lists).
 static bool pruned_applicable(sg_ctx *ctx, const sg_csr *A, const sg_postings *Bt, int32_t stride, double threshold, double *delta,
-                              bool *symmetric, int *status, bool any_size = false) {
+                              bool *symmetric, int *status, bool any_size = false, bool *below_envelope = nullptr) {
     *symmetric = false;
     *status = SG_OK;
+    if (below_envelope) *below_envelope = false;
     const char *pr = ctx->opt("SG_PRUNE");
     // (top_n of 65 .. 128: the pruned kernel keeps a row's best 64 in its register list; a row that fills the list may have
     //  more matches and is handed to the exact kernel, which runs a pass per 64 entries -- rows_with_full_lists_kernel)
     if ((pr && pr[0] == '0') || !Bt->cosine_like || !Bt->d_filt || stride > 2 * SG_TOPN_LANES || A->n_rows <= 0 || Bt->nnz <= 0 ||
-        !sg_pruned_supports_tile(Bt->tile_log2) ||
-        !(threshold >= env_double(ctx, "SG_PRUNE_MIN_THRESHOLD", 0.45)))   // below ~0.4 the filter passes too much (profiles/r01_prune_tuning.log)
+        !sg_pruned_supports_tile(Bt->tile_log2))
         return false;
+    const bool thr_ok = threshold >= prune_min_threshold(ctx, Bt->tile_form);   // below ~0.4 the filter passes too much (profiles/r01_prune_tuning.log)
+    if (!thr_ok && !below_envelope) return false;
     // tuned at 663 k: the tile-by-tile form 0.05 (profiles/r01_prune_tuning.log); the stream form, whose rounds are cheaper
     // next to the exact scorings, 0.03 (profiles/r03_sessionG_H_delta.log: 9.76 / 9.95 / 10.10 ms at 0.03 / 0.04 / 0.05;
     // with identical rows grouped the optimum is flat from 0.02 to 0.04: profiles/r03_sessionU_delta_freq_ab.log)
@@ -767,9 +814,13 @@ static bool pruned_applicable(sg_ctx *ctx, const sg_csr *A, const sg_postings *B
     // ... from the size at which halving the (row, tile) visits outweighs the second pass over the pair list
     // and its host round trip: 0.58 vs 0.57 ms at 50 k rows, 0.95 vs 1.20 at 100 k, 14.0 vs 26.8 at 663 k
     // (profiles/r02_sessionM_sym_sweep.log)
-    *symmetric = !(sy && sy[0] == '0') && stride <= SG_TOPN_LANES && A->n_rows == Bt->n_right && A->d_indptr == Bt->b_indptr &&
+    *symmetric = !(sy && sy[0] == '0') && stride <= (below_envelope ? 2 : 1) * SG_TOPN_LANES && A->n_rows == Bt->n_right && A->d_indptr == Bt->b_indptr &&
                  A->d_indices == Bt->b_indices && A->d_data == Bt->b_data &&
                  (any_size || A->n_rows >= (int64_t)env_int(ctx, "SG_SYM_MIN_ROWS", 65536) || (sy && sy[0] == '1'));
+    if (!thr_ok) {
+        *below_envelope = true;
+        return false;
+    }
     return true;
 }
 
@@ -798,6 +849,7 @@ static int spgemm_topn_collapsed(sg_ctx *ctx, const sg_csr *A, const sg_postings
     sg_postings view = *Bt;          // shallow: the same index, seen without the groups
     view.collapse = nullptr;
     view.plain = nullptr;
+    view.view_of = Bt;
     sg_topn *ru = nullptr;
     ++ctx->inner_multiply_depth;
     const int st_inner = sg_spgemm_topn(ctx, self ? c->unique : A, &view, top_n, threshold, 1, &ru);
@@ -958,6 +1010,26 @@ extern "C" int sg_spgemm_topn(sg_ctx *ctx, const sg_csr *A, const sg_postings *B
         return SG_ERR_OVERFLOW;
     }
     const int32_t stride = (int32_t)stride64;
+    // ---- which form of the pruned multiply?  The stream form (the index as built: 4096-column tiles folded eight to an
+    //      accumulator tile, second filter) is the fastest where most candidates are false alarms -- name-matching thresholds.
+    //      As the threshold falls, sums of eight unrelated columns cross the bar ever more often: from SG_ALT_FORM_BELOW (0.65)
+    //      down a self-join runs the tile-by-tile form on an index of its own, built once and kept with the index
+    //      (scripts/form_sweep.py, 200 k / 663 k names at 0.6: 5.4 / 31.4 ms stream, 3.4 / 24.1 ms tile by tile; at 0.8:
+    //      1.3 / 5.1 against 1.8 / 11.7).
+    if (Bt->cosine_like && Bt->d_filt && Bt->fold_log2 > 0 && stride <= 2 * SG_TOPN_LANES && A->n_rows == Bt->n_right &&
+        A->d_indptr == Bt->b_indptr && A->d_indices == Bt->b_indices && A->d_data == Bt->b_data && A->n_rows > 0 &&
+        threshold < env_double(ctx, "SG_ALT_FORM_BELOW", 0.65) && threshold >= prune_min_threshold(ctx, true) &&
+        env_int(ctx, "SG_ALT_FORM", 1) != 0 && !(ctx->opt("SG_PRUNE") && ctx->opt("SG_PRUNE")[0] == '0')) {
+        static std::mutex alt_mu;
+        std::lock_guard<std::mutex> lock(alt_mu);
+        const sg_postings *home = Bt->view_of ? Bt->view_of : Bt;   // (a view is a copy on the caller's stack)
+        if (!home->alt_tile) {
+            SG_TRY(sg_csr_ensure_rows(ctx, A));
+            SG_TRY(sg_postings_build_flags(ctx, A, 0, (Bt->build_flags & SG_POSTINGS_NO_PERMUTATION) | (1 << 8) | SG_POSTINGS_TILE_FORM,
+                                           &home->alt_tile));
+        }
+        Bt = home->alt_tile;
+    }
     sg_topn *r = nullptr;
     SG_TRY(topn_alloc(ctx, A->n_rows, Bt->n_right, stride, A->dtype, &r));
     const size_t s = A->dtype == SG_F64 ? 8 : 4;
@@ -990,13 +1062,20 @@ extern "C" int sg_spgemm_topn(sg_ctx *ctx, const sg_csr *A, const sg_postings *B
     // ---- pruned multiply (sg_spgemm_pruned.hip) when both sides are cosine-like and one register list
     //      holds the row's result; its survivor threshold needs some room below the threshold
     bool prune = false, symmetric = false;
+    bool exact_sym = false;   // the EXACT kernel in the self-join form (every row through its self-join launch)
+    const bool exact_sym_on = env_int(ctx, "SG_EXACT_SYM", 1) != 0;
     double delta = 0.0;
     {
         int pst = SG_OK;
-        prune = pruned_applicable(ctx, A, Bt, stride, threshold, &delta, &symmetric, &pst);
+        bool below = false;
+        prune = pruned_applicable(ctx, A, Bt, stride, threshold, &delta, &symmetric, &pst, false, &below);
         if (pst != SG_OK) {
             sg_topn_free(r);
             return pst;
+        }
+        if (!prune) {
+            exact_sym = below && symmetric && exact_sym_on;
+            symmetric = false;
         }
     }
     // ---- pruned or exact?  On a vocabulary that is small next to the rows (2-grams: a row holds 2 % of all terms) the
@@ -1013,7 +1092,33 @@ extern "C" int sg_spgemm_topn(sg_ctx *ctx, const sg_csr *A, const sg_postings *B
             sg_topn_free(r);
             return pst;
         }
-        if (!keep_pruned) prune = symmetric = false;
+        // (the exact kernel in the self-join form walks half the (row, tile) visits -- 200 k 2-grams: 63 ms one-sided; the
+        //  same factor the pilot grants the pruned kernel's self-join form)
+        if (symmetric && exact_sym_on && keep_pruned && ctx->pilot_ms_pruned > 0.55 * ctx->pilot_ms_exact + 0.3) keep_pruned = false;
+        if (!keep_pruned) {
+            exact_sym = symmetric && exact_sym_on;
+            prune = symmetric = false;
+        }
+    }
+
+    // the exact kernel in the self-join form runs on ITS layout of the index (tile of 2048 / 1024 columns: twice the waves per
+    // CU), built once per index and kept with it
+    const sg_postings *Bx = Bt;
+    if (exact_sym && env_int(ctx, "SG_EXACT_NATIVE", 1) != 0 && Bt->tile_log2 > (A->dtype == SG_F64 ? 10 : 11)) {
+        static std::mutex native_mu;
+        std::lock_guard<std::mutex> lock(native_mu);
+        const sg_postings *home = Bt->view_of ? Bt->view_of : Bt;   // (a view is a copy on the caller's stack)
+        if (!home->exact_native) {
+            int bst = sg_csr_ensure_rows(ctx, A);
+            if (bst == SG_OK)
+                bst = sg_postings_build_flags(ctx, A, 0, (Bt->build_flags & SG_POSTINGS_NO_PERMUTATION) | (1 << 8) | SG_POSTINGS_EXACT_ONLY,
+                                              &home->exact_native);
+            if (bst != SG_OK) {
+                sg_topn_free(r);
+                return bst;
+            }
+        }
+        Bx = home->exact_native;
     }
 
     // counters: [0, n_launch] row counters of the exact launches; then the pruned kernel's row counter, the
@@ -1033,9 +1138,9 @@ extern "C" int sg_spgemm_topn(sg_ctx *ctx, const sg_csr *A, const sg_postings *B
         st = SG_ZERO3(ctx, counters, sizeof(uint32_t) * n_words, r->d_counts, sizeof(int32_t) * (size_t)A->n_rows,
                       ctx->d_stat_words, 7 * sizeof(int64_t));   // ([0], [1]: written by the counting kernels at the end)
         bool sym_done = false;
-        if (symmetric && st == SG_OK)
-            st = sg_spgemm_pruned_symmetric(ctx, A, Bt, stride, r, threshold, delta,
-                                            (unsigned long long *)(ctx->d_stat_words + 2), &sym_done);
+        if ((symmetric || exact_sym) && st == SG_OK)
+            st = sg_spgemm_pruned_symmetric(ctx, A, exact_sym ? Bx : Bt, stride, r, threshold, delta,
+                                            (unsigned long long *)(ctx->d_stat_words + 2), &sym_done, 0, -1, nullptr, nullptr, 1, exact_sym);
         ctx->prune_symmetric = sym_done;
         // everything below reads the rows of A itself (the self-join form read the index's copy in position order): the
         // representatives' matrix of an index over groups is written now if it is still pending

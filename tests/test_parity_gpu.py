@@ -77,6 +77,110 @@ def test_top_n_above_the_register_list_takes_the_pruned_kernel_and_hands_full_ro
     assert_csr_identical(got, P.sp_matmul_topn_port(A, A.T, 129, 0.8, True, 8), "top_n=129")
 
 
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_top_n_above_the_register_list_inside_the_selfjoin_form(ctx, dtype, monkeypatch):
+    """Round 6: max_n_matches of 65 .. 128 no longer leaves the self-join form.  The pass sends a row's own matches (j < i)
+    through the pair list as well -- "row i receives column j" -- and the second pass selects with two register lists
+    (128 entries); no row goes to the exact kernel for its top_n.  Hubs of 150 / 70 / 64 identical and near-identical
+    names (rows with more matches than 64, than top_n, ties at the cut), long names in the wide launch and beyond it (the
+    exact kernel's self-join launch inside the pass), identical rows grouped or not -- the port's result, bit for bit."""
+    from string_grouper_amd.sparse_dot_topn import sp_matmul_topn
+    rng = np.random.default_rng(9)
+    names = list(_names(24000, seed=5))
+    for hub, size in (("NORTHERN LIGHTS HOLDING CO", 150), ("BLUE RIVER PARTNERS", 70), ("KAPPA LTD", 64), ("OMEGA TRADING", 129)):
+        for k, at in enumerate(rng.choice(len(names), size, replace=False)):
+            names[at] = hub + (" " + "ABCDEFGH"[k % 8] if k % 3 == 0 else "")
+    for at in rng.choice(len(names), 40, replace=False):        # rows of 65 .. 128 non-zeros, and a few beyond
+        names[at] = " ".join(names[(at + q) % len(names)] for q in range(4 if at % 2 else 9))
+    A = _tfidf(names, dtype)
+    monkeypatch.setenv("SG_SYM", "1")                          # (the form starts at 65 536 rows by itself)
+    for collapse in ("0", "1"):
+        monkeypatch.setenv("SG_COLLAPSE", collapse)
+        for top_n, thr in ((100, 0.8), (65, 0.6), (128, 0.7), (127, 0.5)):
+            got = sp_matmul_topn(A, A.T, top_n, thr, sort=True, ctx=ctx)
+            st = ctx.stats()
+            assert_csr_identical(got, P.sp_matmul_topn_port(A, A.T, top_n, thr, True, 8), f"top_n={top_n} thr={thr} collapse={collapse}")
+            assert st["prune_symmetric"] == 1 and st["prune_rows"] > 15000, st
+            assert st["exact_rows"] < 40, st                   # only the rows beyond 128 non-zeros: nobody for a full list
+    monkeypatch.setenv("SG_COLLAPSE", "0")
+    got = sp_matmul_topn(A, A.T, 100, 0.8, sort=False, ctx=ctx)
+    assert_csr_identical(got, P.sp_matmul_topn_port(A, A.T, 100, 0.8, False, 8), "sorted by column")
+    monkeypatch.setenv("SG_SYM_PAIR_CAP", "2000")              # a pair list that is too small: the one-sided form, as before
+    got = sp_matmul_topn(A, A.T, 100, 0.8, sort=True, ctx=ctx)
+    assert ctx.stats()["prune_symmetric"] == 0
+    assert_csr_identical(got, P.sp_matmul_topn_port(A, A.T, 100, 0.8, True, 8), "fallback")
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_thresholds_below_the_pruned_kernels_run_the_exact_kernel_in_the_selfjoin_form(ctx, dtype, monkeypatch):
+    """Round 6: below 0.45 the prefix filter passes too much and the exact kernel takes the product -- now in the self-join
+    form: every row through the exact kernel's self-join launch (pairs j <= i over the tiles up to its own, mirrored pairs
+    through the pair list), half the (row, tile) visits.  Same bits as the one-sided exact kernel and the port; a pair
+    list that runs full sends the product back to the one-sided form."""
+    from string_grouper_amd.sparse_dot_topn import sp_matmul_topn
+    rng = np.random.default_rng(10)
+    names = list(_names(24000, seed=6))
+    for k, at in enumerate(rng.choice(len(names), 90, replace=False)):
+        names[at] = "HARBOUR VIEW ESTATES" + (" " + "ABCDEFGH"[k % 8] if k % 3 == 0 else "")
+    A = _tfidf(names, dtype)
+    monkeypatch.setenv("SG_SYM", "1")
+    for collapse in ("0", "1"):
+        monkeypatch.setenv("SG_COLLAPSE", collapse)
+        for top_n, thr in ((10, 0.39), (20, 0.3), (100, 0.35), (3, 0.1), (64, 0.2)):
+            got = sp_matmul_topn(A, A.T, top_n, thr, sort=True, ctx=ctx)
+            st = ctx.stats()
+            assert_csr_identical(got, P.sp_matmul_topn_port(A, A.T, top_n, thr, True, 8), f"top_n={top_n} thr={thr} collapse={collapse}")
+            assert st["prune_rows"] == 0, st
+            if thr >= 0.3:                                      # (at 0.1 the pair list may run full: one-sided, same result)
+                assert st["prune_symmetric"] == 1 and st["exact_rows"] > 15000, st
+    monkeypatch.setenv("SG_COLLAPSE", "0")
+    monkeypatch.setenv("SG_EXACT_SYM", "0")                    # the switch: one-sided exact kernel as in round 5
+    got = sp_matmul_topn(A, A.T, 10, 0.35, sort=True, ctx=ctx)
+    assert ctx.stats()["prune_symmetric"] == 0
+    assert_csr_identical(got, P.sp_matmul_topn_port(A, A.T, 10, 0.35, True, 8), "SG_EXACT_SYM=0")
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_selfjoins_below_name_matching_thresholds_take_the_tile_by_tile_form(ctx, dtype, monkeypatch):
+    """Round 6: from 0.65 down a self-join runs the pruned multiply's tile-by-tile form on an index of its own (2048-column
+    tiles, an accumulator per column; built on first use, kept with the index) -- the stream form's folded accumulators
+    raise ever more false alarms as the threshold falls (scripts/form_sweep.py) -- and the pruned multiply's envelope
+    then starts at 0.40.  Self-join form or one-sided, identical rows grouped or not, top_n on both sides of the register
+    list: the port's bits; and the same bits as with the switch off."""
+    from string_grouper_amd.vectorizer import HipTfidfVectorizer
+    rng = np.random.default_rng(11)
+    names = list(_names(30000, seed=12))
+    for k, at in enumerate(rng.choice(len(names), 80, replace=False)):
+        names[at] = "SILVER LAKE CAPITAL" + (" " + "ABCDEFGH"[k % 8] if k % 3 == 0 else "")
+    (A_ref,), _, _ = O.tfidf_sklearn(names, [names], dtype=dtype)
+    vec = HipTfidfVectorizer(dtype=dtype, ctx=ctx)
+    p = vec.prepare(names)
+    vec.fit_prepared([p])
+    dA = vec.transform_prepared(p)
+    for collapse in ("1", "0"):
+        monkeypatch.setenv("SG_COLLAPSE", collapse)
+        post = ctx.postings_build(dA)
+        for sym in ("1", "0"):
+            monkeypatch.setenv("SG_SYM", sym)
+            for top_n, thr in ((10, 0.4), (20, 0.5), (10, 0.64), (100, 0.45), (64, 0.6)):
+                res = ctx.spgemm_topn(dA, post, top_n, thr, True)
+                st = ctx.stats()
+                what = f"{dtype.__name__} top_n={top_n} thr={thr} SG_SYM={sym} SG_COLLAPSE={collapse}"
+                assert_csr_identical(res.to_scipy(), P.sp_matmul_topn_port(A_ref, A_ref.T, top_n, thr, True, 8), what)
+                res.free()
+                assert st["prune_rows"] > 0 and st["prune_symmetric"] == int(sym), (what, st)
+        # ... the same index serves the name-matching thresholds in the stream form, before and after
+        res = ctx.spgemm_topn(dA, post, 10, 0.8, True)
+        assert_csr_identical(res.to_scipy(), P.sp_matmul_topn_port(A_ref, A_ref.T, 10, 0.8, True, 8), "0.8 on the same index")
+        res.free()
+        monkeypatch.setenv("SG_ALT_FORM", "0")                 # the switch: the stream form at any threshold
+        res = ctx.spgemm_topn(dA, post, 20, 0.5, True)
+        assert_csr_identical(res.to_scipy(), P.sp_matmul_topn_port(A_ref, A_ref.T, 20, 0.5, True, 8), "SG_ALT_FORM=0")
+        res.free()
+        monkeypatch.delenv("SG_ALT_FORM")
+        post.free()
+
+
 def test_random_lists_with_repeats_equal_the_port(ctx):
     """Seeded random jobs around the switches of round 3 -- size on both sides of the grouping's threshold, share and size of
     the repeats, near-duplicates of the hubs (ties at the cut between a group and single rows), top_n from 1 to 128,
