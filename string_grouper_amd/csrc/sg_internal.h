@@ -285,6 +285,8 @@ struct sg_postings {
     // for self-joins at thresholds below SG_ALT_FORM_BELOW (0.65): the stream form folds eight tiles onto one accumulator tile
     // and its false alarms grow as the threshold falls -- 200 k names at 0.5: 9.6 ms against 5.6 (scripts/form_sweep.py).
     mutable sg_postings *alt_tile = nullptr;
+    sg_csr built_from;                   // the matrix handed to the build (a copy of the struct, arrays borrowed: the caller keeps it alive -- include/sg_hip.h)
+    bool built_from_valid = false;
     bool tile_form = false;              // this index IS such a one (SG_POSTINGS_TILE_FORM)
     const sg_postings *view_of = nullptr;   // a shallow copy (the index seen without its groups): the object that owns what is built on demand
     int32_t build_tile_cols = 0, build_flags = 0;

@@ -1162,9 +1162,12 @@ extern "C" int sg_postings_build_flags(sg_ctx *ctx, const sg_csr *B_in, int32_t 
     // ... and rows of a name list's length: the filter walks the candidate's entries like the exact scoring does and saves its
     // memory round trips -- on rows of 60 entries (a record of two lines, fifteen units) it costs more than it saves (100 k
     // long names, SG_Q8 = 1 / 0: 8.9 / 5.8 ms; profiles/r05_family_sweep_q8.log).  SG_Q8=1 forces it for any length.
+    // Where the bar lies (round 6, scripts/q8_band_sweep.py, profiles/r06b_q8_band_sweep.log: 100 k rows cut to 16 .. 57 entries a
+    // row): with the records is the faster up to 45 entries a row (by 3 - 30 %), level at 50, and 50 - 75 % slower at 57 (rows
+    // beyond 60 entries have no copy and pass unseen, a record of two lines costs fifteen units) -- 40 in round 5, 45 now.
     const bool q8_forced = ctx->opt("SG_Q8") && ctx->opt("SG_Q8")[0] == '1';
     const bool want_q8 = want_pruned && !(flags & SG_POSTINGS_TILE_FORM) && B_in->n_cols < ((int64_t)1 << 24) && !(ctx->opt("SG_Q8") && ctx->opt("SG_Q8")[0] == '0') &&
-                         (q8_forced || (double)B_in->nnz <= 40.0 * (double)B_in->n_rows) &&
+                         (q8_forced || (double)B_in->nnz <= 45.0 * (double)B_in->n_rows) &&
                          (ctx->total_mem == 0 || (size_t)SG_Q8_STRIDE * ((size_t)B_in->n_rows + 1) < ctx->total_mem / 16);
     bool fwd_done = false;
     bool aux_written = false;   // the scoring context and the null postings were written by the tables kernel
@@ -1231,6 +1234,12 @@ extern "C" int sg_postings_build_flags(sg_ctx *ctx, const sg_csr *B_in, int32_t 
     p->dtype = B->dtype;
     p->tile_log2 = tile_log2;
     p->tile_form = (flags & SG_POSTINGS_TILE_FORM) != 0;
+    p->built_from = *B_in;
+    p->built_from.owned = false;
+    p->built_from.d_props_words = nullptr;
+    p->built_from.left_groups = nullptr;
+    p->built_from.left_state = 0;
+    p->built_from_valid = true;
     p->n_tiles = (int32_t)n_tiles64;
     p->b_indptr = B_in->d_indptr;      // the caller's matrix: what "A is the matrix the postings were built from" compares
     p->b_indices = B_in->d_indices;

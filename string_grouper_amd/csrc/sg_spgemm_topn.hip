@@ -1016,19 +1016,23 @@ extern "C" int sg_spgemm_topn(sg_ctx *ctx, const sg_csr *A, const sg_postings *B
     //      down a self-join runs the tile-by-tile form on an index of its own, built once and kept with the index
     //      (scripts/form_sweep.py, 200 k / 663 k names at 0.6: 5.4 / 31.4 ms stream, 3.4 / 24.1 ms tile by tile; at 0.8:
     //      1.3 / 5.1 against 1.8 / 11.7).
-    if (Bt->cosine_like && Bt->d_filt && Bt->fold_log2 > 0 && stride <= 2 * SG_TOPN_LANES && A->n_rows == Bt->n_right &&
-        A->d_indptr == Bt->b_indptr && A->d_indices == Bt->b_indices && A->d_data == Bt->b_data && A->n_rows > 0 &&
+    //      One-sided products (master x duplicates) too: the index is then built from the matrix the caller's index was.
+    if (Bt->cosine_like && Bt->d_filt && Bt->fold_log2 > 0 && stride <= 2 * SG_TOPN_LANES && A->n_rows > 0 && Bt->n_right > 0 &&
         threshold < env_double(ctx, "SG_ALT_FORM_BELOW", 0.65) && threshold >= prune_min_threshold(ctx, true) &&
         env_int(ctx, "SG_ALT_FORM", 1) != 0 && !(ctx->opt("SG_PRUNE") && ctx->opt("SG_PRUNE")[0] == '0')) {
-        static std::mutex alt_mu;
-        std::lock_guard<std::mutex> lock(alt_mu);
         const sg_postings *home = Bt->view_of ? Bt->view_of : Bt;   // (a view is a copy on the caller's stack)
-        if (!home->alt_tile) {
-            SG_TRY(sg_csr_ensure_rows(ctx, A));
-            SG_TRY(sg_postings_build_flags(ctx, A, 0, (Bt->build_flags & SG_POSTINGS_NO_PERMUTATION) | (1 << 8) | SG_POSTINGS_TILE_FORM,
-                                           &home->alt_tile));
+        const bool self = A->n_rows == Bt->n_right && A->d_indptr == Bt->b_indptr && A->d_indices == Bt->b_indices && A->d_data == Bt->b_data;
+        const sg_csr *from = self ? A : (home->collapse ? home->collapse->unique : (Bt->built_from_valid ? &Bt->built_from : nullptr));
+        if (from && from->n_rows == Bt->n_right) {
+            static std::mutex alt_mu;
+            std::lock_guard<std::mutex> lock(alt_mu);
+            if (!home->alt_tile) {
+                SG_TRY(sg_csr_ensure_rows(ctx, from));
+                SG_TRY(sg_postings_build_flags(ctx, from, 0, (Bt->build_flags & SG_POSTINGS_NO_PERMUTATION) | (1 << 8) | SG_POSTINGS_TILE_FORM,
+                                               &home->alt_tile));
+            }
+            Bt = home->alt_tile;
         }
-        Bt = home->alt_tile;
     }
     sg_topn *r = nullptr;
     SG_TRY(topn_alloc(ctx, A->n_rows, Bt->n_right, stride, A->dtype, &r));

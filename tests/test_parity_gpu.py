@@ -1934,7 +1934,7 @@ def test_config5_asymmetric_10M_x_1M_fp64_more_than_100k_rows_equal_the_port(ctx
 def test_second_filter_is_used_where_it_pays_and_changes_no_result(ctx):
     """Round 5: the 8-bit copies of the right-hand rows (sg_internal.h: SgScoreCtx::q8).  Same rows with the filter on, off
     (SG_Q8=0) and forced; `sg_stats` says what happened: at a name-matching threshold it rejects most candidates of the first
-    filter; under 0.65 it is not used (every candidate is scored); for rows of more than 40 entries on average the records
+    filter; under 0.65 it is not used (every candidate is scored); for rows of more than 45 entries on average the records
     are not built unless forced."""
     names = _names(120000, seed=5)
     A = _tfidf(names, np.float32)
