@@ -78,6 +78,13 @@ run("SynthNames 200k 3-grams ntop100 0.6", names, None, 100, 0.6)
 for low in (0.45, 0.4, 0.35, 0.3):       # below 0.45 the pruned kernel only runs with SG_PRUNE_MIN_THRESHOLD=<lower>
     run(f"low threshold: 200k 3-grams ntop10 {low}", names, None, 10, low)
 run("long names (3 joined) 100k 3-grams ntop10 0.8", long_names(100000, 5), None, 10, 0.8)
+def very_long(n, k, seed):
+    base = synth_names(n * k, seed)
+    return [" ".join(base[k * i:k * i + k]) for i in range(n)]
+
+
+run("long names (5 joined) 50k 3-grams ntop10 0.8", very_long(50000, 5, 6), None, 10, 0.8)       # ~100 entries: the wide launch
+run("very long (8 joined) 50k 3-grams ntop10 0.8", very_long(50000, 8, 7), None, 10, 0.8)        # ~160 entries: beyond the pruned kernel
 digits = ["%09d" % int(x) for x in rng.integers(0, 10 ** 9, 200000)]
 run("9-digit numbers 200k 3-grams (V<=1000) 0.8", digits, None, 10, 0.8)
 m = synth_names(300000, 3)

@@ -1897,7 +1897,10 @@ static int launch_pruned(sg_ctx *ctx, const sg_csr *A, const sg_postings *Bt, in
                          uint32_t *heavy_count = nullptr, uint32_t *heavy_rows = nullptr, uint32_t part_cfg = 0) {
     const size_t lds = pruned_lds(TILE_LOG2, FOLD_LOG2, A->dtype);
     unsigned grid = pruned_grid(ctx, TILE_LOG2, SYM ? (int64_t)pl.rows() : A->n_rows, FOLD_LOG2, A->dtype);
-    if (WIDE && grid > (unsigned)ctx->num_cu * 4u) grid = (unsigned)ctx->num_cu * 4u;   // few rows, if any: idle waves leave at once
+    // the wide launch: few rows, if any, in a list of names (idle waves leave at once) -- unless the rows are long on average
+    // (about 50 entries and up: a good part of them beyond 64), where a quarter of the chip was all it got (50 k strings of 100
+    // entries: profiles/r06b_long_strings.log)
+    if (WIDE && grid > (unsigned)ctx->num_cu * 4u && (double)A->nnz <= 48.0 * (double)A->n_rows) grid = (unsigned)ctx->num_cu * 4u;
     // (SHARE: see the kernel; only the forms that can run in parts have the second instantiation)
     constexpr bool SPLITS = SYM && !WIDE && FOLD_LOG2 > 0;
     const bool share = SPLITS && (heavy_count != nullptr || part_cfg != 0u);
@@ -2093,7 +2096,7 @@ int sg_spgemm_pruned_symmetric(sg_ctx *ctx, const sg_csr *A, const sg_postings *
     // every wave of the kernel holds one open chunk: count those in
     pl.chunks = (uint32_t)(cap / SG_PAIR_CHUNK);
     if (!cap_forced) pl.chunks += 2u * pruned_grid(ctx, Bt->tile_log2, n, Bt->fold_log2, A->dtype) + (uint32_t)ctx->num_cu * 4u +
-                                  sg_spgemm_exact_selfjoin_grid(ctx, exact_all ? Bt : nullptr);
+                                  sg_spgemm_exact_selfjoin_grid(ctx, Bt);   // (every wave of every launch holds one open chunk)
     if (pl.chunks < 1) pl.chunks = 1;
     cap = (int64_t)pl.chunks * SG_PAIR_CHUNK;
     // [0] row counter [1] flagged count [2..3] pairs [4] chunks handed out [5] row counter of the exact kernel's launch;
@@ -2190,7 +2193,10 @@ int sg_spgemm_pruned_symmetric(sg_ctx *ctx, const sg_csr *A, const sg_postings *
         // pairs (i, j <= i), mirrored ones into the pair list.  Its postings are written now if the index build left them
         // out (name lists have no such rows), and the counts are read again.
         st = sg_postings_ensure_full(ctx, Bt);
-        if (st == SG_OK) st = sg_spgemm_exact_selfjoin_rows(ctx, A, Bt, keep, r, threshold, words + 5, flagged_rows, words + 1, sink);
+        // (a list of long strings hands over most of its rows: then the launch is sized like one over all rows, not like the
+        //  usual handful -- 50 k strings of ~170 characters: scripts/family_sweep.py, "very long")
+        const bool many = (uint32_t)(h[0] >> 32) > 2u * sg_spgemm_exact_selfjoin_grid(ctx);
+        if (st == SG_OK) st = sg_spgemm_exact_selfjoin_rows(ctx, A, Bt, keep, r, threshold, words + 5, flagged_rows, words + 1, sink, many);
         if (st == SG_OK) read_back();
     }
     if (st != SG_OK) {

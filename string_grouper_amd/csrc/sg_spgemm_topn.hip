@@ -792,7 +792,11 @@ static bool pruned_applicable(sg_ctx *ctx, const sg_csr *A, const sg_postings *B
     if ((pr && pr[0] == '0') || !Bt->cosine_like || !Bt->d_filt || stride > 2 * SG_TOPN_LANES || A->n_rows <= 0 || Bt->nnz <= 0 ||
         !sg_pruned_supports_tile(Bt->tile_log2))
         return false;
-    const bool thr_ok = threshold >= prune_min_threshold(ctx, Bt->tile_form);   // below ~0.4 the filter passes too much (profiles/r01_prune_tuning.log)
+    // ... and rows of more than 128 entries are beyond it altogether: where that is the AVERAGE row (strings of 130 characters
+    // and more) nearly every row would be passed on one by one -- 50 k strings of 155 entries: 68 ms that way, 37.5 the
+    // exact kernel alone (profiles/r06b_long_strings.log) -- the exact kernel takes the product as it does below the threshold
+    const bool thr_ok = threshold >= prune_min_threshold(ctx, Bt->tile_form) &&
+                        !((double)A->nnz > env_double(ctx, "SG_PRUNE_MAX_MEAN_ROW", 128.0) * (double)A->n_rows);   // below ~0.4 the filter passes too much (profiles/r01_prune_tuning.log)
     if (!thr_ok && !below_envelope) return false;
     // tuned at 663 k: the tile-by-tile form 0.05 (profiles/r01_prune_tuning.log); the stream form, whose rounds are cheaper
     // next to the exact scorings, 0.03 (profiles/r03_sessionG_H_delta.log: 9.76 / 9.95 / 10.10 ms at 0.03 / 0.04 / 0.05;
@@ -816,7 +820,12 @@ static bool pruned_applicable(sg_ctx *ctx, const sg_csr *A, const sg_postings *B
     // (profiles/r02_sessionM_sym_sweep.log)
     *symmetric = !(sy && sy[0] == '0') && stride <= (below_envelope ? 2 : 1) * SG_TOPN_LANES && A->n_rows == Bt->n_right && A->d_indptr == Bt->b_indptr &&
                  A->d_indices == Bt->b_indices && A->d_data == Bt->b_data &&
-                 (any_size || A->n_rows >= (int64_t)env_int(ctx, "SG_SYM_MIN_ROWS", 65536) || (sy && sy[0] == '1'));
+                 (any_size || A->n_rows >= (int64_t)env_int(ctx, "SG_SYM_MIN_ROWS", 65536) || (sy && sy[0] == '1') ||
+                  // (the bar was set on names, 19 entries a row; longer rows cost more each and the form pays earlier -- 50 k rows
+                  //  of 96 entries: 10.1 ms one-sided, 6.95 in the self-join form -- and the exact kernel in the self-join form
+                  //  halves a product that is many times dearer at the same size)
+                  A->nnz >= (int64_t)19 * (int64_t)env_int(ctx, "SG_SYM_MIN_ROWS", 65536) ||
+                  (!thr_ok && A->n_rows >= (int64_t)env_int(ctx, "SG_EXACT_SYM_MIN_ROWS", 16384)));
     if (!thr_ok) {
         *below_envelope = true;
         return false;

@@ -695,7 +695,9 @@ def pruned_multiply_expected(top_n: int, threshold: float, ctx=None) -> bool:
     opts = ctx.options() if ctx is not None else os.environ
     if opts.get("SG_PRUNE", "1").startswith("0"):
         return False
-    return top_n <= 128 and threshold >= float(opts.get("SG_PRUNE_MIN_THRESHOLD", "0.45"))   # (2 x SG_TOPN_LANES: pruned_applicable)
+    # (2 x SG_TOPN_LANES: pruned_applicable; 0.40: the tile-by-tile form's envelope, prune_min_threshold in sg_spgemm_topn.hip)
+    alt = not opts.get("SG_ALT_FORM", "1").startswith("0")
+    return top_n <= 128 and threshold >= float(opts.get("SG_PRUNE_MIN_THRESHOLD", "0.40" if alt else "0.45"))
 
 
 def sharded_self_join_replicated(ctx, prepared_dev, vectorizer_factory, top_n: int, threshold: float,

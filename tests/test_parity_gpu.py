@@ -181,6 +181,27 @@ def test_selfjoins_below_name_matching_thresholds_take_the_tile_by_tile_form(ctx
         post.free()
 
 
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_long_strings_on_both_sides_of_the_pruned_kernels_row_length(ctx, dtype):
+    """Round 6: strings of ~100 n-grams (the wide launch, now sized by the rows' average length, and the self-join form from
+    19 x 65 536 non-zeros on) and of ~155 (beyond 128 entries a row ON AVERAGE the pruned multiply would pass nearly every
+    row on one by one: the exact kernel takes the product, in the self-join form from 16 384 rows).  The port's bits."""
+    from string_grouper_amd.sparse_dot_topn import sp_matmul_topn
+    base = _names(8 * 17000, seed=21)
+    for k, n, pruned in ((5, 14000, True), (8, 17000, False)):
+        names = [" ".join(base[k * i:k * i + k]) for i in range(n)]
+        names[100:130] = [names[7]] * 30                        # a hub of identical long rows
+        A = _tfidf(names, dtype)
+        assert (A.nnz > 128 * n) != pruned
+        got = sp_matmul_topn(A, A.T, 10, 0.8, sort=True, ctx=ctx)
+        st = ctx.stats()
+        assert_csr_identical(got, P.sp_matmul_topn_port(A, A.T, 10, 0.8, True, 16), f"{k} names joined, {dtype.__name__}")
+        assert st["prune_symmetric"] == 1 and (st["prune_rows"] > 0) == pruned, st
+        left = A[1000:5000]                                       # one-sided: the wide launch / the exact kernel's row list
+        assert_csr_identical(sp_matmul_topn(left, A.T, 10, 0.8, sort=True, ctx=ctx), P.sp_matmul_topn_port(left, A.T, 10, 0.8, True, 16),
+                             f"{k} names joined, one-sided")
+
+
 def test_random_lists_with_repeats_equal_the_port(ctx):
     """Seeded random jobs around the switches of round 3 -- size on both sides of the grouping's threshold, share and size of
     the repeats, near-duplicates of the hubs (ties at the cut between a group and single rows), top_n from 1 to 128,
