@@ -170,6 +170,7 @@ extern "C" int sg_ctx_create(int device, void *hip_stream, sg_ctx **out) {
     }
     SG_HIP_TRY(hipMalloc((void **)&ctx->d_stat_words, 8 * sizeof(int64_t)));
     SG_HIP_TRY(hipHostMalloc((void **)&ctx->h_stat_words, 8 * sizeof(int64_t), hipHostMallocDefault));
+    SG_HIP_TRY(hipHostMalloc((void **)&ctx->h_fetch, SG_H_FETCH_WORDS * sizeof(uint32_t), hipHostMallocDefault));
     SG_HIP_TRY(hipMemsetAsync(ctx->d_stat_words, 0, 8 * sizeof(int64_t), ctx->stream));
     *out = ctx;
     return SG_OK;
@@ -190,6 +191,7 @@ extern "C" int sg_ctx_destroy(sg_ctx *ctx) {
     (void)hipFree(ctx->d_scan_desc);
     for (auto &t : ctx->idf_tables) (void)hipFree(t.d);
     (void)hipHostFree(ctx->h_stat_words);
+    (void)hipHostFree(ctx->h_fetch);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return SG_OK;

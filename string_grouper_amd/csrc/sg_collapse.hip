@@ -639,10 +639,12 @@ static int collapse_groups_table(sg_ctx *ctx, const sg_csr *B, bool forced, bool
     }
     uint32_t h[64 + 32 * 32];
     for (auto &w : h) w = 0;
-    if (st == SG_OK) {
-        if (hipMemcpyAsync(h, totals, sizeof(h), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+    static_assert(sizeof(h) <= SG_H_FETCH_WORDS * sizeof(uint32_t), "the pinned read-back buffer holds the grouping's words");
+    if (st == SG_OK) {   // (through pinned memory: see sg_ctx::h_fetch)
+        if (hipMemcpyAsync(ctx->h_fetch, totals, sizeof(h), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
             hipStreamSynchronize(ctx->stream) != hipSuccess)
             st = SG_ERR_HIP;
+        else memcpy(h, ctx->h_fetch, sizeof(h));
     }
     const uint32_t n_groups = h[0];
     int64_t nnz_u = 0;

@@ -45,6 +45,7 @@ void sg_set_error(const char *fmt, ...);
 // ---------------------------------------------------------------------------------------------
 // Context: device, stream, a caching scratch pool (so that a repeated "step" allocates nothing),
 // per-kernel HIP events.
+#define SG_H_FETCH_WORDS 2048
 struct sg_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -69,6 +70,7 @@ struct sg_ctx {
     double pilot_ms_pruned = 0.0, pilot_ms_exact = 0.0;   // the most recent pruned-or-exact pilot's two estimates (0: none ran)
     int64_t *d_stat_words = nullptr;             // [0]=macs [1]=out_nnz [2..4]=pruned rows/postings/survivors [5]=rows handed to K4 [6]=pairs scored exactly
     int64_t *h_stat_words = nullptr;             // pinned mirror
+    uint32_t *h_fetch = nullptr;                 // pinned, SG_H_FETCH_WORDS words: where small read-backs land (a copy to pageable memory is a round trip of its own, one per copy)
 
     // Tuning switches (SG_*): read from the environment ONCE, when the context is created, changed only through
     // sg_ctx_set_option, listed by sg_ctx_options -- nothing inside an API call looks at the environment (a variable left

@@ -1348,13 +1348,27 @@ extern "C" int sg_vec_fit_end(sg_ctx *ctx, sg_vocab *v, int64_t n_docs_total) {
                     if (st == SG_OK) st = sg_exclusive_scan_i32_to_i64(ctx, c.d_cnt, c.d_indptr, c.n);
                 }
                 if (st != SG_OK) break;
-                hipError_t e = hipMemcpyAsync(&n_terms, d_total, 4, hipMemcpyDeviceToHost, ctx->stream);
+                // (into PINNED memory: a copy to a pageable address is staged and waited for on the spot -- three copies were three
+                //  round trips, 20 - 40 us of idle GPU each; layout: [0] vocabulary, then per column {strings for the last stage,
+                //  -, non-zeros: 64 bits})
+                uint32_t *hf = ctx->h_fetch;
+                const bool pinned = 4 * im->caches.size() + 4 <= SG_H_FETCH_WORDS;
+                hipError_t e = hipMemcpyAsync(pinned ? (void *)hf : (void *)&n_terms, d_total, 4, hipMemcpyDeviceToHost, ctx->stream);
                 for (size_t q = 0; q < im->caches.size() && e == hipSuccess; ++q) {
-                    if (im->caches[q].d_longs) e = hipMemcpyAsync(&n_long[q], im->caches[q].d_longs, 4, hipMemcpyDeviceToHost, ctx->stream);
+                    if (im->caches[q].d_longs)
+                        e = hipMemcpyAsync(pinned ? (void *)(hf + 2 + 4 * q) : (void *)&n_long[q], im->caches[q].d_longs, 4, hipMemcpyDeviceToHost, ctx->stream);
                     if (e == hipSuccess && im->caches[q].d_indptr)
-                        e = hipMemcpyAsync(&nnz_of[q], im->caches[q].d_indptr + im->caches[q].n, 8, hipMemcpyDeviceToHost, ctx->stream);
+                        e = hipMemcpyAsync(pinned ? (void *)(hf + 4 + 4 * q) : (void *)&nnz_of[q], im->caches[q].d_indptr + im->caches[q].n, 8,
+                                           hipMemcpyDeviceToHost, ctx->stream);
                 }
                 if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+                if (pinned && e == hipSuccess) {
+                    n_terms = hf[0];
+                    for (size_t q = 0; q < im->caches.size(); ++q) {
+                        if (im->caches[q].d_longs) n_long[q] = hf[2 + 4 * q];
+                        if (im->caches[q].d_indptr) memcpy(&nnz_of[q], hf + 4 + 4 * q, 8);
+                    }
+                }
                 for (size_t q = 0; q < im->caches.size(); ++q) im->caches[q].nnz = nnz_of[q];
                 if (e != hipSuccess) {
                     sg_set_error("reading the vocabulary size failed: %s", hipGetErrorString(e));
