@@ -205,27 +205,27 @@ def run(args):
             return res
         return one_gpu_step(make_vec)
 
-    def one_gpu_step(factory, prep=None):
+    def one_gpu_step(factory, prep=None, top_n=None, thr=None):
         prep = prepared if prep is None else prep
         vec = factory()
         vec.fit_prepared([prep])
         A = vec.transform_prepared(prep)
         post = ctx.postings_build(A)
-        res = ctx.spgemm_topn(A, post, args.top_n, args.min_similarity, True)
+        res = ctx.spgemm_topn(A, post, args.top_n if top_n is None else top_n, args.min_similarity if thr is None else thr, True)
         ctx.sync()
         res._keep = (A, post, vec)
         return res
 
-    def side_run(factory, k=12, prep=None):
-        """The same step under another setting (other dtype, a switch of the context, another list), timed like the main
-        region on a shorter one: (ms per step, the dominant kernel's ms, its stats)."""
-        one_gpu_step(factory, prep).free()
-        one_gpu_step(factory, prep).free()
+    def side_run(factory, k=12, prep=None, top_n=None, thr=None):
+        """The same step under another setting (other dtype, a switch of the context, another list, other parameters of the
+        public API), timed like the main region on a shorter one: (ms per step, the dominant kernel's ms, its stats)."""
+        one_gpu_step(factory, prep, top_n, thr).free()
+        one_gpu_step(factory, prep, top_n, thr).free()
         torch.cuda.synchronize()
         t = time.perf_counter()
         kms, st = [], None
         for _ in range(k):
-            r = one_gpu_step(factory, prep)
+            r = one_gpu_step(factory, prep, top_n, thr)
             st = ctx.stats()
             kms.append(st["ms_spgemm_kernel"] or st["ms_spgemm_topn"])
             r.free()
@@ -465,6 +465,23 @@ def run(args):
         result[other] = {"ms_per_step": ms, "rows_per_s": args.rows / (ms * 1e-3), "kernel_ms": kms,
                          "kernel_frac_of_hbm_peak": o_bytes / (kms * 1e-3) / 1e9 / HBM_PEAK_GBPS, "steps": 12,
                          "matches": st_o["out_nnz"]}
+
+    if world == 1 and not args.no_side_runs:
+        # ... and at other values of the two parameters the reference leaves to the caller (string_grouper.py:192-193): the whole
+        # step again -- every one rebuilds its indexes, the second one of a form included -- on the same list.  Which form of
+        # the multiply the library picked is read off its statistics ("Which form runs").
+        other_settings = []
+        for top_n, thr in ((100, 0.8), (10, 0.6), (20, 0.5), (10, 0.35)):
+            ms, kms, st_s = side_run(make_vec, k=4, top_n=top_n, thr=thr)
+            if st_s["prune_rows"] > 0:
+                form = "pruned multiply, " + ("stream form + second filter" if thr >= 0.65 else "tile-by-tile form")
+            else:
+                form = "exact kernel"
+            form += ", self-join form" if st_s["prune_symmetric"] else ", one-sided"
+            other_settings.append({"top_n": top_n, "min_similarity": thr, "ms_per_step": ms, "rows_per_s": args.rows / (ms * 1e-3),
+                                   "multiply_ms": st_s["ms_spgemm_topn"], "matches": st_s["out_nnz"], "form": form,
+                                   "rows_handed_to_exact_kernel": st_s["exact_rows"] if st_s["prune_rows"] > 0 else None, "steps": 4})
+        result["other_settings"] = other_settings
 
     if world == 1 and pruned and not args.no_exact_kernel:
         # the exact kernel (K4) on the same input, timed live beside the pruned one: it is what runs when the

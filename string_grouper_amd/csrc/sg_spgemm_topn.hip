@@ -840,8 +840,10 @@ static int spgemm_topn_collapsed(sg_ctx *ctx, const sg_csr *A, const sg_postings
     const SgCollapse *c = Bt->collapse;
     int64_t stride64 = top_n;
     if (stride64 > c->n_orig) stride64 = c->n_orig > 0 ? c->n_orig : 1;
-    if (stride64 > SG_TOPN_LANES) {
-        // more columns per row than one register list: an index over all rows, built once, serves these calls
+    if (stride64 > 2 * SG_TOPN_LANES) {
+        // more columns per row than the multiply on the groups keeps (two register lists since round 6; one before, and
+        // top_n of 65 .. 128 then multiplied every row: 663 k names, top 100: 9.1 ms): an index over all rows, built once,
+        // serves these calls
         {
             // (made on first use; two threads sharing the index must not both make it -- ADVICE r03.  It is built from the
             //  caller's matrix, which has to be alive as long as the index is: include/sg_hip.h, sg_postings_build)
