@@ -1715,8 +1715,15 @@ __global__ void __launch_bounds__(64) pairs_select_kernel(const uint32_t *__rest
                     const bool have = base + (uint32_t)lane < hi;
                     const T s = have ? lval[base + lane] : (T)0;
                     const int c = have ? lcol[base + lane] : 0;
-                    const int mm = (int)min(64u, hi - base);
-                    for (int q = 0; q < mm; ++q) wide.insert_unique(wave_read<T>(s, q), wave_read<int>(c, q), lane);
+                    // (only what can still make the row's best `keep`: see the narrow list below)
+                    const T bar_s = keep <= 64 ? wave_read<T>(wide.lo.s, keep - 1) : wave_read<T>(wide.hi.s, keep - 65);
+                    const int bar_c = keep <= 64 ? wave_read<int>(wide.lo.c, keep - 1) : wave_read<int>(wide.hi.c, keep - 65);
+                    uint64_t todo = __ballot(have && (s > bar_s || (s == bar_s && c < bar_c)));
+                    while (todo) {
+                        const int q = __builtin_ctzll(todo);
+                        todo &= todo - 1;
+                        wide.insert_unique(wave_read<T>(s, q), wave_read<int>(c, q), lane);
+                    }
                 }
                 int cnt = wide.count();
                 if (cnt > keep) cnt = keep;
@@ -1742,8 +1749,19 @@ __global__ void __launch_bounds__(64) pairs_select_kernel(const uint32_t *__rest
                 const bool have = base + (uint32_t)lane < hi;
                 const T s = have ? lval[base + lane] : (T)0;
                 const int c = have ? lcol[base + lane] : 0;
-                const int mm = (int)min(64u, hi - base);
-                for (int q = 0; q < mm; ++q) top.insert_unique(wave_read<T>(s, q), wave_read<int>(c, q), lane);
+                // Only what can still make the row's best `keep` is inserted: the list's keep-th entry is the bar (an empty slot
+                // is (-inf, INT_MAX): everything passes until `keep` are there).  The bar only rises while a batch is worked
+                // off, so the one read in front of it lets too much through, never too little.  At thresholds below the
+                // name-matching range a row receives dozens of pairs for a top_n of ten: 200 k names at 0.3, the second pass
+                // 4.0 -> 2.0 ms.
+                const T bar_s = wave_read<T>(top.s, keep - 1);
+                const int bar_c = wave_read<int>(top.c, keep - 1);
+                uint64_t todo = __ballot(have && (s > bar_s || (s == bar_s && c < bar_c)));
+                while (todo) {
+                    const int q = __builtin_ctzll(todo);
+                    todo &= todo - 1;
+                    top.insert_unique(wave_read<T>(s, q), wave_read<int>(c, q), lane);
+                }
             }
             int cnt = __popcll(__ballot(top.c != INT32_MAX));
             if (cnt > keep) cnt = keep;
