@@ -224,7 +224,8 @@ def test_random_lists_with_repeats_equal_the_port(ctx):
             names = sorted(names)
         dtype = np.float32 if rng.random() < 0.6 else np.float64
         top_n = int(rng.choice([1, 2, 10, 10, 20, 63, 64, 65, 100, 128]))
-        thr = float(rng.choice([0.5, 0.6, 0.75, 0.8, 0.8, 0.9, 0.95]))
+        thr = float(rng.choice([float(x) for x in os.environ["SG_TEST_RANDOM_THRESHOLDS"].split(",")] if os.environ.get("SG_TEST_RANDOM_THRESHOLDS")
+                               else [0.5, 0.6, 0.75, 0.8, 0.8, 0.9, 0.95]))      # (a soak of the low-threshold forms: e.g. 0.25,0.35,0.42,0.55,0.62)
         sym = str(rng.choice(["", "0", "1"]))
         what = f"job {job}: n={n} top_n={top_n} thr={thr} {dtype.__name__} SG_SYM={sym!r} repeats={share}"
         A = _tfidf(names, dtype)
@@ -855,6 +856,43 @@ def _rows_equal_the_port(res, rows, A_host, B_host, top_n, thr, what):
     assert np.array_equal(vals[rows][mask], C_ref.data), f"{what}: scores"
     print(f"{what}: {len(rows)} rows ({int(got_cnt.sum())} matches) identical to the CPU port ({secs:.1f} s on {n_cpu} cores)")
     return len(rows)
+
+
+@pytest.mark.timeout(900)
+def test_forms_outside_the_name_matching_envelope_at_300k_equal_the_exact_kernel_and_the_port(ctx):
+    """Round 6 at a size where the forms run as they are CHOSEN (300 000 names: self-join form, identical rows grouped, the
+    second index built on first use): top 100 at 0.8 (two register lists in the second pass), top 20 at 0.5 and top 10 at 0.62
+    (tile-by-tile form), top 10 at 0.35 (exact kernel in the self-join form on its own layout) -- every row against the
+    one-sided exact kernel (SG_PRUNE=0, SG_EXACT_SYM=0), 20 000 rows of each against the CPU port."""
+    from string_grouper_amd.vectorizer import HipTfidfVectorizer
+    names = _names(300000, seed=17)
+    vec = HipTfidfVectorizer(dtype=np.float32, ctx=ctx)
+    p = vec.prepare(names)
+    vec.fit_prepared([p])
+    dA = vec.transform_prepared(p)
+    A_host = dA.to_scipy()
+    rows = np.concatenate([np.arange(7000), 150000 + np.arange(7000), 293000 + np.arange(7000)])
+    post = ctx.postings_build(dA)
+    for top_n, thr, pruned in ((100, 0.8, True), (20, 0.5, True), (10, 0.62, True), (10, 0.35, False)):
+        res = ctx.spgemm_topn(dA, post, top_n, thr, True)
+        st = ctx.stats()
+        what = f"300 k names, top {top_n} at {thr}"
+        assert st["prune_symmetric"] == 1 and (st["prune_rows"] > 0) == pruned and (st["exact_rows"] == 0) == pruned, (what, st)
+        got = res.to_host()
+        ctx.set_option("SG_PRUNE", "0")
+        ctx.set_option("SG_EXACT_SYM", "0")
+        ref = ctx.spgemm_topn(dA, post, top_n, thr, True)
+        assert ctx.stats()["prune_symmetric"] == 0 and ctx.stats()["prune_rows"] == 0
+        want = ref.to_host()
+        ctx.reset_options()
+        assert np.array_equal(got[2], want[2]), what + ": match counts"
+        mask = np.arange(want[0].shape[1])[None, :] < want[2][:, None]
+        assert np.array_equal(got[0][mask], want[0][mask]) and np.array_equal(got[1][mask], want[1][mask]), what + ": every row vs the exact kernel"
+        _rows_equal_the_port(res, rows, A_host, A_host, top_n, thr, what)
+        res.free()
+        ref.free()
+    post.free()
+    dA.free()
 
 
 def _device_u32(ptr, n):
