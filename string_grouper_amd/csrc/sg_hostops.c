@@ -5,8 +5,8 @@
 // of 2.1 M match rows: a random access to a PyObject header per element to raise its reference count, one thread) and 18 ms
 // in the conversion of the string column to UTF-8 bytes + offsets (profiles/r06_e2e_profile.log).  Both are gathers over
 // immutable objects; neither needs the interpreter:
-//   * sg_host_gather_objects: dst[i] = src[idx[i]] by T threads, then the reference counts raised by T threads, every
-//     thread owning the OBJECTS whose address hashes to it, so that no two threads ever touch the same counter;
+//   * sg_host_gather_objects: dst[i] = src[idx[i]] by T threads with a count per source position, then the reference counts
+//     raised once per source position (atomic adds: one object may sit at several positions);
 //   * sg_host_ascii_lengths / sg_host_ascii_copy: lengths, then bytes, of a column of compact-ASCII str objects (read-only
 //     on the objects).  Anything else in the column -- a non-ASCII str, a non-str -- is reported and the caller takes the
 //     general path (pyarrow), which also raises the reference's TypeError for non-strings.
@@ -15,13 +15,20 @@
 #define PY_SSIZE_T_CLEAN
 #include <Python.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <string.h>
 #include <omp.h>
 
-// 0 ok; 1 an index is out of range; 2 dst does not hold n references to None (a fresh np.empty(n, object) does)
-// Two passes: the pointers (every thread a run of positions: a plain gather), then the reference counts -- every thread
-// walks ALL of dst and counts the objects whose address hashes to it, so that one object is only ever counted by one
-// thread however many positions (of src and of dst) hold it.
+// 0 ok; 1 an index is out of range; 2 dst does not hold n references to None (a fresh np.empty(n, object) does); 3 no memory
+// Three passes, none of which walks anything twice: (1) the indices are checked; (2) every thread gathers the pointers of a
+// run of positions and counts, per SOURCE position, how often it was taken (atomic adds on a table of 4 bytes per source
+// element: it fits the L2, and a sorted index list -- the left side of a match list -- hits the same word in runs);
+// (3) every thread raises the reference counts of a run of source positions by their counts, with ATOMIC adds: one str
+// object may sit at several source positions (a list that repeats a name), i.e. in two threads' runs.  The caller holds the
+// GIL (ctypes.PyDLL), so nothing but these threads touches the counters meanwhile.
+// (Round 6's first form raised the counts position by position, every thread walking ALL positions for the objects whose
+//  address hashed to it: 16 x 2.1 M hash computations, and on a SORTED index list more threads made it slower -- 13.6 ms on
+//  one thread, 101 on eight, on the build container: scripts/take_objects_bench.py has both on the GPU box's host: 8.5 - 14.7 ms -> 1.3 - 1.7 ms on sixteen threads.)
 int sg_host_gather_objects(PyObject **src, int64_t n_src, const int64_t *idx, int64_t n, PyObject **dst, int threads) {
     if (n <= 0) return 0;
     if (dst[0] != Py_None || dst[n - 1] != Py_None) return 2;
@@ -34,16 +41,21 @@ int sg_host_gather_objects(PyObject **src, int64_t n_src, const int64_t *idx, in
         if (j < 0 || j >= n_src) bad = 1;
     }
     if (bad) return 1;                   // (nothing written yet: the caller lets numpy raise)
+    uint32_t *cnt = (uint32_t *)calloc((size_t)n_src + 1, sizeof(uint32_t));
+    if (!cnt) return 3;
 #pragma omp parallel num_threads(threads)
     {
 #pragma omp for schedule(static)
-        for (int64_t i = 0; i < n; ++i) dst[i] = src[idx[i]];
-        const uint64_t t = (uint64_t)omp_get_thread_num(), T = (uint64_t)omp_get_num_threads();
         for (int64_t i = 0; i < n; ++i) {
-            PyObject *o = dst[i];
-            if ((((uint64_t)(uintptr_t)o >> 4) * 0x9E3779B97F4A7C15ull >> 40) % T == t) ++o->ob_refcnt;
+            const int64_t j = idx[i];
+            dst[i] = src[j];
+            __atomic_fetch_add(&cnt[j], 1u, __ATOMIC_RELAXED);
         }
+#pragma omp for schedule(static)
+        for (int64_t j = 0; j < n_src; ++j)
+            if (cnt[j]) __atomic_fetch_add(&src[j]->ob_refcnt, (Py_ssize_t)cnt[j], __ATOMIC_RELAXED);
     }
+    free(cnt);
     Py_None->ob_refcnt -= n;            // the n references to None the fresh array held are gone
     return 0;
 }

@@ -36,7 +36,7 @@ def test_gather_returns_the_same_objects_and_keeps_the_reference_counts_right():
     assert abs(none_after - none_before) < 64                             # the fresh array's references to None were given back
     # other index types, and what numpy refuses
     assert all(a is b for a, b in zip(H.take_objects(arr, idx.astype(np.int32)).tolist(), arr.take(idx).tolist()))
-    # ONE object at many positions (a list that repeats a name): still counted exactly -- by the thread that owns the object
+    # ONE object at many positions (a list that repeats a name): still counted exactly -- the counts are raised by atomic adds
     shared = ["".join(["SHARED ", str(i)]) for i in range(40)]
     rep = np.array([shared[i % 40] for i in range(100000)], dtype=object)
     ridx = rng.integers(0, len(rep), 1500000).astype(np.int64)
