@@ -36,6 +36,14 @@ def _load():
         lib.sg_host_ascii_lengths.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int]
         lib.sg_host_ascii_copy.restype = None
         lib.sg_host_ascii_copy.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int]
+        lib.sg_host_expand_rows.restype = None
+        lib.sg_host_expand_rows.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int]
+        lib.sg_host_widen_i32.restype = None
+        lib.sg_host_widen_i32.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int]
+        lib.sg_host_widen_f32.restype = None
+        lib.sg_host_widen_f32.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int]
+        lib.sg_host_affine_i64.restype = None
+        lib.sg_host_affine_i64.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_int]
         _lib = lib
     except (OSError, AttributeError):
         _lib = None
@@ -88,3 +96,48 @@ def all_exact_str(values: np.ndarray) -> bool:
     if lib is None or len(values) < 4096 or values.dtype != object or values.ndim != 1 or not values.flags.c_contiguous:
         return False
     return bool(lib.sg_host_all_exact_str(values.ctypes.data, len(values), _threads()))
+
+
+_BIG = 262144      # below this numpy's own loop is as fast as starting the threads
+
+
+def expand_rows(row_ptr: np.ndarray) -> np.ndarray:
+    """``np.repeat(np.arange(n), np.diff(row_ptr))`` as int64: the row of every entry of a CSR list."""
+    lib = _load()
+    n = len(row_ptr) - 1
+    m = int(row_ptr[-1]) if n >= 0 and len(row_ptr) else 0
+    if (lib is None or m < _BIG or row_ptr.dtype != np.int64 or not row_ptr.flags.c_contiguous or int(row_ptr[0]) != 0):
+        return np.repeat(np.arange(max(n, 0), dtype=np.int64), np.diff(row_ptr))
+    out = np.empty(m, dtype=np.int64)
+    lib.sg_host_expand_rows(row_ptr.ctypes.data, n, out.ctypes.data, _threads())
+    return out
+
+
+def widen(values: np.ndarray, dtype) -> np.ndarray:
+    """``values.astype(dtype)`` for int32 -> int64 and float32 -> float64 (what the frames hold); anything else: numpy."""
+    lib = _load()
+    dtype = np.dtype(dtype)
+    n = len(values)
+    if lib is None or n < _BIG or values.ndim != 1 or not values.flags.c_contiguous:
+        return values.astype(dtype)
+    if values.dtype == np.int32 and dtype == np.int64:
+        out = np.empty(n, dtype=np.int64)
+        lib.sg_host_widen_i32(values.ctypes.data, n, out.ctypes.data, _threads())
+        return out
+    if values.dtype == np.float32 and dtype == np.float64:
+        out = np.empty(n, dtype=np.float64)
+        lib.sg_host_widen_f32(values.ctypes.data, n, out.ctypes.data, _threads())
+        return out
+    return values.astype(dtype)
+
+
+def affine_i64(values: np.ndarray, start: int, step: int) -> np.ndarray:
+    """``start + values.astype(int64) * step`` for an int64 array (always a new array)."""
+    lib = _load()
+    n = len(values)
+    if lib is None or n < _BIG or values.dtype != np.int64 or values.ndim != 1 or not values.flags.c_contiguous:
+        v = values.astype(np.int64, copy=True)
+        return v if (start == 0 and step == 1) else start + v * step
+    out = np.empty(n, dtype=np.int64)
+    lib.sg_host_affine_i64(values.ctypes.data, n, int(start), int(step), out.ctypes.data, _threads())
+    return out

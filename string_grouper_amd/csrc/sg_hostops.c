@@ -117,3 +117,36 @@ void sg_host_ascii_copy(PyObject **objs, int64_t n, const int64_t *offsets, uint
 #pragma omp parallel for num_threads(threads) schedule(static)
     for (int64_t i = 0; i < n; ++i) memcpy(out + offsets[i], PyUnicode_DATA(objs[i]), (size_t)(offsets[i + 1] - offsets[i]));
 }
+
+// ---- the match list's columns as the frames want them (round 6): rows expanded from the row pointers, columns and scores
+// widened to the reference's int64 / float64 -- numpy's repeat / astype on one thread were 8 of match_strings()' 33 ms at
+// 2.1 M match rows.  Every thread writes a run of ROWS' worth of output (first touch by the thread that fills it).
+void sg_host_expand_rows(const int64_t *row_ptr, int64_t n_rows, int64_t *out_rows, int threads) {
+    if (threads < 1) threads = 1;
+    if (threads > 64) threads = 64;
+#pragma omp parallel for num_threads(threads) schedule(static)
+    for (int64_t r = 0; r < n_rows; ++r)
+        for (int64_t p = row_ptr[r]; p < row_ptr[r + 1]; ++p) out_rows[p] = r;
+}
+
+void sg_host_widen_i32(const int32_t *src, int64_t n, int64_t *dst, int threads) {
+    if (threads < 1) threads = 1;
+    if (threads > 64) threads = 64;
+#pragma omp parallel for num_threads(threads) schedule(static)
+    for (int64_t i = 0; i < n; ++i) dst[i] = (int64_t)src[i];
+}
+
+void sg_host_widen_f32(const float *src, int64_t n, double *dst, int threads) {
+    if (threads < 1) threads = 1;
+    if (threads > 64) threads = 64;
+#pragma omp parallel for num_threads(threads) schedule(static)
+    for (int64_t i = 0; i < n; ++i) dst[i] = (double)src[i];
+}
+
+// dst[i] = start + src[i] * step (the picked rows' labels of a RangeIndex; start 0 / step 1: a copy)
+void sg_host_affine_i64(const int64_t *src, int64_t n, int64_t start, int64_t step, int64_t *dst, int threads) {
+    if (threads < 1) threads = 1;
+    if (threads > 64) threads = 64;
+#pragma omp parallel for num_threads(threads) schedule(static)
+    for (int64_t i = 0; i < n; ++i) dst[i] = start + src[i] * step;
+}

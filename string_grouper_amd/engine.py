@@ -14,6 +14,7 @@ from typing import List, Optional, Sequence, Tuple
 import numpy as np
 import scipy.sparse as sp
 
+from . import _hostops
 from . import _native as N
 from .vectorizer import HipTfidfVectorizer
 
@@ -183,11 +184,13 @@ class HipEngine:
         row_ptr, cols, vals = ml.to_host()
         t = self._tick("match_list_and_download_s", t)
         res.free()
-        rows = np.repeat(np.arange(len(row_ptr) - 1, dtype=np.int64), np.diff(row_ptr))
+        # (round 6: the three expansions on host threads -- _hostops; numpy's own below 262 144 entries or without the helpers)
+        rows = _hostops.expand_rows(row_ptr)
+        cols = _hostops.widen(cols, np.int64)
         if keep_on_device:
-            return rows, cols.astype(np.int64), vals, true_max, DeviceMatchList(ml, n_cols)
+            return rows, cols, vals, true_max, DeviceMatchList(ml, n_cols)
         ml.free()
-        return rows, cols.astype(np.int64), vals, true_max
+        return rows, cols, vals, true_max
 
     def topn_multiply_blocked(self, A: DeviceMatrix, B: DeviceMatrix, n_blocks: Tuple[int, int], top_n: int,
                               threshold: float) -> sp.csr_matrix:

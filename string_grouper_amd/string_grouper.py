@@ -344,7 +344,7 @@ class StringGrouper(object):
             rows, cols, sims, self._true_max_n_matches = out[:4]
             self._matches_list = _concat_columns(      # columns kept as they are: no re-copy
                 [pd.Series(rows, name='master_side', copy=False), pd.Series(cols, name='dupe_side', copy=False),
-                 pd.Series(sims.astype(np.float64, copy=False), name='similarity', copy=False)])
+                 pd.Series(sims if sims.dtype == np.float64 else _hostops.widen(sims, np.float64), name='similarity', copy=False)])
             # the same list stays in HBM for get_groups(): best master per duplicate (K7) / group
             # representatives (K8) come back as one int32 per string
             if len(out) > 4:
@@ -489,8 +489,7 @@ class StringGrouper(object):
                 # the index values of the picked rows, as an ndarray where there is one to be had: a Series built from an
                 # Index copies it (10 ms per side at 2 M rows), RangeIndex.take materialises the range first (6 ms)
                 if type(idx) is pd.RangeIndex:
-                    picked_index = pos.astype(np.int64, copy=True) if (idx.start == 0 and idx.step == 1) \
-                        else idx.start + pos.astype(np.int64) * idx.step
+                    picked_index = _hostops.affine_i64(pos, idx.start, idx.step)      # (a new array: start + pos * step)
                 elif isinstance(idx.dtype, np.dtype) and idx.dtype.kind in 'iufbO':
                     picked_index = idx.to_numpy().take(pos)
                 else:

@@ -77,3 +77,30 @@ def test_ascii_columns_are_copied_out_and_everything_else_goes_the_general_way()
     assert bytes(d3[o3[-2]:]).decode("utf-8") == "Ünïcödé GmbH"
     with pytest.raises(TypeError):
         strprep.to_arrow_buffers(pd.Series(names[:5000] + [None], dtype=object))
+
+
+@needs_lib
+def test_expansions_of_the_match_list_equal_numpys():
+    rng = np.random.default_rng(3)
+    counts = rng.integers(0, 9, 120000)
+    counts[[0, 5, 119999]] = 0                                             # empty rows at both ends
+    row_ptr = np.zeros(len(counts) + 1, np.int64)
+    np.cumsum(counts, out=row_ptr[1:])
+    assert row_ptr[-1] > 300000
+    want = np.repeat(np.arange(len(counts), dtype=np.int64), counts)
+    got = H.expand_rows(row_ptr)
+    assert got.dtype == np.int64 and np.array_equal(got, want)
+    assert np.array_equal(H.expand_rows(row_ptr[:50]), np.repeat(np.arange(49, dtype=np.int64), counts[:49]))   # small: numpy's
+    cols = rng.integers(-5, 2 ** 31 - 1, 400000).astype(np.int32)
+    w = H.widen(cols, np.int64)
+    assert w.dtype == np.int64 and np.array_equal(w, cols.astype(np.int64))
+    vals = rng.random(400000).astype(np.float32)
+    v = H.widen(vals, np.float64)
+    assert v.dtype == np.float64 and np.array_equal(v, vals.astype(np.float64))
+    assert H.widen(vals[::2], np.float64).dtype == np.float64             # not contiguous: numpy's
+    assert np.array_equal(H.widen(cols, np.float64), cols.astype(np.float64))      # another pair of types: numpy's
+    pos = rng.integers(0, 10 ** 6, 500000).astype(np.int64)
+    a = H.affine_i64(pos, 0, 1)
+    assert a is not pos and np.array_equal(a, pos)
+    assert np.array_equal(H.affine_i64(pos, 7, 3), 7 + pos * 3)
+    assert np.array_equal(H.affine_i64(pos[:100], 7, 3), 7 + pos[:100] * 3)
