@@ -8,6 +8,7 @@ engine in this package and ``get_engine()`` raises if the HIP library cannot be 
 """
 from __future__ import annotations
 
+import os
 import time
 from typing import List, Optional, Sequence, Tuple
 
@@ -181,6 +182,10 @@ class HipEngine:
         # which re-sorts every row by column; a float64 result keeps the multiply's score-descending order
         ml = self.ctx.matchlist_build(res, self_join_fix, self_join_fix,
                                       sort_by_column=(not self_join_fix) and dtype == np.float32)
+        if os.environ.get("SG_E2E_SPLIT"):            # (diagnostic: the list's kernels and its download apart)
+            self.ctx.sync()
+            t_ml = time.perf_counter()
+            self.timings["match_list_kernels_s"] = t_ml - t
         row_ptr, cols, vals = ml.to_host()
         t = self._tick("match_list_and_download_s", t)
         res.free()
