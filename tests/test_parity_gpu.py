@@ -895,6 +895,37 @@ def test_forms_outside_the_name_matching_envelope_at_300k_equal_the_exact_kernel
     dA.free()
 
 
+def test_frames_of_the_public_api_with_and_without_the_host_helpers_at_300k(ctx):
+    """Round 6: `match_strings` at a size where the host helpers take over (libsg_host.so: the object gathers, the match
+    list's rows expanded, columns and scores widened, the index labels) against the same call on numpy / pandas alone -- equal
+    frames, column by column and dtype by dtype; with a non-default index and ids as well."""
+    import pandas as pd
+    import string_grouper_amd as sga
+    import string_grouper_amd.engine as E
+    from string_grouper_amd import _hostops as H
+    if H._load() is None:
+        pytest.skip("libsg_host.so not built")
+    E.set_engine(E.HipEngine(ctx))
+    names = pd.Series(_names(300000, seed=23))
+    ids = pd.Series(np.arange(len(names)) * 3 + 7)
+    shifted = names.copy()
+    shifted.index = pd.RangeIndex(10, 10 + 2 * len(names), 2)
+    for dt in (np.float32, np.float64):
+        frames = {}
+        for helpers in (True, False):
+            saved = H._lib
+            if not helpers:
+                H._lib = None
+            try:
+                frames[helpers] = (sga.match_strings(names, max_n_matches=10, min_similarity=0.8, tfidf_matrix_dtype=dt),
+                                   sga.match_strings(shifted, master_id=ids, max_n_matches=10, min_similarity=0.8, tfidf_matrix_dtype=dt))
+            finally:
+                H._lib = saved
+        for a, b in zip(frames[True], frames[False]):
+            assert len(a) > 500000 and list(a.columns) == list(b.columns) and (a.dtypes == b.dtypes).all()
+            assert a.equals(b), dt
+
+
 def _device_u32(ptr, n):
     """Host copy of a uint32 device array of the library (test plumbing: a torch view of the pointer)."""
     import torch
