@@ -431,9 +431,10 @@ def run(args):
         result["roofline"].update(committed_counters(ROOT, args.rows, args.dtype,
                                                      ("K4p-sym" if symmetric else "K4p") if pruned else "K4", k4_avg_ms))
 
-    # (the public API is timed BEFORE the side runs and the exact kernel: after the exact kernel's 0.4 s at full power the
-    #  download of the match list -- 22 MB, device to host -- ran at a tenth of its speed for a while, 2 ms became 20 - 30, and the
-    #  end-to-end figure read 0.045 s instead of 0.022: scripts/e2e_variance.sh)
+    # (the public API is timed right behind the main region, before the side runs and the exact kernel.  Its figure varies
+    #  between runs on the shared boxes: the download of the match list -- 22 MB, device to host -- takes 2 ms on most runs and
+    #  20 - 30 on some, whatever the destination and the copy engine, and the end-to-end figure then reads 0.045 s instead of
+    #  0.022; `match_list_and_download_s` in the split tells which it was: scripts/e2e_variance.sh)
     if world == 1 and not args.no_end_to_end:
         # the public API end to end: pandas Series in, match frame out (host preparation, PCIe, K1-K4p, K6, frames)
         import pandas as pd
