@@ -443,24 +443,56 @@ def run(args):
         eng = E.HipEngine(ctx)
         E.set_engine(eng)
         series = pd.Series(names)
+        # Device-to-host bandwidth as the API call will find it.  On some runs on the shared boxes the match list's 22 MB come
+        # down at ~1 GB/s instead of 10-50 (scripts/e2e_ab.sh, e2e_variance.sh; no cause found that the library controls) and the
+        # figure below records the box, not the library.  Probe until the link is up to speed, five seconds at most; what was
+        # seen is in the line (`d2h_probe_gbps`), and `match_list_and_download_s` of the split says how the call itself fared.
+        d2h_seen = []
+        try:
+            dev_buf = torch.empty(32 << 20, dtype=torch.uint8, device="cuda")
+            host_buf = torch.empty(32 << 20, dtype=torch.uint8).pin_memory()
+            t_probe = time.perf_counter()
+            while time.perf_counter() - t_probe < 5.0:
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                host_buf.copy_(dev_buf)
+                torch.cuda.synchronize()
+                d2h_seen.append(round((32 << 20) / (time.perf_counter() - t0) / 1e9, 2))
+                if len(d2h_seen) >= 3 and min(d2h_seen[-3:]) >= 10.0:
+                    break
+            del dev_buf, host_buf
+        except Exception as e:  # noqa: BLE001 -- a probe, not a requirement
+            d2h_seen.append(f"probe failed: {type(e).__name__}")
         result["end_to_end"] = {"what": "wall-clock of string_grouper_amd.match_strings(pd.Series) -> DataFrame, best of 3 "
-                                        "after one warm-up call; includes host string preparation, H2D, the device hot "
-                                        "path, the device match list (K6), D2H and the pandas frames"}
+                                        "after warm-up calls (until a call is no faster than the one before, at most 8); includes host string preparation, H2D, the device hot "
+                                        "path, the device match list (K6), D2H and the pandas frames",
+                                "d2h_probe_gbps": d2h_seen[:3] + (["..."] if len(d2h_seen) > 6 else []) + d2h_seen[3:][-3:]}
         for dname, dt in (("f32", np.float32), ("f64", np.float64)):
             best, split, n_match = None, None, 0
-            for rep in range(4):
+            # warm-up: until a call is no longer faster than the one before it (at most eight)
+            warm, prev = 0, None
+            while warm < 8:
+                t0 = time.perf_counter()
+                df = sga.match_strings(series, max_n_matches=args.top_n, min_similarity=args.min_similarity, tfidf_matrix_dtype=dt)
+                t = time.perf_counter() - t0
+                del df
+                warm += 1
+                if prev is not None and t > 0.9 * prev:
+                    break
+                prev = t
+            for rep in range(3):
                 t0 = time.perf_counter()
                 df = sga.match_strings(series, max_n_matches=args.top_n, min_similarity=args.min_similarity,
                                        tfidf_matrix_dtype=dt)
                 t = time.perf_counter() - t0
                 n_match = len(df)
-                if rep > 0 and (best is None or t < best):
+                if best is None or t < best:
                     best = t
                     split = dict(eng.timings)
                 del df
             device = split.get("vectorise_s", 0.0) + split.get("multiply_s", 0.0) + split.get("match_list_and_download_s", 0.0)
             split["validation_and_frames_s"] = best - device - split.get("prepare_and_upload_s", 0.0)
-            result["end_to_end"][dname] = {"seconds": best, "rows_per_s": args.rows / best, "match_rows": n_match,
+            result["end_to_end"][dname] = {"seconds": best, "rows_per_s": args.rows / best, "match_rows": n_match, "warm_up_calls": warm,
                                            "split": {k: round(v, 5) for k, v in split.items()}}
 
     if world == 1 and not args.no_side_runs:
