@@ -826,6 +826,10 @@ __global__ void __launch_bounds__(256) weight_normalize_rows16_kernel(const int6
     cmax = max(cmax, __shfl_xor(cmax, 16, 64));
     cmax = max(cmax, __shfl_xor(cmax, 32, 64));
     double carry = 0.0;
+    // (round 6: the columns and weights of the first two trips -- 32 entries, nearly every row of a name list -- stay in
+    //  registers for the second pass, which looked every key up and fetched tf and idf again)
+    int32_t col_keep[2] = {-1, -1};
+    T w_keep[2] = {(T)0, (T)0};
     for (int base = 0; base < cmax; base += 16) {
         const int q = base + sub;
         double w2 = 0.0;
@@ -834,6 +838,13 @@ __global__ void __launch_bounds__(256) weight_normalize_rows16_kernel(const int6
             if (col >= 0) {
                 const T w = tmul<T>((T)tf[b + q], idf[col]);
                 w2 = (double)tmul<T>(w, w);
+                if (base == 0) {
+                    col_keep[0] = col;
+                    w_keep[0] = w;
+                } else if (base == 16) {
+                    col_keep[1] = col;
+                    w_keep[1] = w;
+                }
             }
         }
         double acc = w2;
@@ -851,7 +862,10 @@ __global__ void __launch_bounds__(256) weight_normalize_rows16_kernel(const int6
             const int q = base + sub;
             int32_t col = -1;
             T w = 0;
-            if (q < c) {
+            if (base < 32) {          // (kept by the first pass; -1 / 0 for a lane beyond the row or a key without a column)
+                col = base == 0 ? col_keep[0] : col_keep[1];
+                w = base == 0 ? w_keep[0] : w_keep[1];
+            } else if (q < c) {
                 col = lookup(keys[b + q]);
                 if (col >= 0) w = tmul<T>((T)tf[b + q], idf[col]);
             }
