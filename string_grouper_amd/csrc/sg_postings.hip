@@ -1120,9 +1120,9 @@ extern "C" int sg_postings_build_flags(sg_ctx *ctx, const sg_csr *B_in, int32_t 
     if (tile_cols == 0) {
         tile_cols = B->dtype == SG_F64 ? 1024 : 2048;
         if (want_pruned) {
-            tile_cols = (flags & SG_POSTINGS_TILE_FORM) ? 2048 : 4096;
-            if (flags & SG_POSTINGS_TILE_FORM) {
-            } else if (const char *v = ctx->opt("SG_PRUNE_TILE")) tile_cols = atoi(v) == 13 ? 8192 : (atoi(v) == 11 ? 2048 : 4096);
+            tile_cols = 4096;
+            if (flags & SG_POSTINGS_TILE_FORM) tile_cols = 2048;   // (the tile-by-tile form's own index: sg_spgemm_topn.hip, "which form")
+            else if (const char *v = ctx->opt("SG_PRUNE_TILE")) tile_cols = atoi(v) == 13 ? 8192 : (atoi(v) == 11 ? 2048 : 4096);
         }
     }
     SG_REQUIRE(tile_cols >= 256 && tile_cols <= 32768 && (tile_cols & (tile_cols - 1)) == 0,
