@@ -775,6 +775,8 @@ static int prune_pilot(sg_ctx *ctx, const sg_csr *A, const sg_postings *Bt, int3
 // at 0.4: 9.9 ms against 12.1 for the exact kernel in the self-join form and 20.8 one-sided; at 0.35 the two are level:
 // profiles/r06b_form_sweep.log).  SG_PRUNE_MIN_THRESHOLD overrides both.
 static double prune_min_threshold(const sg_ctx *ctx, bool tile_form) { return env_double(ctx, "SG_PRUNE_MIN_THRESHOLD", tile_form ? 0.40 : 0.45); }
+static std::mutex g_exact_native_mu;   // guards sg_postings::exact_native's first build (two places in sg_spgemm_topn)
+
 // Can the pruned multiply (sg_spgemm_pruned.hip) take this product -- both sides cosine-like, one register list holds a
 // row's result, room below the threshold for its survivor bound -- and can it take its self-join form?
 // below_envelope (the one-GPU multiply asks): set when the threshold ALONE keeps the pruned kernel out -- *symmetric then says
@@ -1049,31 +1051,6 @@ extern "C" int sg_spgemm_topn(sg_ctx *ctx, const sg_csr *A, const sg_postings *B
     SG_TRY(topn_alloc(ctx, A->n_rows, Bt->n_right, stride, A->dtype, &r));
     const size_t s = A->dtype == SG_F64 ? 8 : 4;
 
-    // tiles per launch: keep one launch's postings (~ nnz*(4+s)/n_tiles per tile) near 2 MiB so that
-    // they stay in every XCD's 4 MiB L2 while all rows stream over them
-    // Tile groups (separate launches over a few tiles each, running state kept in the output arrays)
-    // exist for right-hand sides whose postings exceed the 256 MiB Infinity Cache; below that one launch
-    // is faster (measured: 280 ms vs 415 ms at 663 k -- every launch has a tail and a state round trip).
-    int group = env_int(ctx, "SG_TILE_GROUP", 0);
-    if (group <= 0) {
-        const double bytes = (double)Bt->nnz * (double)(4 + s);
-        const double budget = 192.0 * 1024 * 1024;
-        group = bytes <= budget ? Bt->n_tiles : (int)((double)Bt->n_tiles * budget / bytes);
-        if (group < 1) group = 1;
-    }
-    if (group > Bt->n_tiles) group = Bt->n_tiles;
-    const int n_groups = (Bt->n_tiles + group - 1) / group;
-    const int n_pass = (stride + SG_TOPN_LANES - 1) / SG_TOPN_LANES;
-    const int n_launch = n_groups * n_pass;
-
-    const size_t lds = s << Bt->tile_log2;
-    int waves_per_cu = (int)(ctx->lds_per_cu / lds);
-    if (waves_per_cu > 32) waves_per_cu = 32;
-    if (waves_per_cu < 1) waves_per_cu = 1;
-    waves_per_cu = env_int(ctx, "SG_WAVES_PER_CU", waves_per_cu);
-    unsigned grid = (unsigned)ctx->num_cu * (unsigned)waves_per_cu;
-    if ((int64_t)grid > A->n_rows) grid = (unsigned)(A->n_rows > 0 ? A->n_rows : 1);
-
     // ---- pruned multiply (sg_spgemm_pruned.hip) when both sides are cosine-like and one register list
     //      holds the row's result; its survivor threshold needs some room below the threshold
     bool prune = false, symmetric = false;
@@ -1120,8 +1097,7 @@ extern "C" int sg_spgemm_topn(sg_ctx *ctx, const sg_csr *A, const sg_postings *B
     // CU), built once per index and kept with it
     const sg_postings *Bx = Bt;
     if (exact_sym && env_int(ctx, "SG_EXACT_NATIVE", 1) != 0 && Bt->tile_log2 > (A->dtype == SG_F64 ? 10 : 11)) {
-        static std::mutex native_mu;
-        std::lock_guard<std::mutex> lock(native_mu);
+        std::lock_guard<std::mutex> lock(g_exact_native_mu);
         const sg_postings *home = Bt->view_of ? Bt->view_of : Bt;   // (a view is a copy on the caller's stack)
         if (!home->exact_native) {
             int bst = sg_csr_ensure_rows(ctx, A);
@@ -1135,6 +1111,55 @@ extern "C" int sg_spgemm_topn(sg_ctx *ctx, const sg_csr *A, const sg_postings *B
         }
         Bx = home->exact_native;
     }
+
+    // ... and the exact kernel ONE-SIDED (a master x duplicates product below the pruned multiply's thresholds, a self-join too
+    // small for the self-join form) on its own layout as well, where the product is worth a second index: the 4096-column
+    // tiles of the pruned multiply leave it half the waves per CU (200 k names at 0.4: 25.0 ms there, 20.8 on its own)
+    if (!prune && !exact_sym && env_int(ctx, "SG_EXACT_NATIVE", 1) != 0 && Bt->d_filt && Bt->nnz >= ((int64_t)1 << 20) &&
+        Bt->tile_log2 > (A->dtype == SG_F64 ? 10 : 11)) {
+        const sg_postings *home = Bt->view_of ? Bt->view_of : Bt;
+        const bool self = A->n_rows == Bt->n_right && A->d_indptr == Bt->b_indptr && A->d_indices == Bt->b_indices && A->d_data == Bt->b_data;
+        const sg_csr *from = self ? A : (home->collapse ? home->collapse->unique : (Bt->built_from_valid ? &Bt->built_from : nullptr));
+        if (from && from->n_rows == Bt->n_right) {
+            std::lock_guard<std::mutex> lock(g_exact_native_mu);
+            if (!home->exact_native) {
+                int bst = sg_csr_ensure_rows(ctx, from);
+                if (bst == SG_OK)
+                    bst = sg_postings_build_flags(ctx, from, 0, (Bt->build_flags & SG_POSTINGS_NO_PERMUTATION) | (1 << 8) | SG_POSTINGS_EXACT_ONLY,
+                                                  &home->exact_native);
+                if (bst != SG_OK) {
+                    sg_topn_free(r);
+                    return bst;
+                }
+            }
+            Bt = home->exact_native;
+        }
+    }
+
+    // tiles per launch: keep one launch's postings (~ nnz*(4+s)/n_tiles per tile) near 2 MiB so that
+    // they stay in every XCD's 4 MiB L2 while all rows stream over them
+    // Tile groups (separate launches over a few tiles each, running state kept in the output arrays)
+    // exist for right-hand sides whose postings exceed the 256 MiB Infinity Cache; below that one launch
+    // is faster (measured: 280 ms vs 415 ms at 663 k -- every launch has a tail and a state round trip).
+    int group = env_int(ctx, "SG_TILE_GROUP", 0);
+    if (group <= 0) {
+        const double bytes = (double)Bt->nnz * (double)(4 + s);
+        const double budget = 192.0 * 1024 * 1024;
+        group = bytes <= budget ? Bt->n_tiles : (int)((double)Bt->n_tiles * budget / bytes);
+        if (group < 1) group = 1;
+    }
+    if (group > Bt->n_tiles) group = Bt->n_tiles;
+    const int n_groups = (Bt->n_tiles + group - 1) / group;
+    const int n_pass = (stride + SG_TOPN_LANES - 1) / SG_TOPN_LANES;
+    const int n_launch = n_groups * n_pass;
+
+    const size_t lds = s << Bt->tile_log2;
+    int waves_per_cu = (int)(ctx->lds_per_cu / lds);
+    if (waves_per_cu > 32) waves_per_cu = 32;
+    if (waves_per_cu < 1) waves_per_cu = 1;
+    waves_per_cu = env_int(ctx, "SG_WAVES_PER_CU", waves_per_cu);
+    unsigned grid = (unsigned)ctx->num_cu * (unsigned)waves_per_cu;
+    if ((int64_t)grid > A->n_rows) grid = (unsigned)(A->n_rows > 0 ? A->n_rows : 1);
 
     // counters: [0, n_launch] row counters of the exact launches; then the pruned kernel's row counter, the
     // number of rows it handed over, and their list
