@@ -2069,10 +2069,15 @@ int sg_spgemm_pruned_launch(sg_ctx *ctx, const sg_csr *A, const sg_postings *Bt,
 // exact_all: every row is handed to the exact kernel's self-join launch, from the last position down (a row's cost grows
 // with its position) -- thresholds below the pruned kernel's envelope, or products its pilot prices dearer than the exact
 // multiply: half the (row, tile) visits of the one-sided exact kernel, the same pair list and second pass.
-__global__ void __launch_bounds__(256) all_rows_descending_kernel(uint32_t n, uint32_t *__restrict__ rows, uint32_t *count) {
+// rows[i] = n - 1 - first - i for i < count; *len = count (what the launch reads), *listed = first + count (the statistics)
+__global__ void __launch_bounds__(256) all_rows_descending_kernel(uint32_t n, uint32_t first, uint32_t count, uint32_t *__restrict__ rows,
+                                                                  uint32_t *len, uint32_t *listed) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) rows[i] = n - 1u - i;
-    if (i == 0) *count = n;
+    if (i < count) rows[i] = n - 1u - first - i;
+    if (i == 0) {
+        *len = count;
+        *listed = first + count;
+    }
 }
 
 int sg_spgemm_pruned_symmetric(sg_ctx *ctx, const sg_csr *A, const sg_postings *Bt, int32_t keep, sg_topn *r,
@@ -2179,13 +2184,42 @@ int sg_spgemm_pruned_symmetric(sg_ctx *ctx, const sg_csr *A, const sg_postings *
     if (st == SG_OK && exact_all) {
         SgTimer kt(ctx, SG_K_SPGEMM_KERNEL);
         st = sg_postings_ensure_full(ctx, Bt);
-        if (st == SG_OK && n > 0) {
-            hipLaunchKernelGGL(all_rows_descending_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, (uint32_t)n,
-                               flagged_rows, words + 1);
-            if (hipGetLastError() != hipSuccess) st = SG_ERR_HIP;
+        // Large matrices: the most expensive rows -- the last 0.4 % of the positions, which see every column -- go first, in a
+        // launch of their own, and what THEY put into the pair list says whether the list will hold the pass: a row at
+        // position p mirrors the matches j < p, so the whole pass writes about n / (2 k) times what the last k rows do.  At
+        // thresholds far below name matching the pairs outgrow any list (5 M names at 0.38: more than 1.5 G pairs; the pass
+        // wrote 18 GB for 6.5 s before it ran out of chunks, and the one-sided form took its 10 s after that): then the
+        // form is called off here, for 1 % of its work.  [6] / [8]: the two lists' lengths, [5] / [7]: their row counters.
+        uint32_t k_first = 0;
+        if (n >= (int64_t)1000000 && !cap_forced) k_first = (uint32_t)(n / 256 > 4096 ? n / 256 : 4096);
+        if (const char *v = ctx->opt("SG_EXACT_SYM_PILOT_ROWS")) k_first = (uint32_t)atoll(v) < (uint32_t)n ? (uint32_t)atoll(v) : 0u;   // (test hook)
+        auto list_and_launch = [&](uint32_t first, uint32_t count, uint32_t *len_word, uint32_t *counter_word) {
+            hipLaunchKernelGGL(all_rows_descending_kernel, dim3((count + 255u) / 256u), dim3(256), 0, ctx->stream, (uint32_t)n, first, count,
+                               flagged_rows + first, len_word, words + 1);
+            if (hipGetLastError() != hipSuccess) return (int)SG_ERR_HIP;
+            return sg_spgemm_exact_selfjoin_rows(ctx, A, Bt, keep, r, threshold, counter_word, flagged_rows + first, len_word, sink,
+                                                 /*all_rows=*/true);
+        };
+        if (st == SG_OK && n > 0 && k_first > 0) {
+            st = list_and_launch(0u, k_first, words + 6, words + 5);
+            if (st == SG_OK) {
+                e = hipMemcpyAsync(h, words, 24, hipMemcpyDeviceToHost, ctx->stream);
+                if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+                if (e != hipSuccess) st = SG_ERR_HIP;
+            }
+            if (st == SG_OK) {
+                const double open_chunks = 0.5 * (double)sg_spgemm_exact_selfjoin_grid(ctx, Bt);   // (every wave's last chunk is half full on average)
+                const double used = (double)(uint32_t)h[2] > open_chunks ? (double)(uint32_t)h[2] - open_chunks : 0.0;
+                if (used * (double)n / (2.0 * (double)k_first) > 0.9 * (double)pl.chunks) {
+                    ctx->release(d_stats3);
+                    cleanup();
+                    return SG_OK;   // *done stays false: the caller runs the one-sided form
+                }
+                st = list_and_launch(k_first, (uint32_t)n - k_first, words + 8, words + 7);
+            }
+        } else if (st == SG_OK && n > 0) {
+            st = list_and_launch(0u, (uint32_t)n, words + 6, words + 5);
         }
-        if (st == SG_OK && n > 0)
-            st = sg_spgemm_exact_selfjoin_rows(ctx, A, Bt, keep, r, threshold, words + 5, flagged_rows, words + 1, sink, /*all_rows=*/true);
     } else if (st == SG_OK) {
         SgTimer kt(ctx, SG_K_SPGEMM_KERNEL);   // the kernel alone (the launch group's timer also covers the second pass)
         if (A->dtype == SG_F64)

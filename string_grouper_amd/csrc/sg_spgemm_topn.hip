@@ -1110,6 +1110,7 @@ extern "C" int sg_spgemm_topn(sg_ctx *ctx, const sg_csr *A, const sg_postings *B
             }
         }
         Bx = home->exact_native;
+        Bt = Bx;   // (also what the one-sided exact kernel runs on if the form is called off: pair list too small)
     }
 
     // ... and the exact kernel ONE-SIDED (a master x duplicates product below the pruned multiply's thresholds, a self-join too

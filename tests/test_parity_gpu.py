@@ -133,7 +133,19 @@ def test_thresholds_below_the_pruned_kernels_run_the_exact_kernel_in_the_selfjoi
             assert st["prune_rows"] == 0, st
             if thr >= 0.3:                                      # (at 0.1 the pair list may run full: one-sided, same result)
                 assert st["prune_symmetric"] == 1 and st["exact_rows"] > 15000, st
+    # large matrices send the most expensive rows first and judge the pair list by what they write (from a million rows on;
+    # here through the test hook): two launches, the same bits -- and a list the estimate says is too small calls the form off
     monkeypatch.setenv("SG_COLLAPSE", "0")
+    monkeypatch.setenv("SG_EXACT_SYM_PILOT_ROWS", "700")
+    got = sp_matmul_topn(A, A.T, 10, 0.35, sort=True, ctx=ctx)
+    assert ctx.stats()["prune_symmetric"] == 1 and ctx.stats()["exact_rows"] == A.shape[0]
+    assert_csr_identical(got, P.sp_matmul_topn_port(A, A.T, 10, 0.35, True, 8), "rows in two launches")
+    monkeypatch.setenv("SG_SYM_PAIR_CAP", "40000")
+    got = sp_matmul_topn(A, A.T, 10, 0.35, sort=True, ctx=ctx)
+    assert ctx.stats()["prune_symmetric"] == 0
+    assert_csr_identical(got, P.sp_matmul_topn_port(A, A.T, 10, 0.35, True, 8), "called off after the first rows")
+    monkeypatch.delenv("SG_SYM_PAIR_CAP")
+    monkeypatch.delenv("SG_EXACT_SYM_PILOT_ROWS")
     monkeypatch.setenv("SG_EXACT_SYM", "0")                    # the switch: one-sided exact kernel as in round 5
     got = sp_matmul_topn(A, A.T, 10, 0.35, sort=True, ctx=ctx)
     assert ctx.stats()["prune_symmetric"] == 0
