@@ -177,6 +177,17 @@ def test_pruned_multiply_rule_used_for_the_row_split():
     assert pruned_multiply_expected(128, 0.8)          # (65 .. 128: the pruned kernel + a hand-over of full rows)
     assert not pruned_multiply_expected(129, 0.8)
     assert not pruned_multiply_expected(10, 0.3)
+    # round 6: the tile-by-tile form's envelope starts at 0.40 (sg_spgemm_topn.hip, prune_min_threshold) -- 0.45 with the form off
+
+    class _Ctx:
+        def __init__(self, opts):
+            self._o = opts
+
+        def options(self):
+            return self._o
+    assert pruned_multiply_expected(10, 0.42, _Ctx({})) and not pruned_multiply_expected(10, 0.39, _Ctx({}))
+    assert not pruned_multiply_expected(10, 0.42, _Ctx({"SG_ALT_FORM": "0"}))
+    assert pruned_multiply_expected(10, 0.2, _Ctx({"SG_PRUNE_MIN_THRESHOLD": "0.1"})) and not pruned_multiply_expected(10, 0.9, _Ctx({"SG_PRUNE": "0"}))
 
 
 # ------------------------------------------------------------------------------------------------
