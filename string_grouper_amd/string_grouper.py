@@ -63,6 +63,45 @@ DEFAULT_MASTER_ID_NAME: str = f'{DEFAULT_MASTER_NAME}_{DEFAULT_ID_NAME}'
 GROUP_REP_PREFIX: str = 'group_rep_'
 
 
+def _pick_rows(series, positions, default_name, drop_index, mirror):
+    """``series`` at ``positions`` as the frames hold it -- the values (and, unless dropped, the index of the picked rows as
+    ``reset_index`` would name it), index column first unless ``mirror`` -- without pandas' take + reset_index on the common
+    shapes.  Shared by get_matches (both sides) and the group representatives."""
+    name = series.name if series.name else default_name
+    pos = np.asarray(positions)
+    idx = series.index
+    if drop_index or (idx.nlevels == 1 and name not in ('index', 'level_0') and idx.name not in (name,)):
+        # the common shapes, without pandas' take + reset_index (which copy every column twice
+        # at millions of rows): gather values -- and the index, as reset_index would name it --
+        # with numpy and hand the columns over as they are
+        if series.dtype == object:
+            # numpy gather of the string pointers; handing pandas an object ndarray avoids the per-element
+            # missing-value scan that building a Series from a NumpyExtensionArray costs (0.2 s per side at
+            # 2 M rows)
+            # (round 6: the gather itself on a few host threads, _hostops.take_objects -- the same objects; a numpy
+            #  take raises 2 M reference counts one after the other, 22 ms a side at 663 k names)
+            values = pd.Series(_hostops.take_objects(series.to_numpy(), pos), name=name, copy=False, dtype=object)
+        else:
+            values = pd.Series(series.array.take(pos), name=name, copy=False)  # keeps an extension dtype
+        if drop_index:
+            return values
+        # the index values of the picked rows, as an ndarray where there is one to be had: a Series built from an
+        # Index copies it (10 ms per side at 2 M rows), RangeIndex.take materialises the range first (6 ms)
+        if type(idx) is pd.RangeIndex:
+            picked_index = _hostops.affine_i64(pos, idx.start, idx.step)      # (a new array: start + pos * step)
+        elif isinstance(idx.dtype, np.dtype) and idx.dtype.kind in 'iufbO':
+            picked_index = idx.to_numpy().take(pos)
+        else:
+            picked_index = idx.take(pos)              # datetimes, categoricals, extension dtypes: pandas' own way
+        index_col = pd.Series(picked_index, name='index' if idx.name is None else idx.name, copy=False)
+        return _concat_columns([values, index_col] if mirror else [index_col, values])
+    named = series if series.name else series.rename(default_name)
+    picked = named.iloc[pos].reset_index(drop=drop_index)
+    if mirror and isinstance(picked, pd.DataFrame):
+        picked = picked[picked.columns[::-1]]
+    return picked
+
+
 class StringGrouperConfig(NamedTuple):
     """Options of a StringGrouper (field names, order and defaults as string_grouper.py:189-202).
 
@@ -467,55 +506,20 @@ class StringGrouper(object):
 
         right_source = self._master if self._duplicates is None else self._duplicates
 
-        def side(series, positions, default_name, drop_index, mirror):
-            name = series.name if series.name else default_name
-            pos = np.asarray(positions)
-            idx = series.index
-            if drop_index or (idx.nlevels == 1 and name not in ('index', 'level_0') and idx.name not in (name,)):
-                # the common shapes, without pandas' take + reset_index (which copy every column twice
-                # at millions of rows): gather values -- and the index, as reset_index would name it --
-                # with numpy and hand the columns over as they are
-                if series.dtype == object:
-                    # numpy gather of the string pointers; handing pandas an object ndarray avoids the per-element
-                    # missing-value scan that building a Series from a NumpyExtensionArray costs (0.2 s per side at
-                    # 2 M rows)
-                    # (round 6: the gather itself on a few host threads, _hostops.take_objects -- the same objects; a numpy
-                    #  take raises 2 M reference counts one after the other, 22 ms a side at 663 k names)
-                    values = pd.Series(_hostops.take_objects(series.to_numpy(), pos), name=name, copy=False, dtype=object)
-                else:
-                    values = pd.Series(series.array.take(pos), name=name, copy=False)  # keeps an extension dtype
-                if drop_index:
-                    return values
-                # the index values of the picked rows, as an ndarray where there is one to be had: a Series built from an
-                # Index copies it (10 ms per side at 2 M rows), RangeIndex.take materialises the range first (6 ms)
-                if type(idx) is pd.RangeIndex:
-                    picked_index = _hostops.affine_i64(pos, idx.start, idx.step)      # (a new array: start + pos * step)
-                elif isinstance(idx.dtype, np.dtype) and idx.dtype.kind in 'iufbO':
-                    picked_index = idx.to_numpy().take(pos)
-                else:
-                    picked_index = idx.take(pos)              # datetimes, categoricals, extension dtypes: pandas' own way
-                index_col = pd.Series(picked_index, name='index' if idx.name is None else idx.name, copy=False)
-                return _concat_columns([values, index_col] if mirror else [index_col, values])
-            named = series if series.name else series.rename(default_name)
-            picked = named.iloc[pos].reset_index(drop=drop_index)
-            if mirror and isinstance(picked, pd.DataFrame):
-                picked = picked[picked.columns[::-1]]
-            return picked
-
         def prefixed(obj, prefix):
             if isinstance(obj, pd.DataFrame):
                 return obj.rename(columns={c: f"{prefix}{c}" for c in obj.columns}, copy=False)
             return obj.rename(f"{prefix}{obj.name}", copy=False)
 
-        left = side(self._master, pairs.master_side, DEFAULT_COLUMN_NAME, ignore_index, False)
-        right = side(right_source, pairs.dupe_side, DEFAULT_COLUMN_NAME, ignore_index, True)
+        left = _pick_rows(self._master, pairs.master_side, DEFAULT_COLUMN_NAME, ignore_index, False)
+        right = _pick_rows(right_source, pairs.dupe_side, DEFAULT_COLUMN_NAME, ignore_index, True)
         similarity = pairs.similarity.reset_index(drop=True)
         if self._master_id is None:
             parts = [prefixed(left, LEFT_PREFIX), similarity, prefixed(right, RIGHT_PREFIX)]
         else:
             right_ids = self._master_id if self._duplicates is None else self._duplicates_id
-            left_id = side(self._master_id, pairs.master_side, DEFAULT_ID_NAME, True, False)
-            right_id = side(right_ids, pairs.dupe_side, DEFAULT_ID_NAME, True, True)
+            left_id = _pick_rows(self._master_id, pairs.master_side, DEFAULT_ID_NAME, True, False)
+            right_id = _pick_rows(right_ids, pairs.dupe_side, DEFAULT_ID_NAME, True, True)
             parts = [prefixed(left, LEFT_PREFIX), prefixed(left_id, LEFT_PREFIX), similarity,
                      prefixed(right_id, RIGHT_PREFIX), prefixed(right, RIGHT_PREFIX)]
         return _concat_columns(parts)
@@ -644,15 +648,15 @@ class StringGrouper(object):
         prefix = MOST_SIMILAR_PREFIX
         name_col = f'{prefix}{self._master.name if self._master.name else DEFAULT_MASTER_NAME}'
         # both sides as positional tables: the index levels (unless dropped) to the left of the strings
-        m_tbl = self._master.rename(name_col).reset_index(drop=ignore_index)
-        d_tbl = self._duplicates.rename('duplicates').reset_index(drop=ignore_index)
+        m_tbl = self._master.rename(name_col, copy=False).reset_index(drop=ignore_index)      # (copy=False: reset_index makes the new object)
+        d_tbl = self._duplicates.rename('duplicates', copy=False).reset_index(drop=ignore_index)
         if isinstance(d_tbl, pd.DataFrame):
             m_tbl = m_tbl.rename(columns={c: f'{prefix}{c}' for c in m_tbl.columns if str(c) != name_col})
         id_col = None
         if self._master_id is not None:
             id_col = f'{prefix}{self._master_id.name if self._master_id.name else DEFAULT_MASTER_ID_NAME}'
-            m_tbl = pd.concat([m_tbl, self._master_id.rename(id_col).reset_index(drop=True)], axis=1)
-            d_tbl = pd.concat([d_tbl, self._duplicates_id.rename('duplicates_id').reset_index(drop=True)], axis=1)
+            m_tbl = pd.concat([m_tbl, self._master_id.rename(id_col, copy=False).reset_index(drop=True)], axis=1)
+            d_tbl = pd.concat([d_tbl, self._duplicates_id.rename('duplicates_id', copy=False).reset_index(drop=True)], axis=1)
         m_frame = m_tbl.to_frame() if isinstance(m_tbl, pd.Series) else m_tbl
         d_frame = d_tbl.to_frame() if isinstance(d_tbl, pd.Series) else d_tbl
 
@@ -691,7 +695,9 @@ class StringGrouper(object):
 
         prefix = GROUP_REP_PREFIX
         label = f'{prefix}{self._master.name}' if self._master.name else prefix[:-1]
-        output = self._master.iloc[rep].rename(label).reset_index(drop=ignore_index)
+        # (round 6: the strings of 663 k representatives through the threaded gather of get_matches' sides -- pandas' take of an
+        #  object column was 16 of this function's 39 ms; the frame is the one iloc + rename + reset_index builds)
+        output = _pick_rows(self._master.rename(label, copy=False), rep, label, ignore_index, False)
         if isinstance(output, pd.DataFrame):
             output.rename(columns={c: f'{prefix}{c}' for c in output.columns if str(c) != label}, inplace=True)
         if self._master_id is not None:
