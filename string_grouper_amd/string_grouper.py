@@ -647,23 +647,40 @@ class StringGrouper(object):
         (tests/test_host_api.py: fuzz against the mounted reference)."""
         prefix = MOST_SIMILAR_PREFIX
         name_col = f'{prefix}{self._master.name if self._master.name else DEFAULT_MASTER_NAME}'
-        # both sides as positional tables: the index levels (unless dropped) to the left of the strings
-        m_tbl = self._master.rename(name_col, copy=False).reset_index(drop=ignore_index)      # (copy=False: reset_index makes the new object)
+        # both sides as positional tables: the index levels (unless dropped) to the left of the strings.  The MASTER's table is
+        # never built in full (round 6: a copy of 663 k strings and their index for the 165 k rows that are picked from it):
+        # `m_tbl` is its empty head -- the columns and their dtypes, which is what the rest of this function asks of it -- and
+        # the rows of the best masters are gathered directly.
+        best = self._best_master_positions()
+        lonely = best < 0                                   # duplicates without a match
+        m_named = self._master.rename(name_col, copy=False)
+        m_tbl = m_named.iloc[:0].reset_index(drop=ignore_index)
         d_tbl = self._duplicates.rename('duplicates', copy=False).reset_index(drop=ignore_index)
+        if len(self._master) > 0:
+            safe = np.where(lonely, 0, best)
+            picked = _pick_rows(m_named, safe, name_col, ignore_index, False)
+        else:                                               # (nothing to gather from: every duplicate is lonely)
+            safe = None
+            picked = m_tbl.reindex(pd.Index(best)).reset_index(drop=True)
         if isinstance(d_tbl, pd.DataFrame):
             m_tbl = m_tbl.rename(columns={c: f'{prefix}{c}' for c in m_tbl.columns if str(c) != name_col})
+            if isinstance(picked, pd.DataFrame):
+                picked = picked.rename(columns={c: f'{prefix}{c}' for c in picked.columns if str(c) != name_col}, copy=False)
         id_col = None
         if self._master_id is not None:
             id_col = f'{prefix}{self._master_id.name if self._master_id.name else DEFAULT_MASTER_ID_NAME}'
-            m_tbl = pd.concat([m_tbl, self._master_id.rename(id_col, copy=False).reset_index(drop=True)], axis=1)
+            id_named = self._master_id.rename(id_col, copy=False)
+            m_tbl = pd.concat([m_tbl, id_named.iloc[:0].reset_index(drop=True)], axis=1)
+            picked_id = _pick_rows(id_named, safe, id_col, True, False) if safe is not None \
+                else id_named.iloc[:0].reindex(pd.Index(best)).reset_index(drop=True)
+            picked = pd.concat([picked, picked_id], axis=1)
             d_tbl = pd.concat([d_tbl, self._duplicates_id.rename('duplicates_id', copy=False).reset_index(drop=True)], axis=1)
         m_frame = m_tbl.to_frame() if isinstance(m_tbl, pd.Series) else m_tbl
         d_frame = d_tbl.to_frame() if isinstance(d_tbl, pd.Series) else d_tbl
-
-        best = self._best_master_positions()
-        lonely = best < 0                                   # duplicates without a match
-        # the master table's row of every duplicate; -1 is no row of it: those come out empty (and widen their columns)
-        picked = m_frame.reindex(pd.Index(best)).reset_index(drop=True)
+        picked = picked.to_frame() if isinstance(picked, pd.Series) else picked
+        # -1 is no row of the master table: those rows come out empty (and widen their columns, as a reindex does)
+        if safe is not None and lonely.any():
+            picked = pd.concat([picked[c].where(~lonely) for c in picked.columns], axis=1)
 
         picked[name_col] = self._fill_from(picked[name_col], lonely, d_frame['duplicates'], m_frame[name_col].dtype,
                                            m_frame[name_col].dtype)
