@@ -1,7 +1,9 @@
 """EXPERIMENT (round 6; measured and NOT kept -- profiles/r06_row_order_experiment.log: sorting the rows of a band by
 their longest prefix list is SLOWER, 7.67 -> 8.1 ... 11.2 ms, the neighbours then queue on the same accumulators' cache lines and
-the same long lists end together; the debug hook sg_debug_set_row_order it needs is not in the library, the three-file patch
-is in the git history of this script's commit message): does the order in which the self-join pass takes its rows matter?  Rows that share their longest
+the same long lists end together; the debug hook it calls, sg_debug_set_row_order -- an optional
+table of positions read by the whole-matrix self-join launch instead of `sym_hi - 1 - rr` --, was a local patch of
+sg_api.hip / sg_internal.h / sg_spgemm_pruned.hip and is NOT in the library: the script documents the experiment, it does
+not run against this tree): does the order in which the self-join pass takes its rows matter?  Rows that share their longest
 prefix list, taken at the same time, stream that list together (L2 hits instead of fabric traffic).  The order is computed
 on the host here and handed to the library through a debug hook (sg_debug_set_row_order); SG_COLLAPSE=0 so that positions
 are rows.   python scripts/row_order_experiment.py [rows=663000]"""
