@@ -2222,12 +2222,46 @@ int sg_spgemm_pruned_symmetric(sg_ctx *ctx, const sg_csr *A, const sg_postings *
         }
     } else if (st == SG_OK) {
         SgTimer kt(ctx, SG_K_SPGEMM_KERNEL);   // the kernel alone (the launch group's timer also covers the second pass)
-        if (A->dtype == SG_F64)
-            st = dispatch_pruned<double, true>(ctx, A, Bt, keep, r, (double)threshold, s_budget, words, words + 1, flagged_rows,
-                                               d_stats3, pl);
-        else
-            st = dispatch_pruned<float, true>(ctx, A, Bt, keep, r, (float)threshold, s_budget, words, words + 1, flagged_rows,
-                                              d_stats3, pl);
+        auto pruned_pass = [&](const PairList &range) {
+            if (A->dtype == SG_F64)
+                return dispatch_pruned<double, true>(ctx, A, Bt, keep, r, (double)threshold, s_budget, words, words + 1, flagged_rows,
+                                                     d_stats3, range);
+            return dispatch_pruned<float, true>(ctx, A, Bt, keep, r, (float)threshold, s_budget, words, words + 1, flagged_rows, d_stats3,
+                                                range);
+        };
+        // The tile-by-tile form on a large matrix (thresholds below the name-matching range, a million rows and more): the
+        // last 0.4 % of the positions first, as the exact kernel's form does above, and their pairs decide whether the list
+        // will hold the pass -- 5 M names at 0.42 have more than 1 G pairs above the threshold, the pass wrote them for four
+        // seconds before it ran out of chunks and was repeated one-sided (scripts/big_low_thresholds.py).
+        uint32_t k_first = 0;
+        const bool whole = pl.row_lo == 0 && (int64_t)pl.row_hi == n && pl.row_step == 1 && !export_pairs;
+        if (Bt->tile_form && whole && n >= (int64_t)1000000 && !cap_forced) k_first = (uint32_t)(n / 256 > 4096 ? n / 256 : 4096);
+        if (const char *v = ctx->opt("SG_SYM_PILOT_ROWS"))    // (test hook, any form of the pruned multiply)
+            k_first = whole && atoll(v) > 0 && atoll(v) < n ? (uint32_t)atoll(v) : 0u;
+        if (k_first > 0) {
+            PairList first = pl, rest = pl;
+            first.row_lo = (uint32_t)n - k_first;
+            rest.row_hi = (uint32_t)n - k_first;
+            st = pruned_pass(first);
+            if (st == SG_OK) {
+                e = hipMemcpyAsync(h, words, 24, hipMemcpyDeviceToHost, ctx->stream);
+                if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+                if (e != hipSuccess) st = SG_ERR_HIP;
+            }
+            if (st == SG_OK) {
+                const double open_chunks = 0.5 * (double)pruned_grid(ctx, Bt->tile_log2, (int64_t)k_first, Bt->fold_log2, A->dtype);
+                const double used = (double)(uint32_t)h[2] > open_chunks ? (double)(uint32_t)h[2] - open_chunks : 0.0;
+                if (used * (double)n / (2.0 * (double)k_first) > 0.9 * (double)pl.chunks) {
+                    ctx->release(d_stats3);
+                    cleanup();
+                    return SG_OK;   // *done stays false: the caller runs the one-sided form
+                }
+                if (hipMemsetAsync(words, 0, sizeof(uint32_t), ctx->stream) != hipSuccess) st = SG_ERR_HIP;   // the row counter
+            }
+            if (st == SG_OK) st = pruned_pass(rest);
+        } else {
+            st = pruned_pass(pl);
+        }
     }
     // h[0] = {row counter, flagged}, h[1] = pairs, h[2] = chunks handed out
     auto read_back = [&]() {

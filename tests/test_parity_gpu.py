@@ -185,6 +185,24 @@ def test_selfjoins_below_name_matching_thresholds_take_the_tile_by_tile_form(ctx
         res = ctx.spgemm_topn(dA, post, 10, 0.8, True)
         assert_csr_identical(res.to_scipy(), P.sp_matmul_topn_port(A_ref, A_ref.T, 10, 0.8, True, 8), "0.8 on the same index")
         res.free()
+        # large matrices send the last positions first and judge the pair list by what they write (a million rows and more in
+        # the tile-by-tile form; here through the test hook, in both forms): two passes, the same bits -- and a list the
+        # estimate says is too small calls the form off before the rest is multiplied
+        monkeypatch.setenv("SG_SYM", "1")
+        monkeypatch.setenv("SG_SYM_PILOT_ROWS", "900")
+        for top_n, thr in ((20, 0.5), (10, 0.8), (100, 0.6)):
+            res = ctx.spgemm_topn(dA, post, top_n, thr, True)
+            assert ctx.stats()["prune_symmetric"] == 1
+            assert_csr_identical(res.to_scipy(), P.sp_matmul_topn_port(A_ref, A_ref.T, top_n, thr, True, 8), f"first rows first, top {top_n} at {thr}")
+            res.free()
+        monkeypatch.setenv("SG_SYM_PAIR_CAP", "30000")
+        res = ctx.spgemm_topn(dA, post, 20, 0.5, True)
+        assert ctx.stats()["prune_symmetric"] == 0
+        assert_csr_identical(res.to_scipy(), P.sp_matmul_topn_port(A_ref, A_ref.T, 20, 0.5, True, 8), "called off after the first rows")
+        res.free()
+        monkeypatch.delenv("SG_SYM_PAIR_CAP")
+        monkeypatch.delenv("SG_SYM_PILOT_ROWS")
+        monkeypatch.delenv("SG_SYM")
         monkeypatch.setenv("SG_ALT_FORM", "0")                 # the switch: the stream form at any threshold
         res = ctx.spgemm_topn(dA, post, 20, 0.5, True)
         assert_csr_identical(res.to_scipy(), P.sp_matmul_topn_port(A_ref, A_ref.T, 20, 0.5, True, 8), "SG_ALT_FORM=0")
